@@ -1,0 +1,68 @@
+"""The oracle (oracle/hyena_oracle.py) against vectors minted from the real reference
+(oracle/make_golden.py -> tests/golden/*.pt).  CPU only."""
+import pytest
+import torch
+
+from oracle import hyena_oracle as O
+
+
+@pytest.mark.parametrize("name", ["b2d4l8", "b2d3l37", "b1d4l1023", "b2d4l1024", "b2d4l1024_5d",
+                                  "b2d4l1000_bf16", "b1d2l4100"])
+def test_fftconv_oracle_matches_reference_vectors(golden_fftconv, name):
+    c = golden_fftconv[name]
+    u = c["u"].clone().requires_grad_(True)
+    k = c["k"].clone().requires_grad_(True)
+    b = c["bias"].clone().requires_grad_(True)
+    B, D, L = u.shape
+    if c["five_d"]:
+        out = O.fftconv_ref(u.reshape(B, 1, D, 1, L), k, b[None, :, None]).reshape(B, D, L)
+    else:
+        out = O.fftconv_ref(u, k, b)
+    out.backward(c["dout"])
+    # identical op sequence on the same torch build -> bit exact
+    assert torch.equal(out.detach(), c["out"])
+    assert torch.equal(u.grad, c["du"])
+    assert torch.equal(k.grad, c["dk"])
+    assert torch.equal(b.grad, c["dbias"])
+
+
+@pytest.mark.parametrize("name", ["b2d4l8", "b2d3l37"])
+def test_fftconv_oracle_vs_direct_f64(golden_fftconv, name):
+    """The FFT formulation equals the O(L^2) causal convolution (no-FFT float64 truth)."""
+    c = golden_fftconv[name]
+    B, D, L = c["u"].shape
+    u = c["u"].float().reshape(B * D, L)
+    k = c["k"].repeat(B, 1)
+    bias = c["bias"].repeat(B)
+    truth = O.causal_conv_direct_f64(u, k, bias).reshape(B, D, L)
+    rel = (c["out"].double() - truth).norm() / truth.norm()
+    assert rel < 5e-6
+
+
+@pytest.mark.parametrize("name", ["d8l64", "d16l257", "d8l80_trunc"])
+def test_operator_oracle_matches_reference_vectors(golden_operator, name):
+    c = golden_operator[name]
+    sd = {k: v.clone() for k, v in c["state_dict"].items()}
+    params = ["in_proj.weight", "in_proj.bias", "out_proj.weight", "out_proj.bias",
+              "short_filter.weight", "short_filter.bias", "filter_fn.bias"]
+    for p in params:
+        sd[p].requires_grad_(True)
+    u = c["u"].clone().requires_grad_(True)
+    L = min(u.shape[1], c["l_max"])
+    kf = O.hyena_filter(sd, L)
+    assert torch.equal(kf, c["k"])
+    y = O.hyena_operator(sd, u, c["l_max"])
+    assert y.shape == c["y"].shape
+    torch.testing.assert_close(y, c["y"], rtol=1e-5, atol=1e-6)
+    y.backward(c["dy"])
+    torch.testing.assert_close(u.grad, c["du"], rtol=1e-4, atol=1e-6)
+    for p in params:
+        torch.testing.assert_close(sd[p].grad, c["grads"][p], rtol=1e-4, atol=1e-5)
+
+
+def test_pos_emb_and_deltas_restatement(golden_operator):
+    c = golden_operator["d8l64"]
+    z, t = O.positional_embedding(5, c["l_max"])
+    assert torch.equal(z, c["state_dict"]["filter_fn.pos_emb.z"])
+    assert torch.equal(t, c["state_dict"]["filter_fn.pos_emb.t"])
+    assert torch.equal(O.exp_modulation_deltas(c["d_model"]), c["state_dict"]["filter_fn.modulation.deltas"])
