@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- the hot path on N GPUs of one node:  Hyena long convolution (fftconv) forward + backward.
+
+A "step" is one forward + one backward pass of the fused long convolution over one batch of synthetic
+activations already resident in HBM (one Hyena layer call: out = causal_conv(u, k) + bias * u, then
+du, dk, dbias for a random upstream gradient).  Default workload = the configuration BASELINE.json quotes the
+metric on: L = 1,048,576, d = 256, B = 1 per GPU, bf16 activations, fp32 filter (hyenadna-large-1m's layer).
+
+    python bench.py                      # 1 GPU, default K / W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the path shards on the batch axis (independent sequences): every rank runs the same
+per-GPU workload on its own seeded batch (weak scaling).  The convolution itself has no exchange step; the only
+collective of the training step it belongs to is the DDP gradient all-reduce of the model parameters (6.6 M fp32
+for hyenadna-large-1m), which is reproduced here as one RCCL all-reduce of that size per step on a side stream,
+overlapped with the next step's kernels, so that the N-GPU number carries the real communication of the path.
+
+One JSON line on stdout (rank 0).  `roofline` is computed from algorithmic bytes (SURVEY.md 8d:
+5*B*D*L*s + 12*D*L per step) over the HIP-event time of the timed region; `cpu_baseline` is the oracle
+(`oracle/hyena_oracle.py`, a restatement of the reference's torch.fft path) timed on this box's host cores on a
+bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
+MODEL_GRAD_ELEMS = 6_600_000     # fp32 parameters of hyenadna-large-1m (8 layers, d_model 256)
+METRIC = "nucleotides/sec fwd+bwd at L=1M d=256; fftconv achieved HBM GB/s vs peak"
+
+
+def algorithmic_bytes(B, D, L, s):
+    """SURVEY.md 8d, operator boundary of the reference's fftconv: fwd reads u, k and writes out; bwd reads dout, u,
+    k and writes du, dk (+ dbias)."""
+    return 5 * B * D * L * s + 12 * D * L + 8 * D
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seq-len", type=int, default=1048576)
+    ap.add_argument("--d-model", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1, help="sequences per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--chunk", type=int, default=0, help="channels per kernel-chain pass (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allreduce", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true", help="diagnostic; the reported metric needs fwd+bwd")
+    ap.add_argument("--emu", action="store_true",
+                    help="TEST ONLY: run the host logic on the CPU emulation of the kernels with the gloo backend")
+    return ap.parse_args()
+
+
+def cpu_baseline(L, D, dtype, budget_s=25.0):
+    """The oracle (reference torch.fft path) fwd+bwd on the host cores, on a bounded sample of the same workload:
+    the same L, a subset of the D channels (channels are independent), B = 1."""
+    from oracle import hyena_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    # ~50 ns per (channel, position) per core-ish for fwd+bwd; size the sample for roughly 3-6 s per repetition
+    Ds = max(1, min(D, int(4.0e8 * max(cores, 8) / 8 / max(L, 1024) / 12)))
+    g = torch.Generator().manual_seed(0)
+    u = torch.randn(1, Ds, L, generator=g).to(dtype)
+    k = torch.randn(Ds, L, generator=g) * torch.exp(-5.0 * torch.linspace(0, 1, L))[None] * 0.1
+    bias = torch.randn(Ds, generator=g)
+    dout = torch.randn(1, Ds, L, generator=g).to(dtype)
+    best = None
+    t_start = time.perf_counter()
+    for rep in range(4):                      # 1 warm-up + best of 3
+        u_ = u.clone().requires_grad_(True)
+        k_ = k.clone().requires_grad_(True)
+        b_ = bias.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        out = O.fftconv_ref(u_, k_, b_, None, gelu=False)
+        out.backward(dout)
+        dt = time.perf_counter() - t0
+        if rep > 0:
+            best = dt if best is None else min(best, dt)
+        if time.perf_counter() - t_start > budget_s and best is not None:
+            break
+    nt_per_s = L * (Ds / D) / best           # a nucleotide = one position through all D channels
+    return {"value": nt_per_s, "unit": "nt/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fftconv_ref fwd+bwd (torch.fft, fp32 math), B=1, L={L}, {Ds} of {D} channels, "
+                      f"best of 3 after 1 warm-up, {best * 1e3:.0f} ms; scaled by {Ds}/{D} channels"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    from hyena_dna_amd import _lib
+    if args.emu:
+        from tests.hipemu.emu_backend import EmuBackend       # test double, CPU only
+        _lib._backend = EmuBackend()
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a ROCm device (there is no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if args.emu else "nccl", rank=rank, world_size=world,
+                                **({} if args.emu else {"device_id": dev}))
+
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    B, D, L = args.batch, args.d_model, args.seq_len
+    g = torch.Generator(device=dev).manual_seed(2222 + rank)            # 2222 = the reference's train seed
+    u = torch.randn(B, D, L, generator=g, device=dev).to(dtype)
+    k = torch.randn(D, L, generator=g, device=dev) * torch.exp(-5.0 * torch.linspace(0, 1, L, device=dev))[None] * 0.1
+    bias = torch.randn(D, generator=g, device=dev)
+    dout = torch.randn(B, D, L, generator=g, device=dev).to(dtype)
+    chunk = args.chunk if args.chunk > 0 else None
+    grads = torch.zeros(MODEL_GRAD_ELEMS, dtype=torch.float32, device=dev) if world > 1 and not args.no_allreduce else None
+    comm_stream = torch.cuda.Stream(device=dev) if (grads is not None and not args.emu) else None
+
+    def step():
+        out = _lib.fftconv_fwd(u, k, bias, chunk=chunk)
+        if args.fwd_only:
+            return out
+        res = _lib.fftconv_bwd(dout, u, k, bias, chunk=chunk)
+        if grads is not None:
+            if comm_stream is not None:
+                comm_stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(comm_stream):
+                    dist.all_reduce(grads)
+            else:
+                dist.all_reduce(grads)
+        return res
+
+    def sync():
+        if not args.emu:
+            torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        if not args.emu:
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if not args.emu:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if not args.emu:
+        e1.record()
+    if comm_stream is not None:
+        torch.cuda.current_stream(dev).wait_stream(comm_stream)
+    sync()
+    wall = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1) if not args.emu else wall * 1e3
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev if not args.emu else "cpu")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = tmax.item()
+
+    if rank == 0:
+        s = 4 if dtype == torch.float32 else 2
+        ms_per_step = wall * 1e3 / args.steps
+        nt_per_s = B * L * world / (wall / args.steps)
+        abytes = algorithmic_bytes(B, D, L, s)
+        ev_ms_step = ev_ms / args.steps
+        achieved = abytes / (ev_ms_step * 1e-3) / 1e9
+        line = {
+            "metric": METRIC, "value": nt_per_s, "unit": "nt/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"hyenadna-large-1m layer: fftconv fwd+bwd, L={L}, d={D}, B={B}/GPU, "
+                                   f"{args.dtype} activations, fp32 filter and FFT math" +
+                                   (" [FWD ONLY -- diagnostic]" if args.fwd_only else ""),
+                       "seq_len": L, "d_model": D, "batch_per_gpu": B, "io_dtype": args.dtype,
+                       "chunk": int(_lib.lib().hyena_fftconv_default_chunk(B, D, L, 1)) if chunk is None else chunk,
+                       "parallelism": f"dp{world} (batch-sharded, RCCL all-reduce of {MODEL_GRAD_ELEMS} fp32 grads/step)"
+                                      if world > 1 else "single GPU",
+                       "unit_of_work": "one nucleotide through one Hyena long-conv layer call (fwd+bwd), all d channels"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "all launches of one fftconv fwd+bwd step (col_fwd/row_*/col_inv chain)",
+                         "algorithmic_bytes_per_step": abytes, "event_ms_per_step": ev_ms_step},
+        }
+        if not args.no_cpu_baseline and not args.emu:
+            line["cpu_baseline"] = cpu_baseline(L, D, dtype)
+        elif args.emu:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,15 @@
+"""hyena_dna_amd -- MI355X-native Hyena long convolution (HIP/gfx950) behind the reference's own surface.
+
+Scope: the hot path ``HyenaOperator -> HyenaFilter -> fftconv`` of
+HazyResearch/hyena-dna, nothing else.
+
+* ``hyena_dna_amd.fftconv``  mirrors ``src/ops/fftconv.py``      (``fftconv_func``, ``FFTConvFunc``)
+* ``hyena_dna_amd.hyena``    mirrors ``src/models/sequence/hyena.py`` (``HyenaOperator``, ``HyenaFilter``)
+* ``hyena_dna_amd.csrc``     the HIP kernels and the C ABI (``include/hyena_fftconv.h``)
+
+There is no CPU or PyTorch fallback for the convolution: without the compiled gfx950 library the ops raise.
+"""
+from . import _lib  # noqa: F401
+
+__all__ = ["fftconv", "hyena", "build"]
+__version__ = "0.1.0"

@@ -1,0 +1,181 @@
+"""ctypes binding of the C ABI in include/hyena_fftconv.h (libhyena_fftconv.so, built by hyena_dna_amd.build).
+
+The library is loaded lazily on first use.  There is deliberately no fallback: if the shared object is missing
+or a call returns a non-zero status the caller gets an exception, never a silently different code path.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libhyena_fftconv.so")
+ABI_VERSION = 1
+
+HYENA_F32, HYENA_BF16, HYENA_F16 = 0, 1, 2
+MAX_L = 1048576
+
+_DTYPES = {torch.float32: HYENA_F32, torch.bfloat16: HYENA_BF16, torch.float16: HYENA_F16}
+
+_lock = threading.Lock()
+_lib = None
+_tables = {}      # (device index, M) -> uint8 tensor holding the twiddle tables
+_workspace = {}   # (device index, stream) -> uint8 tensor
+
+
+class HyenaLibraryError(RuntimeError):
+    pass
+
+
+class _HipBackend:
+    """Where tensors live and how the library is reached.  The product has exactly this one backend (ROCm device
+    tensors + libhyena_fftconv.so); tests/ substitute a CPU-emulation double to exercise the host logic without
+    a GPU (tests/hipemu/emu_backend.py) -- nothing in this package ever selects another backend."""
+    name = "hip"
+    path = LIB_PATH
+
+    def require(self, t, name):
+        if not t.is_cuda:
+            raise HyenaLibraryError(
+                f"hyena fftconv: `{name}` lives on {t.device}; the HIP kernels need a ROCm device tensor "
+                "(there is no CPU fallback)")
+
+    def guard(self, device):
+        return torch.cuda.device(device)
+
+    def stream(self, device):
+        return torch.cuda.current_stream(device).cuda_stream
+
+
+_backend = _HipBackend()
+
+
+def lib():
+    """The loaded shared library; raises HyenaLibraryError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        LIB_PATH = _backend.path
+        if not os.path.exists(LIB_PATH):
+            raise HyenaLibraryError(
+                f"{LIB_PATH} not found: build it with `python -m hyena_dna_amd.build` (hipcc, gfx950). "
+                "hyena_dna_amd has no CPU/PyTorch fallback for the long convolution.")
+        L = ctypes.CDLL(LIB_PATH)
+        c_int, c_size_t, c_void_p, c_char_p = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_char_p
+        L.hyena_fftconv_abi_version.restype = c_int
+        L.hyena_fftconv_abi_version.argtypes = []
+        L.hyena_fftconv_error_string.restype = c_char_p
+        L.hyena_fftconv_error_string.argtypes = [c_int]
+        L.hyena_fftconv_fft_size.restype = c_int
+        L.hyena_fftconv_fft_size.argtypes = [c_int]
+        L.hyena_fftconv_table_bytes.restype = c_size_t
+        L.hyena_fftconv_table_bytes.argtypes = [c_int]
+        L.hyena_fftconv_init_tables.restype = c_int
+        L.hyena_fftconv_init_tables.argtypes = [c_void_p, c_int]
+        L.hyena_fftconv_default_chunk.restype = c_int
+        L.hyena_fftconv_default_chunk.argtypes = [c_int, c_int, c_int, c_int]
+        L.hyena_fftconv_workspace_bytes.restype = c_size_t
+        L.hyena_fftconv_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
+        L.hyena_fftconv_fwd.restype = c_int
+        L.hyena_fftconv_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+        L.hyena_fftconv_bwd.restype = c_int
+        L.hyena_fftconv_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+        if L.hyena_fftconv_abi_version() != ABI_VERSION:
+            raise HyenaLibraryError(f"{LIB_PATH}: ABI version {L.hyena_fftconv_abi_version()} != {ABI_VERSION}; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise HyenaLibraryError("hyena_fftconv: " + lib().hyena_fftconv_error_string(status).decode())
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPES[dtype]
+    except KeyError:
+        raise TypeError(f"hyena fftconv supports float32 / bfloat16 / float16 activations, got {dtype}") from None
+
+
+def _require_gpu(t, name):
+    _backend.require(t, name)
+
+
+def tables_for(device, L):
+    """Twiddle tables for sequence length L on `device` (cached per transform size)."""
+    M = lib().hyena_fftconv_fft_size(int(L))
+    if M == 0:
+        raise HyenaLibraryError(f"hyena fftconv: unsupported sequence length L={L} (1 <= L <= {MAX_L})")
+    key = (device.index, M)
+    t = _tables.get(key)
+    if t is None:
+        with _lock:
+            t = _tables.get(key)
+            if t is None:
+                nbytes = lib().hyena_fftconv_table_bytes(int(L))
+                t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                with _backend.guard(device):
+                    check(lib().hyena_fftconv_init_tables(t.data_ptr(), int(L)))
+                _tables[key] = t
+    return t
+
+
+def workspace_for(device, nbytes):
+    """A per-(device, stream) scratch buffer, grown on demand and reused across calls."""
+    stream = _backend.stream(device)
+    key = (device.index, stream)
+    w = _workspace.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspace[key] = w
+    return w, stream
+
+
+def _chunk_override():
+    v = os.environ.get("HYENA_FFTCONV_CHUNK")
+    return int(v) if v else 0
+
+
+def fftconv_fwd(u, k, bias, chunk=None):
+    """u (B, D, L) contiguous, k (D, L) fp32, bias (D,) fp32 or None -> out like u."""
+    _require_gpu(u, "u")
+    B, D, L = u.shape
+    out = torch.empty_like(u)
+    chunk = _chunk_override() if chunk is None else int(chunk)
+    tables = tables_for(u.device, L)
+    nbytes = lib().hyena_fftconv_workspace_bytes(B, D, L, 0, chunk)
+    ws, stream = workspace_for(u.device, nbytes)
+    with _backend.guard(u.device):
+        check(lib().hyena_fftconv_fwd(u.data_ptr(), k.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      out.data_ptr(), B, D, L, dtype_code(u.dtype), tables.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), chunk, stream))
+    return out
+
+
+def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None):
+    """Returns (du like u | None, dk (D, L) fp32 | None, dbias (D,) fp32 | None)."""
+    _require_gpu(u, "u")
+    B, D, L = u.shape
+    du = torch.empty_like(u) if need_du else None
+    dk = torch.empty((D, L), dtype=torch.float32, device=u.device) if need_dk else None
+    dbias = torch.empty((D,), dtype=torch.float32, device=u.device) if need_dk else None
+    chunk = _chunk_override() if chunk is None else int(chunk)
+    tables = tables_for(u.device, L)
+    nbytes = lib().hyena_fftconv_workspace_bytes(B, D, L, 1, chunk)
+    ws, stream = workspace_for(u.device, nbytes)
+    with _backend.guard(u.device):
+        check(lib().hyena_fftconv_bwd(dout.data_ptr(), u.data_ptr(), k.data_ptr(),
+                                      bias.data_ptr() if bias is not None else None,
+                                      du.data_ptr() if du is not None else None,
+                                      dk.data_ptr() if dk is not None else None,
+                                      dbias.data_ptr() if dbias is not None else None,
+                                      B, D, L, dtype_code(u.dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      chunk, stream))
+    return du, dk, dbias

@@ -1,0 +1,45 @@
+"""Build libhyena_fftconv.so for gfx950 with hipcc, in-tree (the .so travels with the repo snapshot).
+
+    python -m hyena_dna_amd.build [--force]
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libhyena_fftconv.so")
+SOURCES = [os.path.join(CSRC, "fftconv.hip")]
+HEADERS = [os.path.join(CSRC, "fftconv_kernels.h"), os.path.join(HERE, "..", "include", "hyena_fftconv.h")]
+# -fno-slp-vectorize: hipcc otherwise packs the butterflies into v_pk_*_f32 (no faster on CDNA4) at the
+# price of ~1000 v_mov per kernel and VGPR spills.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"]
+
+
+def find_hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(f) <= t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=True):
+    if not force and up_to_date():
+        return LIB
+    cmd = [find_hipcc()] + FLAGS + SOURCES + ["-o", LIB]
+    if verbose:
+        print("[hyena_dna_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

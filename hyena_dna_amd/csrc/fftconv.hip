@@ -1,0 +1,302 @@
+// fftconv.hip -- host side of libhyena_fftconv.so: the C ABI declared in include/hyena_fftconv.h.
+//
+// Stateless: no allocation, no synchronisation, no globals; every launch goes to the caller's stream, so the
+// entry points can be captured into a hipGraph and are safe to call from the autograd thread (the reference
+// kernels launch on stream 0 without a device guard, csrc/fftconv/fftconv_cuda.cu:812 -- not repeated here).
+//
+// Built by hipcc --offload-arch=gfx950 (product).  With -DHIPEMU it builds against tests/hipemu with g++
+// into a CPU emulation used only by the `not gpu` tests.
+#include "fftconv_kernels.h"
+#include "../../include/hyena_fftconv.h"
+
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+using namespace hyena;
+
+#ifdef HIPEMU
+#define HY_LAUNCH(kernel, grid, block, smem, stream, ...)                              \
+    do {                                                                                \
+        auto _args = std::make_tuple(__VA_ARGS__);                                      \
+        hipemu::launch(grid, block, smem, [&] { std::apply(kernel, _args); });          \
+    } while (0)
+#include <tuple>
+static inline int hy_launch_error() { return 0; }
+#else
+#define HY_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+static inline int hy_launch_error() { return hipGetLastError() != hipSuccess; }
+#endif
+
+namespace {
+
+struct Plan {
+    int L, M, M1;
+};
+
+bool make_plan(int L, Plan* p) {
+    if (L < 1 || L > HYENA_MAX_L) return false;
+    int M = 1024;
+    while (M < L) M <<= 1;
+    p->L = L;
+    p->M = M;
+    p->M1 = M / 1024;
+    return true;
+}
+
+// table layout inside d_tables (c32 units): tw_lo[1024] | tw_row[1024] | tw_rowT[1024] | tw_hi[M1]
+Tables tables_from(const void* d_tables) {
+    const c32* t = reinterpret_cast<const c32*>(d_tables);
+    Tables tab;
+    tab.tw_lo = t;
+    tab.tw_row = t + 1024;
+    tab.tw_rowT = t + 2048;
+    tab.tw_hi = t + 3072;
+    return tab;
+}
+
+template <int DT, bool INV>
+int launch_col_dt(int M1, const ColArgs& a, int rows, void* stream) {
+#define HY_COL_CASE(m1)                                                                              \
+    case m1: {                                                                                       \
+        typedef ColCfg<m1> Cfg;                                                                      \
+        dim3 grid(1024 / Cfg::C, rows), block(Cfg::THREADS);                                         \
+        if (INV) HY_LAUNCH((col_inv_kernel<m1, DT>), grid, block, Cfg::LDS, stream, a);              \
+        else HY_LAUNCH((col_fwd_kernel<m1, DT>), grid, block, Cfg::LDS, stream, a);                  \
+        break;                                                                                       \
+    }
+    switch (M1) {
+        HY_COL_CASE(1)
+        HY_COL_CASE(2)
+        HY_COL_CASE(4)
+        HY_COL_CASE(8)
+        HY_COL_CASE(16)
+        HY_COL_CASE(32)
+        HY_COL_CASE(64)
+        HY_COL_CASE(128)
+        HY_COL_CASE(256)
+        HY_COL_CASE(512)
+        HY_COL_CASE(1024)
+        default: return HYENA_ERR_UNSUPPORTED_L;
+    }
+#undef HY_COL_CASE
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+template <bool INV>
+int launch_col(int dtype, int M1, const ColArgs& a, int rows, void* stream) {
+    if (rows <= 0) return HYENA_OK;
+    switch (dtype) {
+        case HYENA_F32: return launch_col_dt<DT_F32, INV>(M1, a, rows, stream);
+        case HYENA_BF16: return launch_col_dt<DT_BF16, INV>(M1, a, rows, stream);
+        case HYENA_F16: return launch_col_dt<DT_F16, INV>(M1, a, rows, stream);
+        default: return HYENA_ERR_BAD_ARG;
+    }
+}
+
+const size_t ROW_SMEM = 2 * ROW_LDS * sizeof(c32);
+
+template <int MODE>
+int launch_row_conv(const RowArgs& a, void* stream) {
+    const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;   // slot 0 = rows (0, M1/2); slot s = rows (s, M1 - s)
+    HY_LAUNCH((row_conv_kernel<MODE>), dim3(nslots, a.inner, a.B), dim3(64), ROW_SMEM, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+int launch_row_dk(const RowArgs& a, void* stream) {
+    const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;
+    HY_LAUNCH(row_dk_kernel, dim3(nslots, a.inner), dim3(64), 2 * ROW_SMEM, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+int launch_row_spec(const RowArgs& a, void* stream) {
+    HY_LAUNCH(row_spec_kernel, dim3((a.M1 + 1) / 2, a.inner), dim3(64), ROW_SMEM, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+size_t elem_size(int dtype) { return dtype == HYENA_F32 ? 4 : 2; }
+
+const size_t CACHE_BUDGET = 160u << 20;   // bytes of intermediates kept live per chunk (Infinity Cache is 256 MiB)
+
+}  // namespace
+
+extern "C" {
+
+int hyena_fftconv_abi_version(void) { return 1; }
+
+const char* hyena_fftconv_error_string(int status) {
+    switch (status) {
+        case HYENA_OK: return "ok";
+        case HYENA_ERR_BAD_ARG: return "bad argument (null pointer, non-positive size or unknown dtype)";
+        case HYENA_ERR_UNSUPPORTED_L: return "unsupported sequence length (1 <= L <= 1048576)";
+        case HYENA_ERR_WORKSPACE: return "workspace too small";
+        case HYENA_ERR_LAUNCH: return "kernel launch failed";
+        default: return "unknown status";
+    }
+}
+
+int hyena_fftconv_fft_size(int L) {
+    Plan p;
+    return make_plan(L, &p) ? p.M : 0;
+}
+
+size_t hyena_fftconv_table_bytes(int L) {
+    Plan p;
+    if (!make_plan(L, &p)) return 0;
+    return (size_t)(3072 + p.M1) * sizeof(c32);
+}
+
+int hyena_fftconv_init_tables(void* d_tables, int L) {
+    Plan p;
+    if (d_tables == nullptr) return HYENA_ERR_BAD_ARG;
+    if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
+    std::vector<c32> h(3072 + p.M1);
+    const double tau = 6.283185307179586476925286766559;
+    for (int i = 0; i < 1024; ++i) {
+        double a = -tau * (double)i / (double)p.M;
+        h[i].x = (float)std::cos(a);
+        h[i].y = (float)std::sin(a);
+        double r = -tau * (double)i / 1024.0;
+        h[1024 + i].x = (float)std::cos(r);
+        h[1024 + i].y = (float)std::sin(r);
+    }
+    for (int s = 0; s < 32; ++s)
+        for (int j = 0; j < 32; ++j) {
+            double r = -tau * (double)(s * j) / 1024.0;
+            h[2048 + s * 32 + j].x = (float)std::cos(r);
+            h[2048 + s * 32 + j].y = (float)std::sin(r);
+        }
+    for (int i = 0; i < p.M1; ++i) {
+        double a = -tau * (double)i / (double)p.M1;
+        h[3072 + i].x = (float)std::cos(a);
+        h[3072 + i].y = (float)std::sin(a);
+    }
+#ifdef HIPEMU
+    memcpy(d_tables, h.data(), h.size() * sizeof(c32));
+#else
+    if (hipMemcpy(d_tables, h.data(), h.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess)
+        return HYENA_ERR_LAUNCH;
+#endif
+    return HYENA_OK;
+}
+
+int hyena_fftconv_default_chunk(int B, int D, int L, int backward) {
+    Plan p;
+    if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
+    const size_t per_channel = (size_t)(backward ? 2 * B + 2 : B + 1) * p.M * sizeof(c32);
+    size_t c = CACHE_BUDGET / per_channel;
+    if (c < 1) c = 1;
+    if (c > (size_t)D) c = D;
+    return (int)c;
+}
+
+size_t hyena_fftconv_workspace_bytes(int B, int D, int L, int backward, int chunk) {
+    Plan p;
+    if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
+    if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, backward);
+    if (chunk > D) chunk = D;
+    return (size_t)(backward ? 2 * B + 2 : B + 1) * chunk * p.M * sizeof(c32);
+}
+
+int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int dtype,
+                      const void* d_tables, void* workspace, size_t workspace_bytes, int chunk, void* stream) {
+    Plan p;
+    if (u == nullptr || k == nullptr || out == nullptr || d_tables == nullptr || workspace == nullptr || B < 1 ||
+        D < 1 || (dtype != HYENA_F32 && dtype != HYENA_BF16 && dtype != HYENA_F16))
+        return HYENA_ERR_BAD_ARG;
+    if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
+    if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, 0);
+    if (chunk > D) chunk = D;
+    if (workspace_bytes < hyena_fftconv_workspace_bytes(B, D, L, 0, chunk)) return HYENA_ERR_WORKSPACE;
+
+    const Tables tab = tables_from(d_tables);
+    c32* S = reinterpret_cast<c32*>(workspace);                 // [chunk][M]
+    c32* W = S + (size_t)chunk * p.M;                           // [B][chunk][M]
+    const size_t es = elem_size(dtype);
+    int st;
+    for (int d0 = 0; d0 < D; d0 += chunk) {
+        const int cd = (D - d0 < chunk) ? D - d0 : chunk;
+        // filter spectrum of the chunk's channels
+        ColArgs ck;
+        ck.x = k + (size_t)d0 * L; ck.W = S; ck.tab = tab; ck.L = L; ck.inner = cd;
+        ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr;
+        if ((st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
+        RowArgs rs;
+        rs.X = nullptr; rs.U = nullptr; rs.S = S; rs.bias = nullptr; rs.tab = tab; rs.M1 = p.M1; rs.inner = cd; rs.B = 1;
+        rs.scale = 1.0f / (float)p.M;
+        if ((st = launch_row_spec(rs, stream))) return st;
+        // u rows
+        ColArgs cu;
+        cu.x = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cu.W = W; cu.tab = tab; cu.L = L; cu.inner = cd;
+        cu.outer_stride = (long)D * L; cu.inner_stride = L; cu.aux0 = nullptr;
+        if ((st = launch_col<false>(dtype, p.M1, cu, B * cd, stream))) return st;
+        RowArgs rc = rs;
+        rc.X = W; rc.bias = bias ? bias + d0 : nullptr; rc.B = B;
+        if ((st = launch_row_conv<MODE_CONV>(rc, stream))) return st;
+        ColArgs co = cu;
+        co.x = reinterpret_cast<char*>(out) + (size_t)d0 * L * es;
+        if ((st = launch_col<true>(dtype, p.M1, co, B * cd, stream))) return st;
+    }
+    return HYENA_OK;
+}
+
+int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const float* bias, void* du, float* dk,
+                      float* dbias, int B, int D, int L, int dtype, const void* d_tables, void* workspace,
+                      size_t workspace_bytes, int chunk, void* stream) {
+    Plan p;
+    if (dout == nullptr || u == nullptr || k == nullptr || d_tables == nullptr || workspace == nullptr || B < 1 ||
+        D < 1 || (dtype != HYENA_F32 && dtype != HYENA_BF16 && dtype != HYENA_F16))
+        return HYENA_ERR_BAD_ARG;
+    if (dbias != nullptr && dk == nullptr) return HYENA_ERR_BAD_ARG;
+    if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
+    if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, 1);
+    if (chunk > D) chunk = D;
+    if (workspace_bytes < hyena_fftconv_workspace_bytes(B, D, L, 1, chunk)) return HYENA_ERR_WORKSPACE;
+
+    const Tables tab = tables_from(d_tables);
+    c32* S = reinterpret_cast<c32*>(workspace);                 // [chunk][M]   filter spectrum
+    c32* Sdk = S + (size_t)chunk * p.M;                         // [chunk][M]   dk spectrum -> packed dk
+    c32* Wg = Sdk + (size_t)chunk * p.M;                        // [B][chunk][M]
+    c32* Wu = Wg + (size_t)B * chunk * p.M;                     // [B][chunk][M]
+    const size_t es = elem_size(dtype);
+    int st;
+    for (int d0 = 0; d0 < D; d0 += chunk) {
+        const int cd = (D - d0 < chunk) ? D - d0 : chunk;
+        RowArgs rs;
+        rs.X = nullptr; rs.U = nullptr; rs.S = S; rs.bias = nullptr; rs.tab = tab; rs.M1 = p.M1; rs.inner = cd; rs.B = 1;
+        rs.scale = 1.0f / (float)p.M;
+        ColArgs cg;
+        cg.x = reinterpret_cast<const char*>(dout) + (size_t)d0 * L * es; cg.W = Wg; cg.tab = tab; cg.L = L; cg.inner = cd;
+        cg.outer_stride = (long)D * L; cg.inner_stride = L; cg.aux0 = nullptr;
+        if ((st = launch_col<false>(dtype, p.M1, cg, B * cd, stream))) return st;
+        if (dk != nullptr) {
+            ColArgs cu = cg;
+            cu.x = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cu.W = Wu;
+            if ((st = launch_col<false>(dtype, p.M1, cu, B * cd, stream))) return st;
+            RowArgs rd = rs;
+            rd.X = Wg; rd.U = Wu; rd.S = Sdk; rd.B = B;
+            if ((st = launch_row_dk(rd, stream))) return st;
+            ColArgs cdk;
+            cdk.x = dk + (size_t)d0 * L; cdk.W = Sdk; cdk.tab = tab; cdk.L = L; cdk.inner = cd;
+            cdk.outer_stride = 0; cdk.inner_stride = L; cdk.aux0 = dbias ? dbias + d0 : nullptr;
+            if ((st = launch_col<true>(HYENA_F32, p.M1, cdk, cd, stream))) return st;
+        }
+        if (du != nullptr) {
+            ColArgs ck;
+            ck.x = k + (size_t)d0 * L; ck.W = S; ck.tab = tab; ck.L = L; ck.inner = cd;
+            ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr;
+            if ((st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
+            if ((st = launch_row_spec(rs, stream))) return st;
+            RowArgs rc = rs;
+            rc.X = Wg; rc.bias = bias ? bias + d0 : nullptr; rc.B = B;
+            if ((st = launch_row_conv<MODE_CORR>(rc, stream))) return st;
+            ColArgs co = cg;
+            co.x = reinterpret_cast<char*>(du) + (size_t)d0 * L * es;
+            if ((st = launch_col<true>(dtype, p.M1, co, B * cd, stream))) return st;
+        }
+    }
+    return HYENA_OK;
+}
+
+}  // extern "C"

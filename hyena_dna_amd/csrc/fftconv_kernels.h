@@ -1,0 +1,650 @@
+// fftconv_kernels.h -- device code of the MI355X-native Hyena long convolution.
+//
+// What is computed (reference: src/models/sequence/hyena.py:59-88, fftconv_ref):
+//     out = irfft(rfft(u, N) * rfft(k, N) / N, norm="forward")[..., :L] + u * bias,    N >= 2L
+// i.e. a causal linear convolution of every (b, d) row of u with the per-channel filter k[d],
+// all arithmetic in fp32, plus its gradients.
+//
+// How (nothing here follows csrc/fftconv, which tops out at L = 8192 -- SURVEY.md 0.1):
+//   * packed real transform: z[n] = u[2n] + i u[2n+1], a complex FFT of M = N/2 points per row;
+//   * four-step decomposition M = M1 x 1024 with the intermediate W[k1][n2] held in a workspace sized
+//     to stay in the Infinity Cache:
+//         col_fwd : strided size-M1 FFTs over n1 (+ twiddle w_M^(n2 k1)), HBM -> W, coalesced on n2
+//         row_*   : contiguous size-1024 FFTs over n2 on row pairs (k1, M1-k1), the pointwise product
+//                   with the filter spectrum in the packed domain, and the inverse size-1024 FFTs
+//         col_inv : inverse strided size-M1 FFTs, W -> HBM
+//   * every size-1024 / size-M1 transform is two Stockham stages of radix-32 register butterflies
+//     with ONE LDS exchange between them (64-wide wavefronts: a 1024-point row is 32 lanes x 32 points,
+//     a wavefront carries the two rows of a (k1, M1-k1) pair, the partner element of lane t is lane 63-t);
+//   * the bias term rides in the filter spectrum (Ke += bias), dbias falls out of dk[0]: no extra pass.
+//
+// Packed-domain product.  With Z = FFT_M(z), H = FFT_M(packed filter), partner index p = (M - k) mod M,
+//     He = (H[k] + conj(H[p])) / 2,  Ho = (H[k] - conj(H[p])) / (2i),  w = exp(-2 pi i k / M)
+//     conv:  Ke = He (+bias), Ko = Ho          corr:  Ke = conj(He) (+bias), Ko = conj(w Ho)
+//     Z'[k] = (Ke + (i/2)(1 - w) Ko) Z[k] + ((i/2)(1 + w) Ko) conj(Z[p])
+// and IFFT_M(Z') is the packed output.  (Checked against numpy in scratch models and by tests/.)
+//
+// This header is compiled by hipcc for gfx950 (the product) and, with -DHIPEMU, by g++ against
+// tests/hipemu (CPU emulation used only by the `not gpu` tests).
+#pragma once
+
+#ifdef HIPEMU
+#include "hipemu.h"
+#define HY_SMEM(name) char* name = hipemu::S.smem
+#define HY_SHFL_U32(v, lane) hipemu::shfl_u32((v), (lane))
+#define HY_UNROLL
+#define HY_SCHED_FENCE() do {} while (0)
+#else
+#include <hip/hip_runtime.h>
+#define HY_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define HY_SHFL_U32(v, lane) ((uint32_t)__shfl((int)(v), (lane), 64))
+#define HY_UNROLL _Pragma("unroll")
+// stops hipcc from hoisting every load of an unrolled loop to its top (which costs hundreds of VGPRs)
+#define HY_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+#include <stdint.h>
+
+namespace hyena {
+
+struct __attribute__((aligned(8))) c32 {
+    float x, y;
+};
+
+__device__ __forceinline__ c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ c32 cmul(c32 a, c32 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a * conj(b)
+__device__ __forceinline__ c32 cmulc(c32 a, c32 b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+__device__ __forceinline__ c32 cconj(c32 a) { return mk(a.x, -a.y); }
+__device__ __forceinline__ c32 cscale(c32 a, float s) { return mk(a.x * s, a.y * s); }
+
+__device__ __forceinline__ uint32_t f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+__device__ __forceinline__ float u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+
+// Global access as wave-uniform base + 32-bit BYTE offset: lets hipcc use the SGPR-base/VGPR-offset form of
+// global_load/store instead of materialising a 64-bit address pair per access (which spills).
+__device__ __forceinline__ c32 ldg(const c32* base, unsigned idx) {
+    return *reinterpret_cast<const c32*>(reinterpret_cast<const char*>(base) + (size_t)(idx * 8u));
+}
+__device__ __forceinline__ void stg(c32* base, unsigned idx, c32 v) {
+    *reinterpret_cast<c32*>(reinterpret_cast<char*>(base) + (size_t)(idx * 8u)) = v;
+}
+
+__device__ __forceinline__ c32 shfl_c32(c32 v, int lane) {
+    return mk(u2f(HY_SHFL_U32(f2u(v.x), lane)), u2f(HY_SHFL_U32(f2u(v.y), lane)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// element types
+// ---------------------------------------------------------------------------------------------
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return u2f(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round to nearest even, quiet NaN
+    uint32_t u = f2u(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+#ifdef HIPEMU
+__device__ __forceinline__ float f16_to_f32(uint16_t h) {
+    uint32_t s = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0) {
+        if (m == 0) return u2f(s);
+        float v = (float)m * 5.9604644775390625e-08f;   // 2^-24
+        return s ? -v : v;
+    }
+    if (e == 31) return u2f(s | 0x7f800000u | (m << 13));
+    return u2f(s | ((e + 112u) << 23) | (m << 13));
+}
+__device__ __forceinline__ uint16_t f32_to_f16(float f) {   // round to nearest even
+    uint32_t u = f2u(f), s = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(s | 0x7e00u);
+    if (a >= 0x47800000u) return (uint16_t)(s | 0x7c00u);       // >= 65536 -> inf (65520 rounds to inf below)
+    if (a < 0x33000000u) return (uint16_t)s;                    // < 2^-25 -> 0
+    if (a < 0x38800000u) {                                       // subnormal half
+        float v = u2f(a) * 16777216.0f;                          // * 2^24 -> integer part is the mantissa
+        uint32_t m = (uint32_t)v;
+        float r = v - (float)m;
+        if (r > 0.5f || (r == 0.5f && (m & 1u))) ++m;
+        return (uint16_t)(s | m);
+    }
+    uint32_t m = a & 0x7fffffu, e = (a >> 23) - 112u;
+    uint32_t h = (e << 10) | (m >> 13);
+    uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;      // may carry into the exponent (and to inf): correct
+    return (uint16_t)(s | h);
+}
+#else
+__device__ __forceinline__ float f16_to_f32(uint16_t h) {
+    union { uint16_t u; _Float16 f; } c; c.u = h; return (float)c.f;
+}
+__device__ __forceinline__ uint16_t f32_to_f16(float f) {
+    union { uint16_t u; _Float16 f; } c; c.f = (_Float16)f; return c.u;
+}
+#endif
+
+template <int DT> struct Elem;
+template <> struct Elem<DT_F32> {
+    typedef float type;
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ c32 ld2(const float* p) { return *reinterpret_cast<const c32*>(p); }
+    static __device__ __forceinline__ void st2(float* p, c32 v) { *reinterpret_cast<c32*>(p) = v; }
+};
+template <> struct Elem<DT_BF16> {
+    typedef uint16_t type;
+    static __device__ __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+    static __device__ __forceinline__ c32 ld2(const uint16_t* p) {
+        uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+        return mk(u2f(w << 16), u2f(w & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void st2(uint16_t* p, c32 v) {
+        *reinterpret_cast<uint32_t*>(p) = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    }
+};
+template <> struct Elem<DT_F16> {
+    typedef uint16_t type;
+    static __device__ __forceinline__ float ld(const uint16_t* p) { return f16_to_f32(*p); }
+    static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_f16(v); }
+    static __device__ __forceinline__ c32 ld2(const uint16_t* p) {
+        uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+        return mk(f16_to_f32((uint16_t)(w & 0xffffu)), f16_to_f32((uint16_t)(w >> 16)));
+    }
+    static __device__ __forceinline__ void st2(uint16_t* p, c32 v) {
+        *reinterpret_cast<uint32_t*>(p) = (uint32_t)f32_to_f16(v.x) | ((uint32_t)f32_to_f16(v.y) << 16);
+    }
+};
+
+// z[n] = (x[2n], x[2n+1]) of a real row of L samples, zero beyond L.  `vec` = the row base is aligned
+// for a two-element access (L even), wave-uniform.
+template <int DT>
+__device__ __forceinline__ c32 load_pair(const typename Elem<DT>::type* row, int n, int L, bool vec) {
+    const int i = 2 * n;
+    if (i + 1 < L) {
+        if (vec) return Elem<DT>::ld2(row + i);
+        return mk(Elem<DT>::ld(row + i), Elem<DT>::ld(row + i + 1));
+    }
+    if (i < L) return mk(Elem<DT>::ld(row + i), 0.f);
+    return mk(0.f, 0.f);
+}
+template <int DT>
+__device__ __forceinline__ void store_pair(typename Elem<DT>::type* row, int n, int L, bool vec, c32 v) {
+    const int i = 2 * n;
+    if (i + 1 < L) {
+        if (vec) Elem<DT>::st2(row + i, v);
+        else { Elem<DT>::st(row + i, v.x); Elem<DT>::st(row + i + 1, v.y); }
+    } else if (i < L) {
+        Elem<DT>::st(row + i, v.x);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// register butterflies: N-point DFT (N = 1..32, power of two) of v[0..N), natural order in and out.
+// Decimation in frequency with compile-time twiddles; the final bit reversal is register renaming.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr float tw32_cos(int t) {   // cos(2 pi t / 32), t = 0..15
+    return t == 0 ? 1.0f : t == 1 ? 0.98078528040323044913f : t == 2 ? 0.92387953251128675613f
+         : t == 3 ? 0.83146961230254523708f : t == 4 ? 0.70710678118654752440f : t == 5 ? 0.55557023301960222474f
+         : t == 6 ? 0.38268343236508977173f : t == 7 ? 0.19509032201612826785f : t == 8 ? 0.0f
+         : t == 9 ? -0.19509032201612826785f : t == 10 ? -0.38268343236508977173f : t == 11 ? -0.55557023301960222474f
+         : t == 12 ? -0.70710678118654752440f : t == 13 ? -0.83146961230254523708f : t == 14 ? -0.92387953251128675613f
+         : -0.98078528040323044913f;
+}
+__host__ __device__ constexpr float tw32_sin(int t) {   // sin(2 pi t / 32), t = 0..15
+    return t == 0 ? 0.0f : t == 1 ? 0.19509032201612826785f : t == 2 ? 0.38268343236508977173f
+         : t == 3 ? 0.55557023301960222474f : t == 4 ? 0.70710678118654752440f : t == 5 ? 0.83146961230254523708f
+         : t == 6 ? 0.92387953251128675613f : t == 7 ? 0.98078528040323044913f : t == 8 ? 1.0f
+         : t == 9 ? 0.98078528040323044913f : t == 10 ? 0.92387953251128675613f : t == 11 ? 0.83146961230254523708f
+         : t == 12 ? 0.70710678118654752440f : t == 13 ? 0.55557023301960222474f : t == 14 ? 0.38268343236508977173f
+         : 0.19509032201612826785f;
+}
+__host__ __device__ constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+__host__ __device__ constexpr int brev(int q, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((q >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// d * w_32^t (forward) or d * conj(w_32^t) (inverse); t is a compile-time constant after unrolling.
+template <bool INV>
+__device__ __forceinline__ c32 mul_tw32(c32 d, int t) {
+    const float r = 0.70710678118654752440f;
+    if (t == 0) return d;
+    if (t == 8) return INV ? mk(-d.y, d.x) : mk(d.y, -d.x);
+    if (t == 4) return INV ? mk((d.x - d.y) * r, (d.x + d.y) * r) : mk((d.x + d.y) * r, (d.y - d.x) * r);
+    if (t == 12) return INV ? mk(-(d.x + d.y) * r, (d.x - d.y) * r) : mk((d.y - d.x) * r, -(d.x + d.y) * r);
+    const float c = tw32_cos(t), s = tw32_sin(t);
+    return INV ? mk(d.x * c - d.y * s, d.y * c + d.x * s) : mk(d.x * c + d.y * s, d.y * c - d.x * s);
+}
+
+template <int N, bool INV>
+__device__ __forceinline__ void dft_reg(c32 (&v)[N]) {
+    constexpr int LG = ilog2(N);
+    HY_UNROLL
+    for (int st = 0; st < LG; ++st) {
+        const int len = N >> st, half = len >> 1, tstep = 32 / len;
+        HY_UNROLL
+        for (int base = 0; base < N; base += len) {
+            HY_UNROLL
+            for (int j = 0; j < half; ++j) {
+                const c32 a = v[base + j], b = v[base + j + half];
+                v[base + j] = cadd(a, b);
+                v[base + j + half] = mul_tw32<INV>(csub(a, b), j * tstep);
+            }
+        }
+    }
+    HY_UNROLL
+    for (int q = 0; q < N; ++q) {
+        const int p = brev(q, LG);
+        if (q < p) { const c32 t = v[q]; v[q] = v[p]; v[p] = t; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1024-point row transform on a half-wavefront: lane j (0..31) holds v[s] = x[j + 32 s] on entry and
+// X[j + 32 q] on exit (Stockham 32 x 32, natural order).  `xb` = this half's LDS exchange buffer of
+// ROW_LDS c32 (index p -> p + p/32: conflict-free ds_write_b64 / ds_read_b64).  `twT[s*32 + j]` =
+// w_1024^(j s).  All 64 lanes of the workgroup must call it (it contains workgroup barriers).
+// ---------------------------------------------------------------------------------------------
+enum { ROW_N = 1024, ROW_LDS = 1024 + 32 };
+
+__device__ __forceinline__ int row_idx(int p) { return p + (p >> 5); }
+
+template <bool INV>
+__device__ __forceinline__ void row_fft1024(c32 (&v)[32], c32* xb, int j, const c32* __restrict__ twT) {
+    dft_reg<32, INV>(v);
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) xb[j * 33 + q] = v[q];             // position j*32 + q
+    __syncthreads();
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) v[s] = xb[j + 33 * s];             // position j + 32 s
+    __syncthreads();
+    HY_UNROLL
+    for (int s = 1; s < 32; ++s) {
+        const c32 w = ldg(twT, (unsigned)(s * 32 + j));
+        v[s] = INV ? cmulc(v[s], w) : cmul(v[s], w);
+    }
+    dft_reg<32, INV>(v);
+    HY_SCHED_FENCE();   // keep the caller's next phase (and its loads) out of the butterflies: register pressure
+}
+
+// ---------------------------------------------------------------------------------------------
+// tables (device memory, built by the host in double precision)
+//   tw_lo[p]   = w_M^p,            p < 1024
+//   tw_hi[p]   = w_M^(1024 p) = w_M1^p,   p < M1
+//   tw_row[p]  = w_1024^p,         p < 1024
+//   tw_rowT[s*32 + j] = w_1024^(j s)
+// ---------------------------------------------------------------------------------------------
+struct Tables {
+    const c32* tw_lo;
+    const c32* tw_hi;
+    const c32* tw_row;
+    const c32* tw_rowT;
+};
+
+// ---------------------------------------------------------------------------------------------
+// column kernels.  One workgroup = C adjacent columns n2 of one row; thread (c, r) with r < T,
+// T = max(1, M1/32).  Each thread owns E = min(M1, 32) points of its column.
+// ---------------------------------------------------------------------------------------------
+template <int M1> struct ColCfg {
+    static constexpr int T = M1 >= 32 ? M1 / 32 : 1;
+    static constexpr int E = M1 >= 32 ? 32 : M1;
+    static constexpr int C = (256 / T) > 16 ? (256 / T) : 16;
+    static constexpr int THREADS = C * T;
+    static constexpr int NB = 32 / T;                        // stage-2 butterflies per thread (T > 1)
+    static constexpr size_t LDS_TABLES = (1024 + (size_t)M1) * sizeof(c32);
+    static constexpr size_t LDS_PLANE = T > 1 ? (size_t)M1 * C * sizeof(float) : 0;
+    static constexpr size_t LDS = LDS_TABLES + LDS_PLANE;
+};
+
+struct ColArgs {
+    const void* x;      // real rows (col_fwd input / col_inv output)
+    c32* W;             // [rows][M1][1024]
+    Tables tab;
+    int L;              // real samples per row
+    int inner;          // rows per outer index (channels in the chunk)
+    long outer_stride;  // elements between consecutive outer indices (D * L)
+    long inner_stride;  // elements between consecutive inner indices (L)
+    float* aux0;        // col_inv only: if non-null, aux0[row] = real part of output sample 0
+};
+
+__device__ __forceinline__ c32 outer_tw(const c32* tlo, const c32* thi, int n2, int k1) {
+    const int p = n2 * k1;
+    return cmul(tlo[p & 1023], thi[p >> 10]);
+}
+
+template <int M1, int DT>
+__global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_fwd_kernel(ColArgs a) {
+    typedef ColCfg<M1> Cfg;
+    typedef typename Elem<DT>::type elem_t;
+    constexpr int T = Cfg::T, C = Cfg::C, E = Cfg::E;
+    HY_SMEM(smem);
+    c32* tlo = reinterpret_cast<c32*>(smem);
+    c32* thi = tlo + 1024;
+    float* plane = reinterpret_cast<float*>(thi + M1);
+
+    const int tid = threadIdx.x;
+    const int c = tid % C, r = tid / C;
+    const int n2 = blockIdx.x * C + c;
+    const int row = blockIdx.y;
+    const elem_t* xrow = reinterpret_cast<const elem_t*>(a.x) + (long)(row / a.inner) * a.outer_stride +
+                         (long)(row % a.inner) * a.inner_stride;
+    const bool vec = (a.L & 1) == 0;
+    c32* Wrow = a.W + (size_t)row * M1 * 1024;
+
+    for (int i = tid; i < 1024; i += Cfg::THREADS) tlo[i] = a.tab.tw_lo[i];
+    for (int i = tid; i < M1; i += Cfg::THREADS) thi[i] = a.tab.tw_hi[i];
+
+    c32 v[E];
+    HY_UNROLL
+    for (int s = 0; s < E; ++s) {
+        const int n1 = r + T * s;
+        v[s] = load_pair<DT>(xrow, n1 * 1024 + n2, a.L, vec);
+    }
+    dft_reg<E, false>(v);
+
+    if (T == 1) {
+        __syncthreads();   // tables
+        HY_UNROLL
+        for (int q = 0; q < E; ++q) {
+            const c32 w = outer_tw(tlo, thi, n2, q);
+            stg(Wrow, (unsigned)(q * 1024 + n2), cmul(v[q], w));
+        }
+    } else {
+        constexpr int NB = Cfg::NB;
+        c32 x2[32];
+        // exchange, real plane then imaginary plane: position p of column c lives at plane[p*C + c]
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].x;
+        __syncthreads();
+        HY_UNROLL
+        for (int i = 0; i < NB; ++i) {
+            HY_UNROLL
+            for (int s = 0; s < T; ++s) x2[i * T + s].x = plane[((r + T * i) + 32 * s) * C + c];
+        }
+        __syncthreads();
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].y;
+        __syncthreads();
+        HY_UNROLL
+        for (int i = 0; i < NB; ++i) {
+            HY_UNROLL
+            for (int s = 0; s < T; ++s) x2[i * T + s].y = plane[((r + T * i) + 32 * s) * C + c];
+        }
+        HY_UNROLL
+        for (int i = 0; i < NB; ++i) {
+            const int jj = r + T * i;
+            c32 y[T];
+            y[0] = x2[i * T];
+            HY_UNROLL
+            for (int s = 1; s < T; ++s) y[s] = cmul(x2[i * T + s], thi[jj * s]);
+            dft_reg<T, false>(y);
+            HY_UNROLL
+            for (int q = 0; q < T; ++q) {
+                const int k1 = jj + 32 * q;
+                const c32 w = outer_tw(tlo, thi, n2, k1);
+                stg(Wrow, (unsigned)(k1 * 1024 + n2), cmul(y[q], w));
+            }
+        }
+    }
+}
+
+template <int M1, int DT>
+__global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_inv_kernel(ColArgs a) {
+    typedef ColCfg<M1> Cfg;
+    typedef typename Elem<DT>::type elem_t;
+    constexpr int T = Cfg::T, C = Cfg::C, E = Cfg::E;
+    HY_SMEM(smem);
+    c32* tlo = reinterpret_cast<c32*>(smem);
+    c32* thi = tlo + 1024;
+    float* plane = reinterpret_cast<float*>(thi + M1);
+
+    const int tid = threadIdx.x;
+    const int c = tid % C, r = tid / C;
+    const int n2 = blockIdx.x * C + c;
+    const int row = blockIdx.y;
+    elem_t* xrow = reinterpret_cast<elem_t*>(const_cast<void*>(a.x)) + (long)(row / a.inner) * a.outer_stride +
+                   (long)(row % a.inner) * a.inner_stride;
+    const bool vec = (a.L & 1) == 0;
+    const c32* Wrow = a.W + (size_t)row * M1 * 1024;
+
+    for (int i = tid; i < 1024; i += Cfg::THREADS) tlo[i] = a.tab.tw_lo[i];
+    for (int i = tid; i < M1; i += Cfg::THREADS) thi[i] = a.tab.tw_hi[i];
+    __syncthreads();
+
+    c32 v[E];
+    HY_UNROLL
+    for (int s = 0; s < E; ++s) {
+        const int k1 = r + T * s;
+        const c32 w = outer_tw(tlo, thi, n2, k1);
+        v[s] = cmulc(ldg(Wrow, (unsigned)(k1 * 1024 + n2)), w);
+    }
+    dft_reg<E, true>(v);
+
+    if (T == 1) {
+        HY_UNROLL
+        for (int q = 0; q < E; ++q) {
+            const int n = q * 1024 + n2;
+            store_pair<DT>(xrow, n, a.L, vec, v[q]);
+            if (a.aux0 != nullptr && n == 0) a.aux0[row] = v[q].x;
+        }
+    } else {
+        constexpr int NB = Cfg::NB;
+        c32 x2[32];
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].x;
+        __syncthreads();
+        HY_UNROLL
+        for (int i = 0; i < NB; ++i) {
+            HY_UNROLL
+            for (int s = 0; s < T; ++s) x2[i * T + s].x = plane[((r + T * i) + 32 * s) * C + c];
+        }
+        __syncthreads();
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].y;
+        __syncthreads();
+        HY_UNROLL
+        for (int i = 0; i < NB; ++i) {
+            HY_UNROLL
+            for (int s = 0; s < T; ++s) x2[i * T + s].y = plane[((r + T * i) + 32 * s) * C + c];
+        }
+        HY_UNROLL
+        for (int i = 0; i < NB; ++i) {
+            const int jj = r + T * i;
+            c32 y[T];
+            y[0] = x2[i * T];
+            HY_UNROLL
+            for (int s = 1; s < T; ++s) y[s] = cmulc(x2[i * T + s], thi[jj * s]);
+            dft_reg<T, true>(y);
+            HY_UNROLL
+            for (int q = 0; q < T; ++q) {
+                const int n = (jj + 32 * q) * 1024 + n2;
+                store_pair<DT>(xrow, n, a.L, vec, y[q]);
+                if (a.aux0 != nullptr && n == 0) a.aux0[row] = y[q].x;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row kernels.  One workgroup = one wavefront = the row pair (ra, rb) of one (b, channel):
+//   SLOT0: ra = 0 (partner of k2 is (1024 - k2) mod 1024 in the same row), rb = M1/2 (partner 1023 - k2,
+//          same row; exists only if M1 >= 2)
+//   else : ra = slot, rb = M1 - slot, 0 < slot < M1/2 (partner 1023 - k2 in the other row = lane 63 - t,
+//          register 31 - q)
+// Lane t: half = t / 32 picks the row, j = t % 32; v[q] is element k2 = j + 32 q.
+// ---------------------------------------------------------------------------------------------
+struct RowArgs {
+    c32* X;            // [B][inner][M1][1024]  in place (row_conv) / read only (row_dk: dout rows)
+    const c32* U;      // row_dk: [B][inner][M1][1024] column-transformed u rows
+    c32* S;            // [inner][M1][1024] filter spectrum (row_spec: in place; row_conv: read; row_dk: output)
+    const float* bias; // [inner] or null (row_conv)
+    Tables tab;
+    int M1;
+    int inner;
+    int B;
+    float scale;       // 1 / M
+};
+
+enum { MODE_CONV = 0, MODE_CORR = 1 };
+
+// packed-domain product for one element.  x, xp = Z[k], Z[partner]; h, hp = H[k], H[partner]; w = w_M^k.
+template <int MODE>
+__device__ __forceinline__ c32 packed_product(c32 x, c32 xp, c32 h, c32 hp, c32 w, float bias) {
+    // He = (h + conj(hp))/2 ; Ho = (h - conj(hp))/(2i) = -i/2 (h - conj(hp))
+    const c32 He = mk(0.5f * (h.x + hp.x), 0.5f * (h.y - hp.y));
+    const c32 dlt = mk(h.x - hp.x, h.y + hp.y);
+    const c32 Ho = mk(0.5f * dlt.y, -0.5f * dlt.x);
+    c32 Ke, Ko;
+    if (MODE == MODE_CONV) {
+        Ke = mk(He.x + bias, He.y);
+        Ko = Ho;
+    } else {
+        Ke = mk(He.x + bias, -He.y);
+        Ko = cconj(cmul(w, Ho));
+    }
+    // A = Ke + (i/2)(1 - w) Ko ; Bc = (i/2)(1 + w) Ko
+    const c32 t1 = cmul(mk(1.f - w.x, -w.y), Ko);
+    const c32 t2 = cmul(mk(1.f + w.x, w.y), Ko);
+    const c32 A = mk(Ke.x - 0.5f * t1.y, Ke.y + 0.5f * t1.x);
+    const c32 Bc = mk(-0.5f * t2.y, 0.5f * t2.x);
+    return cadd(cmul(A, x), cmulc(Bc, xp));
+}
+
+// Filter spectrum: row transform of the column-transformed packed filter, scaled by 1/M, in place.
+__global__ void __launch_bounds__(64, 2) row_spec_kernel(RowArgs a) {
+    HY_SMEM(smem);
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    c32* xb = reinterpret_cast<c32*>(smem) + half * ROW_LDS;
+    const int row = 2 * blockIdx.x + half;
+    const bool valid = row < a.M1;
+    c32* p = a.S + (size_t)blockIdx.y * a.M1 * 1024;               // wave-uniform base, 32-bit lane offsets
+    const unsigned o = (unsigned)((valid ? row : 0) * 1024 + j);
+    c32 v[32];
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) v[s] = valid ? ldg(p, o + 32 * s) : mk(0.f, 0.f);
+    row_fft1024<false>(v, xb, j, a.tab.tw_rowT);
+    if (valid) {
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) stg(p, o + 32 * q, cscale(v[q], a.scale));
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64, 2) row_conv_kernel(RowArgs a) {
+    HY_SMEM(smem);
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    c32* xb = reinterpret_cast<c32*>(smem) + half * ROW_LDS;
+    const int M1 = a.M1;
+    const int slot = blockIdx.x;                 // 0 = the self-paired rows (0, M1/2); else the pair (slot, M1 - slot)
+    const bool slot0 = slot == 0;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    const int myrow = slot0 ? (half ? (M1 >> 1) : 0) : (half ? M1 - slot : slot);
+    const int prow = slot0 ? myrow : (half ? slot : M1 - slot);
+    const bool valid = slot0 ? (half == 0 || M1 >= 2) : true;
+    // partner element of k2 lives at pk2 = (pk_base - k2) & 1023 of row `prow`
+    const int pk_base = (slot0 && half == 0) ? 1024 : 1023;
+    const c32* xpb = reinterpret_cast<c32*>(smem) + (slot0 ? half : 1 - half) * ROW_LDS;   // partner row's LDS image
+    // wave-uniform bases + 32-bit lane offsets (keeps addresses in SGPRs; 64-bit per-access addresses cost
+    // two VGPRs each and spill)
+    c32* X = a.X + ((size_t)b * a.inner + ch) * M1 * 1024;
+    const c32* Sc = a.S + (size_t)ch * M1 * 1024;
+    const unsigned om = (unsigned)((valid ? myrow : 0) * 1024);    // my row
+    const unsigned op = (unsigned)((valid ? prow : 0) * 1024);     // partner row
+    const float bias = (a.bias != nullptr) ? a.bias[ch] * a.scale : 0.f;
+
+    c32 v[32];
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) v[s] = valid ? ldg(X, om + j + 32 * s) : mk(0.f, 0.f);
+    row_fft1024<false>(v, xb, j, a.tab.tw_rowT);
+
+    const c32 wk1 = a.tab.tw_lo[valid ? myrow : 0];     // w_M^k1
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) xb[j + 33 * q] = v[q];            // natural position k2 = j + 32 q
+    __syncthreads();
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) {
+        const int k2 = j + 32 * q;
+        const int pk2 = (pk_base - k2) & 1023;
+        const c32 xp = xpb[row_idx(pk2)];
+        const c32 w = cmul(wk1, ldg(a.tab.tw_row, (unsigned)k2));
+        v[q] = packed_product<MODE>(v[q], xp, ldg(Sc, om + k2), ldg(Sc, op + pk2), w, bias);
+        if ((q & 7) == 7) HY_SCHED_FENCE();
+    }
+    __syncthreads();
+    row_fft1024<true>(v, xb, j, a.tab.tw_rowT);
+    if (valid) {
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) stg(X, om + j + 32 * q, v[q]);
+    }
+}
+
+// dk spectrum: acc[k] = sum_b corr-product(G_b, U_b); rows of X (= dout) and U are column-transformed only;
+// the result, scaled by 1/M and row-inverse-transformed, goes to S[ch] for col_inv.
+// LDS: two natural-order images per wave (G and U spectra): 2 * 2 * ROW_LDS c32.
+__global__ void __launch_bounds__(64, 2) row_dk_kernel(RowArgs a) {
+    HY_SMEM(smem);
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    c32* xb = reinterpret_cast<c32*>(smem) + half * ROW_LDS;
+    c32* hb = xb + 2 * ROW_LDS;
+    const int M1 = a.M1;
+    const int slot = blockIdx.x;
+    const bool slot0 = slot == 0;
+    const int ch = blockIdx.y;
+    const int myrow = slot0 ? (half ? (M1 >> 1) : 0) : (half ? M1 - slot : slot);
+    const bool valid = slot0 ? (half == 0 || M1 >= 2) : true;
+    const int pk_base = (slot0 && half == 0) ? 1024 : 1023;
+    const int phalf = slot0 ? half : 1 - half;
+    const c32* xpb = reinterpret_cast<c32*>(smem) + phalf * ROW_LDS;
+    const c32* hpb = xpb + 2 * ROW_LDS;
+    const c32 wk1 = a.tab.tw_lo[valid ? myrow : 0];
+    const unsigned om = (unsigned)((valid ? myrow : 0) * 1024 + j);
+
+    c32 acc[32];
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
+
+    for (int b = 0; b < a.B; ++b) {
+        const size_t off = ((size_t)b * a.inner + ch) * M1 * 1024;
+        const c32* X = a.X + off;
+        const c32* U = a.U + off;
+        c32 v[32];
+        // U spectrum -> LDS image hb (natural order)
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) v[s] = valid ? ldg(U, om + 32 * s) : mk(0.f, 0.f);
+        row_fft1024<false>(v, hb, j, a.tab.tw_rowT);
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) hb[j + 33 * q] = v[q];
+        // G spectrum -> registers + LDS image xb
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) v[s] = valid ? ldg(X, om + 32 * s) : mk(0.f, 0.f);
+        row_fft1024<false>(v, xb, j, a.tab.tw_rowT);
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) xb[j + 33 * q] = v[q];
+        __syncthreads();
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) {
+            const int k2 = j + 32 * q;
+            const int pk2 = (pk_base - k2) & 1023;
+            const c32 w = cmul(wk1, ldg(a.tab.tw_row, (unsigned)k2));
+            acc[q] = cadd(acc[q], packed_product<MODE_CORR>(v[q], xpb[row_idx(pk2)], hb[j + 33 * q], hpb[row_idx(pk2)], w, 0.f));
+            if ((q & 7) == 7) HY_SCHED_FENCE();
+        }
+        __syncthreads();
+    }
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) acc[q] = cscale(acc[q], a.scale);
+    row_fft1024<true>(acc, xb, j, a.tab.tw_rowT);
+    if (valid) {
+        c32* O = a.S + (size_t)ch * M1 * 1024;
+        const unsigned oo = (unsigned)(myrow * 1024 + j);
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) stg(O, oo + 32 * q, acc[q]);
+    }
+}
+
+}  // namespace hyena

@@ -1,0 +1,130 @@
+"""Python op seam of the hot path: the MI355X-native counterpart of the reference's ``src/ops/fftconv.py``.
+
+Exports the names ``src/models/sequence/hyena.py:12-16`` imports -- ``fftconv_func``, ``fftconv_ref``,
+``fftconv_heads_ref`` -- plus the autograd function ``FFTConvFunc`` (reference: ``src/ops/fftconv.py:58-108``),
+all backed by the HIP kernels behind the C ABI of ``include/hyena_fftconv.h``.
+
+Semantics (reference ``fftconv_ref``, ``src/models/sequence/hyena.py:59-88``, the function every HyenaDNA config
+runs): ``out = irfft(rfft(u, 2L) * rfft(k, 2L) / 2L, norm='forward')[..., :L] + u * D[..., None]`` with all FFT
+math in fp32 and the result cast back to ``u.dtype``.
+
+Differences from the reference's fused op (all lifts of restrictions):
+* ``u`` may be 3-D ``(B, H, L)`` or the 5-D ``(b, h, v, z, l)`` tensor ``HyenaOperator`` really passes
+  (``hyena.py:396-423``) with ``k`` ``(v, l)`` and ``D`` ``(1, v, 1)`` / ``(v,)``; any ``L`` in ``[1, 2**20]``.
+* saves only ``(u, k, D)`` for backward and recomputes spectra (the reference's autograd keeps ``u_f``,
+  8(L+1) bytes per row).
+* options no HyenaDNA config enables (``gelu``, ``dropout_mask``, ``v``/``q``/``head_dim``, ``k_rev``,
+  ``output_hbl_layout``, ``fftfp16``) raise ``NotImplementedError`` instead of silently running something else.
+There is no CPU / torch.fft fallback in this module.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ["fftconv_func", "FFTConvFunc", "fftconv_ref", "fftconv_heads_ref"]
+
+
+def _unsupported(**opts):
+    bad = [name for name, on in opts.items() if on]
+    if bad:
+        raise NotImplementedError(
+            "hyena_dna_amd.fftconv: option(s) %s are not implemented by the MI355X kernel "
+            "(no HyenaDNA configuration enables them; reference: src/ops/fftconv.py:60-61)" % ", ".join(bad))
+
+
+def _as_rows(u, n_channels):
+    """View/copy ``u`` as a contiguous (B', D, L) tensor whose dim 1 is the filter's channel axis.
+
+    3-D (B, D, L): as is.  5-D (b, h, v, z, l) as passed by HyenaOperator: channel axis is ``v``
+    (k_f.unsqueeze(1) in hyena.py:77-78 broadcasts the filter over b, h and z).
+    Returns (rows, restore) with restore(t) mapping a (B', D, L) tensor back to u's shape.
+    """
+    if u.dim() == 3:
+        if u.shape[1] != n_channels:
+            raise ValueError(f"u has {u.shape[1]} channels but k has {n_channels}")
+        return u.contiguous(), (lambda t: t)
+    if u.dim() == 5:
+        b, h, v, z, l = u.shape
+        if v != n_channels:
+            raise ValueError(f"u has {v} channels (dim 2) but k has {n_channels}")
+        if z == 1:
+            return u.contiguous().view(b * h, v, l), (lambda t: t.view(b, h, v, z, l))
+        rows = u.permute(0, 1, 3, 2, 4).contiguous().view(b * h * z, v, l)
+        return rows, (lambda t: t.view(b, h, z, v, l).permute(0, 1, 3, 2, 4))
+    raise ValueError(f"fftconv expects a 3-D (B, H, L) or 5-D (b, h, v, z, l) input, got shape {tuple(u.shape)}")
+
+
+def _aligned(t):
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
+class FFTConvFunc(torch.autograd.Function):
+    """Autograd contract of the fused op (reference: src/ops/fftconv.py:58-103): grads for (u, k, D)."""
+
+    @staticmethod
+    def forward(ctx, u, k, D, dropout_mask=None, gelu=True, force_fp16_output=False, output_hbl_layout=False,
+                v=None, head_dim=1, q=None, fftfp16=False, k_rev=None):
+        _unsupported(dropout_mask=dropout_mask is not None, gelu=bool(gelu), output_hbl_layout=bool(output_hbl_layout),
+                     v=v is not None, q=q is not None, head_dim=head_dim != 1, fftfp16=bool(fftfp16),
+                     k_rev=k_rev is not None)
+        if k.dim() != 2:
+            raise ValueError(f"k must be (H, L), got {tuple(k.shape)}")
+        H, L = k.shape
+        if u.shape[-1] != L:
+            raise ValueError(f"u has sequence length {u.shape[-1]} but k has {L}")
+        rows, restore = _as_rows(u, H)
+        rows = _aligned(rows)
+        kf = _aligned(k.detach().to(torch.float32).contiguous())
+        bias = None
+        if D is not None:
+            if D.numel() != H:
+                raise ValueError(f"D must have {H} elements, got shape {tuple(D.shape)}")
+            bias = D.detach().to(torch.float32).reshape(H).contiguous()
+        out = _lib.fftconv_fwd(rows, kf, bias)
+        ctx.save_for_backward(rows, kf, bias if bias is not None else torch.empty(0, device=u.device))
+        ctx.has_bias = bias is not None
+        ctx.restore = restore
+        ctx.k_dtype = k.dtype
+        ctx.D_meta = (D.shape, D.dtype) if D is not None else None
+        out = restore(out)
+        if force_fp16_output and u.dtype == torch.float32:      # fftconv.cpp:110 (bf16 input overrides it)
+            out = out.to(torch.float16)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        rows, kf, bias = ctx.saved_tensors
+        bias = bias if ctx.has_bias else None
+        H = kf.shape[0]
+        g, _ = _as_rows(dout.to(rows.dtype), H)
+        g = _aligned(g)
+        need_du = ctx.needs_input_grad[0]
+        need_dk = ctx.needs_input_grad[1] or (ctx.needs_input_grad[2] and ctx.has_bias)
+        du, dk, dbias = _lib.fftconv_bwd(g, rows, kf, bias, need_du=need_du, need_dk=need_dk)
+        du = ctx.restore(du) if (du is not None and need_du) else None
+        dk_out = dk.to(ctx.k_dtype) if (dk is not None and ctx.needs_input_grad[1]) else None
+        dD = None
+        if ctx.needs_input_grad[2] and ctx.D_meta is not None:
+            shape, dtype = ctx.D_meta
+            dD = dbias.reshape(shape).to(dtype)
+        return du, dk_out, dD, None, None, None, None, None, None, None, None, None
+
+
+def fftconv_func(u, k, D, dropout_mask=None, gelu=True, force_fp16_output=False, output_hbl_layout=False, v=None,
+                 head_dim=1, q=None, fftfp16=False, k_rev=None):
+    """Same signature as the reference's ``fftconv_func`` (src/ops/fftconv.py:105-108)."""
+    return FFTConvFunc.apply(u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, head_dim, q,
+                             fftfp16, k_rev)
+
+
+def fftconv_ref(u, k, D, dropout_mask=None, gelu=True, k_rev=None, bidirectional=False):
+    """Name-compatible with the reference's ``fftconv_ref`` (src/ops/fftconv.py:15-34; hyena.py:59-88), but
+    routed through the same HIP kernels: this package ships no torch.fft implementation."""
+    _unsupported(bidirectional=bool(bidirectional))
+    return fftconv_func(u, k, D, dropout_mask=dropout_mask, gelu=gelu, k_rev=k_rev)
+
+
+def fftconv_heads_ref(*args, **kwargs):
+    """Imported by the reference's hyena.py:13 but defined nowhere in the reference; it only has
+    to exist for that import to succeed."""
+    raise NotImplementedError("fftconv_heads_ref does not exist in the reference either (hyena.py:13)")

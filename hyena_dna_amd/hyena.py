@@ -1,0 +1,229 @@
+"""Module seam of the hot path: drop-in counterparts of the reference's ``HyenaOperator`` / ``HyenaFilter``
+(``src/models/sequence/hyena.py:158-448``; standalone copy ``standalone_hyenadna.py:147-293``).
+
+Same constructor keywords (stray ones such as ``layer_idx``/``device``/``dtype`` are tolerated exactly as the
+reference tolerates them via ``**filter_args`` -> ``**kwargs``, hyena.py:290,373-380,177,221,143), same parameter
+and buffer names (so reference checkpoints load with ``load_state_dict``), same ``_optim`` per-parameter
+hyper-parameter tags (src/utils/train.py:142-156), same forward semantics ``(B, L, D) -> (B, L', D)``.  The long
+convolution is ``hyena_dna_amd.fftconv.fftconv_func`` (HIP); there is no torch.fft path here.
+
+Register with the reference's name-based instantiate (src/utils/registry.py:40-41) by
+``registry.layer["hyena"] = "hyena_dna_amd.hyena.HyenaOperator"``.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .fftconv import fftconv_func
+
+__all__ = ["HyenaOperator", "HyenaFilter", "PositionalEmbedding", "ExponentialModulation", "Sin"]
+
+
+class _OptimModule(nn.Module):
+    """register(name, tensor, lr, wd): buffer when lr == 0, else a Parameter tagged with ``_optim``
+    (reference: src/utils/train.py:142-156; consumed by train.py:443-468)."""
+
+    def register(self, name, tensor, lr=None, wd=0.0):
+        if lr == 0.0:
+            self.register_buffer(name, tensor)
+            return
+        self.register_parameter(name, nn.Parameter(tensor))
+        tag = {}
+        if lr is not None:
+            tag["lr"] = lr
+        if wd is not None:
+            tag["weight_decay"] = wd
+        getattr(self, name)._optim = tag
+
+
+class Sin(nn.Module):
+    """sin(freq * x) with a (1, dim) frequency, trainable by default (hyena.py:96-106)."""
+
+    def __init__(self, dim, w=10, train_freq=True):
+        super().__init__()
+        init = w * torch.ones(1, dim)
+        self.freq = nn.Parameter(init) if train_freq else init
+
+    def forward(self, x):
+        return torch.sin(self.freq * x)
+
+
+class PositionalEmbedding(_OptimModule):
+    """z = (t, Re e^{-i f w}, Im e^{-i f w}) over the FULL seq_len, sliced to L on use (hyena.py:109-131)."""
+
+    def __init__(self, emb_dim, seq_len, lr_pos_emb=1e-5, **kwargs):
+        super().__init__()
+        self.seq_len = seq_len
+        t = torch.linspace(0, 1, seq_len)[None, :, None]
+        bands = (emb_dim - 1) // 2
+        pos = torch.linspace(0, seq_len - 1, seq_len)[None, :, None]
+        w = 2 * math.pi * pos / seq_len
+        f = torch.linspace(1e-4, bands - 1, bands)[None, None]
+        z = torch.exp(-1j * f * w)
+        self.register("z", torch.cat([t, z.real, z.imag], dim=-1), lr=lr_pos_emb)
+        self.register("t", t, lr=0.0)
+
+    def forward(self, L):
+        return self.z[:, :L], self.t[:, :L]
+
+
+class ExponentialModulation(_OptimModule):
+    """x * (exp(-t |deltas|) + shift), deltas log-spaced decay rates per channel (hyena.py:134-155)."""
+
+    def __init__(self, d_model, fast_decay_pct=0.3, slow_decay_pct=1.5, target=1e-2, modulation_lr=0.0,
+                 shift: float = 0.0, **kwargs):
+        super().__init__()
+        self.shift = shift
+        hi = math.log(target) / fast_decay_pct
+        lo = math.log(target) / slow_decay_pct
+        self.register("deltas", torch.linspace(lo, hi, d_model)[None, None], lr=modulation_lr)
+
+    def forward(self, t, x):
+        return x * (torch.exp(-t * self.deltas.abs()) + self.shift)
+
+
+class HyenaFilter(_OptimModule):
+    """Implicit long filter: positional embedding -> sine MLP -> exponential modulation (hyena.py:158-267).
+
+    ``forward(x, L, k=None, bias=None)`` applies the long convolution through the HIP op regardless of
+    ``fused_fft_conv`` (kept only as an accepted keyword): this package has no unfused path.
+    """
+
+    def __init__(self, d_model, emb_dim=3, order=16, fused_fft_conv=False, seq_len=1024, lr=1e-3, lr_pos_emb=1e-5,
+                 dropout=0.0, w=1, wd=0, bias=True, num_inner_mlps=2, linear_mixer=False, modulate: bool = True,
+                 normalized=False, bidirectional=False, **kwargs):
+        super().__init__()
+        if bidirectional:
+            raise NotImplementedError("bidirectional=True needs the circular wrap of an exactly-2L FFT "
+                                      "(hyena.py:67-73); not implemented by the MI355X kernel")
+        self.d_model = d_model
+        self.emb_dim = emb_dim
+        self.seq_len = seq_len
+        self.modulate = modulate
+        self.use_bias = bias
+        self.fused_fft_conv = fused_fft_conv
+        self.bias = nn.Parameter(torch.randn(self.d_model))
+        self.dropout = nn.Dropout(dropout)
+        self.bidirectional = bidirectional
+        self.normalized = normalized
+
+        assert emb_dim % 2 != 0 and emb_dim >= 3, \
+            "emb_dim must be odd and greater or equal to 3 (time, sine and cosine)"
+        act = Sin(dim=order, w=w)          # ONE instance shared by every activation slot (hyena.py:199-213)
+        self.pos_emb = PositionalEmbedding(emb_dim, seq_len, lr_pos_emb)
+        if linear_mixer is False:
+            layers = [nn.Linear(emb_dim, order), act]
+            for _ in range(num_inner_mlps):
+                layers += [nn.Linear(order, order), act]
+            layers.append(nn.Linear(order, d_model, bias=False))
+        else:
+            layers = [nn.Linear(emb_dim, d_model, bias=False)]
+        self.implicit_filter = nn.Sequential(*layers)
+        self.modulation = ExponentialModulation(d_model, **kwargs)
+        for child in self.implicit_filter.children():
+            for name, _ in child.state_dict().items():
+                getattr(child, name)._optim = {"weight_decay": wd, "lr": lr}
+
+    def filter(self, L, *args, **kwargs):
+        z, t = self.pos_emb(L)
+        h = self.implicit_filter(z)
+        if self.modulate:
+            h = self.modulation(t, h)
+        if self.normalized:
+            h = h / torch.norm(h, dim=-1, p=1, keepdim=True)
+        return h
+
+    def forward(self, x, L, k=None, bias=None, *args, **kwargs):
+        if k is None:
+            k = self.filter(L)
+        k = k[0] if type(k) is tuple else k
+        if bias is None:
+            bias = self.bias
+        bias = bias if self.use_bias else 0 * bias
+        y = fftconv_func(x, k, bias.to(dtype=torch.float32), dropout_mask=None, gelu=False,
+                         force_fp16_output=torch.is_autocast_enabled())
+        return y.to(dtype=x.dtype)
+
+
+class HyenaOperator(nn.Module):
+    """Hyena operator (hyena.py:270-448): in_proj -> short depthwise conv -> order-N gated long-conv
+    recurrence -> out_proj.  ``forward(u)``: (B, L, D) -> (B, min(L, l_max), D)."""
+
+    def __init__(self, d_model, l_max, order=2, filter_order=64, num_heads=1, inner_factor=1, num_blocks=1,
+                 fused_bias_fc=False, outer_mixing=False, dropout=0.0, filter_dropout=0.0, filter_cls="hyena-filter",
+                 post_order_ffn=False, jit_filter=False, short_filter_order=3, activation="id", return_state=False,
+                 **filter_args):
+        super().__init__()
+        assert d_model % num_heads == 0, f"Model dimension {d_model} must be divisible by num heads {num_heads}"
+        assert l_max % num_blocks == 0, \
+            f"Maximum signal length {l_max} must be divisible by block dimension {num_blocks}"
+        assert order >= 2, f"Order must be at least 2, (got {order})"
+        if fused_bias_fc:
+            raise ImportError("fused_dense is not installed")          # as hyena.py:347-348 without flash_attn
+        if filter_cls not in ("hyena-filter", HyenaFilter):
+            raise NotImplementedError(f"filter_cls={filter_cls!r}: only 'hyena-filter' is provided")
+        if activation not in ("id", "identity", "linear", None):
+            raise NotImplementedError(f"activation={activation!r}: HyenaDNA uses 'id' (hyena.py:288)")
+        if jit_filter:
+            raise NotImplementedError("jit_filter references an undefined attribute in the reference (hyena.py:382)")
+        self.d_model = d_model
+        self.order = order
+        self.l_max = l_max
+        self.num_heads = num_heads
+        self.inner_factor = inner_factor
+        self.block_dim = l_max // num_blocks
+        self.head_dim = d_model // num_heads
+        self.filter_order = filter_order
+        self.post_order_ffn = post_order_ffn
+        self.short_filter_order = short_filter_order
+        self.num_blocks = num_blocks
+        self.filter_dropout = filter_dropout
+        self.jit_filter = jit_filter
+        self.outer_mixing = outer_mixing
+        self.activation = nn.Identity()
+        self.return_state = return_state
+        self.dropout = nn.Dropout(dropout)
+
+        # projections (hyena.py:345-357)
+        self.out_proj = nn.Linear(d_model * inner_factor, d_model)
+        self.in_proj = nn.Linear(d_model, (order + 1) * d_model)
+        if post_order_ffn:
+            self.ord_proj_w = nn.Parameter(torch.randn(order, num_heads, num_heads) / math.sqrt(self.head_dim))
+        # filters (hyena.py:359-382)
+        width = d_model * inner_factor * (order + 1)
+        self.short_filter = nn.Conv1d(width, width, short_filter_order, groups=width, padding=short_filter_order - 1)
+        self.filter_fn = HyenaFilter(self.head_dim * inner_factor * (order - 1), order=filter_order, seq_len=l_max,
+                                     channels=1, dropout=filter_dropout, **filter_args)
+
+    def forward(self, u, *args, **kwargs):
+        l = u.size(-2)
+        l_filter = min(l, self.l_max)
+        u = self.in_proj(u).transpose(1, 2)                                     # b l d -> b d l
+        uc = self.short_filter(u)[..., :l_filter]
+        b = uc.shape[0]
+        h, z, o1 = self.num_heads, self.num_blocks, self.order + 1
+        uc = uc.reshape(b, h, self.head_dim * o1, z, l_filter // z)             # b (ho v) (z l) -> b ho v z l
+        *x, v = uc.split(self.d_model, dim=2)
+        k = self.filter_fn.filter(l_filter)                                     # (1, l, (v o))
+        k = k.reshape(k.shape[0], l_filter, self.head_dim, self.order - 1).permute(0, 3, 2, 1)[0]   # o v l
+        bias = self.filter_fn.bias.reshape(self.head_dim, self.order - 1).transpose(0, 1)            # o v
+        for o, x_i in enumerate(reversed(x[1:])):
+            if self.outer_mixing:
+                v = self.dropout(v.unsqueeze(2) * x_i.unsqueeze(3)).sum(dim=2)
+            else:
+                v = self.dropout(v * x_i)
+            v = self.filter_fn(v, l_filter, k=k[o], bias=bias[o, None, :, None])
+            if self.post_order_ffn:
+                w = self.ord_proj_w[o]
+                v = (w[None, :, :, None, None, None] * v.unsqueeze(2)).sum(dim=1)
+        y = (v * x[0]).permute(0, 3, 4, 1, 2).reshape(b, l_filter, h * self.head_dim)   # b h v z l -> b (z l) (h v)
+        y = self.out_proj(self.activation(y))
+        if self.return_state:
+            return y, None
+        return y
+
+    @property
+    def d_output(self):
+        return self.d_model

@@ -1,0 +1,112 @@
+/* hyena_fftconv.h -- C ABI of the MI355X-native Hyena long-convolution library (libhyena_fftconv.so).
+ *
+ * This is the native FFI seam of the hot path.  It replaces, for every HyenaDNA configuration, what the
+ * reference binds through its pybind11 module `fftconv`:
+ *
+ *   reference                                                   this library
+ *   ---------------------------------------------------------   -----------------------------------
+ *   fftconv_fwd(u, filter, D, v, head_dim, q, dropout_mask,      hyena_fftconv_fwd
+ *       gelu, gelu_inp, gelu_q, fft_size, force_fp16_output,
+ *       output_hbl_layout, fftfp16)
+ *       csrc/fftconv/fftconv.cpp:53-132, called from
+ *       src/ops/fftconv.py:84  (FFTConvFunc.forward)
+ *   fftconv_bwd(dout, u, filter, D, v, head_dim, q, ...)         hyena_fftconv_bwd
+ *       csrc/fftconv/fftconv.cpp:134-236, called from
+ *       src/ops/fftconv.py:96  (FFTConvFunc.backward)
+ *
+ * and, semantically, the pure-PyTorch function every shipped config actually runs:
+ *   fftconv_ref(u, k, D, dropout_mask=None, gelu=False)          src/models/sequence/hyena.py:59-88
+ *       out = irfft(rfft(u, 2L) * rfft(k, 2L) / 2L, norm="forward")[..., :L] + u * D[..., None]
+ *
+ * Differences from the reference's native seam (all of them lifts of its restrictions):
+ *   - the filter is passed in the TIME domain (`k`, fp32, (D, L)); the library owns the spectrum
+ *     (the reference makes the caller run cuFFT first: src/ops/fftconv.py:65);
+ *   - any L >= 1 (odd allowed; the reference requires even L and fft_size <= 16384, fftconv.cpp:114-115);
+ *     the implementation supports L <= 1,048,576;
+ *   - the backward returns dk in the time domain (the reference returns dk_f and the caller runs
+ *     irfft: src/ops/fftconv.py:98) and reduces dk / dbias over the batch itself, deterministically
+ *     (the reference returns per-batch partials and lets the caller .sum(): fftconv.cpp:209-210,235);
+ *   - plain pointers, sizes and a hipStream_t: no torch types.  All device pointers must belong to the
+ *     device that is current for `stream`.  Nothing is allocated, freed or synchronised inside the
+ *     compute entry points (they are hipGraph-capturable); the caller provides the workspace and the
+ *     twiddle tables.
+ *   - options of the reference op that no HyenaDNA config enables (gelu, dropout_mask, head_dim = 8, q, v,
+ *     k_rev / bidirectional) are not part of this ABI.
+ *
+ * Tensors (row-major, contiguous):
+ *   u, out, dout, du : (B, D, L) elements of `dtype`
+ *   k, dk            : (D, L)  fp32
+ *   bias, dbias      : (D,)    fp32      (the reference calls this argument `D`)
+ *
+ * All FFT arithmetic is fp32 for every dtype, as in the reference (hyena.py:75: u.to(k.dtype)).
+ */
+#ifndef HYENA_FFTCONV_H
+#define HYENA_FFTCONV_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types of u / out / dout / du */
+enum { HYENA_F32 = 0, HYENA_BF16 = 1, HYENA_F16 = 2 };
+
+/* status codes (0 = success) */
+enum {
+    HYENA_OK = 0,
+    HYENA_ERR_BAD_ARG = 1,        /* null pointer, non-positive size, unknown dtype */
+    HYENA_ERR_UNSUPPORTED_L = 2,  /* L > HYENA_MAX_L */
+    HYENA_ERR_WORKSPACE = 3,      /* workspace too small for the requested chunking */
+    HYENA_ERR_LAUNCH = 4          /* a kernel launch failed (hipGetLastError() != hipSuccess) */
+};
+
+#define HYENA_MAX_L 1048576
+
+/* ABI version of this header (bumped on any signature change). */
+int hyena_fftconv_abi_version(void);
+
+/* Human-readable text for a status code. */
+const char* hyena_fftconv_error_string(int status);
+
+/* Complex transform length M used for sequence length L: the padded real transform has N = 2M >= 2L
+ * points (M = max(1024, next power of two >= L)); the reference uses N = 2L (hyena.py:61), which gives
+ * the same causal result.  Returns 0 if L is unsupported. */
+int hyena_fftconv_fft_size(int L);
+
+/* Bytes of device memory needed for the twiddle tables of sequence length L, and their one-time
+ * initialisation (host computes in double precision, then a synchronous hipMemcpy to `d_tables`).
+ * The same tables serve every call with the same hyena_fftconv_fft_size(L). */
+size_t hyena_fftconv_table_bytes(int L);
+int hyena_fftconv_init_tables(void* d_tables, int L);
+
+/* Channels processed per pass through the kernel chain ("chunk").  Intermediate spectra of one chunk
+ * live in the workspace; the default keeps them inside the 256 MiB Infinity Cache.
+ * backward = 0 for hyena_fftconv_fwd, 1 for hyena_fftconv_bwd. */
+int hyena_fftconv_default_chunk(int B, int D, int L, int backward);
+
+/* Workspace bytes for the given problem and chunk (chunk <= 0 selects the default). */
+size_t hyena_fftconv_workspace_bytes(int B, int D, int L, int backward, int chunk);
+
+/* out[b,d,:] = causal_conv(u[b,d,:], k[d,:]) + bias[d] * u[b,d,:]          (hyena.py:59-88)
+ * bias may be NULL (treated as 0).  `stream` is a hipStream_t. */
+int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* out,
+                      int B, int D, int L, int dtype,
+                      const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
+                      void* stream);
+
+/* Gradients of the above for upstream gradient dout:
+ *   du[b,d,s]   = sum_{t>=s} dout[b,d,t] k[d,t-s] + bias[d] dout[b,d,s]
+ *   dk[d,s]     = sum_b sum_{t>=s} dout[b,d,t] u[b,d,t-s]
+ *   dbias[d]    = sum_b sum_t dout[b,d,t] u[b,d,t]
+ * du / dk / dbias may each be NULL to skip that output (dbias requires dk's computation and is free with it). */
+int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const float* bias,
+                      void* du, float* dk, float* dbias,
+                      int B, int D, int L, int dtype,
+                      const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYENA_FFTCONV_H */

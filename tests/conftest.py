@@ -24,3 +24,27 @@ def golden_fftconv():
 def golden_operator():
     import torch
     return torch.load(os.path.join(GOLDEN, "hyena_operator_cases.pt"), weights_only=False)
+
+
+@pytest.fixture()
+def emu_backend(monkeypatch):
+    """Route hyena_dna_amd._lib to the CPU emulation of the kernels (test double; never used by the product)."""
+    from hyena_dna_amd import _lib
+    from tests.hipemu.emu_backend import EmuBackend
+    monkeypatch.setattr(_lib, "_backend", EmuBackend())
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_tables", {})
+    monkeypatch.setattr(_lib, "_workspace", {})
+    yield _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The real HIP library on a real GPU; fails (not skips) if it is missing on a GPU box."""
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a ROCm device"
+    from hyena_dna_amd import _lib
+    assert _lib._backend.name == "hip"
+    _lib.lib()
+    return _lib

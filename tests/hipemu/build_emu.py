@@ -1,0 +1,23 @@
+"""Build the CPU emulation of the HIP kernels (TEST INFRASTRUCTURE ONLY; see hipemu.h)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "_emu_fftconv_test_only.so")
+SRC = [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv.hip"), os.path.join(HERE, "hipemu.cpp")]
+DEPS = SRC + [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv_kernels.h"), os.path.join(HERE, "hipemu.h"),
+              os.path.join(ROOT, "include", "hyena_fftconv.h")]
+
+
+def build(force=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(f) <= os.path.getmtime(OUT) for f in DEPS):
+        return OUT
+    cmd = ["g++", "-x", "c++", "-DHIPEMU", "-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared",
+           "-Wno-unknown-pragmas", "-I", HERE] + SRC + ["-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

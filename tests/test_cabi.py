@@ -1,0 +1,63 @@
+"""The product library (hipcc, gfx950) loads on a machine without a GPU and exports every symbol the header
+declares; the pure host-side entry points answer without touching a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "hyena_fftconv.h")
+
+
+@pytest.fixture(scope="module")
+def product_lib():
+    from hyena_dna_amd import build
+    path = build.build(verbose=False)
+    return ctypes.CDLL(path)
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hyena_fftconv_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = declared_symbols()
+    for s in ("hyena_fftconv_fwd", "hyena_fftconv_bwd", "hyena_fftconv_workspace_bytes", "hyena_fftconv_init_tables",
+              "hyena_fftconv_table_bytes", "hyena_fftconv_fft_size", "hyena_fftconv_abi_version",
+              "hyena_fftconv_error_string", "hyena_fftconv_default_chunk"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(product_lib):
+    for s in declared_symbols():
+        assert hasattr(product_lib, s), s
+
+
+def test_host_only_entry_points(product_lib):
+    L = product_lib
+    L.hyena_fftconv_workspace_bytes.restype = ctypes.c_size_t
+    L.hyena_fftconv_table_bytes.restype = ctypes.c_size_t
+    L.hyena_fftconv_error_string.restype = ctypes.c_char_p
+    assert L.hyena_fftconv_abi_version() == 1
+    assert L.hyena_fftconv_fft_size(1024) == 1024 and L.hyena_fftconv_fft_size(160000) == 262144
+    assert L.hyena_fftconv_fft_size(450560) == 524288 and L.hyena_fftconv_fft_size(1 << 20) == 1 << 20
+    assert L.hyena_fftconv_fft_size((1 << 20) + 1) == 0
+    assert L.hyena_fftconv_table_bytes(1 << 20) == (3072 + 1024) * 8
+    # fwd workspace = (B + 1) * chunk * M * 8 bytes
+    assert L.hyena_fftconv_workspace_bytes(1, 256, 1 << 20, 0, 4) == 2 * 4 * (1 << 20) * 8
+    assert L.hyena_fftconv_workspace_bytes(2, 256, 1 << 20, 1, 4) == 6 * 4 * (1 << 20) * 8
+    c = L.hyena_fftconv_default_chunk(1, 256, 1 << 20, 0)
+    assert 1 <= c <= 256 and 2 * c * (1 << 20) * 8 <= 160 << 20
+    assert L.hyena_fftconv_default_chunk(8, 128, 1024, 0) == 128
+    assert b"workspace" in L.hyena_fftconv_error_string(3)
+
+
+def test_python_binding_matches_header(product_lib):
+    """hyena_dna_amd._lib declares argtypes for exactly the functions the header exports."""
+    from hyena_dna_amd import _lib
+    src = open(_lib.__file__).read()
+    for s in declared_symbols():
+        assert ("L." + s) in src, s

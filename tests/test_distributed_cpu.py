@@ -1,0 +1,44 @@
+"""The N > 1 path of bench.py (batch-sharded replicas + the DDP-sized gradient all-reduce, barrier + max-over-ranks
+timing, one JSON line from rank 0) with world_size 2 on CPU: gloo backend, kernels under tests/hipemu."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(nproc, port):
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--emu", "--seq-len", "3000", "--d-model", "4",
+           "--batch", "1", "--dtype", "bf16"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout          # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_world_size_2_gloo():
+    r = _run(2, 29611)
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["unit"] == "nt/s" and r["higher_is_better"] is True and r["vs_baseline"] is None
+    assert r["config"]["seq_len"] == 3000 and "dp2" in r["config"]["parallelism"]
+    # whole-job aggregate: 2 ranks x 1 sequence x 3000 nt per step
+    assert abs(r["value"] - 2 * 3000 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["algorithmic_bytes_per_step"] == 5 * 4 * 3000 * 2 + 12 * 4 * 3000 + 32
+
+
+def test_bench_single_process_line_shape():
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emu", "--steps", "1", "--warmup", "0",
+                        "--seq-len", "1024", "--d-model", "2"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r
+    assert r["n_gpus"] == 1 and r["data"] == "synthetic" and "workload" in r["config"]

@@ -1,0 +1,190 @@
+"""Parity on a real MI355X: the gfx950 library, called through the C ABI (hyena_dna_amd._lib -> ctypes), against the
+oracle (CPU restatement of the reference, pinned to reference-minted golden vectors), plus size-independent
+properties at the BASELINE sizes where the CPU oracle would take too long."""
+import pytest
+import torch
+
+from oracle import hyena_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REL_FP32 = 3e-6        # rel-L2; north_star tolerance is 1e-3, fp32 mode is expected <= 1e-5
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _inputs(B, D, L, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randn(B, D, L, generator=g).to(dtype)
+    k = torch.randn(D, L, generator=g) * torch.exp(-5.0 * torch.linspace(0, 1, L))[None] * 0.1
+    bias = torch.randn(D, generator=g)
+    dout = torch.randn(B, D, L, generator=g).to(dtype)
+    return u, k, bias, dout
+
+
+def _oracle(u, k, bias, dout):
+    u_ = u.clone().requires_grad_(True)
+    k_ = k.clone().requires_grad_(True)
+    b_ = bias.clone().requires_grad_(True)
+    out = O.fftconv_ref(u_, k_, b_)
+    out.backward(dout)
+    return out.detach(), u_.grad, k_.grad, b_.grad
+
+
+def _gpu(gpu_lib, u, k, bias, dout, chunk=None):
+    dev = torch.device("cuda", 0)
+    ud, kd, bd, gd = u.to(dev), k.to(dev), bias.to(dev), dout.to(dev)
+    out = gpu_lib.fftconv_fwd(ud, kd, bd, chunk=chunk)
+    du, dk, dbias = gpu_lib.fftconv_bwd(gd, ud, kd, bd, chunk=chunk)
+    torch.cuda.synchronize()
+    return out.cpu(), du.cpu(), dk.cpu(), dbias.cpu()
+
+
+def test_native_library_is_the_one_loaded(gpu_lib):
+    import os
+    assert os.path.basename(gpu_lib.LIB_PATH) == "libhyena_fftconv.so"
+    maps = open("/proc/self/maps").read()
+    assert "libhyena_fftconv.so" in maps and "_emu_" not in maps
+
+
+@pytest.mark.parametrize("B,D,L,chunk", [
+    (2, 3, 1, None), (2, 3, 8, None), (3, 5, 1023, None), (8, 128, 1024, None), (2, 4, 1025, 3), (2, 3, 2048, None),
+    (1, 3, 5000, None), (2, 2, 8191, None), (1, 4, 16384, 1), (2, 8, 32768, None), (1, 2, 65536, None),
+    (1, 3, 160000, 2), (1, 2, 450560, None), (1, 2, 1048576, None), (1, 1, 1048575, None),
+])
+def test_fp32_fwd_bwd_vs_oracle(gpu_lib, B, D, L, chunk):
+    u, k, bias, dout = _inputs(B, D, L, torch.float32, seed=L)
+    out, du, dk, dbias = _gpu(gpu_lib, u, k, bias, dout, chunk)
+    r_out, r_du, r_dk, r_db = _oracle(u, k, bias, dout)
+    assert _rel(out, r_out) < REL_FP32
+    assert _rel(du, r_du) < REL_FP32
+    assert _rel(dk, r_dk) < REL_FP32
+    assert _rel(dbias, r_db) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,D,L", [(2, 3, 37), (2, 4, 1023), (2, 8, 32768), (1, 2, 160000)])
+def test_half_io_vs_oracle(gpu_lib, dtype, B, D, L):
+    u, k, bias, dout = _inputs(B, D, L, dtype, seed=L + 1)
+    out, du, dk, dbias = _gpu(gpu_lib, u, k, bias, dout)
+    r_out, r_du, r_dk, r_db = _oracle(u, k, bias, dout)
+    assert out.dtype == dtype and du.dtype == dtype and dk.dtype == torch.float32
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    diff = (out.float() - r_out.float()).abs()
+    assert (diff <= eps * r_out.float().abs() + 2e-5).all()          # at most one 16-bit ulp from the reference
+    assert (out != r_out).float().mean() < 0.02
+    t_out, t_du, _, _ = _oracle(u.float(), k, bias, dout.float())      # fp32 result on the same 16-bit inputs
+    assert ((out.float() - t_out).abs() <= 0.5 * eps * t_out.abs() * 1.001 + 2e-5).all()
+    assert ((du.float() - t_du).abs() <= 0.5 * eps * t_du.abs() * 1.001 + 2e-5).all()
+    assert _rel(du.float(), r_du.float()) < 1.5 * eps
+    assert _rel(dk, r_dk) < REL_FP32 and _rel(dbias, r_db) < 1e-5
+    assert _rel(out.float(), r_out.float()) < 1e-3                    # the north_star tolerance
+
+
+@pytest.mark.parametrize("name", ["b2d4l8", "b2d3l37", "b1d4l1023", "b2d4l1024", "b2d4l1024_5d", "b2d4l1000_bf16",
+                                  "b1d2l4100"])
+def test_golden_vectors_from_reference(gpu_lib, golden_fftconv, name):
+    c = golden_fftconv[name]
+    out, du, dk, dbias = _gpu(gpu_lib, c["u"], c["k"], c["bias"], c["dout"])
+    if c["u"].dtype == torch.float32:
+        assert _rel(out, c["out"]) < REL_FP32 and _rel(du, c["du"]) < REL_FP32
+    else:
+        assert _rel(out.float(), c["out"].float()) < 1e-3 and _rel(du.float(), c["du"].float()) < 1.2e-2
+    assert _rel(dk, c["dk"]) < REL_FP32 and _rel(dbias, c["dbias"]) < 1e-5
+
+
+def test_autograd_function_5d_on_gpu(gpu_lib):
+    from hyena_dna_amd.fftconv import fftconv_func
+    dev = torch.device("cuda", 0)
+    B, D, L = 2, 16, 3000
+    u, k, bias, dout = _inputs(B, D, L, torch.float32, seed=11)
+    u_ = u.to(dev).requires_grad_(True)
+    k_ = k.to(dev).requires_grad_(True)
+    b_ = bias.to(dev).requires_grad_(True)
+    out = fftconv_func(u_.reshape(B, 1, D, 1, L), k_, b_[None, :, None], gelu=False)
+    out.backward(dout.to(dev).reshape(B, 1, D, 1, L))
+    r_out, r_du, r_dk, r_db = _oracle(u, k, bias, dout)
+    assert _rel(out.reshape(B, D, L), r_out) < REL_FP32 and _rel(u_.grad, r_du) < REL_FP32
+    assert _rel(k_.grad, r_dk) < REL_FP32 and _rel(b_.grad, r_db) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["d8l64", "d16l257", "d8l80_trunc"])
+def test_operator_mirror_on_gpu(gpu_lib, golden_operator, name):
+    from hyena_dna_amd.hyena import HyenaOperator
+    dev = torch.device("cuda", 0)
+    c = golden_operator[name]
+    op = HyenaOperator(d_model=c["d_model"], l_max=c["l_max"], order=2, filter_order=64, emb_dim=5,
+                       short_filter_order=3, modulate=True, w=10, lr=6e-4, wd=0.0, lr_pos_emb=0.0)
+    op.load_state_dict(c["state_dict"])
+    op = op.to(dev)
+    u = c["u"].to(dev).requires_grad_(True)
+    y = op(u)
+    y.backward(c["dy"].to(dev))
+    torch.testing.assert_close(y.cpu(), c["y"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(u.grad.cpu(), c["du"], rtol=1e-3, atol=1e-5)
+    for n, p in op.named_parameters():
+        torch.testing.assert_close(p.grad.cpu(), c["grads"][n], rtol=2e-3, atol=1e-4, msg=lambda m, n=n: f"{n}: {m}")
+
+
+# ---- properties at the BASELINE sizes (no CPU oracle needed) -------------------------------------------------
+@pytest.mark.parametrize("L,D,B,dtype", [(32768, 256, 8, torch.bfloat16), (160000, 256, 2, torch.bfloat16),
+                                          (450560, 256, 1, torch.bfloat16), (1048576, 256, 1, torch.bfloat16),
+                                          (1048576, 32, 1, torch.float32)])
+def test_properties_at_baseline_sizes(gpu_lib, L, D, B, dtype):
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(L + D)          # device RNG: host randn of 2.7e8 values is slow
+    rn = lambda *shape: torch.randn(*shape, generator=g, device=dev)   # noqa: E731
+    k = rn(D, L) * torch.exp(-5.0 * torch.linspace(0, 1, L, device=dev))[None] * 0.1
+    bias = rn(D)
+    # (1) impulse response: u = delta at position p  ->  out[t] = k[t - p] + bias * delta  (exact up to rounding)
+    p = 12345 % L
+    u = torch.zeros(B, D, L, dtype=dtype, device=dev)
+    u[:, :, p] = 1.0
+    out = gpu_lib.fftconv_fwd(u, k, bias).float()
+    expect = torch.zeros(B, D, L, device=dev)
+    expect[:, :, p:] = k[:, : L - p]
+    expect[:, :, p] += bias
+    err = (out - expect).abs().max().item()
+    tol = 2e-5 if dtype == torch.float32 else 2.0 ** -8 * expect.abs().max().item() + 1e-4
+    assert err <= tol, err
+    # (2) causality: changing u after position c does not change out before c
+    u1 = rn(B, D, L).to(dtype)
+    u2 = u1.clone()
+    c = L // 3
+    u2[:, :, c:] = rn(B, D, L - c).to(dtype)
+    o1 = gpu_lib.fftconv_fwd(u1, k, bias).float()
+    o2 = gpu_lib.fftconv_fwd(u2, k, bias).float()
+    head = (o1[:, :, :c] - o2[:, :, :c]).abs().max().item()
+    assert head <= (5e-5 if dtype == torch.float32 else 2.0 ** -7 * o1[:, :, :c].abs().max().item()), head
+    # (3) adjoint identity <dout, conv(u)> = <du, u> = <dk, k> + <dbias, bias>  (fp32 accumulation on device)
+    dout = rn(B, D, L).to(dtype)
+    du, dk, dbias = gpu_lib.fftconv_bwd(dout, u1, k, bias)
+    dot = lambda a, b: sum((a[i].double() * b[i].double()).sum().item() for i in range(a.shape[0]))   # noqa: E731
+    lhs = dot(dout, o1)
+    mid = dot(du, u1)
+    rhs = dot(dk, k) + (dbias.double() * bias.double()).sum().item()
+    scale = (dot(dout, dout) * dot(o1, o1)) ** 0.5
+    rt = 2e-5 if dtype == torch.float32 else 6e-3
+    assert abs(lhs - mid) <= rt * scale and abs(lhs - rhs) <= rt * scale, (lhs, mid, rhs, scale)
+    # (4) determinism: same inputs, bitwise the same outputs (no atomics anywhere in the path)
+    du_b, dk_b, dbias_b = gpu_lib.fftconv_bwd(dout, u1, k, bias)
+    assert torch.equal(du, du_b) and torch.equal(dk, dk_b) and torch.equal(dbias, dbias_b)
+    assert torch.isfinite(dk).all() and torch.isfinite(du.float()).all()
+
+
+def test_streams_and_chunking_agree(gpu_lib):
+    """Non-default stream + every chunk size give the same bits (the library uses the caller's stream)."""
+    dev = torch.device("cuda", 0)
+    u, k, bias, dout = _inputs(2, 12, 20000, torch.float32, seed=4)
+    ud, kd, bd = u.to(dev), k.to(dev), bias.to(dev)
+    ref = gpu_lib.fftconv_fwd(ud, kd, bd)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        outs = [gpu_lib.fftconv_fwd(ud, kd, bd, chunk=c) for c in (1, 5, 12)]
+    s.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref)

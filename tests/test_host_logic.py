@@ -1,0 +1,150 @@
+"""Host side above the C ABI -- the autograd function and the module mirrors -- on the CPU-emulated kernels,
+against the oracle and the golden vectors minted from the reference's own classes.  No GPU needed."""
+import pytest
+import torch
+
+from oracle import hyena_oracle as O
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def test_product_refuses_cpu_tensors_and_missing_library(monkeypatch, tmp_path):
+    """No fallback: CPU tensors raise, a missing .so raises -- never a silent torch path."""
+    from hyena_dna_amd import _lib, fftconv
+    u, k, D = torch.randn(1, 2, 16), torch.randn(2, 16), torch.randn(2)
+    with pytest.raises(_lib.HyenaLibraryError, match="no CPU fallback"):
+        fftconv.fftconv_func(u, k, D, gelu=False)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib._backend, "path", str(tmp_path / "nope.so"), raising=False)
+    with pytest.raises(_lib.HyenaLibraryError, match="not found"):
+        _lib.lib()
+    monkeypatch.setattr(_lib, "_lib", None)
+
+
+def test_unsupported_options_raise(emu_backend):
+    from hyena_dna_amd.fftconv import fftconv_func, fftconv_heads_ref
+    u, k, D = torch.randn(1, 2, 16), torch.randn(2, 16), torch.randn(2)
+    for kw in (dict(gelu=True), dict(gelu=False, dropout_mask=torch.ones(1, 2)), dict(gelu=False, head_dim=8),
+               dict(gelu=False, k_rev=k), dict(gelu=False, fftfp16=True), dict(gelu=False, output_hbl_layout=True)):
+        with pytest.raises(NotImplementedError):
+            fftconv_func(u, k, D, **kw)
+    with pytest.raises(NotImplementedError):
+        fftconv_heads_ref()
+    with pytest.raises(ValueError):
+        fftconv_func(torch.randn(1, 3, 16), k, D, gelu=False)
+
+
+@pytest.mark.parametrize("five_d", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_autograd_matches_reference_autograd(emu_backend, five_d, dtype):
+    from hyena_dna_amd.fftconv import fftconv_func
+    g = torch.Generator().manual_seed(5)
+    B, D, L = 2, 4, 300
+    u = torch.randn(B, D, L, generator=g).to(dtype)
+    k = torch.randn(D, L, generator=g) * torch.exp(-4 * torch.linspace(0, 1, L)) * 0.2
+    bias = torch.randn(D, generator=g)
+    dout = torch.randn(B, D, L, generator=g).to(dtype)
+
+    def run(fn):
+        u_ = u.clone().requires_grad_(True)
+        k_ = k.clone().requires_grad_(True)
+        b_ = bias.clone().requires_grad_(True)
+        if five_d:      # exactly what HyenaOperator passes (hyena.py:396-423)
+            out = fn(u_.reshape(B, 1, D, 1, L), k_, b_[None, :, None]).reshape(B, D, L)
+        else:
+            out = fn(u_, k_, b_)
+        out.backward(dout)
+        return out.detach(), u_.grad, k_.grad, b_.grad
+
+    got = run(lambda a, b, c: fftconv_func(a, b, c, dropout_mask=None, gelu=False))
+    ref = run(lambda a, b, c: O.fftconv_ref(a, b, c, None, gelu=False))
+    tol = 2e-6 if dtype == torch.float32 else 1.2e-2
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        assert _rel(a.float(), b.float()) < tol
+    assert _rel(got[2], ref[2]) < 2e-6 and _rel(got[3], ref[3]) < 5e-6      # dk, dbias are fp32 on both sides
+
+
+def test_multi_head_and_blocks_layout(emu_backend):
+    """5-D input with h > 1 and z > 1: the filter broadcasts over b, h, z (hyena.py:77-78)."""
+    from hyena_dna_amd.fftconv import fftconv_func
+    g = torch.Generator().manual_seed(9)
+    b, h, v, z, l = 2, 2, 3, 2, 40
+    u = torch.randn(b, h, v, z, l, generator=g, requires_grad=True)
+    k = torch.randn(v, l, generator=g, requires_grad=True)
+    D = torch.randn(1, v, 1, generator=g, requires_grad=True)
+    dout = torch.randn(b, h, v, z, l, generator=g)
+    out = fftconv_func(u, k, D, gelu=False)
+    out.backward(dout)
+    got = (out.detach(), u.grad.clone(), k.grad.clone(), D.grad.clone())
+    for t in (u, k, D):
+        t.grad = None
+    ref = O.fftconv_ref(u, k, D, None, gelu=False)
+    ref.backward(dout)
+    for a, r in zip(got, (ref.detach(), u.grad, k.grad, D.grad)):
+        assert a.shape == r.shape and _rel(a, r) < 3e-6
+
+
+def test_force_fp16_output(emu_backend):
+    from hyena_dna_amd.fftconv import fftconv_func
+    u, k, D = torch.randn(1, 2, 64), torch.randn(2, 64) * 0.1, torch.randn(2)
+    assert fftconv_func(u, k, D, gelu=False, force_fp16_output=True).dtype == torch.float16
+    assert fftconv_func(u.bfloat16(), k, D, gelu=False, force_fp16_output=True).dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("name", ["d8l64", "d16l257", "d8l80_trunc"])
+def test_operator_mirror_loads_reference_state_and_matches(emu_backend, golden_operator, name):
+    """HyenaOperator mirror: load the REFERENCE module's state_dict, reproduce its output and every gradient."""
+    from hyena_dna_amd.hyena import HyenaOperator
+    c = golden_operator[name]
+    op = HyenaOperator(d_model=c["d_model"], l_max=c["l_max"], order=2, filter_order=64, emb_dim=5,
+                       short_filter_order=3, modulate=True, w=10, lr=6e-4, wd=0.0, lr_pos_emb=0.0,
+                       layer_idx=0, device=None, dtype=None)         # stray kwargs as create_mixer_cls passes them
+    missing, unexpected = op.load_state_dict(c["state_dict"], strict=True)
+    assert not missing and not unexpected
+    assert set(op.state_dict().keys()) == set(c["state_dict"].keys())
+    assert torch.equal(op.filter_fn.filter(min(c["u"].shape[1], c["l_max"])), c["k"])
+    u = c["u"].clone().requires_grad_(True)
+    y = op(u)
+    assert y.shape == c["y"].shape
+    torch.testing.assert_close(y, c["y"], rtol=1e-5, atol=2e-6)
+    y.backward(c["dy"])
+    torch.testing.assert_close(u.grad, c["du"], rtol=1e-4, atol=2e-6)
+    for n, p in op.named_parameters():
+        torch.testing.assert_close(p.grad, c["grads"][n], rtol=2e-4, atol=2e-5, msg=lambda m, n=n: f"{n}: {m}")
+
+
+def test_operator_mirror_autocast_bf16(emu_backend, golden_operator):
+    from hyena_dna_amd.hyena import HyenaOperator
+    c = golden_operator["d16l257"]
+    op = HyenaOperator(d_model=c["d_model"], l_max=c["l_max"], order=2, filter_order=64, emb_dim=5,
+                       short_filter_order=3, modulate=True, w=10, lr=6e-4, wd=0.0, lr_pos_emb=0.0)
+    op.load_state_dict(c["state_dict"])
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        y = op(c["u"])
+    assert y.dtype == c["y_autocast_bf16"].dtype
+    assert _rel(y.float(), c["y_autocast_bf16"].float()) < 2e-2
+
+
+def test_optim_tags_and_buffers_match_reference_contract():
+    """_optim tags (src/utils/train.py:142-156) and buffer-vs-parameter split (lr == 0 -> buffer)."""
+    from hyena_dna_amd.hyena import HyenaOperator
+    op = HyenaOperator(d_model=8, l_max=34, order=2, filter_order=16, emb_dim=5, lr=6e-4, wd=0.1, lr_pos_emb=0.0, w=10)
+    names = dict(op.named_parameters())
+    bufs = dict(op.named_buffers())
+    assert "filter_fn.pos_emb.z" in bufs and "filter_fn.pos_emb.t" in bufs and "filter_fn.modulation.deltas" in bufs
+    assert names["filter_fn.implicit_filter.0.weight"]._optim == {"weight_decay": 0.1, "lr": 6e-4}
+    assert names["filter_fn.implicit_filter.1.freq"]._optim == {"weight_decay": 0.1, "lr": 6e-4}
+    assert not hasattr(names["in_proj.weight"], "_optim")
+    op2 = HyenaOperator(d_model=8, l_max=34, emb_dim=5, lr_pos_emb=1e-5)
+    assert dict(op2.named_parameters())["filter_fn.pos_emb.z"]._optim == {"lr": 1e-5, "weight_decay": 0.0}
+    assert op.d_output == 8
+    # one shared Sin instance: the three `freq` keys alias one tensor
+    sd = op.state_dict()
+    assert sd["filter_fn.implicit_filter.1.freq"].data_ptr() == sd["filter_fn.implicit_filter.5.freq"].data_ptr()
+    with pytest.raises(AssertionError):
+        HyenaOperator(d_model=8, l_max=34, order=1)
+    with pytest.raises(ImportError):
+        HyenaOperator(d_model=8, l_max=34, fused_bias_fc=True)
