@@ -61,7 +61,7 @@ int launch_col_dt(int M1, const ColArgs& a, int rows, void* stream) {
 #define HY_COL_CASE(m1)                                                                              \
     case m1: {                                                                                       \
         typedef ColCfg<m1> Cfg;                                                                      \
-        dim3 grid(1024 / Cfg::C, rows), block(Cfg::THREADS);                                         \
+        dim3 grid(1024 / Cfg::C, rows, (!INV && a.x2 != nullptr) ? 2 : 1), block(Cfg::THREADS);     \
         if (INV) HY_LAUNCH((col_inv_kernel<m1, DT>), grid, block, Cfg::LDS, stream, a);              \
         else HY_LAUNCH((col_fwd_kernel<m1, DT>), grid, block, Cfg::LDS, stream, a);                  \
         break;                                                                                       \
@@ -97,27 +97,28 @@ int launch_col(int dtype, int M1, const ColArgs& a, int rows, void* stream) {
 
 const size_t ROW_SMEM = 2 * ROW_LDS * sizeof(c32);
 
-template <int MODE>
 int launch_row_conv(const RowArgs& a, void* stream) {
     const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;   // slot 0 = rows (0, M1/2); slot s = rows (s, M1 - s)
-    HY_LAUNCH((row_conv_kernel<MODE>), dim3(nslots, a.inner, a.B), dim3(64), ROW_SMEM, stream, a);
+    HY_LAUNCH(row_conv_kernel, dim3(nslots, a.inner, a.B), dim3(64), ROW_SMEM, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
 int launch_row_dk(const RowArgs& a, void* stream) {
     const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;
-    HY_LAUNCH(row_dk_kernel, dim3(nslots, a.inner), dim3(64), 2 * ROW_SMEM, stream, a);
+    HY_LAUNCH(row_dk_kernel, dim3(nslots, a.inner), dim3(64), ROW_SMEM, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
+template <int MODE>
 int launch_row_spec(const RowArgs& a, void* stream) {
-    HY_LAUNCH(row_spec_kernel, dim3((a.M1 + 1) / 2, a.inner), dim3(64), ROW_SMEM, stream, a);
+    const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;
+    HY_LAUNCH((row_spec_kernel<MODE>), dim3(nslots, a.inner), dim3(64), ROW_SMEM, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
 size_t elem_size(int dtype) { return dtype == HYENA_F32 ? 4 : 2; }
 
-const size_t CACHE_BUDGET = 160u << 20;   // bytes of intermediates kept live per chunk (Infinity Cache is 256 MiB)
+const size_t CACHE_BUDGET = 384u << 20;   // bytes of intermediates kept live per chunk (Infinity Cache is 256 MiB)
 
 }  // namespace
 
@@ -184,7 +185,7 @@ int hyena_fftconv_init_tables(void* d_tables, int L) {
 int hyena_fftconv_default_chunk(int B, int D, int L, int backward) {
     Plan p;
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
-    const size_t per_channel = (size_t)(backward ? 2 * B + 2 : B + 1) * p.M * sizeof(c32);
+    const size_t per_channel = (size_t)(backward ? 2 * B + 4 : B + 3) * p.M * sizeof(c32);
     size_t c = CACHE_BUDGET / per_channel;
     if (c < 1) c = 1;
     if (c > (size_t)D) c = D;
@@ -196,7 +197,7 @@ size_t hyena_fftconv_workspace_bytes(int B, int D, int L, int backward, int chun
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, backward);
     if (chunk > D) chunk = D;
-    return (size_t)(backward ? 2 * B + 2 : B + 1) * chunk * p.M * sizeof(c32);
+    return (size_t)(backward ? 2 * B + 4 : B + 3) * chunk * p.M * sizeof(c32);
 }
 
 int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int dtype,
@@ -211,29 +212,30 @@ int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* ou
     if (workspace_bytes < hyena_fftconv_workspace_bytes(B, D, L, 0, chunk)) return HYENA_ERR_WORKSPACE;
 
     const Tables tab = tables_from(d_tables);
-    c32* S = reinterpret_cast<c32*>(workspace);                 // [chunk][M]
-    c32* W = S + (size_t)chunk * p.M;                           // [B][chunk][M]
+    c32* Wk = reinterpret_cast<c32*>(workspace);                // [chunk][M]      column-transformed filter
+    c32* S2 = Wk + (size_t)chunk * p.M;                         // [chunk][M][2]   product coefficients {A, Bc}
+    c32* W = S2 + 2 * (size_t)chunk * p.M;                      // [B][chunk][M]
     const size_t es = elem_size(dtype);
     int st;
     for (int d0 = 0; d0 < D; d0 += chunk) {
         const int cd = (D - d0 < chunk) ? D - d0 : chunk;
-        // filter spectrum of the chunk's channels
+        // filter spectrum of the chunk's channels -> product coefficients
         ColArgs ck;
-        ck.x = k + (size_t)d0 * L; ck.W = S; ck.tab = tab; ck.L = L; ck.inner = cd;
-        ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr;
+        ck.x = k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd;
+        ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
         if ((st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
         RowArgs rs;
-        rs.X = nullptr; rs.U = nullptr; rs.S = S; rs.bias = nullptr; rs.tab = tab; rs.M1 = p.M1; rs.inner = cd; rs.B = 1;
-        rs.scale = 1.0f / (float)p.M;
-        if ((st = launch_row_spec(rs, stream))) return st;
+        rs.X = nullptr; rs.U = Wk; rs.S = S2; rs.bias = bias ? bias + d0 : nullptr; rs.tab = tab; rs.M1 = p.M1;
+        rs.inner = cd; rs.B = 1; rs.scale = 1.0f / (float)p.M;
+        if ((st = launch_row_spec<MODE_CONV>(rs, stream))) return st;
         // u rows
         ColArgs cu;
         cu.x = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cu.W = W; cu.tab = tab; cu.L = L; cu.inner = cd;
-        cu.outer_stride = (long)D * L; cu.inner_stride = L; cu.aux0 = nullptr;
+        cu.outer_stride = (long)D * L; cu.inner_stride = L; cu.aux0 = nullptr; cu.x2 = nullptr; cu.W2 = nullptr;
         if ((st = launch_col<false>(dtype, p.M1, cu, B * cd, stream))) return st;
         RowArgs rc = rs;
-        rc.X = W; rc.bias = bias ? bias + d0 : nullptr; rc.B = B;
-        if ((st = launch_row_conv<MODE_CONV>(rc, stream))) return st;
+        rc.X = W; rc.U = nullptr; rc.bias = nullptr; rc.B = B;
+        if ((st = launch_row_conv(rc, stream))) return st;
         ColArgs co = cu;
         co.x = reinterpret_cast<char*>(out) + (size_t)d0 * L * es;
         if ((st = launch_col<true>(dtype, p.M1, co, B * cd, stream))) return st;
@@ -255,8 +257,9 @@ int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const flo
     if (workspace_bytes < hyena_fftconv_workspace_bytes(B, D, L, 1, chunk)) return HYENA_ERR_WORKSPACE;
 
     const Tables tab = tables_from(d_tables);
-    c32* S = reinterpret_cast<c32*>(workspace);                 // [chunk][M]   filter spectrum
-    c32* Sdk = S + (size_t)chunk * p.M;                         // [chunk][M]   dk spectrum -> packed dk
+    c32* Wk = reinterpret_cast<c32*>(workspace);                // [chunk][M]      column-transformed filter
+    c32* S2 = Wk + (size_t)chunk * p.M;                         // [chunk][M][2]   corr-mode product coefficients
+    c32* Sdk = S2 + 2 * (size_t)chunk * p.M;                    // [chunk][M]      dk spectrum -> packed dk
     c32* Wg = Sdk + (size_t)chunk * p.M;                        // [B][chunk][M]
     c32* Wu = Wg + (size_t)B * chunk * p.M;                     // [B][chunk][M]
     const size_t es = elem_size(dtype);
@@ -264,33 +267,32 @@ int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const flo
     for (int d0 = 0; d0 < D; d0 += chunk) {
         const int cd = (D - d0 < chunk) ? D - d0 : chunk;
         RowArgs rs;
-        rs.X = nullptr; rs.U = nullptr; rs.S = S; rs.bias = nullptr; rs.tab = tab; rs.M1 = p.M1; rs.inner = cd; rs.B = 1;
-        rs.scale = 1.0f / (float)p.M;
+        rs.X = nullptr; rs.U = Wk; rs.S = S2; rs.bias = bias ? bias + d0 : nullptr; rs.tab = tab; rs.M1 = p.M1;
+        rs.inner = cd; rs.B = 1; rs.scale = 1.0f / (float)p.M;
         ColArgs cg;
         cg.x = reinterpret_cast<const char*>(dout) + (size_t)d0 * L * es; cg.W = Wg; cg.tab = tab; cg.L = L; cg.inner = cd;
-        cg.outer_stride = (long)D * L; cg.inner_stride = L; cg.aux0 = nullptr;
-        if ((st = launch_col<false>(dtype, p.M1, cg, B * cd, stream))) return st;
+        cg.outer_stride = (long)D * L; cg.inner_stride = L; cg.aux0 = nullptr; cg.x2 = nullptr; cg.W2 = nullptr;
+        ColArgs cgu = cg;                                        // dout (and u, when dk is wanted) in ONE launch
+        if (dk != nullptr) { cgu.x2 = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cgu.W2 = Wu; }
+        if ((st = launch_col<false>(dtype, p.M1, cgu, B * cd, stream))) return st;
         if (dk != nullptr) {
-            ColArgs cu = cg;
-            cu.x = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cu.W = Wu;
-            if ((st = launch_col<false>(dtype, p.M1, cu, B * cd, stream))) return st;
             RowArgs rd = rs;
-            rd.X = Wg; rd.U = Wu; rd.S = Sdk; rd.B = B;
+            rd.X = Wg; rd.U = Wu; rd.S = Sdk; rd.bias = nullptr; rd.B = B;
             if ((st = launch_row_dk(rd, stream))) return st;
             ColArgs cdk;
             cdk.x = dk + (size_t)d0 * L; cdk.W = Sdk; cdk.tab = tab; cdk.L = L; cdk.inner = cd;
-            cdk.outer_stride = 0; cdk.inner_stride = L; cdk.aux0 = dbias ? dbias + d0 : nullptr;
+            cdk.outer_stride = 0; cdk.inner_stride = L; cdk.aux0 = dbias ? dbias + d0 : nullptr; cdk.x2 = nullptr; cdk.W2 = nullptr;
             if ((st = launch_col<true>(HYENA_F32, p.M1, cdk, cd, stream))) return st;
         }
         if (du != nullptr) {
             ColArgs ck;
-            ck.x = k + (size_t)d0 * L; ck.W = S; ck.tab = tab; ck.L = L; ck.inner = cd;
-            ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr;
+            ck.x = k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd;
+            ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
             if ((st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
-            if ((st = launch_row_spec(rs, stream))) return st;
+            if ((st = launch_row_spec<MODE_CORR>(rs, stream))) return st;
             RowArgs rc = rs;
-            rc.X = Wg; rc.bias = bias ? bias + d0 : nullptr; rc.B = B;
-            if ((st = launch_row_conv<MODE_CORR>(rc, stream))) return st;
+            rc.X = Wg; rc.U = nullptr; rc.bias = nullptr; rc.B = B;
+            if ((st = launch_row_conv(rc, stream))) return st;
             ColArgs co = cg;
             co.x = reinterpret_cast<char*>(du) + (size_t)d0 * L * es;
             if ((st = launch_col<true>(dtype, p.M1, co, B * cd, stream))) return st;

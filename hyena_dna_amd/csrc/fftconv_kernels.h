@@ -34,6 +34,7 @@
 #define HY_SHFL_U32(v, lane) hipemu::shfl_u32((v), (lane))
 #define HY_UNROLL
 #define HY_SCHED_FENCE() do {} while (0)
+#define HY_UNIFORM_PTR(T, p) (p)
 #else
 #include <hip/hip_runtime.h>
 #define HY_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
@@ -41,11 +42,24 @@
 #define HY_UNROLL _Pragma("unroll")
 // stops hipcc from hoisting every load of an unrolled loop to its top (which costs hundreds of VGPRs)
 #define HY_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// pins a wave-uniform pointer into SGPRs (and hides it from loop strength reduction, which otherwise turns
+// base + lane offset into 32 loop-carried 64-bit VGPR address pairs)
+#define HY_UNIFORM_PTR(T, p) hyena::uniform_ptr<T>(p)
 #endif
 
 #include <stdint.h>
 
 namespace hyena {
+
+#ifndef HIPEMU
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+#endif
 
 struct __attribute__((aligned(8))) c32 {
     float x, y;
@@ -71,6 +85,49 @@ __device__ __forceinline__ c32 ldg(const c32* base, unsigned idx) {
 __device__ __forceinline__ void stg(c32* base, unsigned idx, c32 v) {
     *reinterpret_cast<c32*>(reinterpret_cast<char*>(base) + (size_t)(idx * 8u)) = v;
 }
+
+// Buffer-addressed global access for the row kernels: address = descriptor base (SGPRs) + one per-lane VGPR byte
+// offset + a scalar byte offset.  All 32 accesses of a lane share ONE address VGPR (hipcc otherwise keeps a
+// 64-bit address pair per access alive across the batch loop and spills); out-of-range accesses are dropped by
+// the hardware bounds check.
+#ifdef HIPEMU
+struct GBuf { char* p; };
+__device__ __forceinline__ GBuf make_gbuf(const void* base, unsigned) { GBuf b; b.p = (char*)base; return b; }
+__device__ __forceinline__ c32 gb_ld(GBuf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const c32*>(b.p + voff + soff); }
+__device__ __forceinline__ void gb_st(GBuf b, unsigned voff, unsigned soff, c32 v) { *reinterpret_cast<c32*>(b.p + voff + soff) = v; }
+struct __attribute__((aligned(16))) c32x2 { c32 a, b; };
+__device__ __forceinline__ c32x2 gb_ld2(GBuf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const c32x2*>(b.p + voff + soff); }
+__device__ __forceinline__ void gb_st2(GBuf b, unsigned voff, unsigned soff, c32x2 v) { *reinterpret_cast<c32x2*>(b.p + voff + soff) = v; }
+#define HY_OPAQUE(x) do {} while (0)
+#else
+struct GBuf { __amdgpu_buffer_rsrc_t r; };
+typedef unsigned hy_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ GBuf make_gbuf(const void* base, unsigned bytes) {
+    GBuf b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<void*>(base)), 0, bytes, 0x00020000);
+    return b;
+}
+__device__ __forceinline__ c32 gb_ld(GBuf b, unsigned voff, unsigned soff) {
+    const hy_u2 w = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0);
+    return mk(u2f(w.x), u2f(w.y));
+}
+__device__ __forceinline__ void gb_st(GBuf b, unsigned voff, unsigned soff, c32 v) {
+    hy_u2 w; w.x = f2u(v.x); w.y = f2u(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(w, b.r, voff, soff, 0);
+}
+struct __attribute__((aligned(16))) c32x2 { c32 a, b; };
+typedef unsigned hy_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c32x2 gb_ld2(GBuf b, unsigned voff, unsigned soff) {
+    const hy_u4 w = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, 0);
+    c32x2 r; r.a = mk(u2f(w.x), u2f(w.y)); r.b = mk(u2f(w.z), u2f(w.w)); return r;
+}
+__device__ __forceinline__ void gb_st2(GBuf b, unsigned voff, unsigned soff, c32x2 v) {
+    hy_u4 w; w.x = f2u(v.a.x); w.y = f2u(v.a.y); w.z = f2u(v.b.x); w.w = f2u(v.b.y);
+    __builtin_amdgcn_raw_buffer_store_b128(w, b.r, voff, soff, 0);
+}
+// makes a value opaque to the optimiser at this point (keeps "lane base + immediate" LDS addressing intact)
+#define HY_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
 
 __device__ __forceinline__ c32 shfl_c32(c32 v, int lane) {
     return mk(u2f(HY_SHFL_U32(f2u(v.x), lane)), u2f(HY_SHFL_U32(f2u(v.y), lane)));
@@ -255,7 +312,7 @@ enum { ROW_N = 1024, ROW_LDS = 1024 + 32 };
 __device__ __forceinline__ int row_idx(int p) { return p + (p >> 5); }
 
 template <bool INV>
-__device__ __forceinline__ void row_fft1024(c32 (&v)[32], c32* xb, int j, const c32* __restrict__ twT) {
+__device__ __forceinline__ void row_fft1024(c32 (&v)[32], c32* xb, int j, GBuf twT) {
     dft_reg<32, INV>(v);
     HY_UNROLL
     for (int q = 0; q < 32; ++q) xb[j * 33 + q] = v[q];             // position j*32 + q
@@ -265,7 +322,7 @@ __device__ __forceinline__ void row_fft1024(c32 (&v)[32], c32* xb, int j, const 
     __syncthreads();
     HY_UNROLL
     for (int s = 1; s < 32; ++s) {
-        const c32 w = ldg(twT, (unsigned)(s * 32 + j));
+        const c32 w = gb_ld(twT, (unsigned)j * 8u, (unsigned)s * 256u);
         v[s] = INV ? cmulc(v[s], w) : cmul(v[s], w);
     }
     dft_reg<32, INV>(v);
@@ -310,6 +367,8 @@ struct ColArgs {
     long outer_stride;  // elements between consecutive outer indices (D * L)
     long inner_stride;  // elements between consecutive inner indices (L)
     float* aux0;        // col_inv only: if non-null, aux0[row] = real part of output sample 0
+    const void* x2;     // col_fwd only: second input tensor of the same shape (blockIdx.z == 1) ...
+    c32* W2;            // ... and where its transform goes; lets dout and u share one launch in the backward
 };
 
 __device__ __forceinline__ c32 outer_tw(const c32* tlo, const c32* thi, int n2, int k1) {
@@ -331,10 +390,11 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_fwd_kernel(ColArgs a)
     const int c = tid % C, r = tid / C;
     const int n2 = blockIdx.x * C + c;
     const int row = blockIdx.y;
-    const elem_t* xrow = reinterpret_cast<const elem_t*>(a.x) + (long)(row / a.inner) * a.outer_stride +
+    const bool second = blockIdx.z != 0;
+    const elem_t* xrow = reinterpret_cast<const elem_t*>(second ? a.x2 : a.x) + (long)(row / a.inner) * a.outer_stride +
                          (long)(row % a.inner) * a.inner_stride;
     const bool vec = (a.L & 1) == 0;
-    c32* Wrow = a.W + (size_t)row * M1 * 1024;
+    c32* Wrow = (second ? a.W2 : a.W) + (size_t)row * M1 * 1024;
 
     for (int i = tid; i < 1024; i += Cfg::THREADS) tlo[i] = a.tab.tw_lo[i];
     for (int i = tid; i < M1; i += Cfg::THREADS) thi[i] = a.tab.tw_hi[i];
@@ -480,9 +540,9 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_inv_kernel(ColArgs a)
 // ---------------------------------------------------------------------------------------------
 struct RowArgs {
     c32* X;            // [B][inner][M1][1024]  in place (row_conv) / read only (row_dk: dout rows)
-    const c32* U;      // row_dk: [B][inner][M1][1024] column-transformed u rows
-    c32* S;            // [inner][M1][1024] filter spectrum (row_spec: in place; row_conv: read; row_dk: output)
-    const float* bias; // [inner] or null (row_conv)
+    const c32* U;      // row_dk: [B][inner][M1][1024] column-transformed u rows; row_spec: filter rows [inner][M1][1024]
+    c32* S;            // row_spec out / row_conv in: [inner][M1][1024] x {A, Bc} (16 B);  row_dk out: [inner][M1][1024] c32
+    const float* bias; // [inner] or null (row_spec)
     Tables tab;
     int M1;
     int inner;
@@ -492,13 +552,13 @@ struct RowArgs {
 
 enum { MODE_CONV = 0, MODE_CORR = 1 };
 
-// packed-domain product for one element.  x, xp = Z[k], Z[partner]; h, hp = H[k], H[partner]; w = w_M^k.
+// Coefficients of the packed-domain product for one element: Z'[k] = A Z[k] + Bc conj(Z[p]).
+// h, hp = H[k], H[partner] (packed filter spectrum); w = w_M^k; bias already scaled.
 template <int MODE>
-__device__ __forceinline__ c32 packed_product(c32 x, c32 xp, c32 h, c32 hp, c32 w, float bias) {
-    // He = (h + conj(hp))/2 ; Ho = (h - conj(hp))/(2i) = -i/2 (h - conj(hp))
+__device__ __forceinline__ c32x2 packed_coeffs(c32 h, c32 hp, c32 w, float bias, float scale) {
+    // He = (h + conj(hp))/2 ; Ho = (h - conj(hp))/(2i)
     const c32 He = mk(0.5f * (h.x + hp.x), 0.5f * (h.y - hp.y));
-    const c32 dlt = mk(h.x - hp.x, h.y + hp.y);
-    const c32 Ho = mk(0.5f * dlt.y, -0.5f * dlt.x);
+    const c32 Ho = mk(0.5f * (h.y + hp.y), -0.5f * (h.x - hp.x));
     c32 Ke, Ko;
     if (MODE == MODE_CONV) {
         Ke = mk(He.x + bias, He.y);
@@ -510,140 +570,246 @@ __device__ __forceinline__ c32 packed_product(c32 x, c32 xp, c32 h, c32 hp, c32 
     // A = Ke + (i/2)(1 - w) Ko ; Bc = (i/2)(1 + w) Ko
     const c32 t1 = cmul(mk(1.f - w.x, -w.y), Ko);
     const c32 t2 = cmul(mk(1.f + w.x, w.y), Ko);
-    const c32 A = mk(Ke.x - 0.5f * t1.y, Ke.y + 0.5f * t1.x);
-    const c32 Bc = mk(-0.5f * t2.y, 0.5f * t2.x);
-    return cadd(cmul(A, x), cmulc(Bc, xp));
+    c32x2 r;
+    r.a = mk((Ke.x - 0.5f * t1.y) * scale, (Ke.y + 0.5f * t1.x) * scale);
+    r.b = mk(-0.5f * t2.y * scale, 0.5f * t2.x * scale);
+    return r;
+}
+template <int MODE>
+__device__ __forceinline__ c32 packed_product(c32 x, c32 xp, c32 h, c32 hp, c32 w, float bias) {
+    const c32x2 c = packed_coeffs<MODE>(h, hp, w, bias, 1.0f);
+    return cadd(cmul(c.a, x), cmulc(c.b, xp));
 }
 
-// Filter spectrum: row transform of the column-transformed packed filter, scaled by 1/M, in place.
+// geometry shared by the row kernels: which rows the two half-waves of slot `slot` own, and where partners live
+struct RowGeom {
+    int myrow, pk_base, phalf;
+    bool valid;
+};
+__device__ __forceinline__ RowGeom row_geom(int slot, int half, int M1) {
+    RowGeom g;
+    const bool slot0 = slot == 0;
+    g.myrow = slot0 ? (half ? (M1 >> 1) : 0) : (half ? M1 - slot : slot);
+    g.valid = slot0 ? (half == 0 || M1 >= 2) : true;
+    g.pk_base = (slot0 && half == 0) ? 1024 : 1023;      // partner of k2 is (pk_base - k2) & 1023 ...
+    g.phalf = slot0 ? half : 1 - half;                   // ... in this half-wave's row
+    if (!g.valid) g.myrow = 0;                           // the idle half (M1 == 1) mirrors row 0; its results are dropped
+    return g;
+}
+
+// Filter spectrum -> product coefficients.  In: U = column-transformed packed filter rows [inner][M1][1024].
+// Out: S[ch][row][k2] = {A, Bc} * (1/M) for the requested MODE, bias folded in (Ke += bias).
+template <int MODE>
 __global__ void __launch_bounds__(64, 2) row_spec_kernel(RowArgs a) {
     HY_SMEM(smem);
     const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
-    c32* xb = reinterpret_cast<c32*>(smem) + half * ROW_LDS;
-    const int row = 2 * blockIdx.x + half;
-    const bool valid = row < a.M1;
-    c32* p = a.S + (size_t)blockIdx.y * a.M1 * 1024;               // wave-uniform base, 32-bit lane offsets
-    const unsigned o = (unsigned)((valid ? row : 0) * 1024 + j);
-    c32 v[32];
-    HY_UNROLL
-    for (int s = 0; s < 32; ++s) v[s] = valid ? ldg(p, o + 32 * s) : mk(0.f, 0.f);
-    row_fft1024<false>(v, xb, j, a.tab.tw_rowT);
-    if (valid) {
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) stg(p, o + 32 * q, cscale(v[q], a.scale));
-    }
-}
-
-template <int MODE>
-__global__ void __launch_bounds__(64, 2) row_conv_kernel(RowArgs a) {
-    HY_SMEM(smem);
-    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
-    c32* xb = reinterpret_cast<c32*>(smem) + half * ROW_LDS;
+    c32* const lds = reinterpret_cast<c32*>(smem);
+    c32* xb = lds + half * ROW_LDS;
     const int M1 = a.M1;
-    const int slot = blockIdx.x;                 // 0 = the self-paired rows (0, M1/2); else the pair (slot, M1 - slot)
-    const bool slot0 = slot == 0;
-    const int ch = blockIdx.y, b = blockIdx.z;
-    const int myrow = slot0 ? (half ? (M1 >> 1) : 0) : (half ? M1 - slot : slot);
-    const int prow = slot0 ? myrow : (half ? slot : M1 - slot);
-    const bool valid = slot0 ? (half == 0 || M1 >= 2) : true;
-    // partner element of k2 lives at pk2 = (pk_base - k2) & 1023 of row `prow`
-    const int pk_base = (slot0 && half == 0) ? 1024 : 1023;
-    const c32* xpb = reinterpret_cast<c32*>(smem) + (slot0 ? half : 1 - half) * ROW_LDS;   // partner row's LDS image
-    // wave-uniform bases + 32-bit lane offsets (keeps addresses in SGPRs; 64-bit per-access addresses cost
-    // two VGPRs each and spill)
-    c32* X = a.X + ((size_t)b * a.inner + ch) * M1 * 1024;
-    const c32* Sc = a.S + (size_t)ch * M1 * 1024;
-    const unsigned om = (unsigned)((valid ? myrow : 0) * 1024);    // my row
-    const unsigned op = (unsigned)((valid ? prow : 0) * 1024);     // partner row
-    const float bias = (a.bias != nullptr) ? a.bias[ch] * a.scale : 0.f;
+    const int ch = blockIdx.y;
+    const RowGeom g = row_geom(blockIdx.x, half, M1);
+    const unsigned rowbytes = (unsigned)M1 * 1024u * 8u;
+    const GBuf in = make_gbuf(a.U + (size_t)ch * M1 * 1024, rowbytes);
+    const GBuf out = make_gbuf(reinterpret_cast<const c32x2*>(a.S) + (size_t)ch * M1 * 1024, 2 * rowbytes);
+    const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
+    const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
+    const unsigned vo = (unsigned)(g.myrow * 1024 + j) * 8u;
 
     c32 v[32];
     HY_UNROLL
-    for (int s = 0; s < 32; ++s) v[s] = valid ? ldg(X, om + j + 32 * s) : mk(0.f, 0.f);
-    row_fft1024<false>(v, xb, j, a.tab.tw_rowT);
-
-    const c32 wk1 = a.tab.tw_lo[valid ? myrow : 0];     // w_M^k1
+    for (int s = 0; s < 32; ++s) v[s] = gb_ld(in, vo, (unsigned)s * 256u);
+    row_fft1024<false>(v, xb, j, twT);
+    const c32 wk1 = a.tab.tw_lo[g.myrow];
     HY_UNROLL
     for (int q = 0; q < 32; ++q) xb[j + 33 * q] = v[q];            // natural position k2 = j + 32 q
     __syncthreads();
-    HY_UNROLL
-    for (int q = 0; q < 32; ++q) {
-        const int k2 = j + 32 * q;
-        const int pk2 = (pk_base - k2) & 1023;
-        const c32 xp = xpb[row_idx(pk2)];
-        const c32 w = cmul(wk1, ldg(a.tab.tw_row, (unsigned)k2));
-        v[q] = packed_product<MODE>(v[q], xp, ldg(Sc, om + k2), ldg(Sc, op + pk2), w, bias);
-        if ((q & 7) == 7) HY_SCHED_FENCE();
-    }
-    __syncthreads();
-    row_fft1024<true>(v, xb, j, a.tab.tw_rowT);
-    if (valid) {
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) stg(X, om + j + 32 * q, v[q]);
-    }
-}
-
-// dk spectrum: acc[k] = sum_b corr-product(G_b, U_b); rows of X (= dout) and U are column-transformed only;
-// the result, scaled by 1/M and row-inverse-transformed, goes to S[ch] for col_inv.
-// LDS: two natural-order images per wave (G and U spectra): 2 * 2 * ROW_LDS c32.
-__global__ void __launch_bounds__(64, 2) row_dk_kernel(RowArgs a) {
-    HY_SMEM(smem);
-    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
-    c32* xb = reinterpret_cast<c32*>(smem) + half * ROW_LDS;
-    c32* hb = xb + 2 * ROW_LDS;
-    const int M1 = a.M1;
-    const int slot = blockIdx.x;
-    const bool slot0 = slot == 0;
-    const int ch = blockIdx.y;
-    const int myrow = slot0 ? (half ? (M1 >> 1) : 0) : (half ? M1 - slot : slot);
-    const bool valid = slot0 ? (half == 0 || M1 >= 2) : true;
-    const int pk_base = (slot0 && half == 0) ? 1024 : 1023;
-    const int phalf = slot0 ? half : 1 - half;
-    const c32* xpb = reinterpret_cast<c32*>(smem) + phalf * ROW_LDS;
-    const c32* hpb = xpb + 2 * ROW_LDS;
-    const c32 wk1 = a.tab.tw_lo[valid ? myrow : 0];
-    const unsigned om = (unsigned)((valid ? myrow : 0) * 1024 + j);
-
-    c32 acc[32];
-    HY_UNROLL
-    for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
-
-    for (int b = 0; b < a.B; ++b) {
-        const size_t off = ((size_t)b * a.inner + ch) * M1 * 1024;
-        const c32* X = a.X + off;
-        const c32* U = a.U + off;
-        c32 v[32];
-        // U spectrum -> LDS image hb (natural order)
-        HY_UNROLL
-        for (int s = 0; s < 32; ++s) v[s] = valid ? ldg(U, om + 32 * s) : mk(0.f, 0.f);
-        row_fft1024<false>(v, hb, j, a.tab.tw_rowT);
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) hb[j + 33 * q] = v[q];
-        // G spectrum -> registers + LDS image xb
-        HY_UNROLL
-        for (int s = 0; s < 32; ++s) v[s] = valid ? ldg(X, om + 32 * s) : mk(0.f, 0.f);
-        row_fft1024<false>(v, xb, j, a.tab.tw_rowT);
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) xb[j + 33 * q] = v[q];
-        __syncthreads();
+    const c32* xpb = lds + g.phalf * ROW_LDS;
+    if (g.valid) {
         HY_UNROLL
         for (int q = 0; q < 32; ++q) {
             const int k2 = j + 32 * q;
-            const int pk2 = (pk_base - k2) & 1023;
-            const c32 w = cmul(wk1, ldg(a.tab.tw_row, (unsigned)k2));
-            acc[q] = cadd(acc[q], packed_product<MODE_CORR>(v[q], xpb[row_idx(pk2)], hb[j + 33 * q], hpb[row_idx(pk2)], w, 0.f));
-            if ((q & 7) == 7) HY_SCHED_FENCE();
+            const c32 hp = xpb[row_idx((g.pk_base - k2) & 1023)];
+            const c32 w = cmul(wk1, gb_ld(twR, (unsigned)j * 8u, (unsigned)q * 256u));
+            gb_st2(out, 2 * vo, (unsigned)q * 512u, packed_coeffs<MODE>(v[q], hp, w, bias, a.scale));
+        }
+    }
+}
+
+// X <- IFFT_row( A * FFT_row(X) + Bc * conj(FFT_row(X)[partner]) ), in place, for every (b, channel, row pair).
+__global__ void __launch_bounds__(64, 2) row_conv_kernel(RowArgs a) {
+    HY_SMEM(smem);
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    c32* const lds = reinterpret_cast<c32*>(smem);
+    c32* xb = lds + half * ROW_LDS;
+    const int M1 = a.M1;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    const RowGeom g = row_geom(blockIdx.x, half, M1);
+    const unsigned rowbytes = (unsigned)M1 * 1024u * 8u;
+    const GBuf X = make_gbuf(a.X + ((size_t)b * a.inner + ch) * M1 * 1024, rowbytes);
+    const GBuf S = make_gbuf(reinterpret_cast<const c32x2*>(a.S) + (size_t)ch * M1 * 1024, 2 * rowbytes);
+    const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192);
+    const unsigned vo = (unsigned)(g.myrow * 1024 + j) * 8u;
+
+    c32 v[32];
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+    row_fft1024<false>(v, xb, j, twT);
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) xb[j + 33 * q] = v[q];            // natural position k2 = j + 32 q
+    __syncthreads();
+    const c32* xpb = lds + g.phalf * ROW_LDS;
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) {
+        const int k2 = j + 32 * q;
+        const c32 xp = xpb[row_idx((g.pk_base - k2) & 1023)];
+        const c32x2 c = gb_ld2(S, 2 * vo, (unsigned)q * 512u);
+        v[q] = cadd(cmul(c.a, v[q]), cmulc(c.b, xp));
+    }
+    __syncthreads();
+    row_fft1024<true>(v, xb, j, twT);
+    if (g.valid) {
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
+    }
+}
+
+// dk spectrum: acc[k] = sum_b corr-product(G_b, U_b), G = dout rows, U = u rows (both column-transformed
+// only); the result, scaled by 1/M and row-inverse-transformed, goes to S[ch] (c32) for col_inv.
+//
+// General slots use the pair form of the product: r_even, r_odd of a real correlation are real sequences, so with
+//     Ge = (g + conj(gp))/2, Go = (g - conj(gp))/(2i)   (same for U),   w = w_M^k
+//     Re = Ge conj(Ue) + Go conj(Uo)        Ro = conj(w) Ge conj(Uo) + Go conj(Ue)
+//     Z'[k] = Re + i Ro                     Z'[p] = conj(Re) + i conj(Ro)
+// one evaluation serves element k and its partner p.  Lane t owns registers q < 16 of its row and computes for
+// them AND for their partners (lane 63 - t, register 31 - q); the partner's results are accumulated locally and
+// handed over once after the batch loop.  Per batch item only the upper register halves travel through LDS (they
+// fit the FFT exchange buffer exactly), so the kernel needs one buffer: 16.9 KB per wavefront.
+//
+// Slot 0 (rows 0 and M1/2, self-paired with an irregular lane map) takes the per-element form with full
+// natural-order images, one row at a time so that the two images fit the same buffer.
+__device__ __forceinline__ void corr_pair(c32 g, c32 gp, c32 u, c32 up, c32 w, c32& zk, c32& zp) {
+    const c32 Ge = mk(0.5f * (g.x + gp.x), 0.5f * (g.y - gp.y));
+    const c32 Go = mk(0.5f * (g.y + gp.y), -0.5f * (g.x - gp.x));
+    const c32 Ue = mk(0.5f * (u.x + up.x), 0.5f * (u.y - up.y));
+    const c32 Uo = mk(0.5f * (u.y + up.y), -0.5f * (u.x - up.x));
+    const c32 GeUo = cmulc(Ge, Uo);
+    const c32 Re = cadd(cmulc(Ge, Ue), cmulc(Go, Uo));
+    const c32 Ro = cadd(cmulc(GeUo, w), cmulc(Go, Ue));
+    zk = mk(Re.x - Ro.y, Re.y + Ro.x);        // Re + i Ro
+    zp = mk(Re.x + Ro.y, Ro.x - Re.y);        // conj(Re) + i conj(Ro)
+}
+
+__global__ void __launch_bounds__(64, 2) row_dk_kernel(RowArgs a) {
+    HY_SMEM(smem);
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    c32* const lds = reinterpret_cast<c32*>(smem);
+    const int M1 = a.M1;
+    const int slot = blockIdx.x;
+    const int ch = blockIdx.y;
+    const unsigned rowbytes = (unsigned)M1 * 1024u * 8u;
+    const GBuf O = make_gbuf(a.S + (size_t)ch * M1 * 1024, rowbytes);
+    const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
+
+    if (slot != 0) {
+        c32* xb = lds + half * ROW_LDS;                    // my row's exchange buffer / upper-half image
+        c32* xl = xb + j;                                  // lane bases: every LDS access below is base + immediate
+        const c32* pl = lds + (1 - half) * ROW_LDS + (31 - j);   // the partner lane's column in the partner row's image
+        HY_OPAQUE(xl);
+        HY_OPAQUE(pl);
+        const int myrow = half ? M1 - slot : slot;
+        const c32 wk1 = a.tab.tw_lo[myrow];
+        const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
+        c32 acc[32];                                       // [q < 16]: mine;  [16 + q]: for the partner's register 31 - q
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
+        for (int b = 0; b < a.B; ++b) {
+            const size_t off = ((size_t)b * a.inner + ch) * M1 * 1024;
+            const GBuf X = make_gbuf(a.X + off, rowbytes), U = make_gbuf(a.U + off, rowbytes);
+            c32 h[32], v[32];
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) h[s] = gb_ld(U, vo, (unsigned)s * 256u);
+            row_fft1024<false>(h, xb, j, twT);
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+            row_fft1024<false>(v, xb, j, twT);
+            HY_UNROLL
+            for (int q = 0; q < 16; ++q) {                 // publish the upper register halves
+                xl[q * 32] = v[16 + q];
+                xl[512 + q * 32] = h[16 + q];
+            }
+            __syncthreads();
+            HY_UNROLL
+            for (int q = 0; q < 16; ++q) {
+                const c32 gp = pl[(15 - q) * 32];          // partner register 31 - q
+                const c32 up = pl[512 + (15 - q) * 32];
+                const c32 w = cmul(wk1, gb_ld(twR, (unsigned)j * 8u, (unsigned)q * 256u));
+                c32 zk, zp;
+                corr_pair(v[q], gp, h[q], up, w, zk, zp);
+                acc[q] = cadd(acc[q], zk);
+                acc[16 + q] = cadd(acc[16 + q], zp);
+            }
+            __syncthreads();
+        }
+        // hand the partner's sums over, assemble my 32 registers, scale
+        HY_UNROLL
+        for (int q = 0; q < 16; ++q) xl[q * 32] = acc[16 + q];
+        __syncthreads();
+        HY_UNROLL
+        for (int q = 0; q < 16; ++q) {
+            acc[q] = cscale(acc[q], a.scale);
+            acc[31 - q] = cscale(pl[q * 32], a.scale);     // partner's entry q is my register 31 - q
         }
         __syncthreads();
-    }
-    HY_UNROLL
-    for (int q = 0; q < 32; ++q) acc[q] = cscale(acc[q], a.scale);
-    row_fft1024<true>(acc, xb, j, a.tab.tw_rowT);
-    if (valid) {
-        c32* O = a.S + (size_t)ch * M1 * 1024;
-        const unsigned oo = (unsigned)(myrow * 1024 + j);
+        row_fft1024<true>(acc, xb, j, twT);
         HY_UNROLL
-        for (int q = 0; q < 32; ++q) stg(O, oo + 32 * q, acc[q]);
+        for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, acc[q]);
+        return;
+    }
+
+    // ---- slot 0: rows 0 and M1/2, one at a time; both half-waves mirror each other (same addresses, same values)
+    c32* A = lds;                 // U image / exchange
+    c32* Bm = lds + ROW_LDS;      // G image / exchange
+    const int nrows = M1 >= 2 ? 2 : 1;
+    for (int rsel = 0; rsel < nrows; ++rsel) {
+        const int myrow = rsel ? (M1 >> 1) : 0;
+        const int pk_base = rsel ? 1023 : 1024;
+        const c32 wk1 = a.tab.tw_lo[myrow];
+        const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
+        c32 acc[32];
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
+        for (int b = 0; b < a.B; ++b) {
+            const size_t off = ((size_t)b * a.inner + ch) * M1 * 1024;
+            const GBuf X = make_gbuf(a.X + off, rowbytes), U = make_gbuf(a.U + off, rowbytes);
+            c32 v[32];
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) v[s] = gb_ld(U, vo, (unsigned)s * 256u);
+            row_fft1024<false>(v, A, j, twT);
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) A[j + 33 * q] = v[q];
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+            row_fft1024<false>(v, Bm, j, twT);
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) Bm[j + 33 * q] = v[q];
+            __syncthreads();
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) {
+                const int k2 = j + 32 * q;
+                const int pk2 = (pk_base - k2) & 1023;
+                const c32 w = cmul(wk1, gb_ld(twR, (unsigned)j * 8u, (unsigned)q * 256u));
+                acc[q] = cadd(acc[q], packed_product<MODE_CORR>(v[q], Bm[row_idx(pk2)], A[j + 33 * q], A[row_idx(pk2)], w, 0.f));
+            }
+            __syncthreads();
+        }
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) acc[q] = cscale(acc[q], a.scale);
+        row_fft1024<true>(acc, A, j, twT);
+        if (half == 0) {
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, acc[q]);
+        }
+        __syncthreads();
     }
 }
 
