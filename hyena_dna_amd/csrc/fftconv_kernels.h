@@ -112,8 +112,14 @@ __device__ __forceinline__ c32 gb_ld(GBuf b, unsigned voff, unsigned soff) {
     return mk(u2f(w.x), u2f(w.y));
 }
 __device__ __forceinline__ void gb_st(GBuf b, unsigned voff, unsigned soff, c32 v) {
+    // STORES never use the scalar-offset field: on gfx950 a buffer_store with an SGPR soffset was observed to read
+    // its data VGPRs late -- a VALU instruction issued a few slots later that re-used a data register (here: the
+    // next iteration's LDS index) leaked into the stored value for lanes 12-15/28-31 of either half-wave, rarely
+    // and timing-dependently (hipcc's hazard recogniser exempts stores that have a register soffset).  With the
+    // offset folded into voffset/immediate the store is an ordinary one.  Found by
+    // tests/test_gpu_parity.py::test_properties_at_baseline_sizes (causality / determinism at D = 256).
     hy_u2 w; w.x = f2u(v.x); w.y = f2u(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(w, b.r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(w, b.r, voff + soff, 0, 0);
 }
 struct __attribute__((aligned(16))) c32x2 { c32 a, b; };
 typedef unsigned hy_u4 __attribute__((ext_vector_type(4)));
@@ -122,8 +128,8 @@ __device__ __forceinline__ c32x2 gb_ld2(GBuf b, unsigned voff, unsigned soff) {
     c32x2 r; r.a = mk(u2f(w.x), u2f(w.y)); r.b = mk(u2f(w.z), u2f(w.w)); return r;
 }
 __device__ __forceinline__ void gb_st2(GBuf b, unsigned voff, unsigned soff, c32x2 v) {
-    hy_u4 w; w.x = f2u(v.a.x); w.y = f2u(v.a.y); w.z = f2u(v.b.x); w.w = f2u(v.b.y);
-    __builtin_amdgcn_raw_buffer_store_b128(w, b.r, voff, soff, 0);
+    gb_st(b, voff, soff, v.a);          // two 8-byte stores (see gb_st for why not one dwordx4 with soffset)
+    gb_st(b, voff + 8u, soff, v.b);
 }
 // makes a value opaque to the optimiser at this point (keeps "lane base + immediate" LDS addressing intact)
 #define HY_OPAQUE(x) asm volatile("" : "+v"(x))
