@@ -45,14 +45,14 @@ bool make_plan(int L, Plan* p) {
     return true;
 }
 
-// table layout inside d_tables (c32 units): tw_lo[1024] | tw_row[1024] | tw_rowT[1024] | tw_hi[M1]
+// table layout inside d_tables (c32 units): tw_lo[1024] | tw_hi[1024 slots, M1 used] | tw_row[1024] | tw_rowT[1024]
 Tables tables_from(const void* d_tables) {
     const c32* t = reinterpret_cast<const c32*>(d_tables);
     Tables tab;
     tab.tw_lo = t;
-    tab.tw_row = t + 1024;
-    tab.tw_rowT = t + 2048;
-    tab.tw_hi = t + 3072;
+    tab.tw_hi = t + 1024;
+    tab.tw_row = t + 2048;
+    tab.tw_rowT = t + 3072;
     return tab;
 }
 
@@ -97,22 +97,17 @@ int launch_col(int dtype, int M1, const ColArgs& a, int rows, void* stream) {
 
 const size_t ROW_SMEM = 2 * ROW_LDS * sizeof(c32);
 
-int launch_row_conv(const RowArgs& a, void* stream) {
-    const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;   // slot 0 = rows (0, M1/2); slot s = rows (s, M1 - s)
-    HY_LAUNCH(row_conv_kernel, dim3(nslots, a.inner, a.B), dim3(64), ROW_SMEM, stream, a);
-    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
-}
-
-int launch_row_dk(const RowArgs& a, void* stream) {
-    const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;
-    HY_LAUNCH(row_dk_kernel, dim3(nslots, a.inner), dim3(64), ROW_SMEM, stream, a);
-    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
-}
-
 template <int MODE>
-int launch_row_spec(const RowArgs& a, void* stream) {
+int launch_row_prod2(const RowArgs& a, void* stream) {
+    const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;   // slot 0 = rows (0, M1/2); slot s = rows (s, M1 - s)
+    HY_LAUNCH((row_prod2_kernel<MODE>), dim3(nslots, a.inner), dim3(64), ROW_SMEM, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+template <bool DO_DU>
+int launch_row_bwd(const RowArgs& a, void* stream) {
     const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;
-    HY_LAUNCH((row_spec_kernel<MODE>), dim3(nslots, a.inner), dim3(64), ROW_SMEM, stream, a);
+    HY_LAUNCH((row_bwd_kernel<DO_DU>), dim3(nslots, a.inner), dim3(64), ROW_SMEM, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
@@ -145,33 +140,34 @@ int hyena_fftconv_fft_size(int L) {
 size_t hyena_fftconv_table_bytes(int L) {
     Plan p;
     if (!make_plan(L, &p)) return 0;
-    return (size_t)(3072 + p.M1) * sizeof(c32);
+    return (size_t)4096 * sizeof(c32);
 }
 
 int hyena_fftconv_init_tables(void* d_tables, int L) {
     Plan p;
     if (d_tables == nullptr) return HYENA_ERR_BAD_ARG;
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
-    std::vector<c32> h(3072 + p.M1);
+    std::vector<c32> h(4096);
+    for (auto& e : h) { e.x = 1.0f; e.y = 0.0f; }
     const double tau = 6.283185307179586476925286766559;
     for (int i = 0; i < 1024; ++i) {
         double a = -tau * (double)i / (double)p.M;
         h[i].x = (float)std::cos(a);
         h[i].y = (float)std::sin(a);
         double r = -tau * (double)i / 1024.0;
-        h[1024 + i].x = (float)std::cos(r);
-        h[1024 + i].y = (float)std::sin(r);
+        h[2048 + i].x = (float)std::cos(r);
+        h[2048 + i].y = (float)std::sin(r);
     }
     for (int s = 0; s < 32; ++s)
         for (int j = 0; j < 32; ++j) {
             double r = -tau * (double)(s * j) / 1024.0;
-            h[2048 + s * 32 + j].x = (float)std::cos(r);
-            h[2048 + s * 32 + j].y = (float)std::sin(r);
+            h[3072 + s * 32 + j].x = (float)std::cos(r);
+            h[3072 + s * 32 + j].y = (float)std::sin(r);
         }
     for (int i = 0; i < p.M1; ++i) {
         double a = -tau * (double)i / (double)p.M1;
-        h[3072 + i].x = (float)std::cos(a);
-        h[3072 + i].y = (float)std::sin(a);
+        h[1024 + i].x = (float)std::cos(a);
+        h[1024 + i].y = (float)std::sin(a);
     }
 #ifdef HIPEMU
     memcpy(d_tables, h.data(), h.size() * sizeof(c32));
@@ -185,7 +181,7 @@ int hyena_fftconv_init_tables(void* d_tables, int L) {
 int hyena_fftconv_default_chunk(int B, int D, int L, int backward) {
     Plan p;
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
-    const size_t per_channel = (size_t)(backward ? 2 * B + 4 : B + 3) * p.M * sizeof(c32);
+    const size_t per_channel = (size_t)(backward ? 2 * B + 2 : B + 1) * p.M * sizeof(c32);
     size_t c = CACHE_BUDGET / per_channel;
     if (c < 1) c = 1;
     if (c > (size_t)D) c = D;
@@ -197,7 +193,7 @@ size_t hyena_fftconv_workspace_bytes(int B, int D, int L, int backward, int chun
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, backward);
     if (chunk > D) chunk = D;
-    return (size_t)(backward ? 2 * B + 4 : B + 3) * chunk * p.M * sizeof(c32);
+    return (size_t)(backward ? 2 * B + 2 : B + 1) * chunk * p.M * sizeof(c32);
 }
 
 int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int dtype,
@@ -213,29 +209,23 @@ int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* ou
 
     const Tables tab = tables_from(d_tables);
     c32* Wk = reinterpret_cast<c32*>(workspace);                // [chunk][M]      column-transformed filter
-    c32* S2 = Wk + (size_t)chunk * p.M;                         // [chunk][M][2]   product coefficients {A, Bc}
-    c32* W = S2 + 2 * (size_t)chunk * p.M;                      // [B][chunk][M]
+    c32* W = Wk + (size_t)chunk * p.M;                          // [B][chunk][M]   column-transformed activations
     const size_t es = elem_size(dtype);
     int st;
     for (int d0 = 0; d0 < D; d0 += chunk) {
         const int cd = (D - d0 < chunk) ? D - d0 : chunk;
-        // filter spectrum of the chunk's channels -> product coefficients
         ColArgs ck;
         ck.x = k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd;
         ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
         if ((st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
-        RowArgs rs;
-        rs.X = nullptr; rs.U = Wk; rs.S = S2; rs.bias = bias ? bias + d0 : nullptr; rs.tab = tab; rs.M1 = p.M1;
-        rs.inner = cd; rs.B = 1; rs.scale = 1.0f / (float)p.M;
-        if ((st = launch_row_spec<MODE_CONV>(rs, stream))) return st;
-        // u rows
         ColArgs cu;
         cu.x = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cu.W = W; cu.tab = tab; cu.L = L; cu.inner = cd;
         cu.outer_stride = (long)D * L; cu.inner_stride = L; cu.aux0 = nullptr; cu.x2 = nullptr; cu.W2 = nullptr;
         if ((st = launch_col<false>(dtype, p.M1, cu, B * cd, stream))) return st;
-        RowArgs rc = rs;
-        rc.X = W; rc.U = nullptr; rc.bias = nullptr; rc.B = B;
-        if ((st = launch_row_conv(rc, stream))) return st;
+        RowArgs rc;
+        rc.X = W; rc.U = Wk; rc.S = nullptr; rc.bias = bias ? bias + d0 : nullptr; rc.K = nullptr; rc.tab = tab;
+        rc.M1 = p.M1; rc.inner = cd; rc.B = B; rc.scale = 1.0f / (float)p.M;
+        if ((st = launch_row_prod2<MODE_CONV>(rc, stream))) return st;
         ColArgs co = cu;
         co.x = reinterpret_cast<char*>(out) + (size_t)d0 * L * es;
         if ((st = launch_col<true>(dtype, p.M1, co, B * cd, stream))) return st;
@@ -258,41 +248,40 @@ int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const flo
 
     const Tables tab = tables_from(d_tables);
     c32* Wk = reinterpret_cast<c32*>(workspace);                // [chunk][M]      column-transformed filter
-    c32* S2 = Wk + (size_t)chunk * p.M;                         // [chunk][M][2]   corr-mode product coefficients
-    c32* Sdk = S2 + 2 * (size_t)chunk * p.M;                    // [chunk][M]      dk spectrum -> packed dk
-    c32* Wg = Sdk + (size_t)chunk * p.M;                        // [B][chunk][M]
-    c32* Wu = Wg + (size_t)B * chunk * p.M;                     // [B][chunk][M]
+    c32* Sdk = Wk + (size_t)chunk * p.M;                        // [chunk][M]      dk rows (batch sum) -> packed dk
+    c32* Wg = Sdk + (size_t)chunk * p.M;                        // [B][chunk][M]   dout rows -> du rows
+    c32* Wu = Wg + (size_t)B * chunk * p.M;                     // [B][chunk][M]   u rows
     const size_t es = elem_size(dtype);
     int st;
     for (int d0 = 0; d0 < D; d0 += chunk) {
         const int cd = (D - d0 < chunk) ? D - d0 : chunk;
-        RowArgs rs;
-        rs.X = nullptr; rs.U = Wk; rs.S = S2; rs.bias = bias ? bias + d0 : nullptr; rs.tab = tab; rs.M1 = p.M1;
-        rs.inner = cd; rs.B = 1; rs.scale = 1.0f / (float)p.M;
         ColArgs cg;
         cg.x = reinterpret_cast<const char*>(dout) + (size_t)d0 * L * es; cg.W = Wg; cg.tab = tab; cg.L = L; cg.inner = cd;
         cg.outer_stride = (long)D * L; cg.inner_stride = L; cg.aux0 = nullptr; cg.x2 = nullptr; cg.W2 = nullptr;
         ColArgs cgu = cg;                                        // dout (and u, when dk is wanted) in ONE launch
         if (dk != nullptr) { cgu.x2 = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cgu.W2 = Wu; }
         if ((st = launch_col<false>(dtype, p.M1, cgu, B * cd, stream))) return st;
+        ColArgs ck;
+        ck.x = k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd;
+        ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
+        if (du != nullptr && (st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
+        RowArgs rb;
+        rb.X = Wg; rb.U = Wu; rb.S = Sdk; rb.bias = bias ? bias + d0 : nullptr; rb.K = Wk; rb.tab = tab;
+        rb.M1 = p.M1; rb.inner = cd; rb.B = B; rb.scale = 1.0f / (float)p.M;
         if (dk != nullptr) {
-            RowArgs rd = rs;
-            rd.X = Wg; rd.U = Wu; rd.S = Sdk; rd.bias = nullptr; rd.B = B;
-            if ((st = launch_row_dk(rd, stream))) return st;
+            if (du != nullptr) st = launch_row_bwd<true>(rb, stream);
+            else st = launch_row_bwd<false>(rb, stream);
+            if (st) return st;
             ColArgs cdk;
             cdk.x = dk + (size_t)d0 * L; cdk.W = Sdk; cdk.tab = tab; cdk.L = L; cdk.inner = cd;
             cdk.outer_stride = 0; cdk.inner_stride = L; cdk.aux0 = dbias ? dbias + d0 : nullptr; cdk.x2 = nullptr; cdk.W2 = nullptr;
             if ((st = launch_col<true>(HYENA_F32, p.M1, cdk, cd, stream))) return st;
+        } else {
+            RowArgs rc = rb;                                     // du only: X = dout rows, H = filter rows, corr
+            rc.U = Wk; rc.K = nullptr; rc.S = nullptr;
+            if ((st = launch_row_prod2<MODE_CORR>(rc, stream))) return st;
         }
         if (du != nullptr) {
-            ColArgs ck;
-            ck.x = k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd;
-            ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
-            if ((st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
-            if ((st = launch_row_spec<MODE_CORR>(rs, stream))) return st;
-            RowArgs rc = rs;
-            rc.X = Wg; rc.U = nullptr; rc.bias = nullptr; rc.B = B;
-            if ((st = launch_row_conv(rc, stream))) return st;
             ColArgs co = cg;
             co.x = reinterpret_cast<char*>(du) + (size_t)d0 * L * es;
             if ((st = launch_col<true>(dtype, p.M1, co, B * cd, stream))) return st;

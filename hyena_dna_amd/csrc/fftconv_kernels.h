@@ -77,6 +77,24 @@ __device__ __forceinline__ c32 cscale(c32 a, float s) { return mk(a.x * s, a.y *
 __device__ __forceinline__ uint32_t f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
 __device__ __forceinline__ float u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
 
+// LDS pointers carry their address space explicitly.  Left generic, hipcc loses track of it once a pointer is
+// passed through a function or selected in a loop, and falls back to FLAT instructions (64-bit address pairs,
+// spills, slower).  lc32 is a built-in vector type because a struct cannot be copied through an
+// address-space-qualified reference.
+#ifdef HIPEMU
+#define HY_LDS
+typedef c32 lc32;
+__device__ __forceinline__ c32 lds_ld(const lc32* p) { return *p; }
+__device__ __forceinline__ void lds_st(lc32* p, c32 v) { *p = v; }
+#define HY_LDS_CAST(T, p) reinterpret_cast<T*>(p)
+#else
+#define HY_LDS __attribute__((address_space(3)))
+typedef float lc32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c32 lds_ld(const HY_LDS lc32* p) { const lc32 t = *p; return mk(t.x, t.y); }
+__device__ __forceinline__ void lds_st(HY_LDS lc32* p, c32 v) { lc32 t; t.x = v.x; t.y = v.y; *p = t; }
+#define HY_LDS_CAST(T, p) ((HY_LDS T*)(p))
+#endif
+
 // Global access as wave-uniform base + 32-bit BYTE offset: lets hipcc use the SGPR-base/VGPR-offset form of
 // global_load/store instead of materialising a 64-bit address pair per access (which spills).
 __device__ __forceinline__ c32 ldg(const c32* base, unsigned idx) {
@@ -222,27 +240,36 @@ template <> struct Elem<DT_F16> {
     }
 };
 
-// z[n] = (x[2n], x[2n+1]) of a real row of L samples, zero beyond L.  `vec` = the row base is aligned
-// for a two-element access (L even), wave-uniform.
+// Pair access z[n] = (x[2n], x[2n+1]) of a real row.  A pair is moved as ONE 4-byte (16-bit types) or 8-byte (fp32)
+// access that may be under-aligned (odd L: odd rows start 2 / 4 bytes off) -- gfx950 global memory handles that, and
+// __builtin_memcpy lets hipcc emit a single global_load/store_dword(x2).  Keeping the raw word and converting
+// later lets a thread issue all its loads back to back (branchy element-wise loads were serialised by hipcc with
+// an s_waitcnt vmcnt(0) after every one).
+template <int DT> struct Pair;
+template <> struct Pair<DT_F32> {
+    typedef c32 raw_t;
+    static __device__ __forceinline__ c32 cvt(raw_t w) { return w; }
+    static __device__ __forceinline__ raw_t pack(c32 v) { return v; }
+};
+template <> struct Pair<DT_BF16> {
+    typedef uint32_t raw_t;
+    static __device__ __forceinline__ c32 cvt(raw_t w) { return mk(u2f(w << 16), u2f(w & 0xffff0000u)); }
+    static __device__ __forceinline__ raw_t pack(c32 v) { return (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16); }
+};
+template <> struct Pair<DT_F16> {
+    typedef uint32_t raw_t;
+    static __device__ __forceinline__ c32 cvt(raw_t w) { return mk(f16_to_f32((uint16_t)(w & 0xffffu)), f16_to_f32((uint16_t)(w >> 16))); }
+    static __device__ __forceinline__ raw_t pack(c32 v) { return (uint32_t)f32_to_f16(v.x) | ((uint32_t)f32_to_f16(v.y) << 16); }
+};
 template <int DT>
-__device__ __forceinline__ c32 load_pair(const typename Elem<DT>::type* row, int n, int L, bool vec) {
-    const int i = 2 * n;
-    if (i + 1 < L) {
-        if (vec) return Elem<DT>::ld2(row + i);
-        return mk(Elem<DT>::ld(row + i), Elem<DT>::ld(row + i + 1));
-    }
-    if (i < L) return mk(Elem<DT>::ld(row + i), 0.f);
-    return mk(0.f, 0.f);
+__device__ __forceinline__ typename Pair<DT>::raw_t load_raw_pair(const typename Elem<DT>::type* row, int n) {
+    typename Pair<DT>::raw_t w;
+    __builtin_memcpy(&w, row + 2 * n, sizeof(w));
+    return w;
 }
 template <int DT>
-__device__ __forceinline__ void store_pair(typename Elem<DT>::type* row, int n, int L, bool vec, c32 v) {
-    const int i = 2 * n;
-    if (i + 1 < L) {
-        if (vec) Elem<DT>::st2(row + i, v);
-        else { Elem<DT>::st(row + i, v.x); Elem<DT>::st(row + i + 1, v.y); }
-    } else if (i < L) {
-        Elem<DT>::st(row + i, v.x);
-    }
+__device__ __forceinline__ void store_raw_pair(typename Elem<DT>::type* row, int n, typename Pair<DT>::raw_t w) {
+    __builtin_memcpy(row + 2 * n, &w, sizeof(w));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -317,28 +344,46 @@ enum { ROW_N = 1024, ROW_LDS = 1024 + 32 };
 
 __device__ __forceinline__ int row_idx(int p) { return p + (p >> 5); }
 
+// Stage twiddles w_1024^(j s), s = 8a + b, as the product tA[a] * tB[b] of ten table entries per lane
+// (tB[b] = w^(j b), b = 1..7; tA[a] = w^(8 j a), a = 1..3): 10 loads (kept in 20 VGPRs for every transform of the
+// kernel) instead of 31, at the price of one extra rounding in 21 of the 31 twiddles.
+struct RowTw {
+    c32 tB[8];   // [0] unused
+    c32 tA[4];   // [0] unused
+};
+__device__ __forceinline__ void load_row_tw(RowTw& t, GBuf twT, int j) {
+    HY_UNROLL
+    for (int b = 1; b < 8; ++b) t.tB[b] = gb_ld(twT, (unsigned)j * 8u, (unsigned)b * 256u);
+    HY_UNROLL
+    for (int a = 1; a < 4; ++a) t.tA[a] = gb_ld(twT, (unsigned)j * 8u, (unsigned)(8 * a) * 256u);
+}
+
 template <bool INV>
-__device__ __forceinline__ void row_fft1024(c32 (&v)[32], c32* xb, int j, GBuf twT) {
+__device__ __forceinline__ void row_fft1024(c32 (&v)[32], HY_LDS lc32* xb, int j, const RowTw& t) {
     dft_reg<32, INV>(v);
     HY_UNROLL
-    for (int q = 0; q < 32; ++q) xb[j * 33 + q] = v[q];             // position j*32 + q
+    for (int q = 0; q < 32; ++q) lds_st(xb + j * 33 + q, v[q]);     // position j*32 + q
     __syncthreads();
     HY_UNROLL
-    for (int s = 0; s < 32; ++s) v[s] = xb[j + 33 * s];             // position j + 32 s
+    for (int s = 0; s < 32; ++s) v[s] = lds_ld(xb + j + 33 * s);    // position j + 32 s
     __syncthreads();
     HY_UNROLL
     for (int s = 1; s < 32; ++s) {
-        const c32 w = gb_ld(twT, (unsigned)j * 8u, (unsigned)s * 256u);
+        const int a = s >> 3, b = s & 7;
+        c32 ta = t.tA[a & 3], tb = t.tB[b];
+        // opaque copies: otherwise hipcc hoists all 21 products out of the batch loop / shares them between the
+        // transforms of a kernel, i.e. keeps 31 twiddles (62 VGPRs) alive and spills
+        HY_OPAQUE(ta.x); HY_OPAQUE(ta.y); HY_OPAQUE(tb.x); HY_OPAQUE(tb.y);
+        const c32 w = (a == 0) ? tb : (b == 0) ? ta : cmul(ta, tb);
         v[s] = INV ? cmulc(v[s], w) : cmul(v[s], w);
     }
     dft_reg<32, INV>(v);
-    HY_SCHED_FENCE();   // keep the caller's next phase (and its loads) out of the butterflies: register pressure
 }
 
 // ---------------------------------------------------------------------------------------------
 // tables (device memory, built by the host in double precision)
 //   tw_lo[p]   = w_M^p,            p < 1024
-//   tw_hi[p]   = w_M^(1024 p) = w_M1^p,   p < M1
+//   tw_hi[p]   = w_M^(1024 p) = w_M1^p,   p < M1      (stored right behind tw_lo: one contiguous copy to LDS)
 //   tw_row[p]  = w_1024^p,         p < 1024
 //   tw_rowT[s*32 + j] = w_1024^(j s)
 // ---------------------------------------------------------------------------------------------
@@ -377,20 +422,61 @@ struct ColArgs {
     c32* W2;            // ... and where its transform goes; lets dout and u share one launch in the backward
 };
 
-__device__ __forceinline__ c32 outer_tw(const c32* tlo, const c32* thi, int n2, int k1) {
+__device__ __forceinline__ c32 outer_tw(const HY_LDS lc32* tlo, const HY_LDS lc32* thi, int n2, int k1) {
     const int p = n2 * k1;
-    return cmul(tlo[p & 1023], thi[p >> 10]);
+    return cmul(lds_ld(tlo + (p & 1023)), lds_ld(thi + (p >> 10)));
+}
+
+// copy tw_lo | tw_hi (contiguous, 1024 + M1 entries) into LDS: all loads first, then all LDS writes
+template <int M1, int THREADS>
+__device__ __forceinline__ void stage_col_tables(HY_LDS lc32* tab, const c32* __restrict__ src, int tid) {
+    constexpr int NTAB = 1024 + M1, NT = (NTAB + THREADS - 1) / THREADS;
+    c32 tt[NT];
+    HY_UNROLL
+    for (int i = 0; i < NT; ++i) {
+        const int idx = tid + i * THREADS;
+        tt[i] = src[idx < NTAB ? idx : NTAB - 1];
+    }
+    HY_UNROLL
+    for (int i = 0; i < NT; ++i) {
+        const int idx = tid + i * THREADS;
+        if (idx < NTAB) lds_st(tab + idx, tt[i]);
+    }
+}
+
+// LDS exchange of the two Stockham stages of a column transform, one float plane at a time:
+// position p of column c lives at plane[p*C + c]; thread (c, r) writes p = r*32 + q, reads p = (r + T i) + 32 s.
+template <int T, int C, int NB>
+__device__ __forceinline__ void col_exchange(const c32 (&v)[32], c32 (&x2)[32], HY_LDS float* plane, int c, int r) {
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].x;
+    __syncthreads();
+    HY_UNROLL
+    for (int i = 0; i < NB; ++i) {
+        HY_UNROLL
+        for (int s = 0; s < T; ++s) x2[i * T + s].x = plane[((r + T * i) + 32 * s) * C + c];
+    }
+    __syncthreads();
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].y;
+    __syncthreads();
+    HY_UNROLL
+    for (int i = 0; i < NB; ++i) {
+        HY_UNROLL
+        for (int s = 0; s < T; ++s) x2[i * T + s].y = plane[((r + T * i) + 32 * s) * C + c];
+    }
 }
 
 template <int M1, int DT>
 __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_fwd_kernel(ColArgs a) {
     typedef ColCfg<M1> Cfg;
     typedef typename Elem<DT>::type elem_t;
+    typedef typename Pair<DT>::raw_t raw_t;
     constexpr int T = Cfg::T, C = Cfg::C, E = Cfg::E;
     HY_SMEM(smem);
-    c32* tlo = reinterpret_cast<c32*>(smem);
-    c32* thi = tlo + 1024;
-    float* plane = reinterpret_cast<float*>(thi + M1);
+    HY_LDS lc32* tlo = HY_LDS_CAST(lc32, smem);
+    HY_LDS lc32* thi = tlo + 1024;
+    HY_LDS float* plane = HY_LDS_CAST(float, thi + M1);
 
     const int tid = threadIdx.x;
     const int c = tid % C, r = tid / C;
@@ -399,21 +485,33 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_fwd_kernel(ColArgs a)
     const bool second = blockIdx.z != 0;
     const elem_t* xrow = reinterpret_cast<const elem_t*>(second ? a.x2 : a.x) + (long)(row / a.inner) * a.outer_stride +
                          (long)(row % a.inner) * a.inner_stride;
-    const bool vec = (a.L & 1) == 0;
     c32* Wrow = (second ? a.W2 : a.W) + (size_t)row * M1 * 1024;
+    const int nfull = a.L >> 1;                         // pairs n < nfull are complete; n == nfull is the odd tail
 
-    for (int i = tid; i < 1024; i += Cfg::THREADS) tlo[i] = a.tab.tw_lo[i];
-    for (int i = tid; i < M1; i += Cfg::THREADS) thi[i] = a.tab.tw_hi[i];
-
+    // all global loads of the thread back to back: E input pairs (+ the table slice)
+    raw_t raw[E];
+    if (nfull > 0) {
+        HY_UNROLL
+        for (int s = 0; s < E; ++s) {
+            const int n = (r + T * s) * 1024 + n2;
+            raw[s] = load_raw_pair<DT>(xrow, n < nfull ? n : 0);
+        }
+    }
+    stage_col_tables<M1, Cfg::THREADS>(tlo, a.tab.tw_lo, tid);
     c32 v[E];
     HY_UNROLL
     for (int s = 0; s < E; ++s) {
-        const int n1 = r + T * s;
-        v[s] = load_pair<DT>(xrow, n1 * 1024 + n2, a.L, vec);
+        const int n = (r + T * s) * 1024 + n2;
+        v[s] = (n < nfull) ? Pair<DT>::cvt(raw[s]) : mk(0.f, 0.f);
+    }
+    if (a.L & 1) {                                      // odd L: the last sample is the real part of pair nfull
+        HY_UNROLL
+        for (int s = 0; s < E; ++s)
+            if ((r + T * s) * 1024 + n2 == nfull) v[s] = mk(Elem<DT>::ld(xrow + a.L - 1), 0.f);
     }
     dft_reg<E, false>(v);
 
-    if (T == 1) {
+    if constexpr (T == 1) {
         __syncthreads();   // tables
         HY_UNROLL
         for (int q = 0; q < E; ++q) {
@@ -423,31 +521,14 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_fwd_kernel(ColArgs a)
     } else {
         constexpr int NB = Cfg::NB;
         c32 x2[32];
-        // exchange, real plane then imaginary plane: position p of column c lives at plane[p*C + c]
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].x;
-        __syncthreads();
-        HY_UNROLL
-        for (int i = 0; i < NB; ++i) {
-            HY_UNROLL
-            for (int s = 0; s < T; ++s) x2[i * T + s].x = plane[((r + T * i) + 32 * s) * C + c];
-        }
-        __syncthreads();
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].y;
-        __syncthreads();
-        HY_UNROLL
-        for (int i = 0; i < NB; ++i) {
-            HY_UNROLL
-            for (int s = 0; s < T; ++s) x2[i * T + s].y = plane[((r + T * i) + 32 * s) * C + c];
-        }
+        col_exchange<T, C, NB>(v, x2, plane, c, r);     // its first barrier also covers the table staging
         HY_UNROLL
         for (int i = 0; i < NB; ++i) {
             const int jj = r + T * i;
             c32 y[T];
             y[0] = x2[i * T];
             HY_UNROLL
-            for (int s = 1; s < T; ++s) y[s] = cmul(x2[i * T + s], thi[jj * s]);
+            for (int s = 1; s < T; ++s) y[s] = cmul(x2[i * T + s], lds_ld(thi + jj * s));
             dft_reg<T, false>(y);
             HY_UNROLL
             for (int q = 0; q < T; ++q) {
@@ -459,15 +540,22 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_fwd_kernel(ColArgs a)
     }
 }
 
+template <int DT>
+__device__ __forceinline__ void col_store(typename Elem<DT>::type* xrow, int n, int nfull, int L, c32 v, float* aux0, int row) {
+    if (n < nfull) store_raw_pair<DT>(xrow, n, Pair<DT>::pack(v));
+    else if (n == nfull && (L & 1)) Elem<DT>::st(xrow + L - 1, v.x);
+    if (aux0 != nullptr && n == 0) aux0[row] = v.x;
+}
+
 template <int M1, int DT>
 __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_inv_kernel(ColArgs a) {
     typedef ColCfg<M1> Cfg;
     typedef typename Elem<DT>::type elem_t;
     constexpr int T = Cfg::T, C = Cfg::C, E = Cfg::E;
     HY_SMEM(smem);
-    c32* tlo = reinterpret_cast<c32*>(smem);
-    c32* thi = tlo + 1024;
-    float* plane = reinterpret_cast<float*>(thi + M1);
+    HY_LDS lc32* tlo = HY_LDS_CAST(lc32, smem);
+    HY_LDS lc32* thi = tlo + 1024;
+    HY_LDS float* plane = HY_LDS_CAST(float, thi + M1);
 
     const int tid = threadIdx.x;
     const int c = tid % C, r = tid / C;
@@ -475,63 +563,35 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_inv_kernel(ColArgs a)
     const int row = blockIdx.y;
     elem_t* xrow = reinterpret_cast<elem_t*>(const_cast<void*>(a.x)) + (long)(row / a.inner) * a.outer_stride +
                    (long)(row % a.inner) * a.inner_stride;
-    const bool vec = (a.L & 1) == 0;
     const c32* Wrow = a.W + (size_t)row * M1 * 1024;
-
-    for (int i = tid; i < 1024; i += Cfg::THREADS) tlo[i] = a.tab.tw_lo[i];
-    for (int i = tid; i < M1; i += Cfg::THREADS) thi[i] = a.tab.tw_hi[i];
-    __syncthreads();
+    const int nfull = a.L >> 1;
 
     c32 v[E];
     HY_UNROLL
-    for (int s = 0; s < E; ++s) {
-        const int k1 = r + T * s;
-        const c32 w = outer_tw(tlo, thi, n2, k1);
-        v[s] = cmulc(ldg(Wrow, (unsigned)(k1 * 1024 + n2)), w);
-    }
+    for (int s = 0; s < E; ++s) v[s] = ldg(Wrow, (unsigned)((r + T * s) * 1024 + n2));   // all loads first
+    stage_col_tables<M1, Cfg::THREADS>(tlo, a.tab.tw_lo, tid);
+    __syncthreads();
+    HY_UNROLL
+    for (int s = 0; s < E; ++s) v[s] = cmulc(v[s], outer_tw(tlo, thi, n2, r + T * s));
     dft_reg<E, true>(v);
 
-    if (T == 1) {
+    if constexpr (T == 1) {
         HY_UNROLL
-        for (int q = 0; q < E; ++q) {
-            const int n = q * 1024 + n2;
-            store_pair<DT>(xrow, n, a.L, vec, v[q]);
-            if (a.aux0 != nullptr && n == 0) a.aux0[row] = v[q].x;
-        }
+        for (int q = 0; q < E; ++q) col_store<DT>(xrow, q * 1024 + n2, nfull, a.L, v[q], a.aux0, row);
     } else {
         constexpr int NB = Cfg::NB;
         c32 x2[32];
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].x;
-        __syncthreads();
-        HY_UNROLL
-        for (int i = 0; i < NB; ++i) {
-            HY_UNROLL
-            for (int s = 0; s < T; ++s) x2[i * T + s].x = plane[((r + T * i) + 32 * s) * C + c];
-        }
-        __syncthreads();
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].y;
-        __syncthreads();
-        HY_UNROLL
-        for (int i = 0; i < NB; ++i) {
-            HY_UNROLL
-            for (int s = 0; s < T; ++s) x2[i * T + s].y = plane[((r + T * i) + 32 * s) * C + c];
-        }
+        col_exchange<T, C, NB>(v, x2, plane, c, r);
         HY_UNROLL
         for (int i = 0; i < NB; ++i) {
             const int jj = r + T * i;
             c32 y[T];
             y[0] = x2[i * T];
             HY_UNROLL
-            for (int s = 1; s < T; ++s) y[s] = cmulc(x2[i * T + s], thi[jj * s]);
+            for (int s = 1; s < T; ++s) y[s] = cmulc(x2[i * T + s], lds_ld(thi + jj * s));
             dft_reg<T, true>(y);
             HY_UNROLL
-            for (int q = 0; q < T; ++q) {
-                const int n = (jj + 32 * q) * 1024 + n2;
-                store_pair<DT>(xrow, n, a.L, vec, y[q]);
-                if (a.aux0 != nullptr && n == 0) a.aux0[row] = y[q].x;
-            }
+            for (int q = 0; q < T; ++q) col_store<DT>(xrow, (jj + 32 * q) * 1024 + n2, nfull, a.L, y[q], a.aux0, row);
         }
     }
 }
@@ -545,10 +605,11 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_inv_kernel(ColArgs a)
 // Lane t: half = t / 32 picks the row, j = t % 32; v[q] is element k2 = j + 32 q.
 // ---------------------------------------------------------------------------------------------
 struct RowArgs {
-    c32* X;            // [B][inner][M1][1024]  in place (row_conv) / read only (row_dk: dout rows)
-    const c32* U;      // row_dk: [B][inner][M1][1024] column-transformed u rows; row_spec: filter rows [inner][M1][1024]
-    c32* S;            // row_spec out / row_conv in: [inner][M1][1024] x {A, Bc} (16 B);  row_dk out: [inner][M1][1024] c32
-    const float* bias; // [inner] or null (row_spec)
+    c32* X;            // [B][inner][M1][1024]  column-transformed activation rows, transformed in place
+    const c32* U;      // row_prod2: filter rows [inner][M1][1024];  row_bwd: u rows [B][inner][M1][1024]
+    c32* S;            // row_bwd out: dk rows [inner][M1][1024]
+    const float* bias; // [inner] or null
+    const c32* K;      // row_bwd: filter rows [inner][M1][1024]
     Tables tab;
     int M1;
     int inner;
@@ -587,6 +648,15 @@ __device__ __forceinline__ c32 packed_product(c32 x, c32 xp, c32 h, c32 hp, c32 
     return cadd(cmul(c.a, x), cmulc(c.b, xp));
 }
 
+// w_M^k for k = k1 + M1 (j + 32 q):  (w_M^k1 * w_1024^j) * w_32^q, the last factor a compile-time constant.
+__device__ __forceinline__ c32 pw_tw(c32 wkj, int q) {
+    HY_OPAQUE(wkj.x); HY_OPAQUE(wkj.y);            // recompute per use instead of keeping 32 hoisted products alive
+    if (q == 0) return wkj;
+    if (q < 16) return mk(wkj.x * tw32_cos(q) + wkj.y * tw32_sin(q), wkj.y * tw32_cos(q) - wkj.x * tw32_sin(q));
+    if (q == 16) return mk(-wkj.x, -wkj.y);
+    return mk(-(wkj.x * tw32_cos(q - 16) + wkj.y * tw32_sin(q - 16)), -(wkj.y * tw32_cos(q - 16) - wkj.x * tw32_sin(q - 16)));
+}
+
 // geometry shared by the row kernels: which rows the two half-waves of slot `slot` own, and where partners live
 struct RowGeom {
     int myrow, pk_base, phalf;
@@ -603,219 +673,285 @@ __device__ __forceinline__ RowGeom row_geom(int slot, int half, int M1) {
     return g;
 }
 
-// Filter spectrum -> product coefficients.  In: U = column-transformed packed filter rows [inner][M1][1024].
-// Out: S[ch][row][k2] = {A, Bc} * (1/M) for the requested MODE, bias folded in (Ke += bias).
+// ---------------------------------------------------------------------------------------------
+// Two-operand row kernels: both operands arrive column-transformed only; the kernel row-transforms both, forms
+// the packed-domain product in its pair form and inverse-transforms.  No spectrum is materialised in memory
+// (row_spec + row_conv move 32 more bytes per point per row through the cache hierarchy), so these are the
+// path for small batches, where the filter's row transform is not amortised anyway.
+//
+// Pair form for a real filter/signal pair (E, O = even/odd spectra of x; He, Ho of h; Ke = He + bias; w = w_M^k):
+//     conv:  Ye = E Ke + w O Ho               Yo = E Ho + O Ke
+//     corr:  Ye = E conj(Ke) + O conj(Ho)     Yo = conj(w) E conj(Ho) + O conj(Ke)
+//     Z'[k] = Ye + i Yo                       Z'[partner] = conj(Ye) + i conj(Yo)
+// ---------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ void __launch_bounds__(64, 2) row_spec_kernel(RowArgs a) {
+__device__ __forceinline__ void prod_pair(c32 x, c32 xp, c32 h, c32 hp, c32 w, float bias, c32& zk, c32& zp) {
+    const c32 E = mk(0.5f * (x.x + xp.x), 0.5f * (x.y - xp.y));
+    const c32 O = mk(0.5f * (x.y + xp.y), -0.5f * (x.x - xp.x));
+    const c32 Ke = mk(0.5f * (h.x + hp.x) + bias, 0.5f * (h.y - hp.y));
+    const c32 Ho = mk(0.5f * (h.y + hp.y), -0.5f * (h.x - hp.x));
+    c32 Ye, Yo;
+    if (MODE == MODE_CONV) {
+        Ye = cadd(cmul(E, Ke), cmul(w, cmul(O, Ho)));
+        Yo = cadd(cmul(E, Ho), cmul(O, Ke));
+    } else {
+        Ye = cadd(cmulc(E, Ke), cmulc(O, Ho));
+        Yo = cadd(cmulc(cmulc(E, Ho), w), cmulc(O, Ke));
+    }
+    zk = mk(Ye.x - Yo.y, Ye.y + Yo.x);
+    zp = mk(Ye.x + Yo.y, Yo.x - Ye.y);
+}
+
+// One pair-form product pass of a general slot.  On entry v = spectrum of X (my 32 registers), h = spectrum of H.
+// On exit v = spectrum of the product, scaled.  xl / pl: my / my partner lane's column in the LDS buffer.
+template <int MODE>
+__device__ __forceinline__ void pair_pass(c32 (&v)[32], const c32 (&h)[32], HY_LDS lc32* xl, const HY_LDS lc32* pl, c32 wkj, float bias,
+                                          float scale) {
+    HY_UNROLL
+    for (int q = 0; q < 16; ++q) {                 // publish the upper register halves
+        lds_st(xl + q * 32, v[16 + q]);
+        lds_st(xl + 512 + q * 32, h[16 + q]);
+    }
+    __syncthreads();
+    HY_UNROLL
+    for (int q = 0; q < 16; ++q) {
+        const c32 xp = lds_ld(pl + (15 - q) * 32);          // partner register 31 - q
+        const c32 hp = lds_ld(pl + 512 + (15 - q) * 32);
+        c32 zk, zp;
+        prod_pair<MODE>(v[q], xp, h[q], hp, pw_tw(wkj, q), bias, zk, zp);
+        v[q] = cscale(zk, scale);
+        v[16 + q] = cscale(zp, scale);             // belongs to the partner's register 31 - q
+    }
+    __syncthreads();
+    HY_UNROLL
+    for (int q = 0; q < 16; ++q) lds_st(xl + q * 32, v[16 + q]);
+    __syncthreads();
+    HY_UNROLL
+    for (int q = 0; q < 16; ++q) v[31 - q] = lds_ld(pl + q * 32);
+    __syncthreads();
+}
+
+// Slot 0 (rows 0 and M1/2) of a two-operand product, one row: per-element form with two natural-order images.
+// v = X spectrum on entry / product spectrum (scaled) on exit; Hs = H spectrum registers.
+template <int MODE>
+__device__ __forceinline__ void slot0_pass(c32 (&v)[32], const c32 (&h)[32], HY_LDS lc32* A, HY_LDS lc32* Bm, int j, int pk_base, c32 wkj,
+                                           float bias, float scale) {
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) { lds_st(A + j + 33 * q, h[q]); lds_st(Bm + j + 33 * q, v[q]); }
+    __syncthreads();
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) {
+        const int pk2 = (pk_base - (j + 32 * q)) & 1023;
+        v[q] = cscale(packed_product<MODE>(v[q], lds_ld(Bm + row_idx(pk2)), h[q], lds_ld(A + row_idx(pk2)), pw_tw(wkj, q), bias), scale);
+    }
+    __syncthreads();
+}
+
+// X[b][ch] <- IFFT_row( product( FFT_row(X[b][ch]), FFT_row(H[ch]) ) ), in place, for b = 0 .. B-1.
+// grid (slots, inner); the filter rows are transformed once per workgroup and stay in registers over the batch loop.
+template <int MODE>
+__global__ void __launch_bounds__(64, 2) row_prod2_kernel(RowArgs a) {
     HY_SMEM(smem);
     const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
-    c32* const lds = reinterpret_cast<c32*>(smem);
-    c32* xb = lds + half * ROW_LDS;
+    HY_LDS lc32* const lds = HY_LDS_CAST(lc32, smem);
     const int M1 = a.M1;
-    const int ch = blockIdx.y;
-    const RowGeom g = row_geom(blockIdx.x, half, M1);
+    const int slot = blockIdx.x, ch = blockIdx.y;
     const unsigned rowbytes = (unsigned)M1 * 1024u * 8u;
-    const GBuf in = make_gbuf(a.U + (size_t)ch * M1 * 1024, rowbytes);
-    const GBuf out = make_gbuf(reinterpret_cast<const c32x2*>(a.S) + (size_t)ch * M1 * 1024, 2 * rowbytes);
+    const GBuf H = make_gbuf(a.U + (size_t)ch * M1 * 1024, rowbytes);
     const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
+    RowTw rtw;
+    load_row_tw(rtw, twT, j);
+    const c32 tj = gb_ld(twR, (unsigned)j * 8u, 0u);
     const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
-    const unsigned vo = (unsigned)(g.myrow * 1024 + j) * 8u;
 
-    c32 v[32];
-    HY_UNROLL
-    for (int s = 0; s < 32; ++s) v[s] = gb_ld(in, vo, (unsigned)s * 256u);
-    row_fft1024<false>(v, xb, j, twT);
-    const c32 wk1 = a.tab.tw_lo[g.myrow];
-    HY_UNROLL
-    for (int q = 0; q < 32; ++q) xb[j + 33 * q] = v[q];            // natural position k2 = j + 32 q
-    __syncthreads();
-    const c32* xpb = lds + g.phalf * ROW_LDS;
-    if (g.valid) {
+    if (slot != 0) {
+        HY_LDS lc32* xb = lds + half * ROW_LDS;
+        HY_LDS lc32* xl = xb + j;
+        const HY_LDS lc32* pl = lds + (1 - half) * ROW_LDS + (31 - j);
+        HY_OPAQUE(xl);
+        HY_OPAQUE(pl);
+        const int myrow = half ? M1 - slot : slot;
+        const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
+        c32 h[32], v[32];
         HY_UNROLL
-        for (int q = 0; q < 32; ++q) {
-            const int k2 = j + 32 * q;
-            const c32 hp = xpb[row_idx((g.pk_base - k2) & 1023)];
-            const c32 w = cmul(wk1, gb_ld(twR, (unsigned)j * 8u, (unsigned)q * 256u));
-            gb_st2(out, 2 * vo, (unsigned)q * 512u, packed_coeffs<MODE>(v[q], hp, w, bias, a.scale));
+        for (int s = 0; s < 32; ++s) h[s] = gb_ld(H, vo, (unsigned)s * 256u);
+        {
+            const GBuf X = make_gbuf(a.X + (size_t)ch * M1 * 1024, rowbytes);
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+        }
+        const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
+        row_fft1024<false>(h, xb, j, rtw);
+        for (int b = 0; b < a.B; ++b) {
+            const GBuf X = make_gbuf(a.X + ((size_t)b * a.inner + ch) * M1 * 1024, rowbytes);
+            if (b > 0) {
+                HY_UNROLL
+                for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+            }
+            row_fft1024<false>(v, xb, j, rtw);
+            pair_pass<MODE>(v, h, xl, pl, wkj, bias, a.scale);
+            row_fft1024<true>(v, xb, j, rtw);
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
+        }
+        return;
+    }
+    // slot 0: rows 0 and M1/2 one at a time; both half-waves mirror each other
+    HY_LDS lc32* A = lds;
+    HY_LDS lc32* Bm = lds + ROW_LDS;
+    const int nrows = M1 >= 2 ? 2 : 1;
+    for (int rsel = 0; rsel < nrows; ++rsel) {
+        const int myrow = rsel ? (M1 >> 1) : 0;
+        const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
+        const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
+        c32 h[32];
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) h[s] = gb_ld(H, vo, (unsigned)s * 256u);
+        row_fft1024<false>(h, A, j, rtw);
+        for (int b = 0; b < a.B; ++b) {
+            const GBuf X = make_gbuf(a.X + ((size_t)b * a.inner + ch) * M1 * 1024, rowbytes);
+            c32 v[32];
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+            row_fft1024<false>(v, Bm, j, rtw);
+            slot0_pass<MODE>(v, h, A, Bm, j, rsel ? 1023 : 1024, wkj, bias, a.scale);
+            row_fft1024<true>(v, Bm, j, rtw);
+            if (half == 0) {
+                HY_UNROLL
+                for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
+            }
+            __syncthreads();
         }
     }
 }
 
-// X <- IFFT_row( A * FFT_row(X) + Bc * conj(FFT_row(X)[partner]) ), in place, for every (b, channel, row pair).
-__global__ void __launch_bounds__(64, 2) row_conv_kernel(RowArgs a) {
+// Backward row kernel: for b = 0 .. B-1:  X[b] = dout rows (-> du rows, in place), U[b] = u rows; K = filter rows;
+// dk rows (summed over b in a fixed order: deterministic) go to S.  One row transform of dout serves both
+// gradients.  The batch sum is carried in S itself (the row's inverse transform is linear, so the partial sums are
+// added after it: one 16 KB read-modify-write per row pair and batch item, served by the L2) rather than in 64
+// accumulator registers.  DO_DU = false skips the du half (dk only).  grid (slots, inner).
+template <bool DO_DU>
+__global__ void __launch_bounds__(64, 2) row_bwd_kernel(RowArgs a) {
     HY_SMEM(smem);
     const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
-    c32* const lds = reinterpret_cast<c32*>(smem);
-    c32* xb = lds + half * ROW_LDS;
+    HY_LDS lc32* const lds = HY_LDS_CAST(lc32, smem);
     const int M1 = a.M1;
-    const int ch = blockIdx.y, b = blockIdx.z;
-    const RowGeom g = row_geom(blockIdx.x, half, M1);
+    const int slot = blockIdx.x, ch = blockIdx.y;
     const unsigned rowbytes = (unsigned)M1 * 1024u * 8u;
-    const GBuf X = make_gbuf(a.X + ((size_t)b * a.inner + ch) * M1 * 1024, rowbytes);
-    const GBuf S = make_gbuf(reinterpret_cast<const c32x2*>(a.S) + (size_t)ch * M1 * 1024, 2 * rowbytes);
-    const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192);
-    const unsigned vo = (unsigned)(g.myrow * 1024 + j) * 8u;
-
-    c32 v[32];
-    HY_UNROLL
-    for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
-    row_fft1024<false>(v, xb, j, twT);
-    HY_UNROLL
-    for (int q = 0; q < 32; ++q) xb[j + 33 * q] = v[q];            // natural position k2 = j + 32 q
-    __syncthreads();
-    const c32* xpb = lds + g.phalf * ROW_LDS;
-    HY_UNROLL
-    for (int q = 0; q < 32; ++q) {
-        const int k2 = j + 32 * q;
-        const c32 xp = xpb[row_idx((g.pk_base - k2) & 1023)];
-        const c32x2 c = gb_ld2(S, 2 * vo, (unsigned)q * 512u);
-        v[q] = cadd(cmul(c.a, v[q]), cmulc(c.b, xp));
-    }
-    __syncthreads();
-    row_fft1024<true>(v, xb, j, twT);
-    if (g.valid) {
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
-    }
-}
-
-// dk spectrum: acc[k] = sum_b corr-product(G_b, U_b), G = dout rows, U = u rows (both column-transformed
-// only); the result, scaled by 1/M and row-inverse-transformed, goes to S[ch] (c32) for col_inv.
-//
-// General slots use the pair form of the product: r_even, r_odd of a real correlation are real sequences, so with
-//     Ge = (g + conj(gp))/2, Go = (g - conj(gp))/(2i)   (same for U),   w = w_M^k
-//     Re = Ge conj(Ue) + Go conj(Uo)        Ro = conj(w) Ge conj(Uo) + Go conj(Ue)
-//     Z'[k] = Re + i Ro                     Z'[p] = conj(Re) + i conj(Ro)
-// one evaluation serves element k and its partner p.  Lane t owns registers q < 16 of its row and computes for
-// them AND for their partners (lane 63 - t, register 31 - q); the partner's results are accumulated locally and
-// handed over once after the batch loop.  Per batch item only the upper register halves travel through LDS (they
-// fit the FFT exchange buffer exactly), so the kernel needs one buffer: 16.9 KB per wavefront.
-//
-// Slot 0 (rows 0 and M1/2, self-paired with an irregular lane map) takes the per-element form with full
-// natural-order images, one row at a time so that the two images fit the same buffer.
-__device__ __forceinline__ void corr_pair(c32 g, c32 gp, c32 u, c32 up, c32 w, c32& zk, c32& zp) {
-    const c32 Ge = mk(0.5f * (g.x + gp.x), 0.5f * (g.y - gp.y));
-    const c32 Go = mk(0.5f * (g.y + gp.y), -0.5f * (g.x - gp.x));
-    const c32 Ue = mk(0.5f * (u.x + up.x), 0.5f * (u.y - up.y));
-    const c32 Uo = mk(0.5f * (u.y + up.y), -0.5f * (u.x - up.x));
-    const c32 GeUo = cmulc(Ge, Uo);
-    const c32 Re = cadd(cmulc(Ge, Ue), cmulc(Go, Uo));
-    const c32 Ro = cadd(cmulc(GeUo, w), cmulc(Go, Ue));
-    zk = mk(Re.x - Ro.y, Re.y + Ro.x);        // Re + i Ro
-    zp = mk(Re.x + Ro.y, Ro.x - Re.y);        // conj(Re) + i conj(Ro)
-}
-
-__global__ void __launch_bounds__(64, 2) row_dk_kernel(RowArgs a) {
-    HY_SMEM(smem);
-    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
-    c32* const lds = reinterpret_cast<c32*>(smem);
-    const int M1 = a.M1;
-    const int slot = blockIdx.x;
-    const int ch = blockIdx.y;
-    const unsigned rowbytes = (unsigned)M1 * 1024u * 8u;
+    const GBuf Kb = make_gbuf(a.K + (size_t)ch * M1 * 1024, rowbytes);
     const GBuf O = make_gbuf(a.S + (size_t)ch * M1 * 1024, rowbytes);
     const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
+    RowTw rtw;
+    load_row_tw(rtw, twT, j);
+    const c32 tj = gb_ld(twR, (unsigned)j * 8u, 0u);
+    const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
 
     if (slot != 0) {
-        c32* xb = lds + half * ROW_LDS;                    // my row's exchange buffer / upper-half image
-        c32* xl = xb + j;                                  // lane bases: every LDS access below is base + immediate
-        const c32* pl = lds + (1 - half) * ROW_LDS + (31 - j);   // the partner lane's column in the partner row's image
+        HY_LDS lc32* xb = lds + half * ROW_LDS;
+        HY_LDS lc32* xl = xb + j;
+        const HY_LDS lc32* pl = lds + (1 - half) * ROW_LDS + (31 - j);
         HY_OPAQUE(xl);
         HY_OPAQUE(pl);
         const int myrow = half ? M1 - slot : slot;
-        const c32 wk1 = a.tab.tw_lo[myrow];
         const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
-        c32 acc[32];                                       // [q < 16]: mine;  [16 + q]: for the partner's register 31 - q
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
+        const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
         for (int b = 0; b < a.B; ++b) {
             const size_t off = ((size_t)b * a.inner + ch) * M1 * 1024;
             const GBuf X = make_gbuf(a.X + off, rowbytes), U = make_gbuf(a.U + off, rowbytes);
             c32 h[32], v[32];
             HY_UNROLL
             for (int s = 0; s < 32; ++s) h[s] = gb_ld(U, vo, (unsigned)s * 256u);
-            row_fft1024<false>(h, xb, j, twT);
             HY_UNROLL
             for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
-            row_fft1024<false>(v, xb, j, twT);
-            HY_UNROLL
-            for (int q = 0; q < 16; ++q) {                 // publish the upper register halves
-                xl[q * 32] = v[16 + q];
-                xl[512 + q * 32] = h[16 + q];
+            row_fft1024<false>(h, xb, j, rtw);
+            row_fft1024<false>(v, xb, j, rtw);
+            {   // dk_b = corr(G, U): result into h (its registers are free once consumed), G stays in v
+                HY_UNROLL
+                for (int q = 0; q < 16; ++q) {
+                    lds_st(xl + q * 32, v[16 + q]);
+                    lds_st(xl + 512 + q * 32, h[16 + q]);
+                }
+                __syncthreads();
+                HY_UNROLL
+                for (int q = 0; q < 16; ++q) {
+                    const c32 gp = lds_ld(pl + (15 - q) * 32);
+                    const c32 up = lds_ld(pl + 512 + (15 - q) * 32);
+                    c32 zk, zp;
+                    prod_pair<MODE_CORR>(v[q], gp, h[q], up, pw_tw(wkj, q), 0.f, zk, zp);
+                    h[q] = cscale(zk, a.scale);
+                    h[16 + q] = cscale(zp, a.scale);
+                }
+                __syncthreads();
+                HY_UNROLL
+                for (int q = 0; q < 16; ++q) lds_st(xl + q * 32, h[16 + q]);
+                __syncthreads();
+                HY_UNROLL
+                for (int q = 0; q < 16; ++q) h[31 - q] = lds_ld(pl + q * 32);
+                __syncthreads();
             }
-            __syncthreads();
-            HY_UNROLL
-            for (int q = 0; q < 16; ++q) {
-                const c32 gp = pl[(15 - q) * 32];          // partner register 31 - q
-                const c32 up = pl[512 + (15 - q) * 32];
-                const c32 w = cmul(wk1, gb_ld(twR, (unsigned)j * 8u, (unsigned)q * 256u));
-                c32 zk, zp;
-                corr_pair(v[q], gp, h[q], up, w, zk, zp);
-                acc[q] = cadd(acc[q], zk);
-                acc[16 + q] = cadd(acc[16 + q], zp);
+            row_fft1024<true>(h, xb, j, rtw);
+            if (b > 0) {
+                HY_UNROLL
+                for (int q = 0; q < 32; ++q) h[q] = cadd(h[q], gb_ld(O, vo, (unsigned)q * 256u));
             }
-            __syncthreads();
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, h[q]);
+            if (DO_DU) {   // du_b = corr(G, K) + bias
+                HY_UNROLL
+                for (int s = 0; s < 32; ++s) h[s] = gb_ld(Kb, vo, (unsigned)s * 256u);
+                row_fft1024<false>(h, xb, j, rtw);
+                pair_pass<MODE_CORR>(v, h, xl, pl, wkj, bias, a.scale);
+                row_fft1024<true>(v, xb, j, rtw);
+                HY_UNROLL
+                for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
+            }
         }
-        // hand the partner's sums over, assemble my 32 registers, scale
-        HY_UNROLL
-        for (int q = 0; q < 16; ++q) xl[q * 32] = acc[16 + q];
-        __syncthreads();
-        HY_UNROLL
-        for (int q = 0; q < 16; ++q) {
-            acc[q] = cscale(acc[q], a.scale);
-            acc[31 - q] = cscale(pl[q * 32], a.scale);     // partner's entry q is my register 31 - q
-        }
-        __syncthreads();
-        row_fft1024<true>(acc, xb, j, twT);
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, acc[q]);
         return;
     }
-
-    // ---- slot 0: rows 0 and M1/2, one at a time; both half-waves mirror each other (same addresses, same values)
-    c32* A = lds;                 // U image / exchange
-    c32* Bm = lds + ROW_LDS;      // G image / exchange
+    HY_LDS lc32* A = lds;
+    HY_LDS lc32* Bm = lds + ROW_LDS;
     const int nrows = M1 >= 2 ? 2 : 1;
     for (int rsel = 0; rsel < nrows; ++rsel) {
         const int myrow = rsel ? (M1 >> 1) : 0;
         const int pk_base = rsel ? 1023 : 1024;
-        const c32 wk1 = a.tab.tw_lo[myrow];
         const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
-        c32 acc[32];
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
+        const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
         for (int b = 0; b < a.B; ++b) {
             const size_t off = ((size_t)b * a.inner + ch) * M1 * 1024;
             const GBuf X = make_gbuf(a.X + off, rowbytes), U = make_gbuf(a.U + off, rowbytes);
-            c32 v[32];
+            c32 h[32], v[32], g[32];
             HY_UNROLL
-            for (int s = 0; s < 32; ++s) v[s] = gb_ld(U, vo, (unsigned)s * 256u);
-            row_fft1024<false>(v, A, j, twT);
-            HY_UNROLL
-            for (int q = 0; q < 32; ++q) A[j + 33 * q] = v[q];
+            for (int s = 0; s < 32; ++s) h[s] = gb_ld(U, vo, (unsigned)s * 256u);
             HY_UNROLL
             for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
-            row_fft1024<false>(v, Bm, j, twT);
+            row_fft1024<false>(h, A, j, rtw);
+            row_fft1024<false>(v, Bm, j, rtw);
             HY_UNROLL
-            for (int q = 0; q < 32; ++q) Bm[j + 33 * q] = v[q];
-            __syncthreads();
-            HY_UNROLL
-            for (int q = 0; q < 32; ++q) {
-                const int k2 = j + 32 * q;
-                const int pk2 = (pk_base - k2) & 1023;
-                const c32 w = cmul(wk1, gb_ld(twR, (unsigned)j * 8u, (unsigned)q * 256u));
-                acc[q] = cadd(acc[q], packed_product<MODE_CORR>(v[q], Bm[row_idx(pk2)], A[j + 33 * q], A[row_idx(pk2)], w, 0.f));
+            for (int q = 0; q < 32; ++q) g[q] = v[q];
+            slot0_pass<MODE_CORR>(v, h, A, Bm, j, pk_base, wkj, 0.f, a.scale);          // v = dk_b spectrum
+            row_fft1024<true>(v, A, j, rtw);
+            if (b > 0) {
+                HY_UNROLL
+                for (int q = 0; q < 32; ++q) v[q] = cadd(v[q], gb_ld(O, vo, (unsigned)q * 256u));
+            }
+            if (half == 0) {
+                HY_UNROLL
+                for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, v[q]);
             }
             __syncthreads();
+            if (DO_DU) {
+                HY_UNROLL
+                for (int s = 0; s < 32; ++s) h[s] = gb_ld(Kb, vo, (unsigned)s * 256u);
+                row_fft1024<false>(h, A, j, rtw);
+                slot0_pass<MODE_CORR>(g, h, A, Bm, j, pk_base, wkj, bias, a.scale);     // g = du_b spectrum
+                row_fft1024<true>(g, A, j, rtw);
+                if (half == 0) {
+                    HY_UNROLL
+                    for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, g[q]);
+                }
+                __syncthreads();
+            }
         }
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) acc[q] = cscale(acc[q], a.scale);
-        row_fft1024<true>(acc, A, j, twT);
-        if (half == 0) {
-            HY_UNROLL
-            for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, acc[q]);
-        }
-        __syncthreads();
     }
 }
 

@@ -45,12 +45,12 @@ def test_host_only_entry_points(product_lib):
     assert L.hyena_fftconv_fft_size(1024) == 1024 and L.hyena_fftconv_fft_size(160000) == 262144
     assert L.hyena_fftconv_fft_size(450560) == 524288 and L.hyena_fftconv_fft_size(1 << 20) == 1 << 20
     assert L.hyena_fftconv_fft_size((1 << 20) + 1) == 0
-    assert L.hyena_fftconv_table_bytes(1 << 20) == (3072 + 1024) * 8
-    # workspace = (B + 3 | 2B + 4) * chunk * M * 8 bytes (fwd | bwd)
-    assert L.hyena_fftconv_workspace_bytes(1, 256, 1 << 20, 0, 4) == (1 + 3) * 4 * (1 << 20) * 8
-    assert L.hyena_fftconv_workspace_bytes(2, 256, 1 << 20, 1, 4) == (2 * 2 + 4) * 4 * (1 << 20) * 8
+    assert L.hyena_fftconv_table_bytes(1 << 20) == 4096 * 8
+    # workspace = (B + 1 | 2B + 2) * chunk * M * 8 bytes (fwd | bwd)
+    assert L.hyena_fftconv_workspace_bytes(1, 256, 1 << 20, 0, 4) == (1 + 1) * 4 * (1 << 20) * 8
+    assert L.hyena_fftconv_workspace_bytes(2, 256, 1 << 20, 1, 4) == (2 * 2 + 2) * 4 * (1 << 20) * 8
     c = L.hyena_fftconv_default_chunk(1, 256, 1 << 20, 0)
-    assert 1 <= c <= 256 and 4 * c * (1 << 20) * 8 <= 384 << 20
+    assert 1 <= c <= 256 and 2 * c * (1 << 20) * 8 <= 384 << 20
     assert L.hyena_fftconv_default_chunk(8, 128, 1024, 0) == 128
     assert b"workspace" in L.hyena_fftconv_error_string(3)
 
