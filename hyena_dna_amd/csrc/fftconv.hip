@@ -97,17 +97,20 @@ int launch_col(int dtype, int M1, const ColArgs& a, int rows, void* stream) {
 
 const size_t ROW_SMEM = 2 * ROW_LDS * sizeof(c32);
 
+const size_t ROW0_SMEM = ROW0_LDS * sizeof(c32);
+
+// rows 0 and M1/2 (self-paired) go through the row0_* kernels, the M1/2 - 1 regular pairs through row_*.
 template <int MODE>
 int launch_row_prod2(const RowArgs& a, void* stream) {
-    const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;   // slot 0 = rows (0, M1/2); slot s = rows (s, M1 - s)
-    HY_LAUNCH((row_prod2_kernel<MODE>), dim3(nslots, a.inner), dim3(64), ROW_SMEM, stream, a);
+    HY_LAUNCH((row0_prod2_kernel<MODE>), dim3(a.M1 >= 2 ? 2 : 1, (a.inner + 1) / 2), dim3(64), ROW0_SMEM, stream, a);
+    if (a.M1 >= 4) HY_LAUNCH((row_prod2_kernel<MODE>), dim3(a.M1 / 2 - 1, a.inner), dim3(64), ROW_SMEM, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
 template <bool DO_DU>
 int launch_row_bwd(const RowArgs& a, void* stream) {
-    const int nslots = a.M1 >= 2 ? a.M1 / 2 : 1;
-    HY_LAUNCH((row_bwd_kernel<DO_DU>), dim3(nslots, a.inner), dim3(64), ROW_SMEM, stream, a);
+    HY_LAUNCH((row0_bwd_kernel<DO_DU>), dim3(a.M1 >= 2 ? 2 : 1, (a.inner + 1) / 2), dim3(64), ROW0_SMEM, stream, a);
+    if (a.M1 >= 4) HY_LAUNCH((row_bwd_kernel<DO_DU>), dim3(a.M1 / 2 - 1, a.inner), dim3(64), ROW_SMEM, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 

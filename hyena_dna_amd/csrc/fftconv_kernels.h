@@ -648,13 +648,20 @@ __device__ __forceinline__ c32 packed_product(c32 x, c32 xp, c32 h, c32 hp, c32 
     return cadd(cmul(c.a, x), cmulc(c.b, xp));
 }
 
-// w_M^k for k = k1 + M1 (j + 32 q):  (w_M^k1 * w_1024^j) * w_32^q, the last factor a compile-time constant.
+// w_M^k for k = k1 + M1 (j + 32 q):  (w_M^k1 * w_1024^j) * w_32^q, the last factor from a 32-entry constant table
+// (a plain array, not a chain of conditionals: the loops calling this must stay under hipcc's unroll size limit;
+// the index is a compile-time constant after unrolling, so the loads fold to immediates).
+#ifdef HIPEMU
+#define HY_CONST_TABLE static const
+#else
+#define HY_CONST_TABLE __device__ static const
+#endif
+HY_CONST_TABLE float HY_COS32[32] = {1.0f, 0.98078528040323043058f, 0.92387953251128673848f, 0.83146961230254523567f, 0.70710678118654757274f, 0.55557023301960228867f, 0.38268343236508983729f, 0.19509032201612833135f, 0.0f, -0.19509032201612819257f, -0.38268343236508972627f, -0.5555702330196019556f, -0.70710678118654746172f, -0.83146961230254534669f, -0.92387953251128673848f, -0.98078528040323043058f, -1.0f, -0.98078528040323043058f, -0.92387953251128684951f, -0.83146961230254545772f, -0.70710678118654768376f, -0.55557023301960217765f, -0.38268343236509033689f, -0.19509032201612866442f, 0.0f, 0.19509032201612830359f, 0.38268343236509000382f, 0.55557023301960184458f, 0.70710678118654735069f, 0.83146961230254523567f, 0.92387953251128651644f, 0.98078528040323031956f};
+HY_CONST_TABLE float HY_SIN32[32] = {0.0f, 0.19509032201612824808f, 0.38268343236508978178f, 0.55557023301960217765f, 0.70710678118654746172f, 0.83146961230254523567f, 0.92387953251128673848f, 0.98078528040323043058f, 1.0f, 0.98078528040323043058f, 0.92387953251128673848f, 0.83146961230254545772f, 0.70710678118654757274f, 0.55557023301960217765f, 0.3826834323650898928f, 0.19509032201612860891f, 0.0f, -0.19509032201612835911f, -0.38268343236508967076f, -0.5555702330196019556f, -0.70710678118654746172f, -0.83146961230254523567f, -0.92387953251128651644f, -0.98078528040323031956f, -1.0f, -0.98078528040323043058f, -0.92387953251128662746f, -0.83146961230254545772f, -0.70710678118654768376f, -0.55557023301960217765f, -0.3826834323650903924f, -0.19509032201612871993f};
 __device__ __forceinline__ c32 pw_tw(c32 wkj, int q) {
     HY_OPAQUE(wkj.x); HY_OPAQUE(wkj.y);            // recompute per use instead of keeping 32 hoisted products alive
-    if (q == 0) return wkj;
-    if (q < 16) return mk(wkj.x * tw32_cos(q) + wkj.y * tw32_sin(q), wkj.y * tw32_cos(q) - wkj.x * tw32_sin(q));
-    if (q == 16) return mk(-wkj.x, -wkj.y);
-    return mk(-(wkj.x * tw32_cos(q - 16) + wkj.y * tw32_sin(q - 16)), -(wkj.y * tw32_cos(q - 16) - wkj.x * tw32_sin(q - 16)));
+    const float c = HY_COS32[q], sn = HY_SIN32[q];
+    return mk(wkj.x * c + wkj.y * sn, wkj.y * c - wkj.x * sn);
 }
 
 // geometry shared by the row kernels: which rows the two half-waves of slot `slot` own, and where partners live
@@ -731,31 +738,16 @@ __device__ __forceinline__ void pair_pass(c32 (&v)[32], const c32 (&h)[32], HY_L
     __syncthreads();
 }
 
-// Slot 0 (rows 0 and M1/2) of a two-operand product, one row: per-element form with two natural-order images.
-// v = X spectrum on entry / product spectrum (scaled) on exit; Hs = H spectrum registers.
-template <int MODE>
-__device__ __forceinline__ void slot0_pass(c32 (&v)[32], const c32 (&h)[32], HY_LDS lc32* A, HY_LDS lc32* Bm, int j, int pk_base, c32 wkj,
-                                           float bias, float scale) {
-    HY_UNROLL
-    for (int q = 0; q < 32; ++q) { lds_st(A + j + 33 * q, h[q]); lds_st(Bm + j + 33 * q, v[q]); }
-    __syncthreads();
-    HY_UNROLL
-    for (int q = 0; q < 32; ++q) {
-        const int pk2 = (pk_base - (j + 32 * q)) & 1023;
-        v[q] = cscale(packed_product<MODE>(v[q], lds_ld(Bm + row_idx(pk2)), h[q], lds_ld(A + row_idx(pk2)), pw_tw(wkj, q), bias), scale);
-    }
-    __syncthreads();
-}
-
-// X[b][ch] <- IFFT_row( product( FFT_row(X[b][ch]), FFT_row(H[ch]) ) ), in place, for b = 0 .. B-1.
-// grid (slots, inner); the filter rows are transformed once per workgroup and stay in registers over the batch loop.
+// X[b][ch] <- IFFT_row( product( FFT_row(X[b][ch]), FFT_row(H[ch]) ) ), in place, for b = 0 .. B-1, for the
+// row pairs (slot, M1 - slot), slot = 1 .. M1/2 - 1.  grid (M1/2 - 1, inner); the filter rows are transformed once
+// per workgroup and stay in registers over the batch loop.  (Rows 0 and M1/2: row0_prod2_kernel.)
 template <int MODE>
 __global__ void __launch_bounds__(64, 2) row_prod2_kernel(RowArgs a) {
     HY_SMEM(smem);
     const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
     HY_LDS lc32* const lds = HY_LDS_CAST(lc32, smem);
     const int M1 = a.M1;
-    const int slot = blockIdx.x, ch = blockIdx.y;
+    const int slot = blockIdx.x + 1, ch = blockIdx.y;
     const unsigned rowbytes = (unsigned)M1 * 1024u * 8u;
     const GBuf H = make_gbuf(a.U + (size_t)ch * M1 * 1024, rowbytes);
     const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
@@ -764,79 +756,42 @@ __global__ void __launch_bounds__(64, 2) row_prod2_kernel(RowArgs a) {
     const c32 tj = gb_ld(twR, (unsigned)j * 8u, 0u);
     const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
 
-    if (slot != 0) {
-        HY_LDS lc32* xb = lds + half * ROW_LDS;
-        HY_LDS lc32* xl = xb + j;
-        const HY_LDS lc32* pl = lds + (1 - half) * ROW_LDS + (31 - j);
-        HY_OPAQUE(xl);
-        HY_OPAQUE(pl);
-        const int myrow = half ? M1 - slot : slot;
-        const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
-        c32 h[32], v[32];
+    HY_LDS lc32* xb = lds + half * ROW_LDS;
+    HY_LDS lc32* xl = xb + j;
+    const HY_LDS lc32* pl = lds + (1 - half) * ROW_LDS + (31 - j);
+    HY_OPAQUE(xl);
+    HY_OPAQUE(pl);
+    const int myrow = half ? M1 - slot : slot;
+    const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
+    c32 h[32], v[32];
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) h[s] = gb_ld(H, vo, (unsigned)s * 256u);
+    const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
+    row_fft1024<false>(h, xb, j, rtw);
+    for (int b = 0; b < a.B; ++b) {
+        const GBuf X = make_gbuf(a.X + ((size_t)b * a.inner + ch) * M1 * 1024, rowbytes);
         HY_UNROLL
-        for (int s = 0; s < 32; ++s) h[s] = gb_ld(H, vo, (unsigned)s * 256u);
-        {
-            const GBuf X = make_gbuf(a.X + (size_t)ch * M1 * 1024, rowbytes);
-            HY_UNROLL
-            for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
-        }
-        const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
-        row_fft1024<false>(h, xb, j, rtw);
-        for (int b = 0; b < a.B; ++b) {
-            const GBuf X = make_gbuf(a.X + ((size_t)b * a.inner + ch) * M1 * 1024, rowbytes);
-            if (b > 0) {
-                HY_UNROLL
-                for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
-            }
-            row_fft1024<false>(v, xb, j, rtw);
-            pair_pass<MODE>(v, h, xl, pl, wkj, bias, a.scale);
-            row_fft1024<true>(v, xb, j, rtw);
-            HY_UNROLL
-            for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
-        }
-        return;
-    }
-    // slot 0: rows 0 and M1/2 one at a time; both half-waves mirror each other
-    HY_LDS lc32* A = lds;
-    HY_LDS lc32* Bm = lds + ROW_LDS;
-    const int nrows = M1 >= 2 ? 2 : 1;
-    for (int rsel = 0; rsel < nrows; ++rsel) {
-        const int myrow = rsel ? (M1 >> 1) : 0;
-        const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
-        const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
-        c32 h[32];
+        for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+        row_fft1024<false>(v, xb, j, rtw);
+        pair_pass<MODE>(v, h, xl, pl, wkj, bias, a.scale);
+        row_fft1024<true>(v, xb, j, rtw);
         HY_UNROLL
-        for (int s = 0; s < 32; ++s) h[s] = gb_ld(H, vo, (unsigned)s * 256u);
-        row_fft1024<false>(h, A, j, rtw);
-        for (int b = 0; b < a.B; ++b) {
-            const GBuf X = make_gbuf(a.X + ((size_t)b * a.inner + ch) * M1 * 1024, rowbytes);
-            c32 v[32];
-            HY_UNROLL
-            for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
-            row_fft1024<false>(v, Bm, j, rtw);
-            slot0_pass<MODE>(v, h, A, Bm, j, rsel ? 1023 : 1024, wkj, bias, a.scale);
-            row_fft1024<true>(v, Bm, j, rtw);
-            if (half == 0) {
-                HY_UNROLL
-                for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
-            }
-            __syncthreads();
-        }
+        for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
     }
 }
 
-// Backward row kernel: for b = 0 .. B-1:  X[b] = dout rows (-> du rows, in place), U[b] = u rows; K = filter rows;
-// dk rows (summed over b in a fixed order: deterministic) go to S.  One row transform of dout serves both
-// gradients.  The batch sum is carried in S itself (the row's inverse transform is linear, so the partial sums are
-// added after it: one 16 KB read-modify-write per row pair and batch item, served by the L2) rather than in 64
-// accumulator registers.  DO_DU = false skips the du half (dk only).  grid (slots, inner).
+// Backward row kernel, row pairs (slot, M1 - slot), slot = 1 .. M1/2 - 1.  For b = 0 .. B-1: X[b] = dout rows
+// (-> du rows, in place), U[b] = u rows; K = filter rows; dk rows (summed over b in a fixed order: deterministic) go
+// to S.  One row transform of dout serves both gradients.  The batch sum is carried in S itself (the row's inverse
+// transform is linear, so the partial sums are added after it: one 16 KB read-modify-write per row pair and batch
+// item, served by the L2) rather than in 64 accumulator registers.  DO_DU = false skips the du half.
 template <bool DO_DU>
 __global__ void __launch_bounds__(64, 2) row_bwd_kernel(RowArgs a) {
     HY_SMEM(smem);
     const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
     HY_LDS lc32* const lds = HY_LDS_CAST(lc32, smem);
     const int M1 = a.M1;
-    const int slot = blockIdx.x, ch = blockIdx.y;
+    const int slot = blockIdx.x + 1, ch = blockIdx.y;
     const unsigned rowbytes = (unsigned)M1 * 1024u * 8u;
     const GBuf Kb = make_gbuf(a.K + (size_t)ch * M1 * 1024, rowbytes);
     const GBuf O = make_gbuf(a.S + (size_t)ch * M1 * 1024, rowbytes);
@@ -846,110 +801,201 @@ __global__ void __launch_bounds__(64, 2) row_bwd_kernel(RowArgs a) {
     const c32 tj = gb_ld(twR, (unsigned)j * 8u, 0u);
     const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
 
-    if (slot != 0) {
-        HY_LDS lc32* xb = lds + half * ROW_LDS;
-        HY_LDS lc32* xl = xb + j;
-        const HY_LDS lc32* pl = lds + (1 - half) * ROW_LDS + (31 - j);
-        HY_OPAQUE(xl);
-        HY_OPAQUE(pl);
-        const int myrow = half ? M1 - slot : slot;
-        const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
-        const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
-        for (int b = 0; b < a.B; ++b) {
-            const size_t off = ((size_t)b * a.inner + ch) * M1 * 1024;
-            const GBuf X = make_gbuf(a.X + off, rowbytes), U = make_gbuf(a.U + off, rowbytes);
-            c32 h[32], v[32];
+    HY_LDS lc32* xb = lds + half * ROW_LDS;
+    HY_LDS lc32* xl = xb + j;
+    const HY_LDS lc32* pl = lds + (1 - half) * ROW_LDS + (31 - j);
+    HY_OPAQUE(xl);
+    HY_OPAQUE(pl);
+    const int myrow = half ? M1 - slot : slot;
+    const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
+    const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
+    for (int b = 0; b < a.B; ++b) {
+        const size_t off = ((size_t)b * a.inner + ch) * M1 * 1024;
+        const GBuf X = make_gbuf(a.X + off, rowbytes), U = make_gbuf(a.U + off, rowbytes);
+        c32 h[32], v[32];
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) h[s] = gb_ld(U, vo, (unsigned)s * 256u);
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+        row_fft1024<false>(h, xb, j, rtw);
+        row_fft1024<false>(v, xb, j, rtw);
+        {   // dk_b = corr(G, U): result into h (its registers are free once consumed), G stays in v
             HY_UNROLL
-            for (int s = 0; s < 32; ++s) h[s] = gb_ld(U, vo, (unsigned)s * 256u);
-            HY_UNROLL
-            for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
-            row_fft1024<false>(h, xb, j, rtw);
-            row_fft1024<false>(v, xb, j, rtw);
-            {   // dk_b = corr(G, U): result into h (its registers are free once consumed), G stays in v
-                HY_UNROLL
-                for (int q = 0; q < 16; ++q) {
-                    lds_st(xl + q * 32, v[16 + q]);
-                    lds_st(xl + 512 + q * 32, h[16 + q]);
-                }
-                __syncthreads();
-                HY_UNROLL
-                for (int q = 0; q < 16; ++q) {
-                    const c32 gp = lds_ld(pl + (15 - q) * 32);
-                    const c32 up = lds_ld(pl + 512 + (15 - q) * 32);
-                    c32 zk, zp;
-                    prod_pair<MODE_CORR>(v[q], gp, h[q], up, pw_tw(wkj, q), 0.f, zk, zp);
-                    h[q] = cscale(zk, a.scale);
-                    h[16 + q] = cscale(zp, a.scale);
-                }
-                __syncthreads();
-                HY_UNROLL
-                for (int q = 0; q < 16; ++q) lds_st(xl + q * 32, h[16 + q]);
-                __syncthreads();
-                HY_UNROLL
-                for (int q = 0; q < 16; ++q) h[31 - q] = lds_ld(pl + q * 32);
-                __syncthreads();
+            for (int q = 0; q < 16; ++q) {
+                lds_st(xl + q * 32, v[16 + q]);
+                lds_st(xl + 512 + q * 32, h[16 + q]);
             }
-            row_fft1024<true>(h, xb, j, rtw);
+            __syncthreads();
+            HY_UNROLL
+            for (int q = 0; q < 16; ++q) {
+                const c32 gp = lds_ld(pl + (15 - q) * 32);
+                const c32 up = lds_ld(pl + 512 + (15 - q) * 32);
+                c32 zk, zp;
+                prod_pair<MODE_CORR>(v[q], gp, h[q], up, pw_tw(wkj, q), 0.f, zk, zp);
+                h[q] = cscale(zk, a.scale);
+                h[16 + q] = cscale(zp, a.scale);
+            }
+            __syncthreads();
+            HY_UNROLL
+            for (int q = 0; q < 16; ++q) lds_st(xl + q * 32, h[16 + q]);
+            __syncthreads();
+            HY_UNROLL
+            for (int q = 0; q < 16; ++q) h[31 - q] = lds_ld(pl + q * 32);
+            __syncthreads();
+        }
+        row_fft1024<true>(h, xb, j, rtw);
+        if (b > 0) {
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) h[q] = cadd(h[q], gb_ld(O, vo, (unsigned)q * 256u));
+        }
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, h[q]);
+        if (DO_DU) {   // du_b = corr(G, K) + bias
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) h[s] = gb_ld(Kb, vo, (unsigned)s * 256u);
+            row_fft1024<false>(h, xb, j, rtw);
+            pair_pass<MODE_CORR>(v, h, xl, pl, wkj, bias, a.scale);
+            row_fft1024<true>(v, xb, j, rtw);
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rows 0 and M1/2 are their own partners (k2 <-> (1024 - k2) mod 1024, resp. 1023 - k2, inside the row) with an
+// irregular lane map, so they take the per-element form of the product, partners read from natural-order LDS
+// images.  A workgroup = one row (blockIdx.x: 0 -> row 0, 1 -> row M1/2) of TWO channels, one per half-wave
+// (the second half idles on an odd channel count); 2 images x 2 halves = 33.8 KB of LDS.  These rows are 2 of M1,
+// so this is a separate small launch and the main kernels above carry no divergent path (and no scratch).
+// ---------------------------------------------------------------------------------------------
+enum { ROW0_LDS = 4 * ROW_LDS };
+
+template <int MODE>
+__device__ __forceinline__ void self_pair_product(c32 (&v)[32], const c32 (&h)[32], HY_LDS lc32* imx, HY_LDS lc32* imh, int j,
+                                                  int pk_base, c32 wkj, float bias, float scale) {
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) { lds_st(imh + j + 33 * q, h[q]); lds_st(imx + j + 33 * q, v[q]); }
+    __syncthreads();
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) {
+        const int pk2 = (pk_base - (j + 32 * q)) & 1023;
+        v[q] = cscale(packed_product<MODE>(v[q], lds_ld(imx + row_idx(pk2)), h[q], lds_ld(imh + row_idx(pk2)), pw_tw(wkj, q), bias), scale);
+    }
+    __syncthreads();
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64, 2) row0_prod2_kernel(RowArgs a) {
+    HY_SMEM(smem);
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    HY_LDS lc32* imx = HY_LDS_CAST(lc32, smem) + half * 2 * ROW_LDS;    // this half-wave's X image / exchange
+    HY_LDS lc32* imh = imx + ROW_LDS;                                   // ... H image / exchange
+    const int M1 = a.M1;
+    const int myrow = blockIdx.x ? (M1 >> 1) : 0;
+    const int pk_base = blockIdx.x ? 1023 : 1024;
+    const int ch_raw = 2 * blockIdx.y + half;
+    const bool valid = ch_raw < a.inner;
+    const int ch = valid ? ch_raw : a.inner - 1;       // the idle half mirrors the last channel; its stores are dropped
+    // the two half-waves work on different channels: the channel goes into the per-lane offset, the descriptor
+    // covers the whole [inner][M1][1024] slab of one batch item (< 4 GB by the host's chunking)
+    const unsigned slab = (unsigned)a.inner * (unsigned)M1 * 1024u * 8u;
+    const GBuf H = make_gbuf(a.U, slab);
+    const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
+    RowTw rtw;
+    load_row_tw(rtw, twT, j);
+    const c32 wkj = cmul(a.tab.tw_lo[myrow], gb_ld(twR, (unsigned)j * 8u, 0u));
+    const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
+    const unsigned vo = ((unsigned)ch * (unsigned)M1 * 1024u + (unsigned)(myrow * 1024 + j)) * 8u;
+
+    c32 h[32];
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) h[s] = gb_ld(H, vo, (unsigned)s * 256u);
+    row_fft1024<false>(h, imh, j, rtw);
+    for (int b = 0; b < a.B; ++b) {
+        const GBuf X = make_gbuf(a.X + (size_t)b * a.inner * M1 * 1024, slab);
+        c32 v[32];
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+        row_fft1024<false>(v, imx, j, rtw);
+        self_pair_product<MODE>(v, h, imx, imh, j, pk_base, wkj, bias, a.scale);
+        row_fft1024<true>(v, imx, j, rtw);
+        if (valid) {
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
+        }
+    }
+}
+
+template <bool DO_DU>
+__global__ void __launch_bounds__(64, 2) row0_bwd_kernel(RowArgs a) {
+    HY_SMEM(smem);
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    HY_LDS lc32* imx = HY_LDS_CAST(lc32, smem) + half * 2 * ROW_LDS;    // G image
+    HY_LDS lc32* imh = imx + ROW_LDS;                                   // U / K image, exchange
+    const int M1 = a.M1;
+    const int myrow = blockIdx.x ? (M1 >> 1) : 0;
+    const int pk_base = blockIdx.x ? 1023 : 1024;
+    const int ch_raw = 2 * blockIdx.y + half;
+    const bool valid = ch_raw < a.inner;
+    const int ch = valid ? ch_raw : a.inner - 1;
+    const unsigned slab = (unsigned)a.inner * (unsigned)M1 * 1024u * 8u;
+    const GBuf Kb = make_gbuf(a.K, slab), O = make_gbuf(a.S, slab);
+    const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
+    RowTw rtw;
+    load_row_tw(rtw, twT, j);
+    const c32 wkj = cmul(a.tab.tw_lo[myrow], gb_ld(twR, (unsigned)j * 8u, 0u));
+    const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
+    const unsigned vo = ((unsigned)ch * (unsigned)M1 * 1024u + (unsigned)(myrow * 1024 + j)) * 8u;
+
+    for (int b = 0; b < a.B; ++b) {
+        const size_t off = (size_t)b * a.inner * M1 * 1024;
+        const GBuf X = make_gbuf(a.X + off, slab), U = make_gbuf(a.U + off, slab);
+        c32 h[32], v[32];
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) h[s] = gb_ld(U, vo, (unsigned)s * 256u);
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+        row_fft1024<false>(h, imh, j, rtw);
+        row_fft1024<false>(v, imx, j, rtw);
+        // dk_b = corr(G, U) per element: the result replaces h, G stays in v and in its image
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) { lds_st(imh + j + 33 * q, h[q]); lds_st(imx + j + 33 * q, v[q]); }
+        __syncthreads();
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) {
+            const int pk2 = (pk_base - (j + 32 * q)) & 1023;
+            h[q] = cscale(packed_product<MODE_CORR>(v[q], lds_ld(imx + row_idx(pk2)), h[q], lds_ld(imh + row_idx(pk2)), pw_tw(wkj, q), 0.f),
+                          a.scale);
+        }
+        __syncthreads();
+        row_fft1024<true>(h, imh, j, rtw);
+        if (valid) {
             if (b > 0) {
                 HY_UNROLL
                 for (int q = 0; q < 32; ++q) h[q] = cadd(h[q], gb_ld(O, vo, (unsigned)q * 256u));
             }
             HY_UNROLL
             for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, h[q]);
-            if (DO_DU) {   // du_b = corr(G, K) + bias
-                HY_UNROLL
-                for (int s = 0; s < 32; ++s) h[s] = gb_ld(Kb, vo, (unsigned)s * 256u);
-                row_fft1024<false>(h, xb, j, rtw);
-                pair_pass<MODE_CORR>(v, h, xl, pl, wkj, bias, a.scale);
-                row_fft1024<true>(v, xb, j, rtw);
-                HY_UNROLL
-                for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
-            }
         }
-        return;
-    }
-    HY_LDS lc32* A = lds;
-    HY_LDS lc32* Bm = lds + ROW_LDS;
-    const int nrows = M1 >= 2 ? 2 : 1;
-    for (int rsel = 0; rsel < nrows; ++rsel) {
-        const int myrow = rsel ? (M1 >> 1) : 0;
-        const int pk_base = rsel ? 1023 : 1024;
-        const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
-        const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
-        for (int b = 0; b < a.B; ++b) {
-            const size_t off = ((size_t)b * a.inner + ch) * M1 * 1024;
-            const GBuf X = make_gbuf(a.X + off, rowbytes), U = make_gbuf(a.U + off, rowbytes);
-            c32 h[32], v[32], g[32];
+        if (DO_DU) {
             HY_UNROLL
-            for (int s = 0; s < 32; ++s) h[s] = gb_ld(U, vo, (unsigned)s * 256u);
+            for (int s = 0; s < 32; ++s) h[s] = gb_ld(Kb, vo, (unsigned)s * 256u);
+            row_fft1024<false>(h, imh, j, rtw);
             HY_UNROLL
-            for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
-            row_fft1024<false>(h, A, j, rtw);
-            row_fft1024<false>(v, Bm, j, rtw);
+            for (int q = 0; q < 32; ++q) lds_st(imh + j + 33 * q, h[q]);       // K image; the G image is still in imx
+            __syncthreads();
             HY_UNROLL
-            for (int q = 0; q < 32; ++q) g[q] = v[q];
-            slot0_pass<MODE_CORR>(v, h, A, Bm, j, pk_base, wkj, 0.f, a.scale);          // v = dk_b spectrum
-            row_fft1024<true>(v, A, j, rtw);
-            if (b > 0) {
-                HY_UNROLL
-                for (int q = 0; q < 32; ++q) v[q] = cadd(v[q], gb_ld(O, vo, (unsigned)q * 256u));
-            }
-            if (half == 0) {
-                HY_UNROLL
-                for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, v[q]);
+            for (int q = 0; q < 32; ++q) {
+                const int pk2 = (pk_base - (j + 32 * q)) & 1023;
+                v[q] = cscale(packed_product<MODE_CORR>(v[q], lds_ld(imx + row_idx(pk2)), h[q], lds_ld(imh + row_idx(pk2)), pw_tw(wkj, q), bias),
+                              a.scale);
             }
             __syncthreads();
-            if (DO_DU) {
+            row_fft1024<true>(v, imx, j, rtw);
+            if (valid) {
                 HY_UNROLL
-                for (int s = 0; s < 32; ++s) h[s] = gb_ld(Kb, vo, (unsigned)s * 256u);
-                row_fft1024<false>(h, A, j, rtw);
-                slot0_pass<MODE_CORR>(g, h, A, Bm, j, pk_base, wkj, bias, a.scale);     // g = du_b spectrum
-                row_fft1024<true>(g, A, j, rtw);
-                if (half == 0) {
-                    HY_UNROLL
-                    for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, g[q]);
-                }
-                __syncthreads();
+                for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
             }
         }
     }
