@@ -116,7 +116,11 @@ int launch_row_bwd(const RowArgs& a, void* stream) {
 
 size_t elem_size(int dtype) { return dtype == HYENA_F32 ? 4 : 2; }
 
-const size_t CACHE_BUDGET = 384u << 20;   // bytes of intermediates kept live per chunk (Infinity Cache is 256 MiB)
+// Intermediates of one chunk.  Measured on MI355X (profiles/mall_bw_r1.txt, chunk sweeps in profiles/): keeping a
+// chunk inside the 256 MiB Infinity Cache buys little (write-then-read runs at 6.0-6.4 TB/s there vs 5.0 TB/s from
+// HBM), while every kernel launch pays a ~30 us ramp/tail at the ~35 us latency of one row workgroup -- so chunks
+// are made as large as a generous workspace allows (all 256 channels at L = 2^20, B = 1: 8 GiB of 288).
+const size_t CACHE_BUDGET = (size_t)8 << 30;
 
 }  // namespace
 
@@ -186,6 +190,8 @@ int hyena_fftconv_default_chunk(int B, int D, int L, int backward) {
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
     const size_t per_channel = (size_t)(backward ? 2 * B + 2 : B + 1) * p.M * sizeof(c32);
     size_t c = CACHE_BUDGET / per_channel;
+    const size_t cmax = ((size_t)1 << 28) / p.M;     // a chunk's [chunk][M] slab stays below 2 GiB (32-bit buffer offsets)
+    if (c > cmax) c = cmax;
     if (c < 1) c = 1;
     if (c > (size_t)D) c = D;
     return (int)c;
@@ -196,6 +202,7 @@ size_t hyena_fftconv_workspace_bytes(int B, int D, int L, int backward, int chun
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, backward);
     if (chunk > D) chunk = D;
+    if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
     return (size_t)(backward ? 2 * B + 2 : B + 1) * chunk * p.M * sizeof(c32);
 }
 
@@ -208,6 +215,7 @@ int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* ou
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, 0);
     if (chunk > D) chunk = D;
+    if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
     if (workspace_bytes < hyena_fftconv_workspace_bytes(B, D, L, 0, chunk)) return HYENA_ERR_WORKSPACE;
 
     const Tables tab = tables_from(d_tables);
@@ -247,6 +255,7 @@ int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const flo
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, 1);
     if (chunk > D) chunk = D;
+    if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
     if (workspace_bytes < hyena_fftconv_workspace_bytes(B, D, L, 1, chunk)) return HYENA_ERR_WORKSPACE;
 
     const Tables tab = tables_from(d_tables);

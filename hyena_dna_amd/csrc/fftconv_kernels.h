@@ -489,10 +489,12 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_fwd_kernel(ColArgs a)
     const int nfull = a.L >> 1;                         // pairs n < nfull are complete; n == nfull is the odd tail
 
     // all global loads of the thread back to back: E input pairs (+ the table slice)
-    raw_t raw[E];
+    // Rows n1 >= M1/2 (s >= E/2) lie beyond L/2 <= M/2 for every supported L: the zero padding is never loaded.
+    constexpr int EL = E >= 2 ? E / 2 : 1;
+    raw_t raw[EL];
     if (nfull > 0) {
         HY_UNROLL
-        for (int s = 0; s < E; ++s) {
+        for (int s = 0; s < EL; ++s) {
             const int n = (r + T * s) * 1024 + n2;
             raw[s] = load_raw_pair<DT>(xrow, n < nfull ? n : 0);
         }
@@ -502,7 +504,7 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_fwd_kernel(ColArgs a)
     HY_UNROLL
     for (int s = 0; s < E; ++s) {
         const int n = (r + T * s) * 1024 + n2;
-        v[s] = (n < nfull) ? Pair<DT>::cvt(raw[s]) : mk(0.f, 0.f);
+        v[s] = (s < EL && n < nfull) ? Pair<DT>::cvt(raw[s < EL ? s : 0]) : mk(0.f, 0.f);
     }
     if (a.L & 1) {                                      // odd L: the last sample is the real part of pair nfull
         HY_UNROLL
