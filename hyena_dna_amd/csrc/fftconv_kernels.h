@@ -468,7 +468,7 @@ __device__ __forceinline__ void col_exchange(const c32 (&v)[32], c32 (&x2)[32], 
 }
 
 template <int M1, int DT>
-__global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_fwd_kernel(ColArgs a) {
+__global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_fwd_kernel(ColArgs a) {
     typedef ColCfg<M1> Cfg;
     typedef typename Elem<DT>::type elem_t;
     typedef typename Pair<DT>::raw_t raw_t;
@@ -550,7 +550,8 @@ __device__ __forceinline__ void col_store(typename Elem<DT>::type* xrow, int n, 
 }
 
 template <int M1, int DT>
-__global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_inv_kernel(ColArgs a) {
+// <= 128 VGPRs (4 waves per SIMD): at 141 only ONE 512-thread workgroup fits a CU and the kernel ran at 2.5 TB/s
+__global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_inv_kernel(ColArgs a) {
     typedef ColCfg<M1> Cfg;
     typedef typename Elem<DT>::type elem_t;
     constexpr int T = Cfg::T, C = Cfg::C, E = Cfg::E;
@@ -577,9 +578,12 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_inv_kernel(ColArgs a)
     for (int s = 0; s < E; ++s) v[s] = cmulc(v[s], outer_tw(tlo, thi, n2, r + T * s));
     dft_reg<E, true>(v);
 
+    // Outputs n1 >= M1/2 lie beyond L/2 <= M/2 for every supported L: never stored, so never computed (the
+    // compiler drops the butterflies that only feed them).
     if constexpr (T == 1) {
+        constexpr int EO = E >= 2 ? E / 2 : 1;
         HY_UNROLL
-        for (int q = 0; q < E; ++q) col_store<DT>(xrow, q * 1024 + n2, nfull, a.L, v[q], a.aux0, row);
+        for (int q = 0; q < EO; ++q) col_store<DT>(xrow, q * 1024 + n2, nfull, a.L, v[q], a.aux0, row);
     } else {
         constexpr int NB = Cfg::NB;
         c32 x2[32];
@@ -593,7 +597,7 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS) col_inv_kernel(ColArgs a)
             for (int s = 1; s < T; ++s) y[s] = cmulc(x2[i * T + s], lds_ld(thi + jj * s));
             dft_reg<T, true>(y);
             HY_UNROLL
-            for (int q = 0; q < T; ++q) col_store<DT>(xrow, (jj + 32 * q) * 1024 + n2, nfull, a.L, y[q], a.aux0, row);
+            for (int q = 0; q < T / 2; ++q) col_store<DT>(xrow, (jj + 32 * q) * 1024 + n2, nfull, a.L, y[q], a.aux0, row);
         }
     }
 }
