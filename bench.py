@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0, help="channels per kernel-chain pass (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allreduce", action="store_true")
+    ap.add_argument("--no-save-spectra", action="store_true",
+                    help="backward recomputes the column spectra of u and k instead of reusing the forward's")
     ap.add_argument("--fwd-only", action="store_true", help="diagnostic; the reported metric needs fwd+bwd")
     ap.add_argument("--emu", action="store_true",
                     help="TEST ONLY: run the host logic on the CPU emulation of the kernels with the gloo backend")
@@ -131,11 +133,18 @@ def main():
     grads = torch.zeros(MODEL_GRAD_ELEMS, dtype=torch.float32, device=dev) if world > 1 and not args.no_allreduce else None
     comm_stream = torch.cuda.Stream(device=dev) if (grads is not None and not args.emu) else None
 
+    save = not args.no_save_spectra and not args.fwd_only
+
     def step():
-        out = _lib.fftconv_fwd(u, k, bias, chunk=chunk)
+        # what hyena_dna_amd.fftconv.FFTConvFunc does per layer call: forward (keeping its column spectra for the
+        # backward unless --no-save-spectra), then the backward for a given upstream gradient
+        if save:
+            out, saved = _lib.fftconv_fwd(u, k, bias, chunk=chunk, save=True)
+        else:
+            out, saved = _lib.fftconv_fwd(u, k, bias, chunk=chunk), None
         if args.fwd_only:
             return out
-        res = _lib.fftconv_bwd(dout, u, k, bias, chunk=chunk)
+        res = _lib.fftconv_bwd(dout, u, k, bias, chunk=chunk, saved=saved)
         if grads is not None:
             if comm_stream is not None:
                 comm_stream.wait_stream(torch.cuda.current_stream(dev))
@@ -185,10 +194,11 @@ def main():
             "metric": METRIC, "value": nt_per_s, "unit": "nt/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"hyenadna-large-1m layer: fftconv fwd+bwd, L={L}, d={D}, B={B}/GPU, "
+            "config": {"workload": f"Hyena long-conv layer call (fftconv fwd+bwd), L={L}, d={D}, B={B}/GPU, "
                                    f"{args.dtype} activations, fp32 filter and FFT math" +
                                    (" [FWD ONLY -- diagnostic]" if args.fwd_only else ""),
                        "seq_len": L, "d_model": D, "batch_per_gpu": B, "io_dtype": args.dtype,
+                       "save_spectra": bool(save),
                        "chunk": int(_lib.lib().hyena_fftconv_default_chunk(B, D, L, 1)) if chunk is None else chunk,
                        "parallelism": f"dp{world} (batch-sharded, RCCL all-reduce of {MODEL_GRAD_ELEMS} fp32 grads/step)"
                                       if world > 1 else "single GPU",

@@ -11,7 +11,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libhyena_fftconv.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 HYENA_F32, HYENA_BF16, HYENA_F16 = 0, 1, 2
 MAX_L = 1048576
@@ -86,6 +86,14 @@ def lib():
         L.hyena_fftconv_bwd.restype = c_int
         L.hyena_fftconv_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+        L.hyena_fftconv_saved_bytes.restype = c_size_t
+        L.hyena_fftconv_saved_bytes.argtypes = [c_int, c_int, c_int]
+        L.hyena_fftconv_fwd_save.restype = c_int
+        L.hyena_fftconv_fwd_save.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                             c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]
+        L.hyena_fftconv_bwd_saved.restype = c_int
+        L.hyena_fftconv_bwd_saved.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                              c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]
         if L.hyena_fftconv_abi_version() != ABI_VERSION:
             raise HyenaLibraryError(f"{LIB_PATH}: ABI version {L.hyena_fftconv_abi_version()} != {ABI_VERSION}; rebuild")
         _lib = L
@@ -143,8 +151,25 @@ def _chunk_override():
     return int(v) if v else 0
 
 
-def fftconv_fwd(u, k, bias, chunk=None):
-    """u (B, D, L) contiguous, k (D, L) fp32, bias (D,) fp32 or None -> out like u."""
+def saved_bytes(B, D, L):
+    """Size of the optional saved-spectrum buffer (column-transformed filter + activations) for (B, D, L)."""
+    return int(lib().hyena_fftconv_saved_bytes(int(B), int(D), int(L)))
+
+
+def save_spectra_default(B, D, L):
+    """Keep the forward's column spectra for the backward?  HYENA_FFTCONV_SAVE_SPECTRA = 0 | 1 | auto (default:
+    on while the buffer stays below HYENA_FFTCONV_SAVE_LIMIT_GB, default 6 GiB per call)."""
+    mode = os.environ.get("HYENA_FFTCONV_SAVE_SPECTRA", "auto").lower()
+    if mode in ("0", "off", "false"):
+        return False
+    if mode in ("1", "on", "true"):
+        return True
+    return saved_bytes(B, D, L) <= float(os.environ.get("HYENA_FFTCONV_SAVE_LIMIT_GB", "6")) * 2 ** 30
+
+
+def fftconv_fwd(u, k, bias, chunk=None, save=False):
+    """u (B, D, L) contiguous, k (D, L) fp32, bias (D,) fp32 or None -> out like u.
+    save=True additionally returns the saved-spectrum buffer for fftconv_bwd(..., saved=)."""
     _require_gpu(u, "u")
     B, D, L = u.shape
     out = torch.empty_like(u)
@@ -152,30 +177,40 @@ def fftconv_fwd(u, k, bias, chunk=None):
     tables = tables_for(u.device, L)
     nbytes = lib().hyena_fftconv_workspace_bytes(B, D, L, 0, chunk)
     ws, stream = workspace_for(u.device, nbytes)
+    bp = bias.data_ptr() if bias is not None else None
     with _backend.guard(u.device):
-        check(lib().hyena_fftconv_fwd(u.data_ptr(), k.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                      out.data_ptr(), B, D, L, dtype_code(u.dtype), tables.data_ptr(),
-                                      ws.data_ptr(), ws.numel(), chunk, stream))
+        if save:
+            saved = torch.empty(saved_bytes(B, D, L), dtype=torch.uint8, device=u.device)
+            check(lib().hyena_fftconv_fwd_save(u.data_ptr(), k.data_ptr(), bp, out.data_ptr(), B, D, L, dtype_code(u.dtype),
+                                               tables.data_ptr(), ws.data_ptr(), ws.numel(), chunk, saved.data_ptr(),
+                                               saved.numel(), stream))
+            return out, saved
+        check(lib().hyena_fftconv_fwd(u.data_ptr(), k.data_ptr(), bp, out.data_ptr(), B, D, L, dtype_code(u.dtype),
+                                      tables.data_ptr(), ws.data_ptr(), ws.numel(), chunk, stream))
     return out
 
 
-def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None):
-    """Returns (du like u | None, dk (D, L) fp32 | None, dbias (D,) fp32 | None)."""
-    _require_gpu(u, "u")
-    B, D, L = u.shape
-    du = torch.empty_like(u) if need_du else None
-    dk = torch.empty((D, L), dtype=torch.float32, device=u.device) if need_dk else None
-    dbias = torch.empty((D,), dtype=torch.float32, device=u.device) if need_dk else None
+def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None, saved=None):
+    """Returns (du like u | None, dk (D, L) fp32 | None, dbias (D,) fp32 | None).
+    With saved= (from fftconv_fwd(save=True)) u and k are not read; pass them for their shapes/dtypes only."""
+    _require_gpu(dout, "dout")
+    B, D, L = dout.shape
+    du = torch.empty_like(dout) if need_du else None
+    dk = torch.empty((D, L), dtype=torch.float32, device=dout.device) if need_dk else None
+    dbias = torch.empty((D,), dtype=torch.float32, device=dout.device) if need_dk else None
     chunk = _chunk_override() if chunk is None else int(chunk)
-    tables = tables_for(u.device, L)
+    tables = tables_for(dout.device, L)
     nbytes = lib().hyena_fftconv_workspace_bytes(B, D, L, 1, chunk)
-    ws, stream = workspace_for(u.device, nbytes)
-    with _backend.guard(u.device):
-        check(lib().hyena_fftconv_bwd(dout.data_ptr(), u.data_ptr(), k.data_ptr(),
-                                      bias.data_ptr() if bias is not None else None,
-                                      du.data_ptr() if du is not None else None,
-                                      dk.data_ptr() if dk is not None else None,
-                                      dbias.data_ptr() if dbias is not None else None,
-                                      B, D, L, dtype_code(u.dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(),
-                                      chunk, stream))
+    ws, stream = workspace_for(dout.device, nbytes)
+    bp = bias.data_ptr() if bias is not None else None
+    ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    with _backend.guard(dout.device):
+        if saved is not None:
+            check(lib().hyena_fftconv_bwd_saved(dout.data_ptr(), bp, ptr(du), ptr(dk), ptr(dbias), B, D, L,
+                                                dtype_code(dout.dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(), chunk,
+                                                saved.data_ptr(), saved.numel(), stream))
+        else:
+            check(lib().hyena_fftconv_bwd(dout.data_ptr(), u.data_ptr(), k.data_ptr(), bp, ptr(du), ptr(dk), ptr(dbias),
+                                          B, D, L, dtype_code(dout.dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          chunk, stream))
     return du, dk, dbias

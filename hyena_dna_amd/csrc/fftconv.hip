@@ -126,7 +126,7 @@ const size_t CACHE_BUDGET = (size_t)8 << 30;
 
 extern "C" {
 
-int hyena_fftconv_abi_version(void) { return 1; }
+int hyena_fftconv_abi_version(void) { return 2; }
 
 const char* hyena_fftconv_error_string(int status) {
     switch (status) {
@@ -206,8 +206,19 @@ size_t hyena_fftconv_workspace_bytes(int B, int D, int L, int backward, int chun
     return (size_t)(backward ? 2 * B + 2 : B + 1) * chunk * p.M * sizeof(c32);
 }
 
-int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int dtype,
-                      const void* d_tables, void* workspace, size_t workspace_bytes, int chunk, void* stream) {
+// saved-spectrum buffer (optional, persists from forward to backward): Wk [D][M] | Wu [B][D][M], complex64
+static inline c32* saved_wk(void* saved) { return reinterpret_cast<c32*>(saved); }
+static inline c32* saved_wu(void* saved, int D, int M) { return reinterpret_cast<c32*>(saved) + (size_t)D * M; }
+
+size_t hyena_fftconv_saved_bytes(int B, int D, int L) {
+    Plan p;
+    if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
+    return (size_t)(B + 1) * D * p.M * sizeof(c32);
+}
+
+static int fwd_impl(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int dtype,
+                    const void* d_tables, void* workspace, size_t workspace_bytes, int chunk, void* saved,
+                    size_t saved_bytes, void* stream) {
     Plan p;
     if (u == nullptr || k == nullptr || out == nullptr || d_tables == nullptr || workspace == nullptr || B < 1 ||
         D < 1 || (dtype != HYENA_F32 && dtype != HYENA_BF16 && dtype != HYENA_F16))
@@ -217,39 +228,49 @@ int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* ou
     if (chunk > D) chunk = D;
     if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
     if (workspace_bytes < hyena_fftconv_workspace_bytes(B, D, L, 0, chunk)) return HYENA_ERR_WORKSPACE;
+    if (saved != nullptr && saved_bytes < hyena_fftconv_saved_bytes(B, D, L)) return HYENA_ERR_WORKSPACE;
 
     const Tables tab = tables_from(d_tables);
-    c32* Wk = reinterpret_cast<c32*>(workspace);                // [chunk][M]      column-transformed filter
-    c32* W = Wk + (size_t)chunk * p.M;                          // [B][chunk][M]   column-transformed activations
+    c32* wsWk = reinterpret_cast<c32*>(workspace);              // [chunk][M]      column-transformed filter
+    c32* wsW = wsWk + (size_t)chunk * p.M;                      // [B][chunk][M]   column-transformed activations
     const size_t es = elem_size(dtype);
     int st;
     for (int d0 = 0; d0 < D; d0 += chunk) {
         const int cd = (D - d0 < chunk) ? D - d0 : chunk;
+        // with a saved-spectrum buffer the column transforms land there (kept for the backward) and the row
+        // kernel writes its product into the workspace instead of transforming in place
+        c32* Wk = saved ? saved_wk(saved) + (size_t)d0 * p.M : wsWk;
+        c32* Wu = saved ? saved_wu(saved, D, p.M) + (size_t)d0 * p.M : wsW;
+        const int ub = saved ? D : cd;
         ColArgs ck;
-        ck.x = k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd;
+        ck.x = k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd; ck.w_bstride = cd;
         ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
         if ((st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
         ColArgs cu;
-        cu.x = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cu.W = W; cu.tab = tab; cu.L = L; cu.inner = cd;
+        cu.x = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cu.W = Wu; cu.tab = tab; cu.L = L; cu.inner = cd;
+        cu.w_bstride = ub;
         cu.outer_stride = (long)D * L; cu.inner_stride = L; cu.aux0 = nullptr; cu.x2 = nullptr; cu.W2 = nullptr;
         if ((st = launch_col<false>(dtype, p.M1, cu, B * cd, stream))) return st;
         RowArgs rc;
-        rc.X = W; rc.U = Wk; rc.S = nullptr; rc.bias = bias ? bias + d0 : nullptr; rc.K = nullptr; rc.tab = tab;
+        rc.X = Wu; rc.U = Wk; rc.S = nullptr; rc.bias = bias ? bias + d0 : nullptr; rc.K = nullptr; rc.Y = wsW;
+        rc.x_bstride = ub; rc.u_bstride = 0; rc.y_bstride = cd; rc.tab = tab;
         rc.M1 = p.M1; rc.inner = cd; rc.B = B; rc.scale = 1.0f / (float)p.M;
         if ((st = launch_row_prod2<MODE_CONV>(rc, stream))) return st;
         ColArgs co = cu;
-        co.x = reinterpret_cast<char*>(out) + (size_t)d0 * L * es;
+        co.x = reinterpret_cast<char*>(out) + (size_t)d0 * L * es; co.W = wsW; co.w_bstride = cd;
         if ((st = launch_col<true>(dtype, p.M1, co, B * cd, stream))) return st;
     }
     return HYENA_OK;
 }
 
-int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const float* bias, void* du, float* dk,
-                      float* dbias, int B, int D, int L, int dtype, const void* d_tables, void* workspace,
-                      size_t workspace_bytes, int chunk, void* stream) {
+static int bwd_impl(const void* dout, const void* u, const float* k, const float* bias, void* du, float* dk,
+                    float* dbias, int B, int D, int L, int dtype, const void* d_tables, void* workspace,
+                    size_t workspace_bytes, int chunk, const void* saved_c, size_t saved_bytes, void* stream) {
     Plan p;
-    if (dout == nullptr || u == nullptr || k == nullptr || d_tables == nullptr || workspace == nullptr || B < 1 ||
-        D < 1 || (dtype != HYENA_F32 && dtype != HYENA_BF16 && dtype != HYENA_F16))
+    void* saved = const_cast<void*>(saved_c);
+    if (dout == nullptr || (u == nullptr && saved == nullptr) || (k == nullptr && saved == nullptr) ||
+        d_tables == nullptr || workspace == nullptr || B < 1 || D < 1 ||
+        (dtype != HYENA_F32 && dtype != HYENA_BF16 && dtype != HYENA_F16))
         return HYENA_ERR_BAD_ARG;
     if (dbias != nullptr && dk == nullptr) return HYENA_ERR_BAD_ARG;
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
@@ -257,35 +278,41 @@ int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const flo
     if (chunk > D) chunk = D;
     if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
     if (workspace_bytes < hyena_fftconv_workspace_bytes(B, D, L, 1, chunk)) return HYENA_ERR_WORKSPACE;
+    if (saved != nullptr && saved_bytes < hyena_fftconv_saved_bytes(B, D, L)) return HYENA_ERR_WORKSPACE;
 
     const Tables tab = tables_from(d_tables);
-    c32* Wk = reinterpret_cast<c32*>(workspace);                // [chunk][M]      column-transformed filter
-    c32* Sdk = Wk + (size_t)chunk * p.M;                        // [chunk][M]      dk rows (batch sum) -> packed dk
+    c32* wsWk = reinterpret_cast<c32*>(workspace);              // [chunk][M]      column-transformed filter
+    c32* Sdk = wsWk + (size_t)chunk * p.M;                      // [chunk][M]      dk rows (batch sum) -> packed dk
     c32* Wg = Sdk + (size_t)chunk * p.M;                        // [B][chunk][M]   dout rows -> du rows
-    c32* Wu = Wg + (size_t)B * chunk * p.M;                     // [B][chunk][M]   u rows
+    c32* wsWu = Wg + (size_t)B * chunk * p.M;                   // [B][chunk][M]   u rows
     const size_t es = elem_size(dtype);
     int st;
     for (int d0 = 0; d0 < D; d0 += chunk) {
         const int cd = (D - d0 < chunk) ? D - d0 : chunk;
+        c32* Wk = saved ? saved_wk(saved) + (size_t)d0 * p.M : wsWk;
+        c32* Wu = saved ? saved_wu(saved, D, p.M) + (size_t)d0 * p.M : wsWu;
+        const int ub = saved ? D : cd;
         ColArgs cg;
         cg.x = reinterpret_cast<const char*>(dout) + (size_t)d0 * L * es; cg.W = Wg; cg.tab = tab; cg.L = L; cg.inner = cd;
+        cg.w_bstride = cd;
         cg.outer_stride = (long)D * L; cg.inner_stride = L; cg.aux0 = nullptr; cg.x2 = nullptr; cg.W2 = nullptr;
         ColArgs cgu = cg;                                        // dout (and u, when dk is wanted) in ONE launch
-        if (dk != nullptr) { cgu.x2 = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cgu.W2 = Wu; }
+        if (dk != nullptr && !saved) { cgu.x2 = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cgu.W2 = Wu; }
         if ((st = launch_col<false>(dtype, p.M1, cgu, B * cd, stream))) return st;
         ColArgs ck;
-        ck.x = k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd;
+        ck.x = saved ? nullptr : k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd; ck.w_bstride = cd;
         ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
-        if (du != nullptr && (st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
+        if (du != nullptr && !saved && (st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
         RowArgs rb;
-        rb.X = Wg; rb.U = Wu; rb.S = Sdk; rb.bias = bias ? bias + d0 : nullptr; rb.K = Wk; rb.tab = tab;
+        rb.X = Wg; rb.U = Wu; rb.S = Sdk; rb.bias = bias ? bias + d0 : nullptr; rb.K = Wk; rb.Y = Wg;
+        rb.x_bstride = cd; rb.u_bstride = ub; rb.y_bstride = cd; rb.tab = tab;
         rb.M1 = p.M1; rb.inner = cd; rb.B = B; rb.scale = 1.0f / (float)p.M;
         if (dk != nullptr) {
             if (du != nullptr) st = launch_row_bwd<true>(rb, stream);
             else st = launch_row_bwd<false>(rb, stream);
             if (st) return st;
             ColArgs cdk;
-            cdk.x = dk + (size_t)d0 * L; cdk.W = Sdk; cdk.tab = tab; cdk.L = L; cdk.inner = cd;
+            cdk.x = dk + (size_t)d0 * L; cdk.W = Sdk; cdk.tab = tab; cdk.L = L; cdk.inner = cd; cdk.w_bstride = cd;
             cdk.outer_stride = 0; cdk.inner_stride = L; cdk.aux0 = dbias ? dbias + d0 : nullptr; cdk.x2 = nullptr; cdk.W2 = nullptr;
             if ((st = launch_col<true>(HYENA_F32, p.M1, cdk, cd, stream))) return st;
         } else {
@@ -300,6 +327,33 @@ int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const flo
         }
     }
     return HYENA_OK;
+}
+
+int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int dtype,
+                      const void* d_tables, void* workspace, size_t workspace_bytes, int chunk, void* stream) {
+    return fwd_impl(u, k, bias, out, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk, nullptr, 0, stream);
+}
+
+int hyena_fftconv_fwd_save(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int dtype,
+                           const void* d_tables, void* workspace, size_t workspace_bytes, int chunk, void* saved,
+                           size_t saved_bytes, void* stream) {
+    if (saved == nullptr) return HYENA_ERR_BAD_ARG;
+    return fwd_impl(u, k, bias, out, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk, saved, saved_bytes, stream);
+}
+
+int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const float* bias, void* du, float* dk,
+                      float* dbias, int B, int D, int L, int dtype, const void* d_tables, void* workspace,
+                      size_t workspace_bytes, int chunk, void* stream) {
+    return bwd_impl(dout, u, k, bias, du, dk, dbias, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk, nullptr, 0,
+                    stream);
+}
+
+int hyena_fftconv_bwd_saved(const void* dout, const float* bias, void* du, float* dk, float* dbias, int B, int D, int L,
+                            int dtype, const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
+                            const void* saved, size_t saved_bytes, void* stream) {
+    if (saved == nullptr) return HYENA_ERR_BAD_ARG;
+    return bwd_impl(dout, nullptr, nullptr, bias, du, dk, dbias, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk,
+                    saved, saved_bytes, stream);
 }
 
 }  // extern "C"

@@ -418,6 +418,8 @@ struct ColArgs {
     long outer_stride;  // elements between consecutive outer indices (D * L)
     long inner_stride;  // elements between consecutive inner indices (L)
     float* aux0;        // col_inv only: if non-null, aux0[row] = real part of output sample 0
+    int w_bstride;      // rows of W between consecutive outer (batch) indices: `inner` for a chunk-local workspace,
+                        // D when W is the persistent saved-spectrum buffer [B][D][M]
     const void* x2;     // col_fwd only: second input tensor of the same shape (blockIdx.z == 1) ...
     c32* W2;            // ... and where its transform goes; lets dout and u share one launch in the backward
 };
@@ -485,7 +487,7 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_fwd_kernel(ColArgs
     const bool second = blockIdx.z != 0;
     const elem_t* xrow = reinterpret_cast<const elem_t*>(second ? a.x2 : a.x) + (long)(row / a.inner) * a.outer_stride +
                          (long)(row % a.inner) * a.inner_stride;
-    c32* Wrow = (second ? a.W2 : a.W) + (size_t)row * M1 * 1024;
+    c32* Wrow = (second ? a.W2 : a.W) + ((size_t)(row / a.inner) * a.w_bstride + (row % a.inner)) * M1 * 1024;
     const int nfull = a.L >> 1;                         // pairs n < nfull are complete; n == nfull is the odd tail
 
     // all global loads of the thread back to back: E input pairs (+ the table slice)
@@ -566,7 +568,7 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_inv_kernel(ColArgs
     const int row = blockIdx.y;
     elem_t* xrow = reinterpret_cast<elem_t*>(const_cast<void*>(a.x)) + (long)(row / a.inner) * a.outer_stride +
                    (long)(row % a.inner) * a.inner_stride;
-    const c32* Wrow = a.W + (size_t)row * M1 * 1024;
+    const c32* Wrow = a.W + ((size_t)(row / a.inner) * a.w_bstride + (row % a.inner)) * M1 * 1024;
     const int nfull = a.L >> 1;
 
     c32 v[E];
@@ -616,6 +618,10 @@ struct RowArgs {
     c32* S;            // row_bwd out: dk rows [inner][M1][1024]
     const float* bias; // [inner] or null
     const c32* K;      // row_bwd: filter rows [inner][M1][1024]
+    c32* Y;            // row_prod2: where the product rows go (X itself when in place), [B][y_bstride..][M1][1024]
+    int x_bstride;     // rows between batch items of X / U / Y: `inner` in a chunk workspace, D in the saved-spectrum
+    int u_bstride;     //   buffer
+    int y_bstride;
     Tables tab;
     int M1;
     int inner;
@@ -775,14 +781,15 @@ __global__ void __launch_bounds__(64, 2) row_prod2_kernel(RowArgs a) {
     const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
     row_fft1024<false>(h, xb, j, rtw);
     for (int b = 0; b < a.B; ++b) {
-        const GBuf X = make_gbuf(a.X + ((size_t)b * a.inner + ch) * M1 * 1024, rowbytes);
+        const GBuf X = make_gbuf(a.X + ((size_t)b * a.x_bstride + ch) * M1 * 1024, rowbytes);
+        const GBuf Y = make_gbuf(a.Y + ((size_t)b * a.y_bstride + ch) * M1 * 1024, rowbytes);
         HY_UNROLL
         for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
         row_fft1024<false>(v, xb, j, rtw);
         pair_pass<MODE>(v, h, xl, pl, wkj, bias, a.scale);
         row_fft1024<true>(v, xb, j, rtw);
         HY_UNROLL
-        for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
+        for (int q = 0; q < 32; ++q) gb_st(Y, vo, (unsigned)q * 256u, v[q]);
     }
 }
 
@@ -816,8 +823,8 @@ __global__ void __launch_bounds__(64, 2) row_bwd_kernel(RowArgs a) {
     const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
     const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
     for (int b = 0; b < a.B; ++b) {
-        const size_t off = ((size_t)b * a.inner + ch) * M1 * 1024;
-        const GBuf X = make_gbuf(a.X + off, rowbytes), U = make_gbuf(a.U + off, rowbytes);
+        const GBuf X = make_gbuf(a.X + ((size_t)b * a.x_bstride + ch) * M1 * 1024, rowbytes);
+        const GBuf U = make_gbuf(a.U + ((size_t)b * a.u_bstride + ch) * M1 * 1024, rowbytes);
         c32 h[32], v[32];
         HY_UNROLL
         for (int s = 0; s < 32; ++s) h[s] = gb_ld(U, vo, (unsigned)s * 256u);
@@ -919,7 +926,8 @@ __global__ void __launch_bounds__(64, 2) row0_prod2_kernel(RowArgs a) {
     for (int s = 0; s < 32; ++s) h[s] = gb_ld(H, vo, (unsigned)s * 256u);
     row_fft1024<false>(h, imh, j, rtw);
     for (int b = 0; b < a.B; ++b) {
-        const GBuf X = make_gbuf(a.X + (size_t)b * a.inner * M1 * 1024, slab);
+        const GBuf X = make_gbuf(a.X + (size_t)b * a.x_bstride * M1 * 1024, slab);
+        const GBuf Y = make_gbuf(a.Y + (size_t)b * a.y_bstride * M1 * 1024, slab);
         c32 v[32];
         HY_UNROLL
         for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
@@ -928,7 +936,7 @@ __global__ void __launch_bounds__(64, 2) row0_prod2_kernel(RowArgs a) {
         row_fft1024<true>(v, imx, j, rtw);
         if (valid) {
             HY_UNROLL
-            for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
+            for (int q = 0; q < 32; ++q) gb_st(Y, vo, (unsigned)q * 256u, v[q]);
         }
     }
 }
@@ -955,8 +963,8 @@ __global__ void __launch_bounds__(64, 2) row0_bwd_kernel(RowArgs a) {
     const unsigned vo = ((unsigned)ch * (unsigned)M1 * 1024u + (unsigned)(myrow * 1024 + j)) * 8u;
 
     for (int b = 0; b < a.B; ++b) {
-        const size_t off = (size_t)b * a.inner * M1 * 1024;
-        const GBuf X = make_gbuf(a.X + off, slab), U = make_gbuf(a.U + off, slab);
+        const GBuf X = make_gbuf(a.X + (size_t)b * a.x_bstride * M1 * 1024, slab);
+        const GBuf U = make_gbuf(a.U + (size_t)b * a.u_bstride * M1 * 1024, slab);
         c32 h[32], v[32];
         HY_UNROLL
         for (int s = 0; s < 32; ++s) h[s] = gb_ld(U, vo, (unsigned)s * 256u);

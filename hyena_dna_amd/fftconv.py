@@ -80,7 +80,15 @@ class FFTConvFunc(torch.autograd.Function):
             if D.numel() != H:
                 raise ValueError(f"D must have {H} elements, got shape {tuple(D.shape)}")
             bias = D.detach().to(torch.float32).reshape(H).contiguous()
-        out = _lib.fftconv_fwd(rows, kf, bias)
+        # keep the forward's column spectra for the backward when any gradient is wanted (time-for-memory trade,
+        # _lib.save_spectra_default); otherwise the backward recomputes them from (u, k)
+        want_grad = any(ctx.needs_input_grad[:3])
+        saved = None
+        if want_grad and _lib.save_spectra_default(*rows.shape):
+            out, saved = _lib.fftconv_fwd(rows, kf, bias, save=True)
+        else:
+            out = _lib.fftconv_fwd(rows, kf, bias)
+        ctx.spectra = saved
         ctx.save_for_backward(rows, kf, bias if bias is not None else torch.empty(0, device=u.device))
         ctx.has_bias = bias is not None
         ctx.restore = restore
@@ -100,7 +108,8 @@ class FFTConvFunc(torch.autograd.Function):
         g = _aligned(g)
         need_du = ctx.needs_input_grad[0]
         need_dk = ctx.needs_input_grad[1] or (ctx.needs_input_grad[2] and ctx.has_bias)
-        du, dk, dbias = _lib.fftconv_bwd(g, rows, kf, bias, need_du=need_du, need_dk=need_dk)
+        du, dk, dbias = _lib.fftconv_bwd(g, rows, kf, bias, need_du=need_du, need_dk=need_dk, saved=ctx.spectra)
+        ctx.spectra = None
         du = ctx.restore(du) if (du is not None and need_du) else None
         dk_out = dk.to(ctx.k_dtype) if (dk is not None and ctx.needs_input_grad[1]) else None
         dD = None

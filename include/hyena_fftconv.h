@@ -81,8 +81,9 @@ size_t hyena_fftconv_table_bytes(int L);
 int hyena_fftconv_init_tables(void* d_tables, int L);
 
 /* Channels processed per pass through the kernel chain ("chunk").  Intermediate spectra of one chunk
- * live in the workspace; the default keeps them inside the 256 MiB Infinity Cache.
- * backward = 0 for hyena_fftconv_fwd, 1 for hyena_fftconv_bwd. */
+ * live in the workspace; the default takes as many channels as an 8 GiB workspace holds (all of them at
+ * every HyenaDNA size): launches are few and large, which measured faster on MI355X than Infinity-Cache-sized
+ * chunks.  backward = 0 for hyena_fftconv_fwd, 1 for hyena_fftconv_bwd. */
 int hyena_fftconv_default_chunk(int B, int D, int L, int backward);
 
 /* Workspace bytes for the given problem and chunk (chunk <= 0 selects the default). */
@@ -105,6 +106,21 @@ int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const flo
                       int B, int D, int L, int dtype,
                       const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
                       void* stream);
+
+/* Optional time-for-memory trade (what the reference's autograd does by keeping u_f, src/ops/fftconv.py:78 keeps
+ * k_f): the forward can leave the column-transformed filter and activations in a caller-owned buffer
+ *     saved = Wk [D][M] | Wu [B][D][M]   complex64,  hyena_fftconv_saved_bytes(B, D, L) bytes
+ * and the backward then skips re-reading u and k and their column transforms (22 of ~150 MB of traffic per row at
+ * L = 2^20).  Results are bitwise those of the plain entry points.  The buffer must stay untouched in between. */
+size_t hyena_fftconv_saved_bytes(int B, int D, int L);
+int hyena_fftconv_fwd_save(const void* u, const float* k, const float* bias, void* out,
+                           int B, int D, int L, int dtype,
+                           const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
+                           void* saved, size_t saved_bytes, void* stream);
+int hyena_fftconv_bwd_saved(const void* dout, const float* bias, void* du, float* dk, float* dbias,
+                            int B, int D, int L, int dtype,
+                            const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
+                            const void* saved, size_t saved_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,8 @@ def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
     for s in ("hyena_fftconv_fwd", "hyena_fftconv_bwd", "hyena_fftconv_workspace_bytes", "hyena_fftconv_init_tables",
               "hyena_fftconv_table_bytes", "hyena_fftconv_fft_size", "hyena_fftconv_abi_version",
-              "hyena_fftconv_error_string", "hyena_fftconv_default_chunk"):
+              "hyena_fftconv_error_string", "hyena_fftconv_default_chunk", "hyena_fftconv_saved_bytes",
+              "hyena_fftconv_fwd_save", "hyena_fftconv_bwd_saved"):
         assert s in syms
 
 
@@ -40,8 +41,10 @@ def test_host_only_entry_points(product_lib):
     L = product_lib
     L.hyena_fftconv_workspace_bytes.restype = ctypes.c_size_t
     L.hyena_fftconv_table_bytes.restype = ctypes.c_size_t
+    L.hyena_fftconv_saved_bytes.restype = ctypes.c_size_t
+    assert L.hyena_fftconv_saved_bytes(1, 256, 1 << 20) == 2 * 256 * (1 << 20) * 8
     L.hyena_fftconv_error_string.restype = ctypes.c_char_p
-    assert L.hyena_fftconv_abi_version() == 1
+    assert L.hyena_fftconv_abi_version() == 2
     assert L.hyena_fftconv_fft_size(1024) == 1024 and L.hyena_fftconv_fft_size(160000) == 262144
     assert L.hyena_fftconv_fft_size(450560) == 524288 and L.hyena_fftconv_fft_size(1 << 20) == 1 << 20
     assert L.hyena_fftconv_fft_size((1 << 20) + 1) == 0

@@ -128,3 +128,18 @@ def test_error_codes(emu_backend):
     st = L.hyena_fftconv_fwd(u.data_ptr(), k.data_ptr(), None, out.data_ptr(), 1, 2, 64, 7, t.data_ptr(),
                              ws.data_ptr(), ws.numel(), 0, None)
     assert st == 1
+
+
+@pytest.mark.parametrize("B,D,L,chunk,dtype", [(1, 3, 5000, 2, torch.float32), (2, 4, 1023, 0, torch.bfloat16),
+                                               (3, 2, 40000, 1, torch.float32), (1, 1, 262144, 0, torch.float32)])
+def test_saved_spectra_backward_is_bitwise_the_recomputing_one(emu_backend, B, D, L, chunk, dtype):
+    """fwd_save + bwd_saved (spectra kept from the forward) give the same bits as fwd + bwd (recomputed)."""
+    u, k, bias, dout = _inputs(B, D, L, dtype, seed=L + 5)
+    out = emu_backend.fftconv_fwd(u, k, bias, chunk=chunk)
+    du, dk, dbias = emu_backend.fftconv_bwd(dout, u, k, bias, chunk=chunk)
+    out2, saved = emu_backend.fftconv_fwd(u, k, bias, chunk=chunk, save=True)
+    assert saved.numel() == emu_backend.saved_bytes(B, D, L)
+    du2, dk2, dbias2 = emu_backend.fftconv_bwd(dout, None, None, bias, chunk=chunk, saved=saved)
+    assert torch.equal(out, out2) and torch.equal(du, du2) and torch.equal(dk, dk2) and torch.equal(dbias, dbias2)
+    du3, dk3, _ = emu_backend.fftconv_bwd(dout, None, None, bias, need_du=True, need_dk=False, chunk=chunk, saved=saved)
+    assert dk3 is None and torch.equal(du3, du)

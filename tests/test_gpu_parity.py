@@ -188,3 +188,15 @@ def test_streams_and_chunking_agree(gpu_lib):
     s.synchronize()
     for o in outs:
         assert torch.equal(o, ref)
+
+
+@pytest.mark.parametrize("B,D,L,dtype", [(2, 8, 32768, torch.bfloat16), (1, 2, 1048576, torch.float32), (3, 5, 1023, torch.float32)])
+def test_saved_spectra_path_is_bitwise_the_recomputing_one(gpu_lib, B, D, L, dtype):
+    dev = torch.device("cuda", 0)
+    u, k, bias, dout = (t.to(dev) for t in _inputs(B, D, L, dtype, seed=L + 9))
+    out = gpu_lib.fftconv_fwd(u, k, bias)
+    du, dk, dbias = gpu_lib.fftconv_bwd(dout, u, k, bias)
+    out2, saved = gpu_lib.fftconv_fwd(u, k, bias, save=True)
+    du2, dk2, dbias2 = gpu_lib.fftconv_bwd(dout, None, None, bias, saved=saved)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(du, du2) and torch.equal(dk, dk2) and torch.equal(dbias, dbias2)
