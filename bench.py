@@ -45,6 +45,20 @@ def algorithmic_bytes(B, D, L, s):
     return 5 * B * D * L * s + 12 * D * L + 8 * D
 
 
+def measured_traffic(L, D, B, io_dtype, save):
+    """HBM bytes per step from the committed PMC run (profiles/pmc_traffic.json, made by scripts/gpu_pmc.sh) if it was
+    taken on this exact configuration; None otherwise (rocprofv3 cannot run inside this process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        c = t["config"]
+        if (c["seq_len"], c["d_model"], c["batch_per_gpu"], c["io_dtype"], c["save_spectra"]) == (L, D, B, io_dtype, bool(save)):
+            return t["traffic_bytes_per_step"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,7 +218,7 @@ def main():
                                       if world > 1 else "single GPU",
                        "unit_of_work": "one nucleotide through one Hyena long-conv layer call (fwd+bwd), all d channels"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(L, D, B, args.dtype, save),
                          "kernel": "all launches of one fftconv fwd+bwd step (col_fwd/row_*/col_inv chain)",
                          "algorithmic_bytes_per_step": abytes, "event_ms_per_step": ev_ms_step},
         }

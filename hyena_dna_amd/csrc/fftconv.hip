@@ -7,7 +7,9 @@
 // Built by hipcc --offload-arch=gfx950 (product).  With -DHIPEMU it builds against tests/hipemu with g++
 // into a CPU emulation used only by the `not gpu` tests.
 #include "fftconv_kernels.h"
+#include "mixer_kernels.h"
 #include "../../include/hyena_fftconv.h"
+#include "../../include/hyena_mixer.h"
 
 #include <cmath>
 #include <cstdio>
@@ -354,6 +356,74 @@ int hyena_fftconv_bwd_saved(const void* dout, const float* bias, void* du, float
     if (saved == nullptr) return HYENA_ERR_BAD_ARG;
     return bwd_impl(dout, nullptr, nullptr, bias, du, dk, dbias, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk,
                     saved, saved_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused mixer shell (include/hyena_mixer.h)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+bool mix_ok(const void* x, const float* w, const float* b, int B, int L, int Lx, int D, int dtype) {
+    return x != nullptr && w != nullptr && b != nullptr && B >= 1 && L >= 1 && Lx >= L && D >= 1 &&
+           (dtype == HYENA_F32 || dtype == HYENA_BF16 || dtype == HYENA_F16);
+}
+dim3 mix_grid(int B, int L, int D) { return dim3((L + MIX_RUN - 1) / MIX_RUN, (D + 63) / 64, B); }
+const size_t MIX_SMEM = 64 * 65 * sizeof(float);
+
+#define HY_MIX_DISPATCH(kernel, smem)                                                                \
+    do {                                                                                             \
+        switch (dtype) {                                                                             \
+            case HYENA_F32: HY_LAUNCH((kernel<DT_F32>), mix_grid(B, L, D), dim3(64), smem, stream, a); break;  \
+            case HYENA_BF16: HY_LAUNCH((kernel<DT_BF16>), mix_grid(B, L, D), dim3(64), smem, stream, a); break; \
+            default: HY_LAUNCH((kernel<DT_F16>), mix_grid(B, L, D), dim3(64), smem, stream, a); break;          \
+        }                                                                                            \
+    } while (0)
+}  // namespace
+
+int hyena_mixer_pre_fwd(const void* x, const float* w, const float* b, void* vg, int B, int L, int Lx, int D, int dtype,
+                        void* stream) {
+    if (!mix_ok(x, w, b, B, L, Lx, D, dtype) || vg == nullptr) return HYENA_ERR_BAD_ARG;
+    MixArgs a;
+    a.x = x; a.w = w; a.b = b; a.a0 = vg; a.a1 = nullptr; a.a2 = nullptr; a.dx = nullptr; a.part = nullptr;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    HY_MIX_DISPATCH(mixer_pre_fwd_kernel, MIX_SMEM);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+int hyena_mixer_post_fwd(const void* y, const void* x, const float* w, const float* b, void* z, int B, int L, int Lx, int D,
+                         int dtype, void* stream) {
+    if (!mix_ok(x, w, b, B, L, Lx, D, dtype) || y == nullptr || z == nullptr) return HYENA_ERR_BAD_ARG;
+    MixArgs a;
+    a.x = x; a.w = w; a.b = b; a.a0 = const_cast<void*>(y); a.a1 = z; a.a2 = nullptr; a.dx = nullptr; a.part = nullptr;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    HY_MIX_DISPATCH(mixer_post_fwd_kernel, MIX_SMEM);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+size_t hyena_mixer_partial_floats(int B, int L, int D) {
+    if (B < 1 || L < 1 || D < 1) return 0;
+    return (size_t)B * ((L + MIX_RUN - 1) / MIX_RUN) * 3 * D * 4;
+}
+
+int hyena_mixer_post_bwd(const void* dz, const void* y, const void* x, const float* w, const float* b, void* dy, void* dx,
+                         float* part, int B, int L, int Lx, int D, int dtype, void* stream) {
+    if (!mix_ok(x, w, b, B, L, Lx, D, dtype) || dz == nullptr || y == nullptr || dy == nullptr || dx == nullptr ||
+        part == nullptr)
+        return HYENA_ERR_BAD_ARG;
+    MixArgs a;
+    a.x = x; a.w = w; a.b = b; a.a0 = const_cast<void*>(y); a.a1 = const_cast<void*>(dz); a.a2 = dy; a.dx = dx; a.part = part;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    HY_MIX_DISPATCH(mixer_post_bwd_kernel, 2 * MIX_SMEM);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+int hyena_mixer_pre_bwd(const void* dvg, const void* x, const float* w, const float* b, void* dx, float* part, int B, int L,
+                        int Lx, int D, int dtype, void* stream) {
+    if (!mix_ok(x, w, b, B, L, Lx, D, dtype) || dvg == nullptr || dx == nullptr || part == nullptr) return HYENA_ERR_BAD_ARG;
+    MixArgs a;
+    a.x = x; a.w = w; a.b = b; a.a0 = const_cast<void*>(dvg); a.a1 = nullptr; a.a2 = nullptr; a.dx = dx; a.part = part;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    HY_MIX_DISPATCH(mixer_pre_bwd_kernel, MIX_SMEM);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
 }  // extern "C"

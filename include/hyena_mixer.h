@@ -1,0 +1,48 @@
+/* hyena_mixer.h -- C ABI of the fused element-wise shell of the Hyena operator (same library, libhyena_fftconv.so).
+ *
+ * Replaces, for the HyenaDNA operator configuration (order 2, one head, one block, inner factor 1, dropout 0,
+ * activation "id", short_filter_order 3), these lines of HyenaOperator.forward
+ * (src/models/sequence/hyena.py:392-439) and their autograd:
+ *
+ *     u  = rearrange(in_proj(u), 'b l d -> b d l')                     hyena.py:391-392
+ *     uc = self.short_filter(u)[..., :l_filter]                        hyena.py:394     nn.Conv1d(3D, 3D, 3, groups=3D, padding=2)
+ *     *x, v = uc.split(d_model, dim=2)                                 hyena.py:396-404
+ *     v = v * x[1]                                                     hyena.py:420     -> hyena_mixer_pre_fwd
+ *     v = fftconv(v, k, bias)                                          hyena.py:423     (hyena_fftconv_*)
+ *     y = rearrange(v * x[0], 'b h v z l -> b (z l) (h v)')            hyena.py:432-439 -> hyena_mixer_post_fwd
+ *
+ * Tensors (row-major, contiguous), `dtype` as in hyena_fftconv.h (HYENA_F32 / HYENA_BF16 / HYENA_F16):
+ *   x   : (B, Lx, 3D)  output of in_proj; channels [0,D) = x0, [D,2D) = x1, [2D,3D) = v
+ *   w   : (3D, 3) fp32 short-filter taps (Conv1d weight (3D,1,3));  b : (3D,) fp32
+ *   vg, y, dy, dvg : (B, D, L);   z, dz : (B, L, D);   L = min(Lx, l_max) positions are processed
+ *   dx  : (B, Lx, 3D); positions >= L are NOT written (zero-fill them when Lx > L)
+ *   part: hyena_mixer_partial_floats(B, L, D) floats of scratch, laid out [B][runs][3D][4] = per-run partial sums of
+ *         (dw[c][0], dw[c][1], dw[c][2], db[c]); summing over the first two axes gives the short filter's gradients
+ *         (post_bwd fills channels [0,D), pre_bwd [D,3D)).  No atomics: results are deterministic.
+ * Arithmetic is fp32; 16-bit tensors are rounded once on store.  All entry points are asynchronous on `stream`.
+ */
+#ifndef HYENA_MIXER_H
+#define HYENA_MIXER_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* vg[b,d,t] = xc[b,2D+d,t] * xc[b,D+d,t],  xc[c,t] = b[c] + w[c,0] x[t-2,c] + w[c,1] x[t-1,c] + w[c,2] x[t,c] */
+int hyena_mixer_pre_fwd(const void* x, const float* w, const float* b, void* vg,
+                        int B, int L, int Lx, int D, int dtype, void* stream);
+/* z[b,t,d] = y[b,d,t] * xc[b,d,t] */
+int hyena_mixer_post_fwd(const void* y, const void* x, const float* w, const float* b, void* z,
+                         int B, int L, int Lx, int D, int dtype, void* stream);
+size_t hyena_mixer_partial_floats(int B, int L, int D);
+/* dy = dz^T * x0c;  dx[..., 0:D] and the partials of channels [0,D) from g = dz^T * y */
+int hyena_mixer_post_bwd(const void* dz, const void* y, const void* x, const float* w, const float* b,
+                         void* dy, void* dx, float* part, int B, int L, int Lx, int D, int dtype, void* stream);
+/* dx[..., D:3D] and the partials of channels [D,3D) from dvg (gradient of vg) */
+int hyena_mixer_pre_bwd(const void* dvg, const void* x, const float* w, const float* b,
+                        void* dx, float* part, int B, int L, int Lx, int D, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYENA_MIXER_H */

@@ -6,8 +6,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "_emu_fftconv_test_only.so")
 SRC = [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv.hip"), os.path.join(HERE, "hipemu.cpp")]
-DEPS = SRC + [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv_kernels.h"), os.path.join(HERE, "hipemu.h"),
-              os.path.join(ROOT, "include", "hyena_fftconv.h")]
+DEPS = SRC + [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv_kernels.h"),
+              os.path.join(ROOT, "hyena_dna_amd", "csrc", "mixer_kernels.h"), os.path.join(HERE, "hipemu.h"),
+              os.path.join(ROOT, "include", "hyena_fftconv.h"), os.path.join(ROOT, "include", "hyena_mixer.h")]
 
 
 def build(force=False):
