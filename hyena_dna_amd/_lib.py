@@ -94,6 +94,20 @@ def lib():
         L.hyena_fftconv_bwd_saved.restype = c_int
         L.hyena_fftconv_bwd_saved.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                               c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]
+        # fused mixer shell (include/hyena_mixer.h)
+        L.hyena_mixer_pre_fwd.restype = c_int
+        L.hyena_mixer_pre_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_mixer_post_fwd.restype = c_int
+        L.hyena_mixer_post_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_void_p]
+        L.hyena_mixer_partial_floats.restype = c_size_t
+        L.hyena_mixer_partial_floats.argtypes = [c_int, c_int, c_int]
+        L.hyena_mixer_post_bwd.restype = c_int
+        L.hyena_mixer_post_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_mixer_pre_bwd.restype = c_int
+        L.hyena_mixer_pre_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_int, c_int, c_int, c_int, c_void_p]
         if L.hyena_fftconv_abi_version() != ABI_VERSION:
             raise HyenaLibraryError(f"{LIB_PATH}: ABI version {L.hyena_fftconv_abi_version()} != {ABI_VERSION}; rebuild")
         _lib = L
@@ -214,3 +228,53 @@ def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None, saved=
                                           B, D, L, dtype_code(dout.dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(),
                                           chunk, stream))
     return du, dk, dbias
+
+
+# ---- fused mixer shell (include/hyena_mixer.h): short depthwise conv + gates + layout changes -----------------------
+def mixer_pre_fwd(x, w, b, L):
+    """x (B, Lx, 3D), w (3D, 3) fp32, b (3D,) fp32 -> vg (B, D, L) = short_conv(x)[v] * short_conv(x)[x1]."""
+    _require_gpu(x, "x")
+    B, Lx, D3 = x.shape
+    D = D3 // 3
+    vg = torch.empty((B, D, L), dtype=x.dtype, device=x.device)
+    with _backend.guard(x.device):
+        check(lib().hyena_mixer_pre_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), vg.data_ptr(), B, L, Lx, D,
+                                        dtype_code(x.dtype), _backend.stream(x.device)))
+    return vg
+
+
+def mixer_post_fwd(y, x, w, b):
+    """y (B, D, L), x (B, Lx, 3D) -> z (B, L, D) = y^T * short_conv(x)[x0]."""
+    _require_gpu(x, "x")
+    B, D, L = y.shape
+    z = torch.empty((B, L, D), dtype=x.dtype, device=x.device)
+    with _backend.guard(x.device):
+        check(lib().hyena_mixer_post_fwd(y.data_ptr(), x.data_ptr(), w.data_ptr(), b.data_ptr(), z.data_ptr(), B, L,
+                                         x.shape[1], D, dtype_code(x.dtype), _backend.stream(x.device)))
+    return z
+
+
+def mixer_partials(x, L):
+    B, Lx, D3 = x.shape
+    n = lib().hyena_mixer_partial_floats(B, L, D3 // 3)
+    return torch.empty(n, dtype=torch.float32, device=x.device).view(B, -1, D3, 4)
+
+
+def mixer_post_bwd(dz, y, x, w, b, dx, part):
+    """-> dy (B, D, L); fills dx[..., 0:D] (positions < L) and part[..., 0:D, :]."""
+    B, D, L = y.shape
+    dy = torch.empty_like(y)
+    with _backend.guard(x.device):
+        check(lib().hyena_mixer_post_bwd(dz.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                         dy.data_ptr(), dx.data_ptr(), part.data_ptr(), B, L, x.shape[1], D,
+                                         dtype_code(x.dtype), _backend.stream(x.device)))
+    return dy
+
+
+def mixer_pre_bwd(dvg, x, w, b, dx, part):
+    """fills dx[..., D:3D] (positions < L) and part[..., D:3D, :]."""
+    B, D, L = dvg.shape
+    with _backend.guard(x.device):
+        check(lib().hyena_mixer_pre_bwd(dvg.data_ptr(), x.data_ptr(), w.data_ptr(), b.data_ptr(), dx.data_ptr(),
+                                        part.data_ptr(), B, L, x.shape[1], D, dtype_code(x.dtype),
+                                        _backend.stream(x.device)))

@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .fftconv import fftconv_func
+from .mixer import hyena_mixer_core
 
 __all__ = ["HyenaOperator", "HyenaFilter", "PositionalEmbedding", "ExponentialModulation", "Sin"]
 
@@ -197,9 +198,22 @@ class HyenaOperator(nn.Module):
         self.filter_fn = HyenaFilter(self.head_dim * inner_factor * (order - 1), order=filter_order, seq_len=l_max,
                                      channels=1, dropout=filter_dropout, **filter_args)
 
+    def _fused_ok(self):
+        """The fused HIP mixer core covers exactly the HyenaDNA operator configuration."""
+        return (self.order == 2 and self.num_heads == 1 and self.num_blocks == 1 and self.inner_factor == 1
+                and not self.outer_mixing and not self.post_order_ffn and self.short_filter_order == 3
+                and (self.dropout.p == 0.0 or not self.training) and self.filter_fn.use_bias is not None)
+
     def forward(self, u, *args, **kwargs):
         l = u.size(-2)
         l_filter = min(l, self.l_max)
+        if self._fused_ok():
+            x = self.in_proj(u)                                                 # (B, L, 3D), hipBLASLt GEMM
+            k = self.filter_fn.filter(l_filter)[0].transpose(0, 1)              # (1, l, D) -> (D, l)
+            fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
+            z = hyena_mixer_core(x, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter)
+            y = self.out_proj(self.activation(z))
+            return (y, None) if self.return_state else y
         u = self.in_proj(u).transpose(1, 2)                                     # b l d -> b d l
         uc = self.short_filter(u)[..., :l_filter]
         b = uc.shape[0]

@@ -1,0 +1,66 @@
+"""The fused core of ``HyenaOperator.forward`` between the two projections (reference:
+``src/models/sequence/hyena.py:392-439``): short depthwise conv (k = 3), ``v * x1`` gate, long convolution,
+``* x0`` gate and the (B, L, C) <-> (B, D, L) layout changes, as one autograd function over the HIP kernels of
+``include/hyena_mixer.h`` + ``include/hyena_fftconv.h``.
+
+Valid for the HyenaDNA operator configuration: order 2, one head, one block, inner factor 1, no outer mixing /
+post-order FFN, dropout 0, identity activation, ``short_filter_order`` 3.  ``hyena_dna_amd.hyena.HyenaOperator`` uses it
+whenever those hold and takes its generic (PyTorch-glue + ``fftconv_func``) path otherwise.
+
+What is kept for the backward: ``x`` (the in_proj output, alive in autograd anyway), ``y`` (the conv output), the filter
+and -- unless disabled -- the forward's column spectra; the three short-conv outputs are recomputed from ``x`` inside the
+backward kernels (3 taps) instead of being stored.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ["hyena_mixer_core", "HyenaMixerFunc"]
+
+
+class HyenaMixerFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sf_weight, sf_bias, k, bias, L):
+        """x (B, Lx, 3D); sf_weight (3D, 1, 3); sf_bias (3D,); k (D, L) fp32; bias (D,) -> z (B, L, D), L <= Lx."""
+        B, Lx, D3 = x.shape
+        D = D3 // 3
+        xc = x.contiguous()
+        w = sf_weight.detach().to(torch.float32).reshape(D3, 3).contiguous()
+        b = sf_bias.detach().to(torch.float32).contiguous()
+        kf = k.detach().to(torch.float32).contiguous()
+        bf = bias.detach().to(torch.float32).reshape(D).contiguous()
+        vg = _lib.mixer_pre_fwd(xc, w, b, L)
+        want_grad = any(ctx.needs_input_grad[:5])
+        spectra = None
+        if want_grad and _lib.save_spectra_default(B, D, L):
+            y, spectra = _lib.fftconv_fwd(vg, kf, bf, save=True)
+        else:
+            y = _lib.fftconv_fwd(vg, kf, bf)
+        z = _lib.mixer_post_fwd(y, xc, w, b)
+        ctx.save_for_backward(xc, w, b, kf, bf, y)
+        ctx.spectra = spectra
+        ctx.meta = (sf_weight.shape, sf_weight.dtype, sf_bias.dtype, k.dtype, bias.shape, bias.dtype, L)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        xc, w, b, kf, bf, y = ctx.saved_tensors
+        w_shape, w_dtype, b_dtype, k_dtype, bias_shape, bias_dtype, L = ctx.meta
+        B, Lx, D3 = xc.shape
+        dz = dz.to(xc.dtype).contiguous()
+        dx = torch.zeros_like(xc) if Lx > L else torch.empty_like(xc)
+        part = _lib.mixer_partials(xc, L)
+        dy = _lib.mixer_post_bwd(dz, y, xc, w, b, dx, part)
+        vg = None if ctx.spectra is not None else _lib.mixer_pre_fwd(xc, w, b, L)      # recompute the conv's input
+        dvg, dk, dbias = _lib.fftconv_bwd(dy, vg, kf, bf, need_du=True, need_dk=True, saved=ctx.spectra)
+        ctx.spectra = None
+        _lib.mixer_pre_bwd(dvg, xc, w, b, dx, part)
+        red = part.sum(dim=(0, 1))                                  # (3D, 4): deterministic two-stage reduction
+        dw = red[:, :3].reshape(w_shape).to(w_dtype)
+        db = red[:, 3].to(b_dtype)
+        return dx, dw, db, dk.to(k_dtype), dbias.reshape(bias_shape).to(bias_dtype), None
+
+
+def hyena_mixer_core(x, sf_weight, sf_bias, k, bias, L):
+    """z = ((fftconv(v * x1, k, bias)) * x0)^T with (x0, x1, v) = short_conv(x^T)[..., :L].split(D)."""
+    return HyenaMixerFunc.apply(x, sf_weight, sf_bias, k, bias, L)

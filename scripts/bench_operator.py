@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Diagnostic (not the contract bench): one HyenaOperator layer fwd+bwd, fused HIP mixer core vs the same module
+forced onto its generic PyTorch-glue path (both use the HIP long convolution)."""
+import sys, os, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hyena_dna_amd.hyena import HyenaOperator
+
+dev = torch.device("cuda", 0)
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+D = 256
+torch.manual_seed(0)
+op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
+                   lr=6e-4, wd=0.0, lr_pos_emb=0.0).to(dev)
+u = torch.randn(B, L, D, device=dev, requires_grad=True)
+dy = torch.randn(B, L, D, device=dev)
+
+
+def run(fused, n=10):
+    HyenaOperator._fused_ok = (lambda self: True) if fused else (lambda self: False)
+    for _ in range(3):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = op(u)
+        y.backward(dy)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = op(u)
+        y.backward(dy)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+a = run(True); b = run(False)
+print(f"HyenaOperator layer fwd+bwd  L={L} B={B} d={D} bf16 autocast: fused mixer core {a:.3f} ms, PyTorch-glue path {b:.3f} ms, x{b / a:.2f}")
