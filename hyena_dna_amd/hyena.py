@@ -136,6 +136,27 @@ class HyenaFilter(_OptimModule):
             h = h / torch.norm(h, dim=-1, p=1, keepdim=True)
         return h
 
+    def filter_dl(self, L):
+        """The same filter as ``filter(L)[0].T`` but produced directly in the (D, L) layout the long convolution
+        reads (channel rows contiguous along L): the last linear layer is applied as ``W @ hidden^T`` and the
+        modulation runs on (D, L), so no (L, D) -> (D, L) transposing copy (8 ms per layer at L = 2^20) is made."""
+        z, t = self.pos_emb(L)
+        # index the Sequential: .children() de-duplicates the ONE Sin instance that sits in three slots
+        layers = [self.implicit_filter[i] for i in range(len(self.implicit_filter))]
+        last = layers[-1]
+        h = z
+        for layer in layers[:-1]:
+            h = layer(h)
+        if not isinstance(last, nn.Linear) or last.bias is not None or h.dim() != 3 or h.shape[0] != 1:
+            return self.filter(L)[0].transpose(0, 1)
+        k = torch.matmul(last.weight.to(h.dtype), h[0].transpose(0, 1))          # (D, order) @ (order, L) -> (D, L)
+        if self.modulate:
+            deltas = self.modulation.deltas.reshape(-1, 1).abs()                   # (D, 1)
+            k = k * (torch.exp(-t.reshape(1, -1) * deltas) + self.modulation.shift)
+        if self.normalized:
+            k = k / torch.norm(k, dim=0, p=1, keepdim=True)
+        return k
+
     def forward(self, x, L, k=None, bias=None, *args, **kwargs):
         if k is None:
             k = self.filter(L)
@@ -209,7 +230,7 @@ class HyenaOperator(nn.Module):
         l_filter = min(l, self.l_max)
         if self._fused_ok():
             x = self.in_proj(u)                                                 # (B, L, 3D), hipBLASLt GEMM
-            k = self.filter_fn.filter(l_filter)[0].transpose(0, 1)              # (1, l, D) -> (D, l)
+            k = self.filter_fn.filter_dl(l_filter)                              # (D, l), rows contiguous along l
             fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
             z = hyena_mixer_core(x, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter)
             y = self.out_proj(self.activation(z))

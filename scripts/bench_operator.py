@@ -32,5 +32,7 @@ def run(fused, n=10):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-a = run(True); b = run(False)
+mode = sys.argv[3] if len(sys.argv) > 3 else "both"
+a = run(True) if mode in ("both", "fused") else float("nan")
+b = run(False) if mode in ("both", "glue") else float("nan")
 print(f"HyenaOperator layer fwd+bwd  L={L} B={B} d={D} bf16 autocast: fused mixer core {a:.3f} ms, PyTorch-glue path {b:.3f} ms, x{b / a:.2f}")
