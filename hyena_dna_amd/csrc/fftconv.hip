@@ -104,14 +104,15 @@ const size_t ROW0_SMEM = ROW0_LDS * sizeof(c32);
 // rows 0 and M1/2 (self-paired) go through the row0_* kernels, the M1/2 - 1 regular pairs through row_*.
 template <int MODE>
 int launch_row_prod2(const RowArgs& a, void* stream) {
-    HY_LAUNCH((row0_prod2_kernel<MODE>), dim3(a.M1 >= 2 ? 2 : 1, (a.inner + 1) / 2), dim3(64), ROW0_SMEM, stream, a);
+    HY_LAUNCH((row0_prod2_kernel<MODE>), dim3(a.M1 >= 2 ? 2 : 1, (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, stream, a);
     if (a.M1 >= 4) HY_LAUNCH((row_prod2_kernel<MODE>), dim3(a.M1 / 2 - 1, a.inner), dim3(64), ROW_SMEM, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
 template <bool DO_DU>
 int launch_row_bwd(const RowArgs& a, void* stream) {
-    HY_LAUNCH((row0_bwd_kernel<DO_DU>), dim3(a.M1 >= 2 ? 2 : 1, (a.inner + 1) / 2), dim3(64), ROW0_SMEM, stream, a);
+    HY_LAUNCH((row0_bwd_kernel<DO_DU>), dim3(a.M1 >= 2 ? 2 : 1, (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, stream, a);
+    HY_LAUNCH(row0_dk_reduce_kernel, dim3(a.M1 >= 2 ? 2 : 1, a.inner), dim3(256), 0, stream, a);
     if (a.M1 >= 4) HY_LAUNCH((row_bwd_kernel<DO_DU>), dim3(a.M1 / 2 - 1, a.inner), dim3(64), ROW_SMEM, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
@@ -205,7 +206,8 @@ size_t hyena_fftconv_workspace_bytes(int B, int D, int L, int backward, int chun
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, backward);
     if (chunk > D) chunk = D;
     if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
-    return (size_t)(backward ? 2 * B + 2 : B + 1) * chunk * p.M * sizeof(c32);
+    return (size_t)(backward ? 2 * B + 2 : B + 1) * chunk * p.M * sizeof(c32) +
+           (backward ? (size_t)B * chunk * 2 * 1024 * sizeof(c32) : 0);      // + per-batch dk rows of the self-paired rows
 }
 
 // saved-spectrum buffer (optional, persists from forward to backward): Wk [D][M] | Wu [B][D][M], complex64
@@ -254,7 +256,7 @@ static int fwd_impl(const void* u, const float* k, const float* bias, void* out,
         cu.outer_stride = (long)D * L; cu.inner_stride = L; cu.aux0 = nullptr; cu.x2 = nullptr; cu.W2 = nullptr;
         if ((st = launch_col<false>(dtype, p.M1, cu, B * cd, stream))) return st;
         RowArgs rc;
-        rc.X = Wu; rc.U = Wk; rc.S = nullptr; rc.bias = bias ? bias + d0 : nullptr; rc.K = nullptr; rc.Y = wsW;
+        rc.X = Wu; rc.U = Wk; rc.S = nullptr; rc.S0 = nullptr; rc.bias = bias ? bias + d0 : nullptr; rc.K = nullptr; rc.Y = wsW;
         rc.x_bstride = ub; rc.u_bstride = 0; rc.y_bstride = cd; rc.tab = tab;
         rc.M1 = p.M1; rc.inner = cd; rc.B = B; rc.scale = 1.0f / (float)p.M;
         if ((st = launch_row_prod2<MODE_CONV>(rc, stream))) return st;
@@ -287,6 +289,7 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
     c32* Sdk = wsWk + (size_t)chunk * p.M;                      // [chunk][M]      dk rows (batch sum) -> packed dk
     c32* Wg = Sdk + (size_t)chunk * p.M;                        // [B][chunk][M]   dout rows -> du rows
     c32* wsWu = Wg + (size_t)B * chunk * p.M;                   // [B][chunk][M]   u rows
+    c32* S0 = wsWu + (size_t)B * chunk * p.M;                   // [B][chunk][2][1024] per-batch dk rows 0 and M1/2
     const size_t es = elem_size(dtype);
     int st;
     for (int d0 = 0; d0 < D; d0 += chunk) {
@@ -306,7 +309,7 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
         ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
         if (du != nullptr && !saved && (st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
         RowArgs rb;
-        rb.X = Wg; rb.U = Wu; rb.S = Sdk; rb.bias = bias ? bias + d0 : nullptr; rb.K = Wk; rb.Y = Wg;
+        rb.X = Wg; rb.U = Wu; rb.S = Sdk; rb.S0 = S0; rb.bias = bias ? bias + d0 : nullptr; rb.K = Wk; rb.Y = Wg;
         rb.x_bstride = cd; rb.u_bstride = ub; rb.y_bstride = cd; rb.tab = tab;
         rb.M1 = p.M1; rb.inner = cd; rb.B = B; rb.scale = 1.0f / (float)p.M;
         if (dk != nullptr) {

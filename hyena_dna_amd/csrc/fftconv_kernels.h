@@ -618,6 +618,7 @@ struct RowArgs {
     c32* S;            // row_bwd out: dk rows [inner][M1][1024]
     const float* bias; // [inner] or null
     const c32* K;      // row_bwd: filter rows [inner][M1][1024]
+    c32* S0;           // row0_bwd: per-batch-item dk rows of the two self-paired rows, [B][inner][2][1024]
     c32* Y;            // row_prod2: where the product rows go (X itself when in place), [B][y_bstride..][M1][1024]
     int x_bstride;     // rows between batch items of X / U / Y: `inner` in a chunk workspace, D in the saved-spectrum
     int u_bstride;     //   buffer
@@ -925,7 +926,9 @@ __global__ void __launch_bounds__(64, 2) row0_prod2_kernel(RowArgs a) {
     HY_UNROLL
     for (int s = 0; s < 32; ++s) h[s] = gb_ld(H, vo, (unsigned)s * 256u);
     row_fft1024<false>(h, imh, j, rtw);
-    for (int b = 0; b < a.B; ++b) {
+    {   // one batch item per workgroup (blockIdx.z): these two rows are 2/M1 of the work but, looped over the batch in
+        // one wavefront, they were 22 % of the time at L = 32k and all of it at L <= 1k
+        const int b = blockIdx.z;
         const GBuf X = make_gbuf(a.X + (size_t)b * a.x_bstride * M1 * 1024, slab);
         const GBuf Y = make_gbuf(a.Y + (size_t)b * a.y_bstride * M1 * 1024, slab);
         c32 v[32];
@@ -954,7 +957,7 @@ __global__ void __launch_bounds__(64, 2) row0_bwd_kernel(RowArgs a) {
     const bool valid = ch_raw < a.inner;
     const int ch = valid ? ch_raw : a.inner - 1;
     const unsigned slab = (unsigned)a.inner * (unsigned)M1 * 1024u * 8u;
-    const GBuf Kb = make_gbuf(a.K, slab), O = make_gbuf(a.S, slab);
+    const GBuf Kb = make_gbuf(a.K, slab);
     const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
     RowTw rtw;
     load_row_tw(rtw, twT, j);
@@ -962,7 +965,8 @@ __global__ void __launch_bounds__(64, 2) row0_bwd_kernel(RowArgs a) {
     const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
     const unsigned vo = ((unsigned)ch * (unsigned)M1 * 1024u + (unsigned)(myrow * 1024 + j)) * 8u;
 
-    for (int b = 0; b < a.B; ++b) {
+    {   // one batch item per workgroup; its dk rows go to S0[b] and row0_dk_reduce_kernel adds them up in batch order
+        const int b = blockIdx.z;
         const GBuf X = make_gbuf(a.X + (size_t)b * a.x_bstride * M1 * 1024, slab);
         const GBuf U = make_gbuf(a.U + (size_t)b * a.u_bstride * M1 * 1024, slab);
         c32 h[32], v[32];
@@ -985,12 +989,9 @@ __global__ void __launch_bounds__(64, 2) row0_bwd_kernel(RowArgs a) {
         __syncthreads();
         row_fft1024<true>(h, imh, j, rtw);
         if (valid) {
-            if (b > 0) {
-                HY_UNROLL
-                for (int q = 0; q < 32; ++q) h[q] = cadd(h[q], gb_ld(O, vo, (unsigned)q * 256u));
-            }
+            c32* P = a.S0 + ((((size_t)b * a.inner + ch) * 2 + blockIdx.x) * 1024) + j;
             HY_UNROLL
-            for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, h[q]);
+            for (int q = 0; q < 32; ++q) P[32 * q] = h[q];
         }
         if (DO_DU) {
             HY_UNROLL
@@ -1012,6 +1013,19 @@ __global__ void __launch_bounds__(64, 2) row0_bwd_kernel(RowArgs a) {
                 for (int q = 0; q < 32; ++q) gb_st(X, vo, (unsigned)q * 256u, v[q]);
             }
         }
+    }
+}
+
+// dk rows 0 and M1/2: sum of the per-batch-item rows written by row0_bwd_kernel, in batch order (deterministic).
+// grid (rows01, inner), 256 threads.
+__global__ void __launch_bounds__(256) row0_dk_reduce_kernel(RowArgs a) {
+    const int ch = blockIdx.y, r01 = blockIdx.x;
+    const int myrow = r01 ? (a.M1 >> 1) : 0;
+    c32* O = a.S + ((size_t)ch * a.M1 + myrow) * 1024;
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+        c32 acc = mk(0.f, 0.f);
+        for (int b = 0; b < a.B; ++b) acc = cadd(acc, a.S0[(((size_t)b * a.inner + ch) * 2 + r01) * 1024 + e]);
+        O[e] = acc;
     }
 }
 

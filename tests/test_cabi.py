@@ -51,7 +51,7 @@ def test_host_only_entry_points(product_lib):
     assert L.hyena_fftconv_table_bytes(1 << 20) == 4096 * 8
     # workspace = (B + 1 | 2B + 2) * chunk * M * 8 bytes (fwd | bwd)
     assert L.hyena_fftconv_workspace_bytes(1, 256, 1 << 20, 0, 4) == (1 + 1) * 4 * (1 << 20) * 8
-    assert L.hyena_fftconv_workspace_bytes(2, 256, 1 << 20, 1, 4) == (2 * 2 + 2) * 4 * (1 << 20) * 8
+    assert L.hyena_fftconv_workspace_bytes(2, 256, 1 << 20, 1, 4) == (2 * 2 + 2) * 4 * (1 << 20) * 8 + 2 * 4 * 2 * 1024 * 8
     c = L.hyena_fftconv_default_chunk(1, 256, 1 << 20, 0)
     assert c == 256
     assert L.hyena_fftconv_default_chunk(8, 128, 1024, 0) == 128
