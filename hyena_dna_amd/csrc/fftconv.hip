@@ -372,6 +372,22 @@ bool mix_ok(const void* x, const float* w, const float* b, int B, int L, int Lx,
 dim3 mix_grid(int B, int L, int D) { return dim3((L + MIX_RUN - 1) / MIX_RUN, (D + 63) / 64, B); }
 const size_t MIX_SMEM = 64 * 65 * sizeof(float);
 
+// the wide-access kernels need full 64-channel tiles and 16-byte-aligned channel rows
+bool mix_wide(int D) { return D % 64 == 0; }
+const size_t MW_SMEM_PRE_FWD = ((MW_TP + 2) * 2 * MW_CS + MW_TC * MW_CS) * sizeof(float);
+const size_t MW_SMEM_POST_FWD = ((MW_TP + 2) * MW_CS + 2 * MW_TC * MW_CS) * sizeof(float);
+const size_t MW_SMEM_POST_BWD = ((MW_TP + 4) * MW_CS + (MW_TP + 2) * MW_CS + MW_TC * MW_YS) * sizeof(float);
+const size_t MW_SMEM_PRE_BWD = (2 * (MW_TP + 4) * MW_CS + 2 * MW_TC * MW_YS) * sizeof(float);
+
+#define HY_MIXW_DISPATCH(kernel, smem)                                                               \
+    do {                                                                                             \
+        switch (dtype) {                                                                             \
+            case HYENA_F32: HY_LAUNCH((kernel<DT_F32>), mix_grid(B, L, D), dim3(MW_THREADS), smem, stream, a); break;   \
+            case HYENA_BF16: HY_LAUNCH((kernel<DT_BF16>), mix_grid(B, L, D), dim3(MW_THREADS), smem, stream, a); break; \
+            default: HY_LAUNCH((kernel<DT_F16>), mix_grid(B, L, D), dim3(MW_THREADS), smem, stream, a); break;          \
+        }                                                                                            \
+    } while (0)
+
 #define HY_MIX_DISPATCH(kernel, smem)                                                                \
     do {                                                                                             \
         switch (dtype) {                                                                             \
@@ -388,7 +404,8 @@ int hyena_mixer_pre_fwd(const void* x, const float* w, const float* b, void* vg,
     MixArgs a;
     a.x = x; a.w = w; a.b = b; a.a0 = vg; a.a1 = nullptr; a.a2 = nullptr; a.dx = nullptr; a.part = nullptr;
     a.B = B; a.L = L; a.D = D; a.Lx = Lx;
-    HY_MIX_DISPATCH(mixer_pre_fwd_kernel, MIX_SMEM);
+    if (mix_wide(D)) HY_MIXW_DISPATCH(mixer_pre_fwd_wide_kernel, MW_SMEM_PRE_FWD);
+    else HY_MIX_DISPATCH(mixer_pre_fwd_kernel, MIX_SMEM);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
@@ -398,7 +415,8 @@ int hyena_mixer_post_fwd(const void* y, const void* x, const float* w, const flo
     MixArgs a;
     a.x = x; a.w = w; a.b = b; a.a0 = const_cast<void*>(y); a.a1 = z; a.a2 = nullptr; a.dx = nullptr; a.part = nullptr;
     a.B = B; a.L = L; a.D = D; a.Lx = Lx;
-    HY_MIX_DISPATCH(mixer_post_fwd_kernel, MIX_SMEM);
+    if (mix_wide(D)) HY_MIXW_DISPATCH(mixer_post_fwd_wide_kernel, MW_SMEM_POST_FWD);
+    else HY_MIX_DISPATCH(mixer_post_fwd_kernel, MIX_SMEM);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
@@ -415,7 +433,8 @@ int hyena_mixer_post_bwd(const void* dz, const void* y, const void* x, const flo
     MixArgs a;
     a.x = x; a.w = w; a.b = b; a.a0 = const_cast<void*>(y); a.a1 = const_cast<void*>(dz); a.a2 = dy; a.dx = dx; a.part = part;
     a.B = B; a.L = L; a.D = D; a.Lx = Lx;
-    HY_MIX_DISPATCH(mixer_post_bwd_kernel, 2 * MIX_SMEM);
+    if (mix_wide(D)) HY_MIXW_DISPATCH(mixer_post_bwd_wide_kernel, MW_SMEM_POST_BWD);
+    else HY_MIX_DISPATCH(mixer_post_bwd_kernel, 2 * MIX_SMEM);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
@@ -425,7 +444,8 @@ int hyena_mixer_pre_bwd(const void* dvg, const void* x, const float* w, const fl
     MixArgs a;
     a.x = x; a.w = w; a.b = b; a.a0 = const_cast<void*>(dvg); a.a1 = nullptr; a.a2 = nullptr; a.dx = dx; a.part = part;
     a.B = B; a.L = L; a.D = D; a.Lx = Lx;
-    HY_MIX_DISPATCH(mixer_pre_bwd_kernel, MIX_SMEM);
+    if (mix_wide(D)) HY_MIXW_DISPATCH(mixer_pre_bwd_wide_kernel, MW_SMEM_PRE_BWD);
+    else HY_MIX_DISPATCH(mixer_pre_bwd_kernel, MIX_SMEM);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 

@@ -261,4 +261,314 @@ __global__ void __launch_bounds__(64) mixer_pre_bwd_kernel(MixArgs a) {
     }
 }
 
+// =====================================================================================================================
+// Wide-access versions (used when D is a multiple of 64): workgroups of 256 threads stage 64-position x 64-channel tiles
+// through LDS with 16-byte global accesses on BOTH layouts (8 bf16 / 4 fp32 per lane; rows of 128 / 256 bytes), compute
+// from LDS with one thread per (channel, every 4th position), and keep the short filter's gradient partials in
+// registers over a run of MIX_NT tiles.  The single-wavefront kernels above (2-byte accesses, sequential windows)
+// reached 0.7-2.6 TB/s; they remain the general-D fallback.
+// =====================================================================================================================
+enum { MW_TP = 64, MW_TC = 64, MW_THREADS = 256, MW_CS = MW_TC + 1 };     // CS: LDS row stride of channel-minor tiles
+
+template <int DT> struct MixVec { enum { N = (DT == DT_F32) ? 4 : 8 }; };
+
+template <int DT>
+__device__ __forceinline__ void vec_load(const typename Elem<DT>::type* p, float (&out)[MixVec<DT>::N]) {
+    struct __attribute__((aligned(4))) Raw { uint32_t w[4]; } r;
+    __builtin_memcpy(&r, p, 16);                                   // one 16-byte access (may be under-aligned)
+    if constexpr (DT == DT_F32) {
+        HY_UNROLL
+        for (int e = 0; e < 4; ++e) out[e] = u2f(r.w[e]);
+    } else {
+        HY_UNROLL
+        for (int e = 0; e < 4; ++e) {
+            const c32 v = Pair<DT>::cvt(r.w[e]);
+            out[2 * e] = v.x;
+            out[2 * e + 1] = v.y;
+        }
+    }
+}
+template <int DT>
+__device__ __forceinline__ void vec_store(typename Elem<DT>::type* p, const float (&in)[MixVec<DT>::N]) {
+    struct __attribute__((aligned(4))) Raw { uint32_t w[4]; } r;
+    if constexpr (DT == DT_F32) {
+        HY_UNROLL
+        for (int e = 0; e < 4; ++e) r.w[e] = f2u(in[e]);
+    } else {
+        HY_UNROLL
+        for (int e = 0; e < 4; ++e) r.w[e] = Pair<DT>::pack(mk(in[2 * e], in[2 * e + 1]));
+    }
+    __builtin_memcpy(p, &r, 16);
+}
+
+// channel-minor tile: rows = positions t_first .. t_first + nrows - 1 of tensor `base` (row stride `ld` elements, channel
+// offset `coff`), 64 channels each -> LDS dst[row * MW_CS + c]; positions outside [0, tlim) read as zero.
+template <int DT>
+__device__ __forceinline__ void load_cm_tile(HY_LDS float* dst, const void* base, size_t boff, int ld, int coff, int t_first,
+                                             int nrows, int tlim, int tid) {
+    typedef typename Elem<DT>::type elem_t;
+    constexpr int N = MixVec<DT>::N, VPR = MW_TC / N;             // vectors per row
+    const elem_t* src = reinterpret_cast<const elem_t*>(base) + boff + coff;
+    HY_UNROLL
+    for (int i = tid; i < nrows * VPR; i += MW_THREADS) {
+        const int row = i / VPR, vl = i % VPR, t = t_first + row;
+        const bool ok = t >= 0 && t < tlim;
+        float v[N];
+        vec_load<DT>(src + (size_t)(ok ? t : 0) * ld + vl * N, v);
+        HY_UNROLL
+        for (int e = 0; e < N; ++e) dst[row * MW_CS + vl * N + e] = ok ? v[e] : 0.f;
+    }
+}
+// store rows (positions t_first ..) of a channel-minor LDS tile, only positions in [t_lo, t_hi)
+template <int DT>
+__device__ __forceinline__ void store_cm_tile(const HY_LDS float* src, void* base, size_t boff, int ld, int coff, int t_first,
+                                              int nrows, int t_lo, int t_hi, int tid) {
+    typedef typename Elem<DT>::type elem_t;
+    constexpr int N = MixVec<DT>::N, VPR = MW_TC / N;
+    elem_t* dst = reinterpret_cast<elem_t*>(base) + boff + coff;
+    HY_UNROLL
+    for (int i = tid; i < nrows * VPR; i += MW_THREADS) {
+        const int row = i / VPR, vl = i % VPR, t = t_first + row;
+        if (t >= t_lo && t < t_hi) {
+            float v[N];
+            HY_UNROLL
+            for (int e = 0; e < N; ++e) v[e] = src[row * MW_CS + vl * N + e];
+            vec_store<DT>(dst + (size_t)t * ld + vl * N, v);
+        }
+    }
+}
+// (B, D, L)-side tile: rows = 64 channels c0 .. c0+63 of batch item b, positions t0 .. t0 + npos - 1 (npos a multiple of
+// the vector length) -> LDS dst[c * ds + p]; positions >= L read as zero.  The last vector of a row may straddle L.
+template <int DT>
+__device__ __forceinline__ void load_dl_tile(HY_LDS float* dst, int ds, const void* base, size_t row0, int L, int t0, int npos,
+                                             int tid) {
+    typedef typename Elem<DT>::type elem_t;
+    constexpr int N = MixVec<DT>::N;
+    const int vpr = npos / N;
+    const elem_t* src = reinterpret_cast<const elem_t*>(base);
+    HY_UNROLL
+    for (int i = tid; i < MW_TC * vpr; i += MW_THREADS) {
+        const int c = i / vpr, vl = i % vpr, t = t0 + vl * N;
+        const elem_t* rp = src + (row0 + c) * (size_t)L;
+        float v[N];
+        if (t + N <= L) {
+            vec_load<DT>(rp + t, v);
+        } else {
+            HY_UNROLL
+            for (int e = 0; e < N; ++e) v[e] = (t + e < L) ? Elem<DT>::ld(rp + t + e) : 0.f;
+        }
+        HY_UNROLL
+        for (int e = 0; e < N; ++e) dst[c * ds + vl * N + e] = v[e];
+    }
+}
+template <int DT>
+__device__ __forceinline__ void store_dl_tile(const HY_LDS float* src, int ds, void* base, size_t row0, int L, int t0, int npos,
+                                              int t_hi, int tid) {
+    typedef typename Elem<DT>::type elem_t;
+    constexpr int N = MixVec<DT>::N;
+    const int vpr = npos / N;
+    elem_t* dst = reinterpret_cast<elem_t*>(base);
+    HY_UNROLL
+    for (int i = tid; i < MW_TC * vpr; i += MW_THREADS) {
+        const int c = i / vpr, vl = i % vpr, t = t0 + vl * N;
+        elem_t* rp = dst + (row0 + c) * (size_t)L;
+        float v[N];
+        HY_UNROLL
+        for (int e = 0; e < N; ++e) v[e] = src[c * ds + vl * N + e];
+        if (t + N <= t_hi) {
+            vec_store<DT>(rp + t, v);
+        } else {
+            HY_UNROLL
+            for (int e = 0; e < N; ++e)
+                if (t + e < t_hi) Elem<DT>::st(rp + t + e, v[e]);
+        }
+    }
+}
+
+// short-conv value at tile row p (row index = position - first_position_of_tile) from a channel-minor LDS tile whose
+// row r holds position (first + r): xc(t) = b + w0 x(t-2) + w1 x(t-1) + w2 x(t), with x(t) in row `r2` and x(t-2) in r2-2
+__device__ __forceinline__ float sconv(const HY_LDS float* xs, int r2, int c, const float (&w)[3], float b) {
+    return b + w[0] * xs[(r2 - 2) * MW_CS + c] + w[1] * xs[(r2 - 1) * MW_CS + c] + w[2] * xs[r2 * MW_CS + c];
+}
+
+template <int DT>
+__global__ void __launch_bounds__(MW_THREADS) mixer_pre_fwd_wide_kernel(MixArgs a) {
+    HY_SMEM(smem);
+    HY_LDS float* xs1 = HY_LDS_CAST(float, smem);                  // [66][65]  x1 rows t0-2 .. t0+63
+    HY_LDS float* xs2 = xs1 + (MW_TP + 2) * MW_CS;                 // [66][65]  v
+    HY_LDS float* vt = xs2 + (MW_TP + 2) * MW_CS;                  // [64][65]  vg tile, [c][p]
+    const int tid = threadIdx.x, c = tid & 63, pq = tid >> 6;
+    const int c0 = blockIdx.y * 64, b = blockIdx.z, D3 = 3 * a.D;
+    float w1[3], w2[3];
+    HY_UNROLL
+    for (int i = 0; i < 3; ++i) { w1[i] = a.w[(a.D + c0 + c) * 3 + i]; w2[i] = a.w[(2 * a.D + c0 + c) * 3 + i]; }
+    const float b1 = a.b[a.D + c0 + c], b2 = a.b[2 * a.D + c0 + c];
+    const size_t xb = (size_t)b * a.Lx * D3;
+    const int t_begin = blockIdx.x * MIX_RUN;
+    for (int st = 0; st < MIX_NT; ++st) {
+        const int t0 = t_begin + st * MW_TP;
+        if (t0 >= a.L) break;
+        load_cm_tile<DT>(xs1, a.x, xb, D3, a.D + c0, t0 - 2, MW_TP + 2, a.L, tid);
+        load_cm_tile<DT>(xs2, a.x, xb, D3, 2 * a.D + c0, t0 - 2, MW_TP + 2, a.L, tid);
+        __syncthreads();
+        HY_UNROLL
+        for (int i = 0; i < MW_TP / 4; ++i) {
+            const int p = pq + 4 * i;
+            vt[c * MW_CS + p] = sconv(xs1, p + 2, c, w1, b1) * sconv(xs2, p + 2, c, w2, b2);
+        }
+        __syncthreads();
+        store_dl_tile<DT>(vt, MW_CS, a.a0, (size_t)b * a.D + c0, a.L, t0, MW_TP, a.L, tid);
+        __syncthreads();
+    }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(MW_THREADS) mixer_post_fwd_wide_kernel(MixArgs a) {
+    HY_SMEM(smem);
+    HY_LDS float* xs0 = HY_LDS_CAST(float, smem);                  // [66][65]
+    HY_LDS float* yt = xs0 + (MW_TP + 2) * MW_CS;                  // [64][65]  y tile [c][p]
+    HY_LDS float* zs = yt + MW_TC * MW_CS;                         // [64][65]  z tile [p][c]
+    const int tid = threadIdx.x, c = tid & 63, pq = tid >> 6;
+    const int c0 = blockIdx.y * 64, b = blockIdx.z, D3 = 3 * a.D;
+    float w0[3];
+    HY_UNROLL
+    for (int i = 0; i < 3; ++i) w0[i] = a.w[(c0 + c) * 3 + i];
+    const float b0 = a.b[c0 + c];
+    const size_t xb = (size_t)b * a.Lx * D3;
+    const int t_begin = blockIdx.x * MIX_RUN;
+    for (int st = 0; st < MIX_NT; ++st) {
+        const int t0 = t_begin + st * MW_TP;
+        if (t0 >= a.L) break;
+        load_cm_tile<DT>(xs0, a.x, xb, D3, c0, t0 - 2, MW_TP + 2, a.L, tid);
+        load_dl_tile<DT>(yt, MW_CS, a.a0, (size_t)b * a.D + c0, a.L, t0, MW_TP, tid);
+        __syncthreads();
+        HY_UNROLL
+        for (int i = 0; i < MW_TP / 4; ++i) {
+            const int p = pq + 4 * i;
+            zs[p * MW_CS + c] = sconv(xs0, p + 2, c, w0, b0) * yt[c * MW_CS + p];
+        }
+        __syncthreads();
+        store_cm_tile<DT>(zs, a.a1, (size_t)b * a.L * a.D, a.D, c0, t0, MW_TP, 0, a.L, tid);
+        __syncthreads();
+    }
+}
+
+// reduce the per-thread partials of a channel over its 4 position-phases and write them
+__device__ __forceinline__ void write_partials(HY_LDS float* red, float* dst, const float (&dw)[3], float db, int c, int pq) {
+    red[(pq * 64 + c) * 4 + 0] = dw[0];
+    red[(pq * 64 + c) * 4 + 1] = dw[1];
+    red[(pq * 64 + c) * 4 + 2] = dw[2];
+    red[(pq * 64 + c) * 4 + 3] = db;
+    __syncthreads();
+    if (pq == 0) {
+        HY_UNROLL
+        for (int k = 0; k < 4; ++k)
+            dst[c * 4 + k] = ((red[(0 * 64 + c) * 4 + k] + red[(1 * 64 + c) * 4 + k]) + red[(2 * 64 + c) * 4 + k]) + red[(3 * 64 + c) * 4 + k];
+    }
+    __syncthreads();
+}
+
+enum { MW_YS = 72 + 1 };   // LDS row stride of a (B, D, L)-side tile that carries 2 halo positions (72 = 66 rounded up to a vector)
+
+template <int DT>
+__global__ void __launch_bounds__(MW_THREADS) mixer_post_bwd_wide_kernel(MixArgs a) {
+    HY_SMEM(smem);
+    HY_LDS float* xs0 = HY_LDS_CAST(float, smem);                  // [68][65]  x0 rows t0-2 .. t0+65; later the dx tile
+    HY_LDS float* gs = xs0 + (MW_TP + 4) * MW_CS;                  // [66][65]  dz rows t0 .. t0+65, then g = dz * y
+    HY_LDS float* ys = gs + (MW_TP + 2) * MW_CS;                   // [64][73]  y tile [c][p], then dy
+    const int tid = threadIdx.x, c = tid & 63, pq = tid >> 6;
+    const int c0 = blockIdx.y * 64, b = blockIdx.z, D3 = 3 * a.D;
+    float w0[3];
+    HY_UNROLL
+    for (int i = 0; i < 3; ++i) w0[i] = a.w[(c0 + c) * 3 + i];
+    const float b0 = a.b[c0 + c];
+    const size_t xb = (size_t)b * a.Lx * D3;
+    const int t_begin = blockIdx.x * MIX_RUN;
+    float dw[3] = {0.f, 0.f, 0.f}, db = 0.f;
+    for (int st = 0; st < MIX_NT; ++st) {
+        const int t0 = t_begin + st * MW_TP;
+        if (t0 >= a.L) break;
+        load_cm_tile<DT>(xs0, a.x, xb, D3, c0, t0 - 2, MW_TP + 4, a.L, tid);
+        load_cm_tile<DT>(gs, a.a1, (size_t)b * a.L * a.D, a.D, c0, t0, MW_TP + 2, a.L, tid);
+        load_dl_tile<DT>(ys, MW_YS, a.a0, (size_t)b * a.D + c0, a.L, t0, 72, tid);
+        __syncthreads();
+        for (int p = pq; p < MW_TP + 2; p += 4) {
+            const float dzv = gs[p * MW_CS + c];
+            const float g = dzv * ys[c * MW_YS + p];
+            gs[p * MW_CS + c] = g;
+            if (p < MW_TP) {                                       // own position: dy, dw, db
+                ys[c * MW_YS + p] = dzv * sconv(xs0, p + 2, c, w0, b0);
+                dw[0] += g * xs0[p * MW_CS + c];
+                dw[1] += g * xs0[(p + 1) * MW_CS + c];
+                dw[2] += g * xs0[(p + 2) * MW_CS + c];
+                db += g;
+            }
+        }
+        __syncthreads();
+        HY_UNROLL
+        for (int i = 0; i < MW_TP / 4; ++i) {                      // dx(t) = w0 g(t+2) + w1 g(t+1) + w2 g(t)
+            const int p = pq + 4 * i;
+            xs0[p * MW_CS + c] = w0[0] * gs[(p + 2) * MW_CS + c] + w0[1] * gs[(p + 1) * MW_CS + c] + w0[2] * gs[p * MW_CS + c];
+        }
+        __syncthreads();
+        store_dl_tile<DT>(ys, MW_YS, a.a2, (size_t)b * a.D + c0, a.L, t0, MW_TP, a.L, tid);
+        store_cm_tile<DT>(xs0, a.dx, xb, D3, c0, t0, MW_TP, 0, a.L, tid);
+        __syncthreads();
+    }
+    write_partials(gs, a.part + (((size_t)b * gridDim.x + blockIdx.x) * D3 + c0) * 4, dw, db, c, pq);
+}
+
+template <int DT>
+__global__ void __launch_bounds__(MW_THREADS) mixer_pre_bwd_wide_kernel(MixArgs a) {
+    HY_SMEM(smem);
+    HY_LDS float* xs1 = HY_LDS_CAST(float, smem);                  // [68][65]  x1 rows t0-2 .. t0+65; later dx1
+    HY_LDS float* xs2 = xs1 + (MW_TP + 4) * MW_CS;                 // [68][65]  v; later dx2
+    HY_LDS float* ds = xs2 + (MW_TP + 4) * MW_CS;                  // [64][73]  dvg tile [c][p]; g1 overwrites it in place
+    HY_LDS float* g2s = ds + MW_TC * MW_YS;                        // [64][73]  g2 [c][p]
+    const int tid = threadIdx.x, c = tid & 63, pq = tid >> 6;
+    const int c0 = blockIdx.y * 64, b = blockIdx.z, D3 = 3 * a.D;
+    float w1[3], w2[3];
+    HY_UNROLL
+    for (int i = 0; i < 3; ++i) { w1[i] = a.w[(a.D + c0 + c) * 3 + i]; w2[i] = a.w[(2 * a.D + c0 + c) * 3 + i]; }
+    const float b1 = a.b[a.D + c0 + c], b2 = a.b[2 * a.D + c0 + c];
+    const size_t xb = (size_t)b * a.Lx * D3;
+    const int t_begin = blockIdx.x * MIX_RUN;
+    float dw1[3] = {0.f, 0.f, 0.f}, db1 = 0.f, dw2[3] = {0.f, 0.f, 0.f}, db2 = 0.f;
+    for (int st = 0; st < MIX_NT; ++st) {
+        const int t0 = t_begin + st * MW_TP;
+        if (t0 >= a.L) break;
+        load_cm_tile<DT>(xs1, a.x, xb, D3, a.D + c0, t0 - 2, MW_TP + 4, a.L, tid);
+        load_cm_tile<DT>(xs2, a.x, xb, D3, 2 * a.D + c0, t0 - 2, MW_TP + 4, a.L, tid);
+        load_dl_tile<DT>(ds, MW_YS, a.a0, (size_t)b * a.D + c0, a.L, t0, 72, tid);
+        __syncthreads();
+        for (int p = pq; p < MW_TP + 2; p += 4) {
+            const float dv = ds[c * MW_YS + p];                    // zero for positions >= L
+            const float g1 = dv * sconv(xs2, p + 2, c, w2, b2);    // gradient of x1c = dvg * vc
+            const float g2 = dv * sconv(xs1, p + 2, c, w1, b1);    // gradient of vc  = dvg * x1c
+            ds[c * MW_YS + p] = g1;
+            g2s[c * MW_YS + p] = g2;
+            if (p < MW_TP) {
+                dw1[0] += g1 * xs1[p * MW_CS + c]; dw1[1] += g1 * xs1[(p + 1) * MW_CS + c]; dw1[2] += g1 * xs1[(p + 2) * MW_CS + c];
+                db1 += g1;
+                dw2[0] += g2 * xs2[p * MW_CS + c]; dw2[1] += g2 * xs2[(p + 1) * MW_CS + c]; dw2[2] += g2 * xs2[(p + 2) * MW_CS + c];
+                db2 += g2;
+            }
+        }
+        __syncthreads();
+        HY_UNROLL
+        for (int i = 0; i < MW_TP / 4; ++i) {
+            const int p = pq + 4 * i;
+            xs1[p * MW_CS + c] = w1[0] * ds[c * MW_YS + p + 2] + w1[1] * ds[c * MW_YS + p + 1] + w1[2] * ds[c * MW_YS + p];
+            xs2[p * MW_CS + c] = w2[0] * g2s[c * MW_YS + p + 2] + w2[1] * g2s[c * MW_YS + p + 1] + w2[2] * g2s[c * MW_YS + p];
+        }
+        __syncthreads();
+        store_cm_tile<DT>(xs1, a.dx, xb, D3, a.D + c0, t0, MW_TP, 0, a.L, tid);
+        store_cm_tile<DT>(xs2, a.dx, xb, D3, 2 * a.D + c0, t0, MW_TP, 0, a.L, tid);
+        __syncthreads();
+    }
+    float* base = a.part + ((size_t)b * gridDim.x + blockIdx.x) * D3 * 4;
+    write_partials(g2s, base + (size_t)(a.D + c0) * 4, dw1, db1, c, pq);
+    write_partials(g2s, base + (size_t)(2 * a.D + c0) * 4, dw2, db2, c, pq);
+}
+
 }  // namespace hyena

@@ -19,7 +19,8 @@ def _ref_core(x, w, b, k, bias, L):
     return (y * x0).transpose(1, 2)
 
 
-@pytest.mark.parametrize("B,Lx,L,D", [(2, 70, 70, 8), (1, 1500, 1500, 5), (2, 2100, 2048, 70), (1, 130, 64, 64)])
+@pytest.mark.parametrize("B,Lx,L,D", [(2, 70, 70, 8), (1, 1500, 1500, 5), (2, 2100, 2048, 70), (1, 130, 64, 64),
+                                      (2, 1023, 1023, 128), (1, 2500, 2049, 64), (1, 66, 66, 192), (2, 7, 7, 64)])
 def test_mixer_core_fp32_vs_oracle(emu_backend, B, Lx, L, D):
     from hyena_dna_amd.mixer import hyena_mixer_core
     g = torch.Generator().manual_seed(B * 1000 + L + D)
@@ -49,7 +50,7 @@ def test_mixer_core_fp32_vs_oracle(emu_backend, B, Lx, L, D):
 def test_mixer_core_bf16(emu_backend):
     from hyena_dna_amd.mixer import hyena_mixer_core
     g = torch.Generator().manual_seed(3)
-    B, L, D = 2, 300, 16
+    B, L, D = 2, 301, 64
     x = torch.randn(B, L, 3 * D, generator=g).bfloat16()
     w = torch.randn(3 * D, 1, 3, generator=g) * 0.5
     b = torch.randn(3 * D, generator=g) * 0.1
