@@ -28,6 +28,18 @@ class HyenaLibraryError(RuntimeError):
     pass
 
 
+class FilterParams(ctypes.Structure):
+    """hyena_filter_params of include/hyena_filter.h."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("z", "t", "w0", "b0", "w1", "b1", "w2", "b2", "w3", "freq", "deltas")] + \
+               [("shift", ctypes.c_float), ("modulate", ctypes.c_int), ("z_stride", ctypes.c_int),
+                ("L", ctypes.c_int), ("E", ctypes.c_int), ("D", ctypes.c_int)]
+
+
+class FilterGrads(ctypes.Structure):
+    """hyena_filter_grads of include/hyena_filter.h."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("dw0", "db0", "dw1", "db1", "dw2", "db2", "dw3", "dfreq", "dz")]
+
+
 class _HipBackend:
     """Where tensors live and how the library is reached.  The product has exactly this one backend (ROCm device
     tensors + libhyena_fftconv.so); tests/ substitute a CPU-emulation double to exercise the host logic without
@@ -108,6 +120,18 @@ def lib():
         L.hyena_mixer_pre_bwd.restype = c_int
         L.hyena_mixer_pre_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_int, c_int, c_int, c_int, c_void_p]
+        # fused implicit filter (include/hyena_filter.h)
+        L.hyena_filter_supported.restype = c_int
+        L.hyena_filter_supported.argtypes = [c_int, c_int, c_int, c_int]
+        L.hyena_filter_saved_bytes.restype = c_size_t
+        L.hyena_filter_saved_bytes.argtypes = [c_int]
+        L.hyena_filter_workspace_bytes.restype = c_size_t
+        L.hyena_filter_workspace_bytes.argtypes = [c_int, c_int]
+        L.hyena_filter_fwd.restype = c_int
+        L.hyena_filter_fwd.argtypes = [ctypes.POINTER(FilterParams), c_void_p, c_void_p, c_void_p]
+        L.hyena_filter_bwd.restype = c_int
+        L.hyena_filter_bwd.argtypes = [ctypes.POINTER(FilterParams), c_void_p, c_void_p, ctypes.POINTER(FilterGrads),
+                                       c_void_p, c_size_t, c_void_p]
         if L.hyena_fftconv_abi_version() != ABI_VERSION:
             raise HyenaLibraryError(f"{LIB_PATH}: ABI version {L.hyena_fftconv_abi_version()} != {ABI_VERSION}; rebuild")
         _lib = L
@@ -278,3 +302,51 @@ def mixer_pre_bwd(dvg, x, w, b, dx, part):
         check(lib().hyena_mixer_pre_bwd(dvg.data_ptr(), x.data_ptr(), w.data_ptr(), b.data_ptr(), dx.data_ptr(),
                                         part.data_ptr(), B, L, x.shape[1], D, dtype_code(x.dtype),
                                         _backend.stream(x.device)))
+
+
+# ---- fused implicit filter (include/hyena_filter.h) ---------------------------------------------------------------------
+def filter_supported(L, E, order, D):
+    return bool(lib().hyena_filter_supported(int(L), int(E), int(order), int(D)))
+
+
+def _filter_params(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate):
+    L, E = z.shape
+    p = FilterParams()
+    for name, ten in (("z", z), ("t", t), ("w0", w0), ("b0", b0), ("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2), ("w3", w3),
+                      ("freq", freq), ("deltas", deltas)):
+        if ten is not None:
+            _require_gpu(ten, name)
+            assert ten.dtype == torch.float32 and ten.is_contiguous(), name
+        setattr(p, name, None if ten is None else ten.data_ptr())
+    p.shift, p.modulate, p.z_stride, p.L, p.E, p.D = float(shift), int(bool(modulate)), z.stride(0), L, E, w3.shape[0]
+    return p
+
+
+def filter_fwd(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate, save):
+    """z (L, E), t (L,), weights as in include/hyena_filter.h -> k (D, L) [, saved pre-activations (3, 64, L)]."""
+    p = _filter_params(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate)
+    k = torch.empty((p.D, p.L), dtype=torch.float32, device=z.device)
+    saved = torch.empty((3, 64, p.L), dtype=torch.float32, device=z.device) if save else None
+    with _backend.guard(z.device):
+        check(lib().hyena_filter_fwd(ctypes.byref(p), k.data_ptr(), None if saved is None else saved.data_ptr(),
+                                     _backend.stream(z.device)))
+    return (k, saved) if save else k
+
+
+def filter_bwd(dk, saved, z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate, need_dz):
+    """-> (dw0, db0, dw1, db1, dw2, db2, dw3, dfreq, dz or None); dz is (L, E)."""
+    p = _filter_params(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate)
+    _require_gpu(dk, "dk")
+    assert dk.dtype == torch.float32 and dk.is_contiguous() and dk.shape == (p.D, p.L)
+    outs = [torch.empty_like(x) for x in (w0, b0, w1, b1, w2, b2, w3, freq)]
+    dzt = torch.empty((p.E, p.L), dtype=torch.float32, device=z.device) if need_dz else None
+    g = FilterGrads()
+    for name, ten in zip(("dw0", "db0", "dw1", "db1", "dw2", "db2", "dw3", "dfreq"), outs):
+        setattr(g, name, ten.data_ptr())
+    g.dz = None if dzt is None else dzt.data_ptr()
+    nbytes = lib().hyena_filter_workspace_bytes(p.L, p.D)
+    with _backend.guard(z.device):
+        ws, stream = workspace_for(z.device, nbytes)
+        check(lib().hyena_filter_bwd(ctypes.byref(p), dk.data_ptr(), saved.data_ptr(), ctypes.byref(g), ws.data_ptr(),
+                                     ws.numel(), stream))
+    return tuple(outs) + (None if dzt is None else dzt.t().contiguous(),)

@@ -8,8 +8,10 @@
 // into a CPU emulation used only by the `not gpu` tests.
 #include "fftconv_kernels.h"
 #include "mixer_kernels.h"
+#include "filter_kernels.h"
 #include "../../include/hyena_fftconv.h"
 #include "../../include/hyena_mixer.h"
+#include "../../include/hyena_filter.h"
 
 #include <cmath>
 #include <cstdio>
@@ -446,6 +448,138 @@ int hyena_mixer_pre_bwd(const void* dvg, const void* x, const float* w, const fl
     a.B = B; a.L = L; a.D = D; a.Lx = Lx;
     if (mix_wide(D)) HY_MIXW_DISPATCH(mixer_pre_bwd_wide_kernel, MW_SMEM_PRE_BWD);
     else HY_MIX_DISPATCH(mixer_pre_bwd_kernel, MIX_SMEM);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused implicit filter (include/hyena_filter.h)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+// kernels that stage the whole weight set in LDS need more than the 64 KiB a launch may ask for by default
+template <typename K>
+void flt_allow_lds(K kernel, size_t bytes) {
+#ifndef HIPEMU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+#else
+    (void)kernel; (void)bytes;
+#endif
+}
+
+int flt_grid(int L) {
+    const int n = (L + FLT_WG_POS - 1) / FLT_WG_POS;
+    return n < FLT_MAX_WG ? n : FLT_MAX_WG;
+}
+
+size_t flt_part_floats(int D) {
+    const int no = D > 128 ? D : 128;
+    return (size_t)FLT_MAX_WG * ((size_t)no * FLT_O + 1024);
+}
+
+bool flt_params_ok(const hyena_filter_params* p) {
+    return p != nullptr && p->z && p->t && p->w0 && p->b0 && p->w1 && p->b1 && p->w2 && p->b2 && p->w3 && p->freq &&
+           (p->deltas || !p->modulate) && p->z_stride >= p->E && hyena_filter_supported(p->L, p->E, FLT_O, p->D);
+}
+
+template <int D>
+void launch_filter_fwd(const FilterArgs& a, void* stream) {
+    const int ntiles = (a.L + FLT_TP - 1) / FLT_TP;
+    int grid = (ntiles + FLT_WAVES - 1) / FLT_WAVES;
+    if (grid > FLT_MAX_WG) grid = FLT_MAX_WG;
+    if (a.acts != nullptr) {
+        flt_allow_lds(filter_fwd_kernel<D, true>, FltFwdLds<D>::BYTES);
+        HY_LAUNCH((filter_fwd_kernel<D, true>), dim3(grid), dim3(FLT_THREADS), FltFwdLds<D>::BYTES, stream, a);
+    } else {
+        flt_allow_lds(filter_fwd_kernel<D, false>, FltFwdLds<D>::BYTES);
+        HY_LAUNCH((filter_fwd_kernel<D, false>), dim3(grid), dim3(FLT_THREADS), FltFwdLds<D>::BYTES, stream, a);
+    }
+}
+
+template <int NO, int NI, int MODE>
+void launch_filter_layer_bwd(FilterBwdArgs a, float* part, float* dw, float* db, float* dfreq, bool first_freq, void* stream) {
+    typedef FltBwdCfg<NO, NI> Cfg;
+    const int grid = flt_grid(a.L);
+    const int slots = grid * Cfg::KS;
+    a.part_w = part;
+    a.part_b = db != nullptr ? part + (size_t)slots * NO * NI : nullptr;
+    a.part_f = part + (size_t)slots * NO * NI + (size_t)2 * slots * NO;
+    flt_allow_lds(filter_layer_bwd_kernel<NO, NI, MODE>, Cfg::BYTES);
+    HY_LAUNCH((filter_layer_bwd_kernel<NO, NI, MODE>), dim3(grid), dim3(FLT_THREADS), Cfg::BYTES, stream, a);
+    const int nw = NO * a.ni;
+    if (NI == a.ni) {
+        HY_LAUNCH(filter_reduce_kernel, dim3((nw + 255) / 256), dim3(256), 0, stream, (const float*)a.part_w, dw, slots, nw, 0);
+    } else {
+        // layer 0 with E < 8: partial rows are 8 wide; reduce into a scratch tail of `part`, then the host-side
+        // caller's dw0 gets the first E columns (done below by a strided second pass)
+        float* tmp = a.part_f + (size_t)grid * FLT_WAVES * FLT_O;
+        HY_LAUNCH(filter_reduce_kernel, dim3((NO * NI + 255) / 256), dim3(256), 0, stream, (const float*)a.part_w, tmp, slots, NO * NI, 0);
+        HY_LAUNCH(filter_compact_kernel, dim3((nw + 255) / 256), dim3(256), 0, stream, (const float*)tmp, dw, NO, NI, a.ni);
+    }
+    if (db != nullptr)
+        HY_LAUNCH(filter_reduce_kernel, dim3((NO + 255) / 256), dim3(256), 0, stream, (const float*)a.part_b, db, 2 * slots, NO, 0);
+    if (MODE & FLT_ACT)
+        HY_LAUNCH(filter_reduce_kernel, dim3(1), dim3(256), 0, stream, (const float*)a.part_f, dfreq, grid * FLT_WAVES, FLT_O,
+                  first_freq ? 0 : 1);
+}
+}  // namespace
+
+extern "C" {
+
+int hyena_filter_supported(int L, int E, int order, int D) {
+    return L >= 1 && L <= HYENA_MAX_L && E >= 1 && E <= FLT_E && order == FLT_O && (D == 64 || D == 128 || D == 256);
+}
+
+size_t hyena_filter_saved_bytes(int L) { return L >= 1 ? (size_t)3 * FLT_O * L * sizeof(float) : 0; }
+
+size_t hyena_filter_workspace_bytes(int L, int D) {
+    if (L < 1 || D < 1) return 0;
+    return ((size_t)2 * FLT_O * L + flt_part_floats(D)) * sizeof(float);
+}
+
+int hyena_filter_fwd(const hyena_filter_params* p, float* k, float* saved, void* stream) {
+    if (!flt_params_ok(p) || k == nullptr) return HYENA_ERR_BAD_ARG;
+    FilterArgs a;
+    a.z = p->z; a.t = p->t; a.w0 = p->w0; a.b0 = p->b0; a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2; a.w3 = p->w3;
+    a.freq = p->freq; a.deltas = p->deltas; a.k = k; a.acts = saved; a.shift = p->shift; a.modulate = p->modulate;
+    a.L = p->L; a.E = p->E; a.zs = p->z_stride; a.D = p->D;
+    switch (p->D) {
+        case 64: launch_filter_fwd<64>(a, stream); break;
+        case 128: launch_filter_fwd<128>(a, stream); break;
+        default: launch_filter_fwd<256>(a, stream); break;
+    }
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+int hyena_filter_bwd(const hyena_filter_params* p, const float* dk, const float* saved, const hyena_filter_grads* g,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!flt_params_ok(p) || dk == nullptr || saved == nullptr || g == nullptr || workspace == nullptr) return HYENA_ERR_BAD_ARG;
+    if (!g->dw0 || !g->db0 || !g->dw1 || !g->db1 || !g->dw2 || !g->db2 || !g->dw3 || !g->dfreq) return HYENA_ERR_BAD_ARG;
+    if (workspace_bytes < hyena_filter_workspace_bytes(p->L, p->D)) return HYENA_ERR_WORKSPACE;
+    const int L = p->L;
+    float* dA = static_cast<float*>(workspace);
+    float* dB = dA + (size_t)FLT_O * L;
+    float* part = dB + (size_t)FLT_O * L;
+    const float* a0 = saved;
+    const float* a1 = saved + (size_t)FLT_O * L;
+    const float* a2 = saved + (size_t)2 * FLT_O * L;
+
+    FilterBwdArgs a;
+    a.freq = p->freq; a.t = p->t; a.deltas = p->deltas; a.shift = p->shift; a.modulate = p->modulate; a.L = L; a.zs = p->z_stride;
+    // last layer: delta_out = dk * modulation;  dW3, and delta_2 -> dA
+    a.dout = dk; a.w = p->w3; a.aprev = a2; a.dprev = dA; a.ni = FLT_O;
+    switch (p->D) {
+        case 64: launch_filter_layer_bwd<64, FLT_O, FLT_ACT | FLT_MOD>(a, part, g->dw3, nullptr, g->dfreq, true, stream); break;
+        case 128: launch_filter_layer_bwd<128, FLT_O, FLT_ACT | FLT_MOD>(a, part, g->dw3, nullptr, g->dfreq, true, stream); break;
+        default: launch_filter_layer_bwd<256, FLT_O, FLT_ACT | FLT_MOD>(a, part, g->dw3, nullptr, g->dfreq, true, stream); break;
+    }
+    a.modulate = 0;
+    a.dout = dA; a.w = p->w2; a.aprev = a1; a.dprev = dB;
+    launch_filter_layer_bwd<FLT_O, FLT_O, FLT_ACT>(a, part, g->dw2, g->db2, g->dfreq, false, stream);
+    a.dout = dB; a.w = p->w1; a.aprev = a0; a.dprev = dA;
+    launch_filter_layer_bwd<FLT_O, FLT_O, FLT_ACT>(a, part, g->dw1, g->db1, g->dfreq, false, stream);
+    a.dout = dA; a.w = p->w0; a.aprev = p->z; a.dprev = g->dz; a.ni = p->E;
+    launch_filter_layer_bwd<FLT_O, FLT_E, 0>(a, part, g->dw0, g->db0, g->dfreq, false, stream);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 

@@ -1,0 +1,59 @@
+"""The implicit Hyena filter as one autograd function over the fused HIP kernels of ``include/hyena_filter.h``.
+
+Reference: ``HyenaFilter.filter`` (``src/models/sequence/hyena.py:229-238``) = positional embedding slice (130-131) ->
+``Linear(E, 64) / Sin / Linear(64, 64) / Sin / Linear(64, 64) / Sin / Linear(64, D, bias=False)`` (199-215) ->
+``ExponentialModulation`` (152-155), then the ``l d -> d l`` rearrange of ``HyenaOperator.forward`` (405-412).  The
+function returns the filter directly as ``(D, L)`` fp32, the layout ``hyena_fftconv_*`` reads.
+
+``hyena_dna_amd.hyena.HyenaFilter.filter_dl`` uses it whenever ``fused_filter_ok`` holds (the HyenaDNA configuration)
+and takes its PyTorch path otherwise.  All arithmetic is fp32 also under autocast (the reference's four GEMMs run in
+bf16 there); the pre-activations of the three sine layers (3 x 64 x L fp32) are what is kept for the backward.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ["hyena_filter_dl", "HyenaFilterFunc", "fused_filter_ok"]
+
+
+def fused_filter_ok(L, emb_dim, order, d_model, num_inner_mlps, normalized, linear_mixer):
+    return (not normalized and not linear_mixer and num_inner_mlps == 2
+            and _lib.filter_supported(L, emb_dim, order, d_model))
+
+
+def _f32(x):
+    return None if x is None else x.detach().to(torch.float32).contiguous()
+
+
+class HyenaFilterFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate):
+        """z (L, E), t (L,), w0 (64, E), b0 (64,), w1/w2 (64, 64), b1/b2 (64,), w3 (D, 64), freq (64,), deltas (D,)
+        -> k (D, L) fp32."""
+        args = [_f32(x) for x in (z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas)]
+        want_grad = any(ctx.needs_input_grad)
+        if any(ctx.needs_input_grad[i] for i in (1, 10)):
+            raise NotImplementedError("gradients w.r.t. pos_emb.t / modulation.deltas are not provided by the fused "
+                                      "filter kernels (both are buffers in every HyenaDNA configuration)")
+        if want_grad:
+            k, saved = _lib.filter_fwd(*args, shift, modulate, save=True)
+            ctx.save_for_backward(saved, *args)
+        else:
+            k = _lib.filter_fwd(*args, shift, modulate, save=False)
+        ctx.meta = (shift, modulate, [x.dtype for x in (z, w0, b0, w1, b1, w2, b2, w3, freq)])
+        return k
+
+    @staticmethod
+    def backward(ctx, dk):
+        saved, *args = ctx.saved_tensors
+        shift, modulate, dtypes = ctx.meta
+        g = _lib.filter_bwd(dk.to(torch.float32).contiguous(), saved, *args, shift, modulate, need_dz=ctx.needs_input_grad[0])
+        dw0, db0, dw1, db1, dw2, db2, dw3, dfreq, dz = g
+        outs = [dz, dw0, db0, dw1, db1, dw2, db2, dw3, dfreq]
+        outs = [None if o is None else o.to(dt) for o, dt in zip(outs, dtypes)]
+        dz, dw0, db0, dw1, db1, dw2, db2, dw3, dfreq = outs
+        return dz, None, dw0, db0, dw1, db1, dw2, db2, dw3, dfreq, None, None, None
+
+
+def hyena_filter_dl(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift=0.0, modulate=True):
+    return HyenaFilterFunc.apply(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate)

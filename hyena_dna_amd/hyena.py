@@ -17,9 +17,15 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .fftconv import fftconv_func
+from .filter import fused_filter_ok, hyena_filter_dl
 from .mixer import hyena_mixer_core
 
 __all__ = ["HyenaOperator", "HyenaFilter", "PositionalEmbedding", "ExponentialModulation", "Sin"]
+
+
+def _fused_filter_requires_gpu():
+    from . import _lib
+    return _lib._backend.name == "hip"
 
 
 class _OptimModule(nn.Module):
@@ -143,6 +149,12 @@ class HyenaFilter(_OptimModule):
         z, t = self.pos_emb(L)
         # index the Sequential: .children() de-duplicates the ONE Sin instance that sits in three slots
         layers = [self.implicit_filter[i] for i in range(len(self.implicit_filter))]
+        if self._fused_filter_ok(L, layers, z):
+            lin = layers[0::2]
+            mod = self.modulation
+            return hyena_filter_dl(z[0], t.reshape(-1), lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
+                                   lin[2].weight, lin[2].bias, lin[3].weight, layers[1].freq.reshape(-1),
+                                   mod.deltas.reshape(-1), mod.shift, self.modulate)
         last = layers[-1]
         h = z
         for layer in layers[:-1]:
@@ -156,6 +168,19 @@ class HyenaFilter(_OptimModule):
         if self.normalized:
             k = k / torch.norm(k, dim=0, p=1, keepdim=True)
         return k
+
+    def _fused_filter_ok(self, L, layers, z):
+        """The fused HIP filter kernels (include/hyena_filter.h) cover exactly the HyenaDNA filter configuration."""
+        if len(layers) != 7 or not z.is_cuda and _fused_filter_requires_gpu():
+            return False
+        lin, act = layers[0::2], layers[1::2]
+        if not all(isinstance(m, nn.Linear) for m in lin) or not all(m is act[0] for m in act) or not isinstance(act[0], Sin):
+            return False
+        if any(m.bias is None for m in lin[:3]) or lin[3].bias is not None:
+            return False
+        if isinstance(self.modulation.deltas, nn.Parameter) and self.modulation.deltas.requires_grad and torch.is_grad_enabled():
+            return False
+        return fused_filter_ok(L, z.shape[-1], lin[0].out_features, lin[3].out_features, 2, self.normalized, False)
 
     def forward(self, x, L, k=None, bias=None, *args, **kwargs):
         if k is None:

@@ -1,0 +1,76 @@
+/* hyena_filter.h -- C ABI of the fused implicit-filter kernels of libhyena_fftconv.so.
+ *
+ * Replaces, for the HyenaDNA filter configuration, what the reference computes in
+ *   HyenaFilter.filter(L)                      src/models/sequence/hyena.py:229-238
+ *     PositionalEmbedding.forward              hyena.py:130-131     z[:, :L], t[:, :L]
+ *     implicit_filter (Linear/Sin x3, Linear)  hyena.py:199-215, Sin: 96-106
+ *     ExponentialModulation.forward            hyena.py:152-155
+ * followed by the `(l, d) -> (d, l)` rearrange of HyenaOperator.forward (hyena.py:405-412), and the autograd graph
+ * PyTorch builds for it:
+ *     a0 = W0 z_l + b0,  a1 = W1 sin(f a0) + b1,  a2 = W2 sin(f a1) + b2,  y = W3 sin(f a2)
+ *     k[d, l] = y[d] * (exp(-t_l |delta_d|) + shift)            (modulate = 0:  k = y)
+ *
+ * Supported shapes (hyena_filter_supported): filter order 64 with two inner layers, emb_dim <= 8, D in {64, 128, 256}.
+ * Anything else is left to the caller's generic path.  All tensors fp32, row-major, device memory of the device that
+ * is current for `stream`; nothing is allocated or synchronised inside the entry points.
+ */
+#ifndef HYENA_FILTER_H
+#define HYENA_FILTER_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    const float* z;        /* (L, z_stride): rows of pos_emb.z (hyena.py:128), first E columns are the embedding */
+    const float* t;        /* (L,)          pos_emb.t (hyena.py:129) */
+    const float* w0;       /* (64, E)       implicit_filter.0.weight */
+    const float* b0;       /* (64,)         implicit_filter.0.bias */
+    const float* w1;       /* (64, 64)      implicit_filter.2.weight */
+    const float* b1;
+    const float* w2;       /* (64, 64)      implicit_filter.4.weight */
+    const float* b2;
+    const float* w3;       /* (D, 64)       implicit_filter.6.weight (no bias, hyena.py:210) */
+    const float* freq;     /* (64,)         the ONE Sin.freq shared by the three activations (hyena.py:199) */
+    const float* deltas;   /* (D,)          modulation.deltas (hyena.py:149); may be NULL when modulate == 0 */
+    float shift;           /* modulation.shift (hyena.py:144) */
+    int modulate;          /* HyenaFilter.modulate (hyena.py:176) */
+    int z_stride;
+    int L, E, D;
+} hyena_filter_params;
+
+typedef struct {           /* gradients, same shapes as the parameters; every pointer required except dz */
+    float* dw0;
+    float* db0;
+    float* dw1;
+    float* db1;
+    float* dw2;
+    float* db2;
+    float* dw3;
+    float* dfreq;
+    float* dz;             /* (E, L) gradient of the embedding rows, TRANSPOSED; NULL when pos_emb.z is a buffer */
+} hyena_filter_grads;
+
+/* 1 if the fused kernels cover this configuration. */
+int hyena_filter_supported(int L, int E, int order, int D);
+
+/* Bytes of the pre-activation buffer the forward fills for the backward (3 x 64 x L floats). */
+size_t hyena_filter_saved_bytes(int L);
+
+/* Bytes of scratch the backward needs (two (64, L) gradient buffers + per-workgroup partial sums). */
+size_t hyena_filter_workspace_bytes(int L, int D);
+
+/* k (D, L) <- filter.  `saved` may be NULL (inference). */
+int hyena_filter_fwd(const hyena_filter_params* p, float* k, float* saved, void* stream);
+
+/* Gradients of the parameters for upstream gradient dk (D, L).  `saved` is what hyena_filter_fwd filled for the same
+ * parameters.  Reductions over L are deterministic (fixed-order partial sums, no atomics). */
+int hyena_filter_bwd(const hyena_filter_params* p, const float* dk, const float* saved, const hyena_filter_grads* g,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYENA_FILTER_H */

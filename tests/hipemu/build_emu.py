@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "_emu_fftconv_test_only.so")
 SRC = [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv.hip"), os.path.join(HERE, "hipemu.cpp")]
 DEPS = SRC + [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv_kernels.h"),
-              os.path.join(ROOT, "hyena_dna_amd", "csrc", "mixer_kernels.h"), os.path.join(HERE, "hipemu.h"),
+              os.path.join(ROOT, "hyena_dna_amd", "csrc", "mixer_kernels.h"),
+              os.path.join(ROOT, "hyena_dna_amd", "csrc", "filter_kernels.h"), os.path.join(ROOT, "include", "hyena_filter.h"), os.path.join(HERE, "hipemu.h"),
               os.path.join(ROOT, "include", "hyena_fftconv.h"), os.path.join(ROOT, "include", "hyena_mixer.h")]
 
 
@@ -15,7 +16,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(f) <= os.path.getmtime(OUT) for f in DEPS):
         return OUT
     cmd = ["g++", "-x", "c++", "-DHIPEMU", "-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared",
-           "-Wno-unknown-pragmas", "-I", HERE] + SRC + ["-o", OUT]
+           "-Wno-unknown-pragmas", "-Wno-psabi", "-I", HERE] + SRC + ["-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 

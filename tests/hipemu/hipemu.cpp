@@ -44,33 +44,58 @@ static void run_block(dim3 grid, dim3 block, size_t smem_bytes, const std::funct
         for (size_t i = old; i < nthreads; ++i) S.fibers[i].stack = (char*)malloc(STACK_BYTES);
     }
     S.xchg.assign(nthreads, 0);
+    S.xchg2.assign(nthreads, 0);
     std::vector<char> smem(smem_bytes + 64);
     memset(smem.data(), 0xFF, smem.size());   // NaN pattern: uninitialised LDS reads show up
     S.smem = (char*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);
     for (unsigned t = 0; t < nthreads; ++t) init_fiber(S.fibers[t]);
+    // Cooperative scheduler.  A fibre runs until it yields at a block barrier (kind 1) or at a wave-level
+    // rendezvous (kind 2: shuffles, MFMA operand exchange).  Wave rendezvous release as soon as every live lane of
+    // that wave has arrived, so waves of one block may execute different numbers of them between block barriers.
+    enum { RUNNABLE = 0, AT_BARRIER = 1, AT_WAVE = 2 };
+    std::vector<unsigned char> st(nthreads, RUNNABLE);
     unsigned alive = nthreads;
     while (alive) {
-        int kind = -1;
-        unsigned finished = 0, yielded = 0;
+        bool progressed = false;
         for (unsigned t = 0; t < nthreads; ++t) {
             Fiber& f = S.fibers[t];
-            if (f.done) continue;
+            if (f.done || st[t] != RUNNABLE) continue;
             S.cur = (int)t;
             S.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
             hipemu_switch(&S.sched_sp, f.sp);
-            if (f.done) { --alive; ++finished; continue; }
-            ++yielded;
-            if (kind < 0) kind = f.yield_kind;
-            else if (kind != f.yield_kind) {
-                fprintf(stderr, "hipemu: divergent synchronisation in block (%u,%u,%u) thread %u\n", bx, by, bz, t);
-                abort();
+            progressed = true;
+            if (f.done) { --alive; continue; }
+            st[t] = f.yield_kind == 1 ? AT_BARRIER : AT_WAVE;
+        }
+        for (unsigned w0 = 0; w0 < nthreads; w0 += WAVE) {
+            unsigned live = 0, waiting = 0;
+            for (unsigned t = w0; t < w0 + WAVE && t < nthreads; ++t) {
+                if (S.fibers[t].done) continue;
+                ++live;
+                if (st[t] == AT_WAVE) ++waiting;
+            }
+            if (live && waiting == live) {
+                for (unsigned t = w0; t < w0 + WAVE && t < nthreads; ++t)
+                    if (!S.fibers[t].done) st[t] = RUNNABLE;
+                progressed = true;
             }
         }
-        if (finished && yielded) {
-            // legal on a GPU only if the finished threads never reach that barrier; our kernels never
-            // do that, so flag it.
-            fprintf(stderr, "hipemu: %u threads exited while %u wait at a barrier (block %u,%u,%u)\n",
-                    finished, yielded, bx, by, bz);
+        unsigned at_barrier = 0;
+        for (unsigned t = 0; t < nthreads; ++t)
+            if (!S.fibers[t].done && st[t] == AT_BARRIER) ++at_barrier;
+        if (alive && at_barrier == alive) {
+            if (alive != nthreads) {
+                // legal on a GPU only if the finished threads never reach that barrier; our kernels never
+                // do that, so flag it.
+                fprintf(stderr, "hipemu: %u threads exited while %u wait at a barrier (block %u,%u,%u)\n",
+                        nthreads - alive, alive, bx, by, bz);
+                abort();
+            }
+            for (unsigned t = 0; t < nthreads; ++t) st[t] = RUNNABLE;
+            progressed = true;
+        }
+        if (alive && !progressed) {
+            fprintf(stderr, "hipemu: deadlock (divergent synchronisation) in block (%u,%u,%u)\n", bx, by, bz);
             abort();
         }
     }

@@ -50,6 +50,7 @@ struct State {
     int cur;
     const std::function<void()>* body;
     std::vector<uint32_t> xchg;   // shuffle exchange slots, one per thread
+    std::vector<uint32_t> xchg2;  // second operand slot (MFMA B operand)
 };
 
 extern thread_local State S;
@@ -72,6 +73,29 @@ inline uint32_t shfl_u32(uint32_t v, int src_lane) {
     uint32_t r = S.xchg[wave_base + (src_lane & (WAVE - 1))];
     yield(2);
     return r;
+}
+
+// v_mfma_f32_32x32x2_f32: D = A(32x2) * B(2x32) + C, one wave.  Lane l supplies A[l & 31][l >> 5] and
+// B[l >> 5][l & 31]; it owns C/D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][l & 31] for r in [0, 16).
+typedef float floatx16 __attribute__((vector_size(64)));
+inline floatx16 mfma_f32_32x32x2f32(float a, float b, floatx16 c) {
+    int t = S.cur, lane = t & (WAVE - 1), base = t - lane;
+    memcpy(&S.xchg[t], &a, 4);
+    memcpy(&S.xchg2[t], &b, 4);
+    yield(2);
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            memcpy(&av, &S.xchg[base + row + 32 * k], 4);
+            memcpy(&bv, &S.xchg2[base + col + 32 * k], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    yield(2);
+    return c;
 }
 
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);

@@ -8,6 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "hyena_fftconv.h")
+ALL_HEADERS = sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
 
 
 @pytest.fixture(scope="module")
@@ -21,6 +22,34 @@ def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(hyena_fftconv_\w+)\s*\(", text)))
+
+
+def declared_symbols_all_headers():
+    out = set()
+    for h in ALL_HEADERS:
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        out.update(re.findall(r"\b(hyena_(?:fftconv|mixer|filter)_\w+)\s*\(", text))
+    return sorted(out)
+
+
+def test_every_header_symbol_is_exported(product_lib):
+    syms = declared_symbols_all_headers()
+    assert {"hyena_mixer_pre_fwd", "hyena_mixer_post_bwd", "hyena_filter_fwd", "hyena_filter_bwd",
+            "hyena_filter_supported", "hyena_filter_workspace_bytes", "hyena_filter_saved_bytes"} <= set(syms)
+    for s in syms:
+        assert hasattr(product_lib, s), s
+
+
+def test_filter_host_only_entry_points(product_lib):
+    L = product_lib
+    L.hyena_filter_saved_bytes.restype = ctypes.c_size_t
+    L.hyena_filter_workspace_bytes.restype = ctypes.c_size_t
+    assert L.hyena_filter_supported(1 << 20, 5, 64, 256) == 1 and L.hyena_filter_supported(1024, 5, 64, 128) == 1
+    assert L.hyena_filter_supported(1024, 5, 16, 128) == 0 and L.hyena_filter_supported(1024, 9, 64, 128) == 0
+    assert L.hyena_filter_supported(1024, 5, 64, 96) == 0 and L.hyena_filter_supported((1 << 20) + 1, 5, 64, 256) == 0
+    assert L.hyena_filter_saved_bytes(1000) == 3 * 64 * 1000 * 4
+    assert L.hyena_filter_workspace_bytes(1000, 256) == (2 * 64 * 1000 + 256 * (256 * 64 + 1024)) * 4
+    assert L.hyena_filter_fwd(None, None, None, None) == 1          # HYENA_ERR_BAD_ARG, no device touched
 
 
 def test_header_declares_the_expected_entry_points():

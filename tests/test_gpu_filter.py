@@ -1,0 +1,105 @@
+"""MI355X parity of the fused implicit-filter kernels (include/hyena_filter.h) through the C ABI: values and every
+parameter gradient against the oracle's restatement of HyenaFilter.filter (hyena.py:229-238) evaluated in fp64 on the
+CPU, and -- at the full HyenaDNA lengths -- against the module's own PyTorch-op path on the same GPU."""
+import pytest
+import torch
+
+from oracle import hyena_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["pos_emb.z", "implicit_filter.0.weight", "implicit_filter.0.bias", "implicit_filter.2.weight",
+         "implicit_filter.2.bias", "implicit_filter.4.weight", "implicit_filter.4.bias", "implicit_filter.6.weight",
+         "implicit_filter.1.freq"]
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm().clamp_min(1e-30)).item()
+
+
+def _make_filter(D, L, emb_dim=5, seed=0, **kw):
+    from hyena_dna_amd.hyena import HyenaFilter
+    torch.manual_seed(seed)
+    f = HyenaFilter(D, emb_dim=emb_dim, order=64, seq_len=L + 2, w=10, lr_pos_emb=kw.pop("lr_pos_emb", 1e-5), **kw)
+    with torch.no_grad():
+        for m in f.implicit_filter:
+            if isinstance(m, torch.nn.Linear) and m.bias is not None:
+                m.bias.normal_(0, 0.3)
+    return f
+
+
+def _oracle_filter(sd, L, dtype):
+    sd = {"filter_fn." + k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in sd.items()}
+    return O.hyena_filter(sd, L)[0].transpose(0, 1), sd
+
+
+@pytest.mark.parametrize("D,L,emb_dim", [(64, 300, 5), (128, 1024, 5), (256, 4099, 5), (256, 32768, 5), (128, 7, 3), (256, 1, 7)])
+def test_fused_filter_vs_oracle(gpu_lib, D, L, emb_dim):
+    f = _make_filter(D, L, emb_dim=emb_dim, seed=D + L).cuda()
+    layers = [f.implicit_filter[i] for i in range(len(f.implicit_filter))]
+    assert f._fused_filter_ok(L, layers, f.pos_emb.z[:, :L])
+    k = f.filter_dl(L)
+    assert k.shape == (D, L) and k.dtype == torch.float32 and k.is_cuda
+    dk = torch.randn(D, L, generator=torch.Generator().manual_seed(1))
+    k.backward(dk.cuda())
+    truth, sd64 = _oracle_filter(f.state_dict(), L, torch.float64)
+    truth.backward(dk.double())
+    ref32, sd32 = _oracle_filter(f.state_dict(), L, torch.float32)
+    ref32.backward(dk)
+    # fp32 kernels vs the reference's fp32 path, both measured against fp64: no worse than 4x the reference's own
+    # rounding error (sin(10 x) amplifies one fp32 rounding of x to ~1e-6 relative) + 1e-6
+    assert _rel(k, truth) < 4 * _rel(ref32, truth) + 1e-6, (_rel(k, truth), _rel(ref32, truth))
+    params = dict(f.named_parameters())
+    for name in NAMES:
+        got = params[name].grad
+        if name.endswith("freq"):          # one Sin instance in three slots: its gradient is the sum over the slots
+            want = sum(sd64[f"filter_fn.implicit_filter.{i}.freq"].grad for i in (1, 3, 5))
+            ref = sum(sd32[f"filter_fn.implicit_filter.{i}.freq"].grad for i in (1, 3, 5))
+        else:
+            want, ref = sd64["filter_fn." + name].grad, sd32["filter_fn." + name].grad
+        assert got is not None and got.shape == want.shape, name
+        assert _rel(got, want) < 4 * _rel(ref, want) + 2e-6, (name, _rel(got, want), _rel(ref, want))
+
+
+@pytest.mark.parametrize("D,L", [(256, 160000), (256, 450560), (256, 1048576), (256, 1048575)])
+def test_fused_filter_at_hyenadna_lengths(gpu_lib, D, L):
+    """full-size: fused kernels vs the module's PyTorch-op path (the reference's graph; checked against the oracle on
+    the CPU by tests/test_host_logic.py) on the same device, fp32, values + gradients; and run-to-run determinism"""
+    f = _make_filter(D, L, seed=3, lr_pos_emb=0.0).cuda()           # HyenaDNA: z is a buffer (lr_pos_emb = 0)
+    dk = torch.randn(D, L, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    k = f.filter_dl(L)
+    k.backward(dk)
+    got = {n: p.grad.clone() for n, p in f.named_parameters() if p.grad is not None}
+    f.zero_grad(set_to_none=True)
+    k2 = f.filter_dl(L)
+    k2.backward(dk)
+    assert torch.equal(k, k2)
+    for n, p in f.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(got[n], p.grad), n                   # fixed-order reductions: bitwise reproducible
+    f.zero_grad(set_to_none=True)
+    kr = f.filter(L)[0].transpose(0, 1)
+    kr.backward(dk)
+    assert _rel(k, kr) < 2e-5, _rel(k, kr)
+    for n, p in f.named_parameters():
+        if p.grad is not None:
+            assert n in got, n
+            assert _rel(got[n], p.grad) < 2e-4, (n, _rel(got[n], p.grad))      # both sum ~1e6 fp32 terms per entry
+
+
+def test_operator_uses_the_fused_filter(gpu_lib):
+    """HyenaOperator in the HyenaDNA configuration under bf16 autocast: filter comes from the fused kernels (fp32)"""
+    from hyena_dna_amd.hyena import HyenaOperator
+    torch.manual_seed(0)
+    op = HyenaOperator(d_model=128, l_max=1026, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True,
+                       w=10, lr=6e-4, wd=0.0, lr_pos_emb=0.0).cuda()
+    u = torch.randn(2, 1024, 128, device="cuda")
+    k_fused = op.filter_fn.filter_dl(1024)
+    k_ref = op.filter_fn.filter(1024)[0].transpose(0, 1)
+    assert _rel(k_fused, k_ref) < 2e-5
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = op(u)
+    y.float().square().mean().backward()
+    assert y.dtype == torch.bfloat16
+    for n, p in op.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
