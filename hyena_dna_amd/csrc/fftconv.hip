@@ -458,14 +458,21 @@ int hyena_mixer_pre_bwd(const void* dvg, const void* x, const float* w, const fl
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 // kernels that stage the whole weight set in LDS need more than the 64 KiB a launch may ask for by default
+// (per device: the attribute is re-applied whenever the calling thread's current device changes)
 template <typename K>
-void flt_allow_lds(K kernel, size_t bytes) {
+void flt_allow_lds(K kernel, size_t bytes, int* device_done) {
 #ifndef HIPEMU
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (*device_done == dev) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    *device_done = dev;
 #else
-    (void)kernel; (void)bytes;
+    (void)kernel; (void)bytes; (void)device_done;
 #endif
 }
+
+const size_t FLT_RED_SMEM = FLT_RED_J * FLT_RED_S * sizeof(float);
 
 int flt_grid(int L) {
     const int n = (L + FLT_WG_POS - 1) / FLT_WG_POS;
@@ -487,11 +494,12 @@ void launch_filter_fwd(const FilterArgs& a, void* stream) {
     const int ntiles = (a.L + FLT_TP - 1) / FLT_TP;
     int grid = (ntiles + FLT_WAVES - 1) / FLT_WAVES;
     if (grid > FLT_MAX_WG) grid = FLT_MAX_WG;
+    static thread_local int done_save = -1, done_plain = -1;
     if (a.acts != nullptr) {
-        flt_allow_lds(filter_fwd_kernel<D, true>, FltFwdLds<D>::BYTES);
+        flt_allow_lds(filter_fwd_kernel<D, true>, FltFwdLds<D>::BYTES, &done_save);
         HY_LAUNCH((filter_fwd_kernel<D, true>), dim3(grid), dim3(FLT_THREADS), FltFwdLds<D>::BYTES, stream, a);
     } else {
-        flt_allow_lds(filter_fwd_kernel<D, false>, FltFwdLds<D>::BYTES);
+        flt_allow_lds(filter_fwd_kernel<D, false>, FltFwdLds<D>::BYTES, &done_plain);
         HY_LAUNCH((filter_fwd_kernel<D, false>), dim3(grid), dim3(FLT_THREADS), FltFwdLds<D>::BYTES, stream, a);
     }
 }
@@ -504,22 +512,23 @@ void launch_filter_layer_bwd(FilterBwdArgs a, float* part, float* dw, float* db,
     a.part_w = part;
     a.part_b = db != nullptr ? part + (size_t)slots * NO * NI : nullptr;
     a.part_f = part + (size_t)slots * NO * NI + (size_t)2 * slots * NO;
-    flt_allow_lds(filter_layer_bwd_kernel<NO, NI, MODE>, Cfg::BYTES);
+    static thread_local int done = -1;
+    flt_allow_lds(filter_layer_bwd_kernel<NO, NI, MODE>, Cfg::BYTES, &done);
     HY_LAUNCH((filter_layer_bwd_kernel<NO, NI, MODE>), dim3(grid), dim3(FLT_THREADS), Cfg::BYTES, stream, a);
     const int nw = NO * a.ni;
     if (NI == a.ni) {
-        HY_LAUNCH(filter_reduce_kernel, dim3((nw + 255) / 256), dim3(256), 0, stream, (const float*)a.part_w, dw, slots, nw, 0);
+        HY_LAUNCH(filter_reduce_kernel, dim3((nw + FLT_RED_J - 1) / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream, (const float*)a.part_w, dw, slots, nw, 0);
     } else {
         // layer 0 with E < 8: partial rows are 8 wide; reduce into a scratch tail of `part`, then the host-side
         // caller's dw0 gets the first E columns (done below by a strided second pass)
         float* tmp = a.part_f + (size_t)grid * FLT_WAVES * FLT_O;
-        HY_LAUNCH(filter_reduce_kernel, dim3((NO * NI + 255) / 256), dim3(256), 0, stream, (const float*)a.part_w, tmp, slots, NO * NI, 0);
+        HY_LAUNCH(filter_reduce_kernel, dim3((NO * NI + FLT_RED_J - 1) / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream, (const float*)a.part_w, tmp, slots, NO * NI, 0);
         HY_LAUNCH(filter_compact_kernel, dim3((nw + 255) / 256), dim3(256), 0, stream, (const float*)tmp, dw, NO, NI, a.ni);
     }
     if (db != nullptr)
-        HY_LAUNCH(filter_reduce_kernel, dim3((NO + 255) / 256), dim3(256), 0, stream, (const float*)a.part_b, db, 2 * slots, NO, 0);
+        HY_LAUNCH(filter_reduce_kernel, dim3((NO + FLT_RED_J - 1) / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream, (const float*)a.part_b, db, 2 * slots, NO, 0);
     if (MODE & FLT_ACT)
-        HY_LAUNCH(filter_reduce_kernel, dim3(1), dim3(256), 0, stream, (const float*)a.part_f, dfreq, grid * FLT_WAVES, FLT_O,
+        HY_LAUNCH(filter_reduce_kernel, dim3(FLT_O / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream, (const float*)a.part_f, dfreq, grid * FLT_WAVES, FLT_O,
                   first_freq ? 0 : 1);
 }
 }  // namespace

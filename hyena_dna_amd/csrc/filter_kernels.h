@@ -495,13 +495,32 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
     }
 }
 
-// out[j] (+)= sum_c part[c][j], fixed order
+// out[j] (+)= sum_c part[c][j] in a fixed order: a workgroup owns 16 outputs, its 16 thread rows sum interleaved
+// slices of c (independent loads in flight), thread row 0 adds the slices in order.
+enum { FLT_RED_J = 16, FLT_RED_S = 16 };
 __global__ void __launch_bounds__(256) filter_reduce_kernel(const float* part, float* out, int count, int n, int accumulate) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    float s = accumulate ? out[j] : 0.f;
-    for (int c = 0; c < count; ++c) s += part[(size_t)c * n + j];
-    out[j] = s;
+    HY_SMEM(smem);
+    HY_LDS float* sm = HY_LDS_CAST(float, smem);            // [FLT_RED_S][FLT_RED_J]
+    const int jj = threadIdx.x & (FLT_RED_J - 1), cs = threadIdx.x / FLT_RED_J;
+    const int j = blockIdx.x * FLT_RED_J + jj;
+    const int jc = j < n ? j : n - 1;
+    float s = 0.f;
+    int c = cs;
+    for (; c + 7 * FLT_RED_S < count; c += 8 * FLT_RED_S) {
+        float v[8];
+        HY_UNROLL
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u * FLT_RED_S) * n + jc];
+        HY_UNROLL
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < count; c += FLT_RED_S) s += part[(size_t)c * n + jc];
+    sm[cs * FLT_RED_J + jj] = s;
+    __syncthreads();
+    if (cs == 0 && j < n) {
+        float r = accumulate ? out[j] : 0.f;
+        for (int q = 0; q < FLT_RED_S; ++q) r += sm[q * FLT_RED_J + jj];
+        out[j] = r;
+    }
 }
 
 // dst (rows, used) <- first `used` columns of src (rows, cols)
