@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from .fftconv import fftconv_func
 from .filter import fused_filter_ok, hyena_filter_dl
 from .mixer import hyena_mixer_core
+from .projection import hyena_linear
 
 __all__ = ["HyenaOperator", "HyenaFilter", "PositionalEmbedding", "ExponentialModulation", "Sin"]
 
@@ -254,11 +255,11 @@ class HyenaOperator(nn.Module):
         l = u.size(-2)
         l_filter = min(l, self.l_max)
         if self._fused_ok():
-            x = self.in_proj(u)                                                 # (B, L, 3D), hipBLASLt GEMM
+            x = hyena_linear(u, self.in_proj.weight, self.in_proj.bias)         # (B, L, 3D), hipBLASLt GEMM
             k = self.filter_fn.filter_dl(l_filter)                              # (D, l), rows contiguous along l
             fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
             z = hyena_mixer_core(x, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter)
-            y = self.out_proj(self.activation(z))
+            y = hyena_linear(self.activation(z), self.out_proj.weight, self.out_proj.bias)
             return (y, None) if self.return_state else y
         u = self.in_proj(u).transpose(1, 2)                                     # b l d -> b d l
         uc = self.short_filter(u)[..., :l_filter]

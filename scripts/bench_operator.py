@@ -12,7 +12,7 @@ D = 256
 torch.manual_seed(0)
 op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
                    lr=6e-4, wd=0.0, lr_pos_emb=0.0).to(dev)
-u = torch.randn(B, L, D, device=dev, requires_grad=True)
+u = torch.randn(B, L, D, device=dev, dtype=torch.bfloat16, requires_grad=True)
 dy = torch.randn(B, L, D, device=dev)
 
 
@@ -25,6 +25,8 @@ def run(fused, n=10):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
+        op.zero_grad(set_to_none=True)       # as an optimizer step would; u is an activation in a real model
+        u.grad = None
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = op(u)
         y.backward(dy)

@@ -103,3 +103,21 @@ def test_operator_uses_the_fused_filter(gpu_lib):
     assert y.dtype == torch.bfloat16
     for n, p in op.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_split_k_projection_on_gpu(gpu_lib):
+    """in_proj-shaped linear under bf16 autocast: split-K weight gradient vs an fp64 computation on the same bf16 data"""
+    from hyena_dna_amd.projection import hyena_linear
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(1, 65536, 256, device="cuda", generator=g, requires_grad=True)
+    lin = torch.nn.Linear(256, 768).cuda()
+    dy = torch.randn(1, 65536, 768, device="cuda", generator=g)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = hyena_linear(x, lin.weight, lin.bias)
+        yr = lin(x)
+    assert y.dtype == torch.bfloat16 and torch.equal(y, yr)
+    y.backward(dy)
+    xb, dyb = x.detach().bfloat16().double()[0], dy.bfloat16().double()[0]
+    assert _rel(lin.weight.grad, dyb.t() @ xb) < 4e-3            # one bf16 rounding of the fp32-accumulated result
+    assert _rel(lin.bias.grad, dyb.sum(0)) < 4e-3
+    assert _rel(x.grad, (dyb @ lin.weight.detach().bfloat16().double())[None]) < 4e-3

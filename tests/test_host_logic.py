@@ -148,3 +148,26 @@ def test_optim_tags_and_buffers_match_reference_contract():
         HyenaOperator(d_model=8, l_max=34, order=1)
     with pytest.raises(ImportError):
         HyenaOperator(d_model=8, l_max=34, fused_bias_fc=True)
+
+
+def test_split_k_linear_gradients_match_linear():
+    """hyena_dna_amd/projection.py: the slice-batched weight gradient equals autograd's dy^T x (hyena.py:391,440)"""
+    from hyena_dna_amd.projection import SplitKLinearFunc, split_count
+    assert split_count(1 << 20) == 64 and split_count(32768) == 8 and split_count(160000) == 32 and split_count(8191) == 1
+    for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-2)):
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(2, 8192, 16, generator=g).to(dt).requires_grad_()
+        w = (torch.randn(24, 16, generator=g) * 0.1).to(dt).requires_grad_()
+        b = torch.randn(24, generator=g).to(dt).requires_grad_()
+        y = SplitKLinearFunc.apply(x, w, b)
+        dy = torch.randn(y.shape, generator=g).to(dt)
+        y.backward(dy)
+        got = [t.grad.clone() for t in (x, w, b)]
+        for t in (x, w, b):
+            t.grad = None
+        ref = torch.nn.functional.linear(x, w, b)
+        assert torch.equal(y, ref)
+        ref.backward(dy)
+        for a, t in zip(got, (x, w, b)):
+            assert a.dtype == t.grad.dtype
+            assert ((a.float() - t.grad.float()).norm() / t.grad.float().norm()).item() < tol
