@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0, help="channels per kernel-chain pass (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allreduce", action="store_true")
+    ap.add_argument("--no-operator", action="store_true", help="skip the secondary whole-layer measurement")
     ap.add_argument("--no-save-spectra", action="store_true",
                     help="backward recomputes the column spectra of u and k instead of reusing the forward's")
     ap.add_argument("--fwd-only", action="store_true", help="diagnostic; the reported metric needs fwd+bwd")
@@ -110,6 +111,38 @@ def cpu_baseline(L, D, dtype, budget_s=25.0):
     return {"value": nt_per_s, "unit": "nt/s", "cores": cores, "kind": "port",
             "sample": f"oracle fftconv_ref fwd+bwd (torch.fft, fp32 math), B=1, L={L}, {Ds} of {D} channels, "
                       f"best of 3 after 1 warm-up, {best * 1e3:.0f} ms; scaled by {Ds}/{D} channels"}
+
+
+def operator_layer(L, D, B, dtype, dev, steps=5, warmup=2):
+    """Secondary figure (not `value`): one whole HyenaOperator layer -- in_proj, short conv, gates, implicit filter, long
+    conv, out_proj -- forward + backward under autocast, HyenaDNA configuration (hg38_hyena.yaml:20-30), random init."""
+    from hyena_dna_amd.hyena import HyenaOperator
+    torch.manual_seed(0)
+    op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
+                       lr=6e-4, wd=0.0, lr_pos_emb=0.0).to(dev)
+    u = torch.randn(B, L, D, device=dev, dtype=dtype, requires_grad=True)
+    dy = torch.randn(B, L, D, device=dev, dtype=dtype)
+
+    def step():
+        op.zero_grad(set_to_none=True)
+        u.grad = None
+        with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
+            y = op(u)
+        y.backward(dy)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / steps
+    return {"ms_per_step": ms, "value": B * L / ms * 1e3, "unit": "nt/s", "steps": steps,
+            "workload": f"one HyenaOperator layer fwd+bwd (projections + short conv + gates + implicit filter + long conv), "
+                        f"L={L}, d={D}, B={B}, {str(dtype).split('.')[-1]} autocast; secondary figure, not `value`"}
 
 
 def main():
@@ -222,6 +255,11 @@ def main():
                          "kernel": "all launches of one fftconv fwd+bwd step (col_fwd/row_*/col_inv chain)",
                          "algorithmic_bytes_per_step": abytes, "event_ms_per_step": ev_ms_step},
         }
+        if world == 1 and not args.emu and not args.no_operator and not args.fwd_only:
+            try:
+                line["operator_layer"] = operator_layer(L, D, B, dtype, dev)
+            except Exception as e:                                   # secondary: never lose the contract line over it
+                line["operator_layer"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline and not args.emu:
             line["cpu_baseline"] = cpu_baseline(L, D, dtype)
         elif args.emu:

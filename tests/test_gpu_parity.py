@@ -240,3 +240,33 @@ def test_fused_mixer_core_vs_oracle(gpu_lib, B, Lx, L, D, dtype):
     z2 = hyena_mixer_core(*ts2, L)
     z2.backward(dz.to(dev))
     assert torch.equal(z2, z) and all(torch.equal(a.grad, b_.grad) for a, b_ in zip(ts, ts2))
+
+
+def test_hipgraph_capture_and_replay(gpu_lib):
+    """The entry points allocate nothing, never synchronise and launch on the caller's stream, so forward + backward can
+    be captured into a hipGraph (torch.cuda.CUDAGraph) and replayed on new data -- the launch-bound regime at L = 1k."""
+    dev = torch.device("cuda", 0)
+    u, k, bias, dout = (t.to(dev) for t in _inputs(4, 16, 1024, torch.bfloat16, seed=9))
+    u2, k2, _, dout2 = (t.to(dev) for t in _inputs(4, 16, 1024, torch.bfloat16, seed=10))
+
+    def run():
+        out, saved = gpu_lib.fftconv_fwd(u, k, bias, save=True)
+        return (out,) + tuple(gpu_lib.fftconv_bwd(dout, u, k, bias, saved=saved))
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                 # warm-up: twiddle tables (one synchronous copy) are created here
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = run()
+    for dst, src in ((u, u2), (k, k2), (dout, dout2)):
+        dst.copy_(src)
+    graph.replay()
+    torch.cuda.synchronize()
+    got = [t.clone() for t in captured]
+    want = run()
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
