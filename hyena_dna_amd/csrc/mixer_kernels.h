@@ -301,24 +301,6 @@ __device__ __forceinline__ void vec_store(typename Elem<DT>::type* p, const floa
     __builtin_memcpy(p, &r, 16);
 }
 
-// channel-minor tile: rows = positions t_first .. t_first + nrows - 1 of tensor `base` (row stride `ld` elements, channel
-// offset `coff`), 64 channels each -> LDS dst[row * MW_CS + c]; positions outside [0, tlim) read as zero.
-template <int DT>
-__device__ __forceinline__ void load_cm_tile(HY_LDS float* dst, const void* base, size_t boff, int ld, int coff, int t_first,
-                                             int nrows, int tlim, int tid) {
-    typedef typename Elem<DT>::type elem_t;
-    constexpr int N = MixVec<DT>::N, VPR = MW_TC / N;             // vectors per row
-    const elem_t* src = reinterpret_cast<const elem_t*>(base) + boff + coff;
-    HY_UNROLL
-    for (int i = tid; i < nrows * VPR; i += MW_THREADS) {
-        const int row = i / VPR, vl = i % VPR, t = t_first + row;
-        const bool ok = t >= 0 && t < tlim;
-        float v[N];
-        vec_load<DT>(src + (size_t)(ok ? t : 0) * ld + vl * N, v);
-        HY_UNROLL
-        for (int e = 0; e < N; ++e) dst[row * MW_CS + vl * N + e] = ok ? v[e] : 0.f;
-    }
-}
 // store rows (positions t_first ..) of a channel-minor LDS tile, only positions in [t_lo, t_hi)
 template <int DT>
 __device__ __forceinline__ void store_cm_tile(const HY_LDS float* src, void* base, size_t boff, int ld, int coff, int t_first,
@@ -337,30 +319,8 @@ __device__ __forceinline__ void store_cm_tile(const HY_LDS float* src, void* bas
         }
     }
 }
-// (B, D, L)-side tile: rows = 64 channels c0 .. c0+63 of batch item b, positions t0 .. t0 + npos - 1 (npos a multiple of
-// the vector length) -> LDS dst[c * ds + p]; positions >= L read as zero.  The last vector of a row may straddle L.
-template <int DT>
-__device__ __forceinline__ void load_dl_tile(HY_LDS float* dst, int ds, const void* base, size_t row0, int L, int t0, int npos,
-                                             int tid) {
-    typedef typename Elem<DT>::type elem_t;
-    constexpr int N = MixVec<DT>::N;
-    const int vpr = npos / N;
-    const elem_t* src = reinterpret_cast<const elem_t*>(base);
-    HY_UNROLL
-    for (int i = tid; i < MW_TC * vpr; i += MW_THREADS) {
-        const int c = i / vpr, vl = i % vpr, t = t0 + vl * N;
-        const elem_t* rp = src + (row0 + c) * (size_t)L;
-        float v[N];
-        if (t + N <= L) {
-            vec_load<DT>(rp + t, v);
-        } else {
-            HY_UNROLL
-            for (int e = 0; e < N; ++e) v[e] = (t + e < L) ? Elem<DT>::ld(rp + t + e) : 0.f;
-        }
-        HY_UNROLL
-        for (int e = 0; e < N; ++e) dst[c * ds + vl * N + e] = v[e];
-    }
-}
+// (B, D, L)-side tile store: rows = 64 channels of batch item b (row0 = b * D + c0), positions t0 .. t0 + npos - 1 from
+// LDS src[c * ds + p]; only positions < t_hi are written.
 template <int DT>
 __device__ __forceinline__ void store_dl_tile(const HY_LDS float* src, int ds, void* base, size_t row0, int L, int t0, int npos,
                                               int t_hi, int tid) {
@@ -385,10 +345,131 @@ __device__ __forceinline__ void store_dl_tile(const HY_LDS float* src, int ds, v
     }
 }
 
+// ---- two-phase tile movement: fetch = global -> registers (raw 16-byte vectors, every load issued back to back),
+// commit = registers -> LDS as fp32.  A kernel fetches tile s+1 right after committing tile s, so the loads are in
+// flight while it computes and stores tile s (the single-phase movers above expose the full load latency per tile).
+struct RawVec { uint32_t w[4]; };
+
+template <int DT>
+__device__ __forceinline__ void raw_to_f32(const RawVec& r, float (&out)[MixVec<DT>::N]) {
+    if constexpr (DT == DT_F32) {
+        HY_UNROLL
+        for (int e = 0; e < 4; ++e) out[e] = u2f(r.w[e]);
+    } else {
+        HY_UNROLL
+        for (int e = 0; e < 4; ++e) {
+            const c32 v = Pair<DT>::cvt(r.w[e]);
+            out[2 * e] = v.x;
+            out[2 * e + 1] = v.y;
+        }
+    }
+}
+
+template <int DT, int NROWS>
+struct CmFetch {
+    static constexpr int N = MixVec<DT>::N, VPR = MW_TC / N, TOTAL = NROWS * VPR, CNT = (TOTAL + MW_THREADS - 1) / MW_THREADS;
+    RawVec v[CNT];
+};
+template <int DT, int NROWS>
+__device__ __forceinline__ void fetch_cm(CmFetch<DT, NROWS>& f, const void* base, size_t boff, int ld, int coff, int t_first,
+                                         int tlim, int tid) {
+    typedef typename Elem<DT>::type elem_t;
+    typedef CmFetch<DT, NROWS> F;
+    const elem_t* src = reinterpret_cast<const elem_t*>(base) + boff + coff;
+    HY_UNROLL
+    for (int j = 0; j < F::CNT; ++j) {
+        const int i = tid + j * MW_THREADS;
+        const int row = i / F::VPR, vl = i % F::VPR, t = t_first + row;
+        const bool ok = i < F::TOTAL && t >= 0 && t < tlim;
+        __builtin_memcpy(&f.v[j], src + (size_t)(ok ? t : 0) * ld + vl * F::N, 16);
+    }
+}
+template <int DT, int NROWS>
+__device__ __forceinline__ void commit_cm(HY_LDS float* dst, const CmFetch<DT, NROWS>& f, int t_first, int tlim, int tid) {
+    typedef CmFetch<DT, NROWS> F;
+    HY_UNROLL
+    for (int j = 0; j < F::CNT; ++j) {
+        const int i = tid + j * MW_THREADS;
+        const int row = i / F::VPR, vl = i % F::VPR, t = t_first + row;
+        if (i < F::TOTAL) {
+            const bool ok = t >= 0 && t < tlim;
+            float v[F::N];
+            raw_to_f32<DT>(f.v[j], v);
+            HY_UNROLL
+            for (int e = 0; e < F::N; ++e) dst[row * MW_CS + vl * F::N + e] = ok ? v[e] : 0.f;
+        }
+    }
+}
+
+template <int DT, int NPOS>
+struct DlFetch {
+    static constexpr int N = MixVec<DT>::N, VPR = NPOS / N, TOTAL = MW_TC * VPR, CNT = (TOTAL + MW_THREADS - 1) / MW_THREADS;
+    RawVec v[CNT];
+};
+template <int DT, int NPOS>
+__device__ __forceinline__ void fetch_dl(DlFetch<DT, NPOS>& f, const void* base, size_t row0, int L, int t0, int tid) {
+    typedef typename Elem<DT>::type elem_t;
+    typedef DlFetch<DT, NPOS> F;
+    const elem_t* src = reinterpret_cast<const elem_t*>(base);
+    HY_UNROLL
+    for (int j = 0; j < F::CNT; ++j) {
+        const int i = tid + j * MW_THREADS;
+        const int c = (i / F::VPR) & (MW_TC - 1), vl = i % F::VPR, t = t0 + vl * F::N;
+        const elem_t* rp = src + (row0 + c) * (size_t)L;
+        // a vector that would straddle the end of the row is fetched from the last full vector of the row instead and
+        // re-aligned at commit time (rows shorter than one vector take the element-wise path there)
+        const int ts = t + F::N <= L ? t : (L >= F::N ? L - F::N : 0);
+        if (L >= F::N) __builtin_memcpy(&f.v[j], rp + ts, 16);
+        else {
+            HY_UNROLL
+            for (int e = 0; e < 4; ++e) f.v[j].w[e] = 0u;
+        }
+    }
+}
+template <int DT, int NPOS>
+__device__ __forceinline__ void commit_dl(HY_LDS float* dst, int ds, const DlFetch<DT, NPOS>& f, const void* base, size_t row0,
+                                          int L, int t0, int tid) {
+    typedef typename Elem<DT>::type elem_t;
+    typedef DlFetch<DT, NPOS> F;
+    HY_UNROLL
+    for (int j = 0; j < F::CNT; ++j) {
+        const int i = tid + j * MW_THREADS;
+        const int c = i / F::VPR, vl = i % F::VPR, t = t0 + vl * F::N;
+        if (i < F::TOTAL) {
+            float v[F::N];
+            raw_to_f32<DT>(f.v[j], v);
+            if (t + F::N <= L) {
+                HY_UNROLL
+                for (int e = 0; e < F::N; ++e) dst[c * ds + vl * F::N + e] = v[e];
+            } else if (L >= F::N) {
+                // fetched from [L - N, L): element e of the wanted vector (position t + e) sits at index t + e - (L - N)
+                const int sh = t - (L - F::N);
+                HY_UNROLL
+                for (int e = 0; e < F::N; ++e) {
+                    float x = 0.f;
+                    HY_UNROLL
+                    for (int q = 0; q < F::N; ++q) x = (q == e + sh) ? v[q] : x;
+                    dst[c * ds + vl * F::N + e] = (t + e < L) ? x : 0.f;
+                }
+            } else {
+                const elem_t* rp = reinterpret_cast<const elem_t*>(base) + (row0 + c) * (size_t)L;
+                HY_UNROLL
+                for (int e = 0; e < F::N; ++e) dst[c * ds + vl * F::N + e] = (t + e < L) ? Elem<DT>::ld(rp + t + e) : 0.f;
+            }
+        }
+    }
+}
+
 // short-conv value at tile row p (row index = position - first_position_of_tile) from a channel-minor LDS tile whose
 // row r holds position (first + r): xc(t) = b + w0 x(t-2) + w1 x(t-1) + w2 x(t), with x(t) in row `r2` and x(t-2) in r2-2
 __device__ __forceinline__ float sconv(const HY_LDS float* xs, int r2, int c, const float (&w)[3], float b) {
     return b + w[0] * xs[(r2 - 2) * MW_CS + c] + w[1] * xs[(r2 - 1) * MW_CS + c] + w[2] * xs[r2 * MW_CS + c];
+}
+
+// tiles of 64 positions in the run of MIX_RUN positions that starts at t_begin
+__device__ __forceinline__ int mw_tiles(int L, int t_begin) {
+    const int n = (L - t_begin + MW_TP - 1) / MW_TP;
+    return n < MIX_NT ? n : MIX_NT;
 }
 
 template <int DT>
@@ -405,12 +486,19 @@ __global__ void __launch_bounds__(MW_THREADS) mixer_pre_fwd_wide_kernel(MixArgs 
     const float b1 = a.b[a.D + c0 + c], b2 = a.b[2 * a.D + c0 + c];
     const size_t xb = (size_t)b * a.Lx * D3;
     const int t_begin = blockIdx.x * MIX_RUN;
-    for (int st = 0; st < MIX_NT; ++st) {
+    const int nst = mw_tiles(a.L, t_begin);
+    CmFetch<DT, MW_TP + 2> f1, f2;
+    fetch_cm(f1, a.x, xb, D3, a.D + c0, t_begin - 2, a.L, tid);
+    fetch_cm(f2, a.x, xb, D3, 2 * a.D + c0, t_begin - 2, a.L, tid);
+    for (int st = 0; st < nst; ++st) {
         const int t0 = t_begin + st * MW_TP;
-        if (t0 >= a.L) break;
-        load_cm_tile<DT>(xs1, a.x, xb, D3, a.D + c0, t0 - 2, MW_TP + 2, a.L, tid);
-        load_cm_tile<DT>(xs2, a.x, xb, D3, 2 * a.D + c0, t0 - 2, MW_TP + 2, a.L, tid);
+        commit_cm(xs1, f1, t0 - 2, a.L, tid);
+        commit_cm(xs2, f2, t0 - 2, a.L, tid);
         __syncthreads();
+        if (st + 1 < nst) {
+            fetch_cm(f1, a.x, xb, D3, a.D + c0, t0 + MW_TP - 2, a.L, tid);
+            fetch_cm(f2, a.x, xb, D3, 2 * a.D + c0, t0 + MW_TP - 2, a.L, tid);
+        }
         HY_UNROLL
         for (int i = 0; i < MW_TP / 4; ++i) {
             const int p = pq + 4 * i;
@@ -418,7 +506,6 @@ __global__ void __launch_bounds__(MW_THREADS) mixer_pre_fwd_wide_kernel(MixArgs 
         }
         __syncthreads();
         store_dl_tile<DT>(vt, MW_CS, a.a0, (size_t)b * a.D + c0, a.L, t0, MW_TP, a.L, tid);
-        __syncthreads();
     }
 }
 
@@ -436,12 +523,21 @@ __global__ void __launch_bounds__(MW_THREADS) mixer_post_fwd_wide_kernel(MixArgs
     const float b0 = a.b[c0 + c];
     const size_t xb = (size_t)b * a.Lx * D3;
     const int t_begin = blockIdx.x * MIX_RUN;
-    for (int st = 0; st < MIX_NT; ++st) {
+    const int nst = mw_tiles(a.L, t_begin);
+    const size_t yrow = (size_t)b * a.D + c0;
+    CmFetch<DT, MW_TP + 2> f0;
+    DlFetch<DT, MW_TP> fy;
+    fetch_cm(f0, a.x, xb, D3, c0, t_begin - 2, a.L, tid);
+    fetch_dl(fy, a.a0, yrow, a.L, t_begin, tid);
+    for (int st = 0; st < nst; ++st) {
         const int t0 = t_begin + st * MW_TP;
-        if (t0 >= a.L) break;
-        load_cm_tile<DT>(xs0, a.x, xb, D3, c0, t0 - 2, MW_TP + 2, a.L, tid);
-        load_dl_tile<DT>(yt, MW_CS, a.a0, (size_t)b * a.D + c0, a.L, t0, MW_TP, tid);
+        commit_cm(xs0, f0, t0 - 2, a.L, tid);
+        commit_dl(yt, MW_CS, fy, a.a0, yrow, a.L, t0, tid);
         __syncthreads();
+        if (st + 1 < nst) {
+            fetch_cm(f0, a.x, xb, D3, c0, t0 + MW_TP - 2, a.L, tid);
+            fetch_dl(fy, a.a0, yrow, a.L, t0 + MW_TP, tid);
+        }
         HY_UNROLL
         for (int i = 0; i < MW_TP / 4; ++i) {
             const int p = pq + 4 * i;
@@ -449,7 +545,6 @@ __global__ void __launch_bounds__(MW_THREADS) mixer_post_fwd_wide_kernel(MixArgs
         }
         __syncthreads();
         store_cm_tile<DT>(zs, a.a1, (size_t)b * a.L * a.D, a.D, c0, t0, MW_TP, 0, a.L, tid);
-        __syncthreads();
     }
 }
 
@@ -485,13 +580,25 @@ __global__ void __launch_bounds__(MW_THREADS) mixer_post_bwd_wide_kernel(MixArgs
     const size_t xb = (size_t)b * a.Lx * D3;
     const int t_begin = blockIdx.x * MIX_RUN;
     float dw[3] = {0.f, 0.f, 0.f}, db = 0.f;
-    for (int st = 0; st < MIX_NT; ++st) {
+    const int nst = mw_tiles(a.L, t_begin);
+    const size_t yrow = (size_t)b * a.D + c0, zoff = (size_t)b * a.L * a.D;
+    CmFetch<DT, MW_TP + 4> f0;
+    CmFetch<DT, MW_TP + 2> fz;
+    DlFetch<DT, 72> fy;
+    fetch_cm(f0, a.x, xb, D3, c0, t_begin - 2, a.L, tid);
+    fetch_cm(fz, a.a1, zoff, a.D, c0, t_begin, a.L, tid);
+    fetch_dl(fy, a.a0, yrow, a.L, t_begin, tid);
+    for (int st = 0; st < nst; ++st) {
         const int t0 = t_begin + st * MW_TP;
-        if (t0 >= a.L) break;
-        load_cm_tile<DT>(xs0, a.x, xb, D3, c0, t0 - 2, MW_TP + 4, a.L, tid);
-        load_cm_tile<DT>(gs, a.a1, (size_t)b * a.L * a.D, a.D, c0, t0, MW_TP + 2, a.L, tid);
-        load_dl_tile<DT>(ys, MW_YS, a.a0, (size_t)b * a.D + c0, a.L, t0, 72, tid);
+        commit_cm(xs0, f0, t0 - 2, a.L, tid);
+        commit_cm(gs, fz, t0, a.L, tid);
+        commit_dl(ys, MW_YS, fy, a.a0, yrow, a.L, t0, tid);
         __syncthreads();
+        if (st + 1 < nst) {
+            fetch_cm(f0, a.x, xb, D3, c0, t0 + MW_TP - 2, a.L, tid);
+            fetch_cm(fz, a.a1, zoff, a.D, c0, t0 + MW_TP, a.L, tid);
+            fetch_dl(fy, a.a0, yrow, a.L, t0 + MW_TP, tid);
+        }
         for (int p = pq; p < MW_TP + 2; p += 4) {
             const float dzv = gs[p * MW_CS + c];
             const float g = dzv * ys[c * MW_YS + p];
@@ -534,13 +641,24 @@ __global__ void __launch_bounds__(MW_THREADS) mixer_pre_bwd_wide_kernel(MixArgs 
     const size_t xb = (size_t)b * a.Lx * D3;
     const int t_begin = blockIdx.x * MIX_RUN;
     float dw1[3] = {0.f, 0.f, 0.f}, db1 = 0.f, dw2[3] = {0.f, 0.f, 0.f}, db2 = 0.f;
-    for (int st = 0; st < MIX_NT; ++st) {
+    const int nst = mw_tiles(a.L, t_begin);
+    const size_t drow = (size_t)b * a.D + c0;
+    CmFetch<DT, MW_TP + 4> f1, f2;
+    DlFetch<DT, 72> fd;
+    fetch_cm(f1, a.x, xb, D3, a.D + c0, t_begin - 2, a.L, tid);
+    fetch_cm(f2, a.x, xb, D3, 2 * a.D + c0, t_begin - 2, a.L, tid);
+    fetch_dl(fd, a.a0, drow, a.L, t_begin, tid);
+    for (int st = 0; st < nst; ++st) {
         const int t0 = t_begin + st * MW_TP;
-        if (t0 >= a.L) break;
-        load_cm_tile<DT>(xs1, a.x, xb, D3, a.D + c0, t0 - 2, MW_TP + 4, a.L, tid);
-        load_cm_tile<DT>(xs2, a.x, xb, D3, 2 * a.D + c0, t0 - 2, MW_TP + 4, a.L, tid);
-        load_dl_tile<DT>(ds, MW_YS, a.a0, (size_t)b * a.D + c0, a.L, t0, 72, tid);
+        commit_cm(xs1, f1, t0 - 2, a.L, tid);
+        commit_cm(xs2, f2, t0 - 2, a.L, tid);
+        commit_dl(ds, MW_YS, fd, a.a0, drow, a.L, t0, tid);
         __syncthreads();
+        if (st + 1 < nst) {
+            fetch_cm(f1, a.x, xb, D3, a.D + c0, t0 + MW_TP - 2, a.L, tid);
+            fetch_cm(f2, a.x, xb, D3, 2 * a.D + c0, t0 + MW_TP - 2, a.L, tid);
+            fetch_dl(fd, a.a0, drow, a.L, t0 + MW_TP, tid);
+        }
         for (int p = pq; p < MW_TP + 2; p += 4) {
             const float dv = ds[c * MW_YS + p];                    // zero for positions >= L
             const float g1 = dv * sconv(xs2, p + 2, c, w2, b2);    // gradient of x1c = dvg * vc
