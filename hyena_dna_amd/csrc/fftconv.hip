@@ -43,6 +43,8 @@ bool make_plan(int L, Plan* p) {
     if (L < 1 || L > HYENA_MAX_L) return false;
     int M = 1024;
     while (M < L) M <<= 1;
+    if (L > 131072 && L <= 163840) M = 163840;      // 160 x 1024 (32 x 5 column transform): hyenadna-medium-160k's
+                                                    // 160000 is served by N = 327680 instead of 524288
     p->L = L;
     p->M = M;
     p->M1 = M / 1024;
@@ -79,6 +81,7 @@ int launch_col_dt(int M1, const ColArgs& a, int rows, void* stream) {
         HY_COL_CASE(32)
         HY_COL_CASE(64)
         HY_COL_CASE(128)
+        HY_COL_CASE(160)
         HY_COL_CASE(256)
         HY_COL_CASE(512)
         HY_COL_CASE(1024)

@@ -334,6 +334,32 @@ __device__ __forceinline__ void dft_reg(c32 (&v)[N]) {
     }
 }
 
+// 5-point DFT (the odd factor of M1 = 160 = 32 x 5, which serves L = 160000 with N = 327680 instead of 524288)
+template <bool INV>
+__device__ __forceinline__ void dft5_reg(c32 (&v)[5]) {
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;     // cos(2 pi / 5), cos(4 pi / 5)
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;      // sin(2 pi / 5), sin(4 pi / 5)
+    const c32 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    const c32 m1 = mk(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+    const c32 m2 = mk(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+    const c32 n1 = mk(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    const c32 n2 = mk(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    v[0] = cadd(v[0], cadd(t1, t2));
+    // forward: y1 = m1 - i n1, y4 = m1 + i n1, y2 = m2 - i n2, y3 = m2 + i n2;  inverse: signs swapped
+    const c32 a1 = mk(m1.x + n1.y, m1.y - n1.x), b1 = mk(m1.x - n1.y, m1.y + n1.x);
+    const c32 a2 = mk(m2.x + n2.y, m2.y - n2.x), b2 = mk(m2.x - n2.y, m2.y + n2.x);
+    v[1] = INV ? b1 : a1;
+    v[4] = INV ? a1 : b1;
+    v[2] = INV ? b2 : a2;
+    v[3] = INV ? a2 : b2;
+}
+// second Stockham stage of a column transform: T points
+template <int T, bool INV>
+__device__ __forceinline__ void dft_stage2(c32 (&y)[T]) {
+    if constexpr (T == 5) dft5_reg<INV>(y);
+    else dft_reg<T, INV>(y);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 1024-point row transform on a half-wavefront: lane j (0..31) holds v[s] = x[j + 32 s] on entry and
 // X[j + 32 q] on exit (Stockham 32 x 32, natural order).  `xb` = this half's LDS exchange buffer of
@@ -401,9 +427,12 @@ struct Tables {
 template <int M1> struct ColCfg {
     static constexpr int T = M1 >= 32 ? M1 / 32 : 1;
     static constexpr int E = M1 >= 32 ? 32 : M1;
-    static constexpr int C = (256 / T) > 16 ? (256 / T) : 16;
+    static constexpr bool POW2 = (T & (T - 1)) == 0;         // M1 = 160: T = 5 (the only non-power-of-two size)
+    static constexpr int C = !POW2 ? 64 : (256 / T) > 16 ? (256 / T) : 16;
     static constexpr int THREADS = C * T;
-    static constexpr int NB = 32 / T;                        // stage-2 butterflies per thread (T > 1)
+    static constexpr int NB = (32 + T - 1) / T;              // stage-2 butterflies per thread (T > 1); for T = 5 the
+                                                             // 32 of them split 7/7/6/6/6 (jj = r + T i < 32)
+    static constexpr int TO = (T + 1) / 2;                   // stage-2 outputs q < TO can lie below M1/2
     static constexpr size_t LDS_TABLES = (1024 + (size_t)M1) * sizeof(c32);
     static constexpr size_t LDS_PLANE = T > 1 ? (size_t)M1 * C * sizeof(float) : 0;
     static constexpr size_t LDS = LDS_TABLES + LDS_PLANE;
@@ -449,14 +478,15 @@ __device__ __forceinline__ void stage_col_tables(HY_LDS lc32* tab, const c32* __
 // LDS exchange of the two Stockham stages of a column transform, one float plane at a time:
 // position p of column c lives at plane[p*C + c]; thread (c, r) writes p = r*32 + q, reads p = (r + T i) + 32 s.
 template <int T, int C, int NB>
-__device__ __forceinline__ void col_exchange(const c32 (&v)[32], c32 (&x2)[32], HY_LDS float* plane, int c, int r) {
+__device__ __forceinline__ void col_exchange(const c32 (&v)[32], c32 (&x2)[NB * T], HY_LDS float* plane, int c, int r) {
     HY_UNROLL
     for (int q = 0; q < 32; ++q) plane[(r * 32 + q) * C + c] = v[q].x;
     __syncthreads();
     HY_UNROLL
     for (int i = 0; i < NB; ++i) {
+        const int jj = (NB * T == 32 || r + T * i < 32) ? r + T * i : 0;       // T = 5: the last butterfly of r >= 2 is idle
         HY_UNROLL
-        for (int s = 0; s < T; ++s) x2[i * T + s].x = plane[((r + T * i) + 32 * s) * C + c];
+        for (int s = 0; s < T; ++s) x2[i * T + s].x = plane[(jj + 32 * s) * C + c];
     }
     __syncthreads();
     HY_UNROLL
@@ -464,8 +494,9 @@ __device__ __forceinline__ void col_exchange(const c32 (&v)[32], c32 (&x2)[32], 
     __syncthreads();
     HY_UNROLL
     for (int i = 0; i < NB; ++i) {
+        const int jj = (NB * T == 32 || r + T * i < 32) ? r + T * i : 0;
         HY_UNROLL
-        for (int s = 0; s < T; ++s) x2[i * T + s].y = plane[((r + T * i) + 32 * s) * C + c];
+        for (int s = 0; s < T; ++s) x2[i * T + s].y = plane[(jj + 32 * s) * C + c];
     }
 }
 
@@ -524,16 +555,17 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_fwd_kernel(ColArgs
         }
     } else {
         constexpr int NB = Cfg::NB;
-        c32 x2[32];
+        c32 x2[NB * T];
         col_exchange<T, C, NB>(v, x2, plane, c, r);     // its first barrier also covers the table staging
         HY_UNROLL
         for (int i = 0; i < NB; ++i) {
             const int jj = r + T * i;
+            if (NB * T != 32 && jj >= 32) break;
             c32 y[T];
             y[0] = x2[i * T];
             HY_UNROLL
             for (int s = 1; s < T; ++s) y[s] = cmul(x2[i * T + s], lds_ld(thi + jj * s));
-            dft_reg<T, false>(y);
+            dft_stage2<T, false>(y);
             HY_UNROLL
             for (int q = 0; q < T; ++q) {
                 const int k1 = jj + 32 * q;
@@ -588,18 +620,20 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_inv_kernel(ColArgs
         for (int q = 0; q < EO; ++q) col_store<DT>(xrow, q * 1024 + n2, nfull, a.L, v[q], a.aux0, row);
     } else {
         constexpr int NB = Cfg::NB;
-        c32 x2[32];
+        c32 x2[NB * T];
         col_exchange<T, C, NB>(v, x2, plane, c, r);
         HY_UNROLL
         for (int i = 0; i < NB; ++i) {
             const int jj = r + T * i;
+            if (NB * T != 32 && jj >= 32) break;
             c32 y[T];
             y[0] = x2[i * T];
             HY_UNROLL
             for (int s = 1; s < T; ++s) y[s] = cmulc(x2[i * T + s], lds_ld(thi + jj * s));
-            dft_reg<T, true>(y);
+            dft_stage2<T, true>(y);
+            // power-of-two T: outputs q >= T/2 are all >= M1/2; T = 5: q = 2 straddles it, col_store drops n >= L/2
             HY_UNROLL
-            for (int q = 0; q < T / 2; ++q) col_store<DT>(xrow, (jj + 32 * q) * 1024 + n2, nfull, a.L, y[q], a.aux0, row);
+            for (int q = 0; q < Cfg::TO; ++q) col_store<DT>(xrow, (jj + 32 * q) * 1024 + n2, nfull, a.L, y[q], a.aux0, row);
         }
     }
 }

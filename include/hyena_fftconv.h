@@ -70,8 +70,9 @@ int hyena_fftconv_abi_version(void);
 const char* hyena_fftconv_error_string(int status);
 
 /* Complex transform length M used for sequence length L: the padded real transform has N = 2M >= 2L
- * points (M = max(1024, next power of two >= L)); the reference uses N = 2L (hyena.py:61), which gives
- * the same causal result.  Returns 0 if L is unsupported. */
+ * points (M = max(1024, next power of two >= L), except 131072 < L <= 163840, where M = 160 * 1024 -- a 32 x 5 column
+ * transform that serves hyenadna-medium-160k's L = 160000 with N = 327680 instead of 524288); the reference uses
+ * N = 2L (hyena.py:61), which gives the same causal result.  Returns 0 if L is unsupported. */
 int hyena_fftconv_fft_size(int L);
 
 /* Bytes of device memory needed for the twiddle tables of sequence length L, and their one-time

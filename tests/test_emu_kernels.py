@@ -34,7 +34,8 @@ def _inputs(B, D, L, dtype, seed=0):
 @pytest.mark.parametrize("B,D,L,chunk", [
     (2, 3, 1, 0), (2, 3, 8, 0), (1, 2, 1023, 0), (2, 2, 1024, 1), (1, 3, 1025, 2), (1, 2, 2048, 0),
     (2, 2, 3000, 0), (1, 2, 8191, 0), (1, 1, 16384, 0), (2, 2, 32768, 1), (1, 1, 65536, 0), (1, 2, 100000, 0),
-    (1, 1, 160000, 0), (1, 1, 262144, 0), (1, 1, 450560, 0),
+    (1, 1, 160000, 0), (2, 2, 131073, 1), (1, 2, 163839, 0), (1, 1, 163840, 0), (1, 1, 163841, 0), (1, 1, 262144, 0),
+    (1, 1, 450560, 0),
 ])
 def test_fp32_fwd_bwd_vs_oracle(emu_backend, B, D, L, chunk):
     u, k, bias, dout = _inputs(B, D, L, torch.float32, seed=L)
@@ -44,7 +45,8 @@ def test_fp32_fwd_bwd_vs_oracle(emu_backend, B, D, L, chunk):
     assert _rel(out, r_out) < REL_FP32
     assert _rel(du, r_du) < REL_FP32
     assert _rel(dk, r_dk) < REL_FP32
-    assert _rel(dbias, r_db) < 5e-6
+    # dbias is ONE fp32 sum of B*L products per channel; the fp32 oracle itself is ~1e-5 from the exact value at L > 1e5
+    assert _rel(dbias, r_db) < (5e-6 if L <= 100000 else 2e-5)
 
 
 def test_fp32_L_1M(emu_backend):
