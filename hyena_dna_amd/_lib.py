@@ -211,6 +211,8 @@ def fftconv_fwd(u, k, bias, chunk=None, save=False):
     _require_gpu(u, "u")
     B, D, L = u.shape
     out = torch.empty_like(u)
+    if B == 0:                                   # empty batch: nothing to launch (torch.fft returns an empty tensor too)
+        return (out, torch.empty(0, dtype=torch.uint8, device=u.device)) if save else out
     chunk = _chunk_override() if chunk is None else int(chunk)
     tables = tables_for(u.device, L)
     nbytes = lib().hyena_fftconv_workspace_bytes(B, D, L, 0, chunk)
@@ -236,6 +238,8 @@ def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None, saved=
     du = torch.empty_like(dout) if need_du else None
     dk = torch.empty((D, L), dtype=torch.float32, device=dout.device) if need_dk else None
     dbias = torch.empty((D,), dtype=torch.float32, device=dout.device) if need_dk else None
+    if B == 0:                                   # empty batch: the parameter gradients are sums over nothing
+        return du, None if dk is None else dk.zero_(), None if dbias is None else dbias.zero_()
     chunk = _chunk_override() if chunk is None else int(chunk)
     tables = tables_for(dout.device, L)
     nbytes = lib().hyena_fftconv_workspace_bytes(B, D, L, 1, chunk)

@@ -171,3 +171,19 @@ def test_split_k_linear_gradients_match_linear():
         for a, t in zip(got, (x, w, b)):
             assert a.dtype == t.grad.dtype
             assert ((a.float() - t.grad.float()).norm() / t.grad.float().norm()).item() < tol
+
+
+def test_empty_batch_and_oversize_length(emu_backend):
+    """edge cases at the op seam: an empty batch behaves like torch.fft's path (empty output, zero parameter gradients);
+    a length beyond HYENA_MAX_L is refused loudly instead of silently taking another path"""
+    from hyena_dna_amd.fftconv import fftconv_func
+    from hyena_dna_amd._lib import HyenaLibraryError
+    u = torch.zeros(0, 3, 50, requires_grad=True)
+    k = torch.randn(3, 50, requires_grad=True)
+    bias = torch.randn(3, requires_grad=True)
+    y = fftconv_func(u, k, bias, dropout_mask=None, gelu=False)
+    assert y.shape == (0, 3, 50)
+    y.sum().backward()
+    assert torch.count_nonzero(k.grad) == 0 and torch.count_nonzero(bias.grad) == 0 and u.grad.shape == u.shape
+    with pytest.raises(HyenaLibraryError):
+        emu_backend.fftconv_fwd(torch.zeros(1, 1, (1 << 20) + 1), torch.zeros(1, (1 << 20) + 1), None)
