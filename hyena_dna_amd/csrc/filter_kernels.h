@@ -391,6 +391,18 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
                 HY_UNROLL
                 for (int r = 0; r < 16; ++r) dh[q][r] = 0.f;
             }
+            // the saved pre-activations of this tile: all loads issued now, they land while the MFMAs below run (loaded one
+            // by one next to their use they serialise behind the stores: vmcnt counts both)
+            f32x16 apv[ACT ? Cfg::NIB : 1];
+            if (ACT) {
+                HY_UNROLL
+                for (int q = 0; q < Cfg::NIB; ++q) {
+                    HY_UNROLL
+                    for (int r = 0; r < 16; ++r)
+                        apv[q][r] = fb_ld(Ab, vpos + (unsigned)(4 * half) * L4, (unsigned)(32 * q + crow(r, 0)) * L4);
+                }
+            }
+            HY_SCHED_FENCE();
             for (int s0 = 0; s0 < NO / 2; s0 += 16) {
                 float dv[16];
                 HY_UNROLL
@@ -416,7 +428,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
                     HY_UNROLL
                     for (int r = 0; r < 16; ++r) {
                         const int f = 32 * q + crow(r, half);
-                        const float ap = fb_ld(Ab, vpos + (unsigned)(4 * half) * L4, (unsigned)(f - 4 * half) * L4);
+                        const float ap = apv[q][r];
                         const float fr = freq[f];
                         float sn, cs;
                         hy_sincos(fr * ap, &sn, &cs);
