@@ -66,11 +66,53 @@ struct __attribute__((aligned(8))) c32 {
 };
 
 __device__ __forceinline__ c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
+#if defined(HIPEMU) || !defined(HY_PACKED_F32)
 __device__ __forceinline__ c32 cadd(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ c32 csub(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ c32 cmul(c32 a, c32 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 // a * conj(b)
 __device__ __forceinline__ c32 cmulc(c32 a, c32 b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+#else
+// Packed fp32 VALU (v_pk_add/mul/fma_f32: two fp32 lanes of one 64-bit register pair per instruction, the 157 TFLOP/s
+// path of CDNA4).  A complex value IS a register pair, so a complex add is one instruction and a complex multiply two:
+//     t = (a.x w.x, a.y w.x)                     v_pk_mul_f32, second source broadcast from its low half
+//     r = (-a.y w.y + t.x, a.x w.y + t.y)        v_pk_fma_f32, first source with swapped halves (op_sel) and its low
+//                                                 lane negated (neg_lo), second source broadcast from its high half
+// Written as inline asm: hipcc's own SLP packing of the scalar formulation scatters the halves over unpaired registers
+// (v_mov chains, spills -- hence -fno-slp-vectorize).
+// OPT-IN (-DHY_PACKED_F32), off by default: parity-green on MI355X (tests/test_gpu_parity.py) but it changes nothing --
+// 6.63 vs 6.64 ms at L = 2^20, 1.545 vs 1.542 ms at L = 32768 x 8 (profiles/README.md, r1ae).  The kernels are bound by
+// HBM (B = 1) or by per-wavefront latency at 2 waves per SIMD (B = 8), not by VALU issue, even though their arithmetic
+// rate (23-33 TFLOP/s) looks close to the unpacked one-flop-per-lane ceiling.
+typedef float hy_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hy_f2 tov(c32 a) { hy_f2 v; v.x = a.x; v.y = a.y; return v; }
+__device__ __forceinline__ c32 toc(hy_f2 v) { return mk(v.x, v.y); }
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) {
+    hy_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(tov(a)), "v"(tov(b)));
+    return toc(r);
+}
+__device__ __forceinline__ c32 csub(c32 a, c32 b) {
+    hy_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(tov(a)), "v"(tov(b)));
+    return toc(r);
+}
+__device__ __forceinline__ c32 cmul(c32 a, c32 b) {
+    hy_f2 t, r;
+    const hy_f2 av = tov(a), bv = tov(b);
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "v"(bv));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+    return toc(r);
+}
+// a * conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+__device__ __forceinline__ c32 cmulc(c32 a, c32 b) {
+    hy_f2 t, r;
+    const hy_f2 av = tov(a), bv = tov(b);
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "v"(bv));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+    return toc(r);
+}
+#endif
 __device__ __forceinline__ c32 cconj(c32 a) { return mk(a.x, -a.y); }
 __device__ __forceinline__ c32 cscale(c32 a, float s) { return mk(a.x * s, a.y * s); }
 
