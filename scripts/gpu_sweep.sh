@@ -8,7 +8,7 @@ mkdir -p $out
 : > $out/unfused.jsonl
 for cfg in "1024 8 128" "32768 8 256" "160000 2 256" "450560 1 256" "1048576 1 256"; do
     set -- $cfg
-    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --seq-len $1 --batch $2 --d-model $3 >> $out/sweep.jsonl
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-operator --seq-len $1 --batch $2 --d-model $3 >> $out/sweep.jsonl
     timeout 300 python scripts/bench_unfused_gpu.py $1 $2 $3 bf16 >> $out/unfused.jsonl
 done
 python - "$out" <<'PY'
