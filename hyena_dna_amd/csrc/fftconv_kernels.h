@@ -764,22 +764,6 @@ __device__ __forceinline__ c32 pw_tw(c32 wkj, int q) {
     return mk(wkj.x * c + wkj.y * sn, wkj.y * c - wkj.x * sn);
 }
 
-// geometry shared by the row kernels: which rows the two half-waves of slot `slot` own, and where partners live
-struct RowGeom {
-    int myrow, pk_base, phalf;
-    bool valid;
-};
-__device__ __forceinline__ RowGeom row_geom(int slot, int half, int M1) {
-    RowGeom g;
-    const bool slot0 = slot == 0;
-    g.myrow = slot0 ? (half ? (M1 >> 1) : 0) : (half ? M1 - slot : slot);
-    g.valid = slot0 ? (half == 0 || M1 >= 2) : true;
-    g.pk_base = (slot0 && half == 0) ? 1024 : 1023;      // partner of k2 is (pk_base - k2) & 1023 ...
-    g.phalf = slot0 ? half : 1 - half;                   // ... in this half-wave's row
-    if (!g.valid) g.myrow = 0;                           // the idle half (M1 == 1) mirrors row 0; its results are dropped
-    return g;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Two-operand row kernels: both operands arrive column-transformed only; the kernel row-transforms both, forms
 // the packed-domain product in its pair form and inverse-transforms.  No spectrum is materialised in memory

@@ -172,7 +172,9 @@ class HyenaFilter(_OptimModule):
 
     def _fused_filter_ok(self, L, layers, z):
         """The fused HIP filter kernels (include/hyena_filter.h) cover exactly the HyenaDNA filter configuration."""
-        if len(layers) != 7 or not z.is_cuda and _fused_filter_requires_gpu():
+        if len(layers) != 7:
+            return False
+        if not z.is_cuda and _fused_filter_requires_gpu():       # host tensors: only the test double has a "device" there
             return False
         lin, act = layers[0::2], layers[1::2]
         if not all(isinstance(m, nn.Linear) for m in lin) or not all(m is act[0] for m in act) or not isinstance(act[0], Sin):
