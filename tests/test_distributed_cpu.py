@@ -42,3 +42,14 @@ def test_bench_single_process_line_shape():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in r
     assert r["n_gpus"] == 1 and r["data"] == "synthetic" and "workload" in r["config"]
+
+
+def test_ddp_operator_world_size_2():
+    """batch-sharded DDP over the operator (fused mixer shell, fused filter, long conv -- all through autograd Functions):
+    all-reduced gradients == single-process gradients over the whole batch"""
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", os.path.join(ROOT, "tests", "_ddp_worker.py")]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    assert "DDP_OK world=2" in p.stdout, p.stdout[-1500:]

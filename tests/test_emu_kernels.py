@@ -145,3 +145,30 @@ def test_saved_spectra_backward_is_bitwise_the_recomputing_one(emu_backend, B, D
     assert torch.equal(out, out2) and torch.equal(du, du2) and torch.equal(dk, dk2) and torch.equal(dbias, dbias2)
     du3, dk3, _ = emu_backend.fftconv_bwd(dout, None, None, bias, need_du=True, need_dk=False, chunk=chunk, saved=saved)
     assert dk3 is None and torch.equal(du3, du)
+
+
+def test_randomised_shapes_vs_oracle(emu_backend):
+    """40 seeded random (B, D, L, dtype, chunk, bias?) cases, L up to 6000 (M1 = 1 ... 8), ragged everything"""
+    rng = torch.Generator().manual_seed(20240924)
+    dts = [torch.float32, torch.bfloat16, torch.float16]
+    for case in range(40):
+        B = int(torch.randint(1, 4, (1,), generator=rng))
+        D = int(torch.randint(1, 6, (1,), generator=rng))
+        L = int(torch.randint(1, 6001, (1,), generator=rng))
+        dtype = dts[int(torch.randint(0, 3, (1,), generator=rng))]
+        chunk = int(torch.randint(0, D + 1, (1,), generator=rng))
+        u, k, bias, dout = _inputs(B, D, L, dtype, seed=1000 + case)
+        use_bias = bool(torch.randint(0, 4, (1,), generator=rng))
+        bb = bias if use_bias else None
+        out = emu_backend.fftconv_fwd(u, k, bb, chunk=chunk)
+        du, dk, dbias = emu_backend.fftconv_bwd(dout, u, k, bb, chunk=chunk)
+        r_out, r_du, r_dk, r_db = _oracle(u.float(), k, bias if use_bias else torch.zeros(D), dout.float())
+        tag = (case, B, D, L, dtype, chunk, use_bias)
+        if dtype == torch.float32:
+            assert _rel(out, r_out) < REL_FP32 and _rel(du, r_du) < REL_FP32, tag
+        else:   # one 16-bit rounding of the fp32 result
+            tol = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+            assert (out.float() - r_out).abs().max() <= tol * r_out.abs().max() + 1e-6, tag
+            assert (du.float() - r_du).abs().max() <= tol * r_du.abs().max() + 1e-6, tag
+        assert _rel(dk, r_dk) < 2e-5 if dtype != torch.float32 else _rel(dk, r_dk) < REL_FP32, tag
+        assert _rel(dbias, r_db) < 2e-5, tag

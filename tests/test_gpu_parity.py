@@ -270,3 +270,30 @@ def test_hipgraph_capture_and_replay(gpu_lib):
     torch.cuda.synchronize()
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+def test_randomised_shapes_vs_oracle_gpu(gpu_lib):
+    """24 seeded random (B, D, L, dtype, chunk, bias?) cases on the gfx950 binary, L up to 150000 (M1 = 1 ... 160)"""
+    rng = torch.Generator().manual_seed(20240925)
+    dts = [torch.float32, torch.bfloat16, torch.float16]
+    lmax = [700, 5000, 40000, 150000]
+    for case in range(24):
+        B = int(torch.randint(1, 4, (1,), generator=rng))
+        D = int(torch.randint(1, 7, (1,), generator=rng))
+        L = int(torch.randint(1, lmax[case % 4] + 1, (1,), generator=rng))
+        dtype = dts[int(torch.randint(0, 3, (1,), generator=rng))]
+        chunk = int(torch.randint(0, D + 1, (1,), generator=rng))
+        use_bias = bool(torch.randint(0, 4, (1,), generator=rng))
+        u, k, bias, dout = _inputs(B, D, L, dtype, seed=2000 + case)
+        if not use_bias:
+            bias = torch.zeros(D)
+        out, du, dk, dbias = _gpu(gpu_lib, u, k, bias, dout, chunk=chunk or None)
+        r_out, r_du, r_dk, r_db = _oracle(u.float(), k, bias, dout.float())
+        tag = (case, B, D, L, dtype, chunk, use_bias)
+        if dtype == torch.float32:
+            assert _rel(out, r_out) < 3e-6 and _rel(du, r_du) < 3e-6, tag
+        else:
+            tol = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+            assert (out.float().cpu() - r_out).abs().max() <= tol * r_out.abs().max() + 1e-6, tag
+            assert (du.float().cpu() - r_du).abs().max() <= tol * r_du.abs().max() + 1e-6, tag
+        assert _rel(dk, r_dk) < 2e-5 and _rel(dbias, r_db) < 3e-5, tag
