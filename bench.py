@@ -260,9 +260,9 @@ def main():
                 line["operator_layer"] = operator_layer(L, D, B, dtype, dev)
             except Exception as e:                                   # secondary: never lose the contract line over it
                 line["operator_layer"] = {"error": repr(e)[:200]}
-        if not args.no_cpu_baseline and not args.emu:
-            line["cpu_baseline"] = cpu_baseline(L, D, dtype)
-        elif args.emu:
+        if world == 1 and not args.no_cpu_baseline and not args.emu:
+            line["cpu_baseline"] = cpu_baseline(L, D, dtype)          # rank 0 at N = 1 only (other ranks would idle at the barrier)
+        else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if world > 1:
