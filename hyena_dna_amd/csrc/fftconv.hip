@@ -114,11 +114,27 @@ int launch_row_prod2(const RowArgs& a, void* stream) {
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
+// From this batch size on the regular row pairs of the backward run as row_dk_kernel (+ row_prod2_kernel<MODE_CORR> for
+// du) instead of the fused row_bwd_kernel (see row_dk_kernel).
+const int ROW_BWD_SPLIT_BATCH = 4;
+
 template <bool DO_DU>
 int launch_row_bwd(const RowArgs& a, void* stream) {
     HY_LAUNCH((row0_bwd_kernel<DO_DU>), dim3(a.M1 >= 2 ? 2 : 1, (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, stream, a);
     HY_LAUNCH(row0_dk_reduce_kernel, dim3(a.M1 >= 2 ? 2 : 1, a.inner), dim3(256), 0, stream, a);
-    if (a.M1 >= 4) HY_LAUNCH((row_bwd_kernel<DO_DU>), dim3(a.M1 / 2 - 1, a.inner), dim3(64), ROW_SMEM, stream, a);
+    if (a.M1 >= 4) {
+        const dim3 grid(a.M1 / 2 - 1, a.inner);
+        if (a.B >= ROW_BWD_SPLIT_BATCH) {
+            HY_LAUNCH(row_dk_kernel, grid, dim3(64), ROW_SMEM, stream, a);       // reads the dout rows before du replaces them
+            if (DO_DU) {
+                RowArgs c = a;                                                    // du = corr(dout, k) + bias, in place
+                c.U = a.K; c.u_bstride = 0; c.Y = a.X; c.y_bstride = a.x_bstride;
+                HY_LAUNCH((row_prod2_kernel<MODE_CORR>), grid, dim3(64), ROW_SMEM, stream, c);
+            }
+        } else {
+            HY_LAUNCH((row_bwd_kernel<DO_DU>), grid, dim3(64), ROW_SMEM, stream, a);
+        }
+    }
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 

@@ -947,6 +947,75 @@ __global__ void __launch_bounds__(64, 2) row_bwd_kernel(RowArgs a) {
     }
 }
 
+// dk rows only, for batches: the batch sum is carried in 64 accumulator registers in the frequency domain and
+// inverse-transformed ONCE (row_bwd_kernel re-reads and re-transforms the filter row and read-modify-writes the dk
+// rows per batch item -- right for B = 1, where it shares the transform of dout between du and dk; from B = 4 on
+// this kernel + row_prod2_kernel<MODE_CORR> for du is faster: 4 instead of 5 row transforms per item, no RMW).
+__global__ void __launch_bounds__(64, 2) row_dk_kernel(RowArgs a) {
+    HY_SMEM(smem);
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    HY_LDS lc32* const lds = HY_LDS_CAST(lc32, smem);
+    const int M1 = a.M1;
+    const int slot = blockIdx.x + 1, ch = blockIdx.y;
+    const unsigned rowbytes = (unsigned)M1 * 1024u * 8u;
+    const GBuf O = make_gbuf(a.S + (size_t)ch * M1 * 1024, rowbytes);
+    const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
+    RowTw rtw;
+    load_row_tw(rtw, twT, j);
+    const c32 tj = gb_ld(twR, (unsigned)j * 8u, 0u);
+    HY_LDS lc32* xb = lds + half * ROW_LDS;
+    HY_LDS lc32* xl = xb + j;
+    const HY_LDS lc32* pl = lds + (1 - half) * ROW_LDS + (31 - j);
+    HY_OPAQUE(xl);
+    HY_OPAQUE(pl);
+    const int myrow = half ? M1 - slot : slot;
+    const unsigned vo = (unsigned)(myrow * 1024 + j) * 8u;
+    const c32 wkj = cmul(a.tab.tw_lo[myrow], tj);
+    c32 acc[32];
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
+    for (int b = 0; b < a.B; ++b) {
+        const GBuf X = make_gbuf(a.X + ((size_t)b * a.x_bstride + ch) * M1 * 1024, rowbytes);
+        const GBuf U = make_gbuf(a.U + ((size_t)b * a.u_bstride + ch) * M1 * 1024, rowbytes);
+        c32 h[32], v[32];
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) h[s] = gb_ld(U, vo, (unsigned)s * 256u);
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) v[s] = gb_ld(X, vo, (unsigned)s * 256u);
+        row_fft1024<false>(h, xb, j, rtw);
+        row_fft1024<false>(v, xb, j, rtw);
+        HY_UNROLL
+        for (int q = 0; q < 16; ++q) {
+            lds_st(xl + q * 32, v[16 + q]);
+            lds_st(xl + 512 + q * 32, h[16 + q]);
+        }
+        __syncthreads();
+        HY_UNROLL
+        for (int q = 0; q < 16; ++q) {
+            const c32 gp = lds_ld(pl + (15 - q) * 32);
+            const c32 up = lds_ld(pl + 512 + (15 - q) * 32);
+            c32 zk, zp;
+            prod_pair<MODE_CORR>(v[q], gp, h[q], up, pw_tw(wkj, q), 0.f, zk, zp);
+            acc[q] = cadd(acc[q], zk);
+            acc[16 + q] = cadd(acc[16 + q], zp);
+        }
+        __syncthreads();
+    }
+    // partner values belong to the other row of the pair: hand them over, then one inverse transform for the whole batch
+    HY_UNROLL
+    for (int q = 0; q < 16; ++q) {
+        acc[q] = cscale(acc[q], a.scale);
+        lds_st(xl + q * 32, cscale(acc[16 + q], a.scale));
+    }
+    __syncthreads();
+    HY_UNROLL
+    for (int q = 0; q < 16; ++q) acc[31 - q] = lds_ld(pl + q * 32);
+    __syncthreads();
+    row_fft1024<true>(acc, xb, j, rtw);
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) gb_st(O, vo, (unsigned)q * 256u, acc[q]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Rows 0 and M1/2 are their own partners (k2 <-> (1024 - k2) mod 1024, resp. 1023 - k2, inside the row) with an
 // irregular lane map, so they take the per-element form of the product, partners read from natural-order LDS

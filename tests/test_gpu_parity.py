@@ -278,7 +278,7 @@ def test_randomised_shapes_vs_oracle_gpu(gpu_lib):
     dts = [torch.float32, torch.bfloat16, torch.float16]
     lmax = [700, 5000, 40000, 150000]
     for case in range(24):
-        B = int(torch.randint(1, 4, (1,), generator=rng))
+        B = int(torch.randint(1, 7, (1,), generator=rng))
         D = int(torch.randint(1, 7, (1,), generator=rng))
         L = int(torch.randint(1, lmax[case % 4] + 1, (1,), generator=rng))
         dtype = dts[int(torch.randint(0, 3, (1,), generator=rng))]
