@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 using namespace hyena;
@@ -116,7 +117,8 @@ int launch_row_prod2(const RowArgs& a, void* stream) {
 
 // From this batch size on the regular row pairs of the backward run as row_dk_kernel (+ row_prod2_kernel<MODE_CORR> for
 // du) instead of the fused row_bwd_kernel (see row_dk_kernel).
-const int ROW_BWD_SPLIT_BATCH = 4;
+const int ROW_BWD_SPLIT_BATCH = 2;     // measured: B = 1 fused 6.62 vs split 7.05 ms (L = 2^20); B = 2: 2.11 vs 2.09 (L = 160000);
+                                       // B = 3: 0.690 vs 0.661, B = 8: 1.56 vs 1.44 ms (L = 32768)
 
 template <bool DO_DU>
 int launch_row_bwd(const RowArgs& a, void* stream) {

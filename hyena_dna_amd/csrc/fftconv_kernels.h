@@ -949,7 +949,7 @@ __global__ void __launch_bounds__(64, 2) row_bwd_kernel(RowArgs a) {
 
 // dk rows only, for batches: the batch sum is carried in 64 accumulator registers in the frequency domain and
 // inverse-transformed ONCE (row_bwd_kernel re-reads and re-transforms the filter row and read-modify-writes the dk
-// rows per batch item -- right for B = 1, where it shares the transform of dout between du and dk; from B = 4 on
+// rows per batch item -- right for B = 1, where it shares the transform of dout between du and dk; from B = 2 on
 // this kernel + row_prod2_kernel<MODE_CORR> for du is faster: 4 instead of 5 row transforms per item, no RMW).
 __global__ void __launch_bounds__(64, 2) row_dk_kernel(RowArgs a) {
     HY_SMEM(smem);
