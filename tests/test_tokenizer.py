@@ -1,0 +1,40 @@
+"""The vectorised DNA tokenisation against vectors minted from the reference's CharacterTokenizer as HG38Dataset calls it
+(oracle/make_golden_tokenizer.py), plus a million-nucleotide sample."""
+import os
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_matches_reference_tokenizer_bit_for_bit():
+    from hyena_dna_amd.tokenizer import DNACharTokenizerLUT
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "tokenizer_cases.pt"))
+    tok = DNACharTokenizerLUT()
+    assert tok.vocab == g["vocab"] and tok.pad_token_id == g["pad_token_id"] and tok.sep_token_id == g["sep_token_id"]
+    assert len(g["cases"]) >= 14
+    for c in g["cases"]:
+        data, target = tok.sample(c["seq"], c["max_length"], add_eos=c["add_eos"], replace_N_token=c["replace_N_token"])
+        assert data.dtype == torch.int64 and torch.equal(data, c["data"]), c["seq"][:30]
+        assert torch.equal(target, c["target"]), c["seq"][:30]
+
+
+def test_million_nucleotides_and_edge_cases():
+    from hyena_dna_amd.tokenizer import DNACharTokenizerLUT
+    tok = DNACharTokenizerLUT()
+    g = torch.Generator().manual_seed(0)
+    idx = torch.randint(0, 5, (1 << 20,), generator=g)
+    seq = "".join("ACGTN"[i] for i in idx.tolist())
+    t0 = time.perf_counter()
+    data, target = tok.sample(seq, (1 << 20) + 2, add_eos=True)
+    dt = time.perf_counter() - t0
+    assert dt < 0.5                                                      # the reference's per-character path takes seconds
+    assert data.shape == ((1 << 20) + 1,) and data[0] == tok.pad_token_id and target[-1] == tok.sep_token_id
+    assert torch.equal(data[1:], idx + 7) and torch.equal(target[:-1], idx + 7)
+    # bytes input, non-ASCII characters (one [UNK] per character, not per UTF-8 byte), right padding, empty string
+    assert tok.encode(b"ACGT", 6, add_eos=True).tolist() == [4, 7, 8, 9, 10, 1]
+    assert tok.encode("AéC", 4, add_eos=False).tolist() == [4, 7, 6, 8]
+    assert DNACharTokenizerLUT(padding_side="right").encode("AC", 5, add_eos=True).tolist() == [7, 8, 1, 4, 4]
+    assert tok.encode("", 3, add_eos=True).tolist() == [4, 4, 1]
+    assert tok.decode(tok.encode("GATTACA", 7, add_eos=False)) == "GATTACA"
