@@ -132,6 +132,18 @@ def lib():
         L.hyena_filter_bwd.restype = c_int
         L.hyena_filter_bwd.argtypes = [ctypes.POINTER(FilterParams), c_void_p, c_void_p, ctypes.POINTER(FilterGrads),
                                        c_void_p, c_size_t, c_void_p]
+        # fused residual add + LayerNorm (include/hyena_block.h)
+        c_long, c_float = ctypes.c_long, ctypes.c_float
+        L.hyena_add_norm_supported.restype = c_int
+        L.hyena_add_norm_supported.argtypes = [c_int, c_int, c_int]
+        L.hyena_add_norm_fwd.restype = c_int
+        L.hyena_add_norm_fwd.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,
+                                         c_void_p, c_void_p, c_long, c_int, c_void_p]
+        L.hyena_add_norm_partial_floats.restype = c_size_t
+        L.hyena_add_norm_partial_floats.argtypes = [c_long, c_int]
+        L.hyena_add_norm_bwd.restype = c_int
+        L.hyena_add_norm_bwd.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]
         if L.hyena_fftconv_abi_version() != ABI_VERSION:
             raise HyenaLibraryError(f"{LIB_PATH}: ABI version {L.hyena_fftconv_abi_version()} != {ABI_VERSION}; rebuild")
         _lib = L
@@ -354,3 +366,48 @@ def filter_bwd(dk, saved, z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift,
         check(lib().hyena_filter_bwd(ctypes.byref(p), dk.data_ptr(), saved.data_ptr(), ctypes.byref(g), ws.data_ptr(),
                                      ws.numel(), stream))
     return tuple(outs) + (None if dzt is None else dzt.t().contiguous(),)
+
+
+# ---- fused residual add + LayerNorm of a block (include/hyena_block.h) ------------------------------------------------
+def add_norm_supported(D, x_dtype, out_dtype):
+    try:
+        return bool(lib().hyena_add_norm_supported(int(D), dtype_code(x_dtype), dtype_code(out_dtype)))
+    except TypeError:
+        return False
+
+
+def add_norm_fwd(x0, residual, weight, bias, eps, out_dtype):
+    """x0 (rows, D), residual (rows, D) fp32 or None -> out (rows, D) out_dtype, residual' fp32, mean, rstd (rows,)."""
+    _require_gpu(x0, "x0")
+    rows, D = x0.shape
+    out = torch.empty((rows, D), dtype=out_dtype, device=x0.device)
+    res_out = torch.empty((rows, D), dtype=torch.float32, device=x0.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x0.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x0.device)
+    if rows == 0:
+        return out, res_out, mean, rstd
+    with _backend.guard(x0.device):
+        check(lib().hyena_add_norm_fwd(x0.data_ptr(), dtype_code(x0.dtype), None if residual is None else residual.data_ptr(),
+                                       weight.data_ptr(), bias.data_ptr(), float(eps), out.data_ptr(), dtype_code(out_dtype),
+                                       res_out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, _backend.stream(x0.device)))
+    return out, res_out, mean, rstd
+
+
+def add_norm_bwd(dout, d_res_out, res_out, weight, mean, rstd, dx_dtype, need_dres):
+    """-> dx0 (rows, D) dx_dtype, d_residual_in fp32 or None, dweight (D,), dbias (D,)."""
+    _require_gpu(dout, "dout")
+    rows, D = dout.shape
+    dev = dout.device
+    dx = torch.empty((rows, D), dtype=dx_dtype, device=dev)
+    dres = torch.empty((rows, D), dtype=torch.float32, device=dev) if need_dres else None
+    dw = torch.zeros(D, dtype=torch.float32, device=dev)
+    db = torch.zeros(D, dtype=torch.float32, device=dev)
+    if rows == 0:
+        return dx, dres, dw, db
+    part = torch.empty(lib().hyena_add_norm_partial_floats(rows, D), dtype=torch.float32, device=dev)
+    with _backend.guard(dev):
+        check(lib().hyena_add_norm_bwd(dout.data_ptr(), dtype_code(dout.dtype), None if d_res_out is None else d_res_out.data_ptr(),
+                                       res_out.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                       dtype_code(dx_dtype), None if dres is None else dres.data_ptr(), dw.data_ptr(),
+                                       db.data_ptr(), part.data_ptr(), rows, D, _backend.stream(dev)))
+    return dx, dres, dw, db

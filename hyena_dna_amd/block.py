@@ -1,0 +1,75 @@
+"""The residual glue of a HyenaDNA block -- (dropout ->) add -> LayerNorm -- on the fused HIP kernels of
+``include/hyena_block.h``, behind the name and signature the reference imports for exactly this
+(``src/models/sequence/long_conv_lm.py:31``: ``from flash_attn.ops.layer_norm import dropout_add_layer_norm``; used at
+``long_conv_lm.py:387-396`` and, inside flash_attn's ``Block``, for the two norms of every layer --
+restated unfused at ``src/models/sequence/simple_lm.py:267-271, 280-284``).
+
+    out            = LayerNorm(dropout(x0) + residual)                          prenorm=False
+    out, residual' = LayerNorm(dropout(x0) + residual), dropout(x0) + residual   prenorm=True
+
+``residual'`` is fp32 (``residual_in_fp32=True``, what HyenaDNA trains with); ``out`` has ``x0``'s dtype, computed in
+fp32 and rounded once.  The dropout itself (p > 0 only: HyenaDNA's ``resid_dropout`` is 0) is PyTorch's, applied before the
+kernel.  Shapes outside the kernels' coverage (D not a multiple of 64 or > 1024) and host tensors take the same graph
+in PyTorch ops.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+__all__ = ["dropout_add_layer_norm", "AddLayerNormFunc"]
+
+
+class AddLayerNormFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, residual, weight, bias, eps, prenorm):
+        shape = x0.shape
+        D = shape[-1]
+        x2 = x0.reshape(-1, D).contiguous()
+        r2 = None if residual is None else residual.reshape(-1, D).to(torch.float32).contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        b = bias.detach().to(torch.float32).contiguous()
+        out, res_out, mean, rstd = _lib.add_norm_fwd(x2, r2, w, b, eps, x0.dtype)
+        ctx.save_for_backward(res_out, w, mean, rstd)
+        ctx.meta = (shape, x0.dtype, None if residual is None else residual.dtype, weight.dtype, bias.dtype, prenorm)
+        ctx.mark_non_differentiable()
+        if prenorm:
+            return out.view(shape), res_out.view(shape)
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, dout, *rest):
+        res_out, w, mean, rstd = ctx.saved_tensors
+        shape, x_dtype, r_dtype, w_dtype, b_dtype, prenorm = ctx.meta
+        D = shape[-1]
+        dres_out = rest[0] if prenorm and rest and rest[0] is not None else None
+        d2 = dout.reshape(-1, D).contiguous()
+        h2 = None if dres_out is None else dres_out.reshape(-1, D).to(torch.float32).contiguous()
+        dx, dres, dw, db = _lib.add_norm_bwd(d2, h2, res_out, w, mean, rstd, x_dtype, need_dres=r_dtype is not None)
+        return (dx.view(shape), None if dres is None else dres.view(shape).to(r_dtype), dw.to(w_dtype), db.to(b_dtype),
+                None, None)
+
+
+def _fused_ok(x0, residual, weight):
+    if not (x0.is_cuda or _lib._backend.name != "hip"):
+        return False
+    if residual is not None and residual.shape != x0.shape:
+        return False
+    return weight is not None and _lib.add_norm_supported(x0.shape[-1], x0.dtype, x0.dtype)
+
+
+def dropout_add_layer_norm(x0, residual, weight, bias, dropout_p, epsilon, rowscale=None, layerscale=None, prenorm=False,
+                           residual_in_fp32=False, return_dropout_mask=False):
+    """Drop-in for ``flash_attn.ops.layer_norm.dropout_add_layer_norm`` as the reference calls it."""
+    if rowscale is not None or layerscale is not None or return_dropout_mask:
+        raise NotImplementedError("rowscale / layerscale / return_dropout_mask are not used by any HyenaDNA configuration")
+    if dropout_p > 0.0:
+        x0 = F.dropout(x0, dropout_p, training=True)      # the reference passes p = 0 in eval mode (long_conv_lm.py:392)
+    if residual_in_fp32 and _fused_ok(x0, residual, weight):
+        return AddLayerNormFunc.apply(x0, residual, weight, bias, epsilon, prenorm)
+    # generic graph (simple_lm.py:267-271)
+    res = x0 + residual if residual is not None else x0
+    if residual_in_fp32:
+        res = res.to(torch.float32)
+    out = F.layer_norm(res.to(weight.dtype), (x0.shape[-1],), weight, bias, epsilon).to(x0.dtype)
+    return (out, res) if prenorm else out

@@ -1,0 +1,154 @@
+// block_kernels.h -- the residual glue of a HyenaDNA block around the mixer: (dropout ->) add -> LayerNorm, fused.
+//
+// Reference (prenorm block, src/models/sequence/simple_lm.py:267-271 / 280-284, long_conv_lm.py:381-396; the fused path
+// the reference takes when flash_attn is installed is flash_attn.ops.layer_norm.dropout_add_layer_norm):
+//     residual' = dropout(x0) + residual            (fp32 when residual_in_fp32)
+//     out       = LayerNorm(residual'; weight, bias, eps)
+// returning (out, residual') for prenorm blocks, out alone for the final norm.  HyenaDNA trains with residual dropout 0;
+// a non-zero dropout is applied by the caller before the kernel (hyena_dna_amd/block.py).
+//
+// One pass forward (read x0, residual; write out, residual'; + mean / rstd per row), one pass backward (read dout,
+// residual', d residual'; write dx0 = d residual; per-workgroup partial weight / bias gradients, summed in a fixed
+// order by filter_reduce_kernel).  A wavefront owns one row: lane l holds the E = D / 64 consecutive channels l E ..
+// l E + E - 1 (one 16-byte access per tensor at D = 256), row statistics by a 6-step butterfly over the wavefront.
+// Unfused, PyTorch spends an add, a cast, a LayerNorm and (under autocast) another cast on this: ~2.5x the traffic.
+#pragma once
+#include "fftconv_kernels.h"
+
+namespace hyena {
+
+enum { BLK_WAVES = 4, BLK_THREADS = BLK_WAVES * 64, BLK_MAX_GRID = 2048 };
+
+struct AddNormArgs {
+    const void* x;          // (rows, D) elements of XDT        fwd: x0          bwd: dout
+    const float* res_in;    // (rows, D) fp32 or null           fwd: residual    bwd: gradient w.r.t. residual' (or null)
+    const float* weight;    // (D,)
+    const float* bias;      // (D,)  fwd only
+    void* out;              // (rows, D) elements of ODT        fwd: out         bwd: dx0
+    float* res_out;         // (rows, D) fp32                   fwd: residual'   bwd: gradient w.r.t. residual (or null)
+    const float* saved;     // bwd: residual' as written by the forward
+    float* mean;            // (rows,)  fwd: out, bwd: in
+    float* rstd;            // (rows,)
+    float* part;            // bwd: [gridDim.x][2][D] partial (dweight | dbias)
+    long rows;
+    int D;
+    float eps;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+    HY_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) v += u2f(HY_SHFL_U32(f2u(v), (int)((threadIdx.x & 63) ^ m)));
+    return v;
+}
+
+// E consecutive elements of a row as ONE access (rows start at multiples of D elements and c0 = lane * E, so the
+// address is a multiple of E elements: 16 bytes for fp32 at D = 256, 8 bytes for 16-bit types)
+template <int DT, int E>
+__device__ __forceinline__ void blk_load(const void* base, size_t off, float (&v)[E]) {
+    typedef typename Elem<DT>::type elem_t;
+    struct __attribute__((aligned(sizeof(elem_t) * (E > 4 ? 4 : E)))) Raw { elem_t e[E]; } raw;
+    raw = *reinterpret_cast<const Raw*>(reinterpret_cast<const elem_t*>(base) + off);
+    HY_UNROLL
+    for (int e = 0; e < E; ++e) v[e] = Elem<DT>::ld(&raw.e[e]);
+}
+template <int DT, int E>
+__device__ __forceinline__ void blk_store(void* base, size_t off, const float (&v)[E]) {
+    typedef typename Elem<DT>::type elem_t;
+    struct __attribute__((aligned(sizeof(elem_t) * (E > 4 ? 4 : E)))) Raw { elem_t e[E]; } raw;
+    HY_UNROLL
+    for (int e = 0; e < E; ++e) Elem<DT>::st(&raw.e[e], v[e]);
+    *reinterpret_cast<Raw*>(reinterpret_cast<elem_t*>(base) + off) = raw;
+}
+
+template <int XDT, int ODT, int E>
+__global__ void __launch_bounds__(BLK_THREADS) add_norm_fwd_kernel(AddNormArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = lane * E;
+    float w[E], b[E];
+    HY_UNROLL
+    for (int e = 0; e < E; ++e) { w[e] = a.weight[c0 + e]; b[e] = a.bias[c0 + e]; }
+    const float inv_d = 1.f / (float)a.D;
+    for (long row = (long)blockIdx.x * BLK_WAVES + wave; row < a.rows; row += (long)gridDim.x * BLK_WAVES) {
+        const size_t off = (size_t)row * a.D + c0;
+        float r[E];
+        blk_load<XDT, E>(a.x, off, r);
+        if (a.res_in != nullptr) {
+            float q[E];
+            blk_load<DT_F32, E>(a.res_in, off, q);
+            HY_UNROLL
+            for (int e = 0; e < E; ++e) r[e] += q[e];
+        }
+        float s = 0.f;
+        HY_UNROLL
+        for (int e = 0; e < E; ++e) s += r[e];
+        const float mean = wave_sum(s) * inv_d;
+        float v = 0.f;
+        HY_UNROLL
+        for (int e = 0; e < E; ++e) v += (r[e] - mean) * (r[e] - mean);
+        const float rstd = 1.f / sqrtf(wave_sum(v) * inv_d + a.eps);
+        float o[E];
+        HY_UNROLL
+        for (int e = 0; e < E; ++e) o[e] = (r[e] - mean) * rstd * w[e] + b[e];
+        blk_store<ODT, E>(a.out, off, o);
+        blk_store<DT_F32, E>(a.res_out, off, r);
+        if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    }
+}
+
+template <int GDT, int ODT, int E>
+__global__ void __launch_bounds__(BLK_THREADS) add_norm_bwd_kernel(AddNormArgs a) {
+    HY_SMEM(smem);
+    HY_LDS float* red = HY_LDS_CAST(float, smem);            // [BLK_WAVES][2][64 * E]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = lane * E;
+    float w[E], dw[E], db[E];
+    HY_UNROLL
+    for (int e = 0; e < E; ++e) { w[e] = a.weight[c0 + e]; dw[e] = 0.f; db[e] = 0.f; }
+    const float inv_d = 1.f / (float)a.D;
+    for (long row = (long)blockIdx.x * BLK_WAVES + wave; row < a.rows; row += (long)gridDim.x * BLK_WAVES) {
+        const size_t off = (size_t)row * a.D + c0;
+        float g[E], r[E];
+        blk_load<GDT, E>(a.x, off, g);
+        blk_load<DT_F32, E>(a.saved, off, r);
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        float s1 = 0.f, s2 = 0.f, xh[E];
+        HY_UNROLL
+        for (int e = 0; e < E; ++e) {
+            xh[e] = (r[e] - mean) * rstd;
+            const float dxh = g[e] * w[e];
+            s1 += dxh;
+            s2 += dxh * xh[e];
+            dw[e] += g[e] * xh[e];
+            db[e] += g[e];
+        }
+        s1 = wave_sum(s1) * inv_d;
+        s2 = wave_sum(s2) * inv_d;
+        float dr[E];
+        HY_UNROLL
+        for (int e = 0; e < E; ++e) dr[e] = rstd * (g[e] * w[e] - s1 - xh[e] * s2);
+        if (a.res_in != nullptr) {
+            float h[E];
+            blk_load<DT_F32, E>(a.res_in, off, h);
+            HY_UNROLL
+            for (int e = 0; e < E; ++e) dr[e] += h[e];
+        }
+        blk_store<ODT, E>(a.out, off, dr);
+        if (a.res_out != nullptr) blk_store<DT_F32, E>(a.res_out, off, dr);
+    }
+    // weight / bias gradient partials of this workgroup: the 4 wavefronts are added in order
+    const int D = 64 * E;
+    HY_UNROLL
+    for (int e = 0; e < E; ++e) {
+        red[(wave * 2 + 0) * D + c0 + e] = dw[e];
+        red[(wave * 2 + 1) * D + c0 + e] = db[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += BLK_THREADS) {
+        float s = 0.f;
+        HY_UNROLL
+        for (int q = 0; q < BLK_WAVES; ++q) s += red[q * 2 * D + i];
+        a.part[(size_t)blockIdx.x * 2 * D + i] = s;
+    }
+}
+
+}  // namespace hyena

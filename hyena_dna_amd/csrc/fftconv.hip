@@ -9,9 +9,11 @@
 #include "fftconv_kernels.h"
 #include "mixer_kernels.h"
 #include "filter_kernels.h"
+#include "block_kernels.h"
 #include "../../include/hyena_fftconv.h"
 #include "../../include/hyena_mixer.h"
 #include "../../include/hyena_filter.h"
+#include "../../include/hyena_block.h"
 
 #include <cmath>
 #include <cstdio>
@@ -610,6 +612,101 @@ int hyena_filter_bwd(const hyena_filter_params* p, const float* dk, const float*
     launch_filter_layer_bwd<FLT_O, FLT_O, FLT_ACT>(a, part, g->dw1, g->db1, g->dfreq, false, stream);
     a.dout = dA; a.w = p->w0; a.aprev = p->z; a.dprev = g->dz; a.ni = p->E;
     launch_filter_layer_bwd<FLT_O, FLT_E, 0>(a, part, g->dw0, g->db0, g->dfreq, false, stream);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused residual add + LayerNorm of a block (include/hyena_block.h)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+int blk_grid(long rows) {
+    const long g = (rows + BLK_WAVES - 1) / BLK_WAVES;
+    return (int)(g < BLK_MAX_GRID ? g : BLK_MAX_GRID);
+}
+bool blk_dtype_ok(int d) { return d == HYENA_F32 || d == HYENA_BF16 || d == HYENA_F16; }
+
+template <int XDT, int ODT>
+int blk_launch_e(bool fwd, const AddNormArgs& a, void* stream) {
+    const int grid = blk_grid(a.rows);
+#define HY_BLK_CASE(e)                                                                                                    \
+    case e:                                                                                                               \
+        if (fwd) HY_LAUNCH((add_norm_fwd_kernel<XDT, ODT, e>), dim3(grid), dim3(BLK_THREADS), 0, stream, a);              \
+        else HY_LAUNCH((add_norm_bwd_kernel<XDT, ODT, e>), dim3(grid), dim3(BLK_THREADS),                                 \
+                       (size_t)BLK_WAVES * 2 * 64 * e * sizeof(float), stream, a);                                        \
+        break;
+    switch (a.D / 64) {
+        HY_BLK_CASE(1)
+        HY_BLK_CASE(2)
+        HY_BLK_CASE(4)
+        HY_BLK_CASE(8)
+        HY_BLK_CASE(16)
+        default: return HYENA_ERR_BAD_ARG;
+    }
+#undef HY_BLK_CASE
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+template <int XDT>
+int blk_launch_o(bool fwd, int odt, const AddNormArgs& a, void* stream) {
+    switch (odt) {
+        case HYENA_F32: return blk_launch_e<XDT, DT_F32>(fwd, a, stream);
+        case HYENA_BF16: return blk_launch_e<XDT, DT_BF16>(fwd, a, stream);
+        default: return blk_launch_e<XDT, DT_F16>(fwd, a, stream);
+    }
+}
+int blk_launch(bool fwd, int xdt, int odt, const AddNormArgs& a, void* stream) {
+    switch (xdt) {
+        case HYENA_F32: return blk_launch_o<DT_F32>(fwd, odt, a, stream);
+        case HYENA_BF16: return blk_launch_o<DT_BF16>(fwd, odt, a, stream);
+        default: return blk_launch_o<DT_F16>(fwd, odt, a, stream);
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int hyena_add_norm_supported(int D, int x_dtype, int out_dtype) {
+    const int e = D / 64;
+    return D >= 64 && D % 64 == 0 && (e == 1 || e == 2 || e == 4 || e == 8 || e == 16) && blk_dtype_ok(x_dtype) &&
+           blk_dtype_ok(out_dtype);
+}
+
+int hyena_add_norm_fwd(const void* x0, int x_dtype, const float* residual_in, const float* weight, const float* bias, float eps,
+                       void* out, int out_dtype, float* residual_out, float* mean, float* rstd, long rows, int D, void* stream) {
+    if (x0 == nullptr || weight == nullptr || bias == nullptr || out == nullptr || residual_out == nullptr || mean == nullptr ||
+        rstd == nullptr || rows < 1 || !hyena_add_norm_supported(D, x_dtype, out_dtype))
+        return HYENA_ERR_BAD_ARG;
+    AddNormArgs a;
+    a.x = x0; a.res_in = residual_in; a.weight = weight; a.bias = bias; a.out = out; a.res_out = residual_out; a.saved = nullptr;
+    a.mean = mean; a.rstd = rstd; a.part = nullptr; a.rows = rows; a.D = D; a.eps = eps;
+    return blk_launch(true, x_dtype, out_dtype, a, stream);
+}
+
+size_t hyena_add_norm_partial_floats(long rows, int D) {
+    if (rows < 1 || D < 1) return 0;
+    return (size_t)blk_grid(rows) * 2 * D;
+}
+
+int hyena_add_norm_bwd(const void* dout, int dout_dtype, const float* d_residual_out, const float* residual_out,
+                       const float* weight, const float* mean, const float* rstd, void* dx0, int dx_dtype,
+                       float* d_residual_in, float* dweight, float* dbias, float* partial, long rows, int D, void* stream) {
+    if (dout == nullptr || residual_out == nullptr || weight == nullptr || mean == nullptr || rstd == nullptr || dx0 == nullptr ||
+        dweight == nullptr || dbias == nullptr || partial == nullptr || rows < 1 || !hyena_add_norm_supported(D, dout_dtype, dx_dtype))
+        return HYENA_ERR_BAD_ARG;
+    AddNormArgs a;
+    a.x = dout; a.res_in = d_residual_out; a.weight = weight; a.bias = nullptr; a.out = dx0; a.res_out = d_residual_in;
+    a.saved = residual_out; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.part = partial;
+    a.rows = rows; a.D = D; a.eps = 0.f;
+    const int st = blk_launch(false, dout_dtype, dx_dtype, a, stream);
+    if (st) return st;
+    const int grid = blk_grid(rows);
+    // partial rows are [dweight (D) | dbias (D)]: two reductions with a row stride of 2 D
+    HY_LAUNCH(filter_reduce_strided_kernel, dim3((D + FLT_RED_J - 1) / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream,
+              (const float*)partial, dweight, grid, D, 2 * D);
+    HY_LAUNCH(filter_reduce_strided_kernel, dim3((D + FLT_RED_J - 1) / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream,
+              (const float*)(partial + D), dbias, grid, D, 2 * D);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 

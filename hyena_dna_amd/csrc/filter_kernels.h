@@ -535,6 +535,24 @@ __global__ void __launch_bounds__(256) filter_reduce_kernel(const float* part, f
     }
 }
 
+// the same reduction over partial rows that are `stride` floats apart (n <= stride)
+__global__ void __launch_bounds__(256) filter_reduce_strided_kernel(const float* part, float* out, int count, int n, int stride) {
+    HY_SMEM(smem);
+    HY_LDS float* sm = HY_LDS_CAST(float, smem);
+    const int jj = threadIdx.x & (FLT_RED_J - 1), cs = threadIdx.x / FLT_RED_J;
+    const int j = blockIdx.x * FLT_RED_J + jj;
+    const int jc = j < n ? j : n - 1;
+    float s = 0.f;
+    for (int c = cs; c < count; c += FLT_RED_S) s += part[(size_t)c * stride + jc];
+    sm[cs * FLT_RED_J + jj] = s;
+    __syncthreads();
+    if (cs == 0 && j < n) {
+        float r = 0.f;
+        for (int q = 0; q < FLT_RED_S; ++q) r += sm[q * FLT_RED_J + jj];
+        out[j] = r;
+    }
+}
+
 // dst (rows, used) <- first `used` columns of src (rows, cols)
 __global__ void __launch_bounds__(256) filter_compact_kernel(const float* src, float* dst, int rows, int cols, int used) {
     const int j = blockIdx.x * 256 + threadIdx.x;

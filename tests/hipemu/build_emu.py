@@ -8,7 +8,8 @@ OUT = os.path.join(HERE, "_emu_fftconv_test_only.so")
 SRC = [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv.hip"), os.path.join(HERE, "hipemu.cpp")]
 DEPS = SRC + [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv_kernels.h"),
               os.path.join(ROOT, "hyena_dna_amd", "csrc", "mixer_kernels.h"),
-              os.path.join(ROOT, "hyena_dna_amd", "csrc", "filter_kernels.h"), os.path.join(ROOT, "include", "hyena_filter.h"), os.path.join(HERE, "hipemu.h"),
+              os.path.join(ROOT, "hyena_dna_amd", "csrc", "filter_kernels.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "block_kernels.h"),
+              os.path.join(ROOT, "include", "hyena_block.h"), os.path.join(ROOT, "include", "hyena_filter.h"), os.path.join(HERE, "hipemu.h"),
               os.path.join(ROOT, "include", "hyena_fftconv.h"), os.path.join(ROOT, "include", "hyena_mixer.h")]
 
 

@@ -1,0 +1,87 @@
+"""MI355X parity of the fused residual add + LayerNorm (include/hyena_block.h) through the C ABI against the reference's
+unfused graph (src/models/sequence/simple_lm.py:267-271) evaluated in fp64 on the CPU, and at a full HyenaDNA layer
+size (2^20 positions x 256 channels) against the same graph in PyTorch ops on the GPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm().clamp_min(1e-30)).item()
+
+
+def _graph(x0, residual, weight, bias, eps, out_dtype):
+    res = x0.to(residual.dtype) + residual if residual is not None else x0.to(weight.dtype)
+    return F.layer_norm(res.to(weight.dtype), (x0.shape[-1],), weight, bias, eps).to(out_dtype), res
+
+
+@pytest.mark.parametrize("shape,dtype,with_res", [((2, 37, 64), torch.float32, True), ((3, 1000, 128), torch.bfloat16, True),
+                                                  ((1, 4099, 256), torch.bfloat16, False), ((2, 513, 256), torch.float16, True),
+                                                  ((1, 77, 1024), torch.bfloat16, True)])
+def test_add_norm_vs_fp64_graph(gpu_lib, shape, dtype, with_res):
+    from hyena_dna_amd.block import dropout_add_layer_norm
+    g = torch.Generator().manual_seed(sum(shape))
+    D = shape[-1]
+    x0 = torch.randn(shape, generator=g).to(dtype)
+    residual = torch.randn(shape, generator=g) * 2 if with_res else None
+    weight, bias = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    dout, dres = torch.randn(shape, generator=g).to(dtype), torch.randn(shape, generator=g)
+
+    def run(dev, fused, wide):
+        t = lambda a: None if a is None else (a.double() if wide else a).to(dev)      # noqa: E731
+        xs = t(x0).requires_grad_(True)
+        rs = None if residual is None else t(residual).requires_grad_(True)
+        ws, bs = t(weight).requires_grad_(True), t(bias).requires_grad_(True)
+        if fused:
+            out, res = dropout_add_layer_norm(xs, rs, ws, bs, 0.0, 1e-5, prenorm=True, residual_in_fp32=True)
+        else:
+            out, res = _graph(xs, rs, ws, bs, 1e-5, xs.dtype)
+        torch.autograd.backward([out, res], [t(dout).to(out.dtype), t(dres).to(res.dtype)])
+        return [out.detach(), res.detach(), xs.grad, None if rs is None else rs.grad, ws.grad, bs.grad]
+
+    got = run("cuda", True, False)
+    want = run("cpu", False, True)
+    ulp = {torch.float32: 2e-6, torch.bfloat16: 2 ** -7, torch.float16: 2 ** -10}[dtype]
+    for n, a, r in zip(["out", "residual", "dx0", "dresidual", "dweight", "dbias"], got, want):
+        if r is None:
+            assert a is None, n
+            continue
+        if n in ("out", "dx0"):
+            assert a.dtype == dtype
+            assert (a.double().cpu() - r).abs().max() <= ulp * r.abs().max() + 1e-6, n
+        else:
+            assert _rel(a, r) < 5e-6, (n, _rel(a, r))
+
+
+def test_add_norm_at_layer_size(gpu_lib):
+    from hyena_dna_amd.block import dropout_add_layer_norm
+    B, L, D = 1, 1 << 20, 256
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x0 = torch.randn(B, L, D, device="cuda", generator=g).bfloat16().requires_grad_(True)
+    residual = (torch.randn(B, L, D, device="cuda", generator=g) * 2).requires_grad_(True)
+    ln = torch.nn.LayerNorm(D).cuda()
+    with torch.no_grad():
+        ln.weight.add_(0.2 * torch.randn(D, device="cuda", generator=g))
+    dout = torch.randn(B, L, D, device="cuda", generator=g).bfloat16()
+    dres = torch.randn(B, L, D, device="cuda", generator=g)
+
+    def run(fused):
+        for t in (x0, residual, ln.weight, ln.bias):
+            t.grad = None
+        if fused:
+            out, res = dropout_add_layer_norm(x0, residual, ln.weight, ln.bias, 0.0, ln.eps, prenorm=True, residual_in_fp32=True)
+        else:
+            out, res = _graph(x0, residual, ln.weight, ln.bias, ln.eps, x0.dtype)
+        torch.autograd.backward([out, res], [dout, dres])
+        return [out.detach(), res.detach(), x0.grad.clone(), residual.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone()]
+
+    a, b = run(True), run(False)
+    a2 = run(True)
+    for n, x, y, x2 in zip(["out", "residual", "dx0", "dresidual", "dweight", "dbias"], a, b, a2):
+        assert torch.equal(x, x2), n                                    # fixed-order reductions: reproducible
+        if n in ("out", "dx0"):
+            assert (x.float() - y.float()).abs().max() <= 2 ** -7 * y.float().abs().max() + 1e-6, n
+        else:
+            assert _rel(x, y) < (2e-4 if n in ("dweight", "dbias") else 5e-6), (n, _rel(x, y))   # 1e6-term fp32 sums
