@@ -47,4 +47,4 @@ def timeit(fn, n=10):
 
 tf, tu = timeit(fused), timeit(unfused)
 gb = rows * D * (2 + 4 + 2 + 4 + 2 + 4 + 4 + 2 + 4) / 1e9      # fwd: x0, res in; out, res' out; bwd: dout, dres', res' in; dx0, dres out
-print(f"add+LayerNorm rows={rows} D={D}: fused fwd+bwd {tf:.3f} ms ({gb / tf:.0f} GB/s of {gb:.2f} GB), PyTorch ops {tu:.3f} ms, x{tu / tf:.2f}")
+print(f"add+LayerNorm rows={rows} D={D}: fused fwd+bwd {tf:.3f} ms ({gb / tf:.2f} TB/s over {gb:.2f} GB), PyTorch ops {tu:.3f} ms, x{tu / tf:.2f}")

@@ -35,7 +35,8 @@ def declared_symbols_all_headers():
 def test_every_header_symbol_is_exported(product_lib):
     syms = declared_symbols_all_headers()
     assert {"hyena_mixer_pre_fwd", "hyena_mixer_post_bwd", "hyena_filter_fwd", "hyena_filter_bwd",
-            "hyena_filter_supported", "hyena_filter_workspace_bytes", "hyena_filter_saved_bytes"} <= set(syms)
+            "hyena_filter_supported", "hyena_filter_workspace_bytes", "hyena_filter_saved_bytes", "hyena_add_norm_fwd",
+            "hyena_add_norm_bwd", "hyena_add_norm_supported", "hyena_add_norm_partial_floats"} <= set(syms)
     for s in syms:
         assert hasattr(product_lib, s), s
 
