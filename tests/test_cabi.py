@@ -28,7 +28,7 @@ def declared_symbols_all_headers():
     out = set()
     for h in ALL_HEADERS:
         text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
-        out.update(re.findall(r"\b(hyena_(?:fftconv|mixer|filter)_\w+)\s*\(", text))
+        out.update(re.findall(r"\b(hyena_(?:fftconv|mixer|filter|add_norm)_\w+)\s*\(", text))
     return sorted(out)
 
 
