@@ -85,3 +85,11 @@ def test_add_norm_at_layer_size(gpu_lib):
             assert (x.float() - y.float()).abs().max() <= 2 ** -7 * y.float().abs().max() + 1e-6, n
         else:
             assert _rel(x, y) < (2e-4 if n in ("dweight", "dbias") else 5e-6), (n, _rel(x, y))   # 1e6-term fp32 sums
+
+
+def test_tiny_lm_trains_on_the_gpu(gpu_lib):
+    """every fused piece in one training loop under bf16 autocast on the MI355X: a 2-layer stack learns periodic DNA"""
+    from tests._tiny_lm import train
+    losses = train("cuda", steps=40, d=128, L=2048, B=4, n_layer=2, autocast_dtype=torch.bfloat16)
+    assert all(l == l for l in losses)
+    assert losses[-1] < 0.35 * losses[0], (losses[0], losses[-1])

@@ -187,3 +187,12 @@ def test_empty_batch_and_oversize_length(emu_backend):
     assert torch.count_nonzero(k.grad) == 0 and torch.count_nonzero(bias.grad) == 0 and u.grad.shape == u.shape
     with pytest.raises(HyenaLibraryError):
         emu_backend.fftconv_fwd(torch.zeros(1, 1, (1 << 20) + 1), torch.zeros(1, (1 << 20) + 1), None)
+
+
+def test_tiny_lm_trains_on_the_emulated_kernels(emu_backend):
+    """all autograd Functions together (fused filter, mixer shell, long conv, add+LayerNorm, tokenizer): the loss of a
+    2-layer stack on periodic DNA falls"""
+    from tests._tiny_lm import train
+    losses = train("cpu", steps=8, d=64, L=70, B=2, n_layer=2)
+    assert all(l == l for l in losses)                       # finite
+    assert losses[-1] < 0.8 * losses[0], losses
