@@ -1,0 +1,26 @@
+"""INTEGRATION.md seams 1 and 2 end to end: the unmodified reference `src.models.sequence.hyena.HyenaOperator` with
+`fused_fft_conv=True` and this repository's path overlay runs its long convolutions through `fftconv_func` of this
+package (kernels under tests/hipemu here) and matches its own torch.fft path, values and all gradients; and the
+reference's registry + `instantiate` build this package's fully fused operator, which loads a reference state dict
+(strict) and matches the reference operator.
+Needs the reference checkout: runs in the build container, skipped where /root/reference does not exist (GPU box)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("HYENA_REFERENCE", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "models", "sequence")), reason="reference checkout not present")
+def test_reference_operator_runs_through_the_overlay(tmp_path):
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.pop("PYTHONPATH", None)
+    # a neutral working directory: `python script` puts the script's directory first on sys.path, the worker then orders
+    # overlay / repo / reference itself
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_overlay_worker.py")], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    assert "OVERLAY_OK" in p.stdout and "REGISTRY_OK" in p.stdout, p.stdout[-1500:]
