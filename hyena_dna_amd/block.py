@@ -9,8 +9,8 @@ restated unfused at ``src/models/sequence/simple_lm.py:267-271, 280-284``).
 
 ``residual'`` is fp32 (``residual_in_fp32=True``, what HyenaDNA trains with); ``out`` has ``x0``'s dtype, computed in
 fp32 and rounded once.  The dropout itself (p > 0 only: HyenaDNA's ``resid_dropout`` is 0) is PyTorch's, applied before the
-kernel.  Shapes outside the kernels' coverage (D not a multiple of 64 or > 1024) and host tensors take the same graph
-in PyTorch ops.
+kernel.  Shapes outside the kernels' coverage (D not a multiple of 64, or > 1024) take the same graph in PyTorch ops on
+the same device; host tensors are refused (``HyenaLibraryError``), as is a missing library.
 """
 import torch
 import torch.nn.functional as F
@@ -51,8 +51,7 @@ class AddLayerNormFunc(torch.autograd.Function):
 
 
 def _fused_ok(x0, residual, weight):
-    if not (x0.is_cuda or _lib._backend.name != "hip"):
-        return False
+    _lib._require_gpu(x0, "x0")           # host tensors are refused like everywhere else in this package: no CPU fallback
     if residual is not None and residual.shape != x0.shape:
         return False
     return weight is not None and _lib.add_norm_supported(x0.shape[-1], x0.dtype, x0.dtype)

@@ -196,3 +196,11 @@ def test_tiny_lm_trains_on_the_emulated_kernels(emu_backend):
     losses = train("cpu", steps=8, d=64, L=70, B=2, n_layer=2)
     assert all(l == l for l in losses)                       # finite
     assert losses[-1] < 0.8 * losses[0], losses
+
+
+def test_block_glue_refuses_cpu_tensors_without_the_test_double():
+    """no silent CPU path for the add + LayerNorm either (the emulator backend is only ever installed by tests)"""
+    from hyena_dna_amd.block import dropout_add_layer_norm
+    from hyena_dna_amd._lib import HyenaLibraryError
+    with pytest.raises(HyenaLibraryError):
+        dropout_add_layer_norm(torch.randn(2, 3, 64), None, torch.ones(64), torch.zeros(64), 0.0, 1e-5, residual_in_fp32=True)
