@@ -48,6 +48,8 @@ bool make_plan(int L, Plan* p) {
     while (M < L) M <<= 1;
     if (L > 131072 && L <= 163840) M = 163840;      // 160 x 1024 (32 x 5 column transform): hyenadna-medium-160k's
                                                     // 160000 is served by N = 327680 instead of 524288
+    if (L > 262144 && L <= 458752) M = 458752;      // 448 x 1024 (32 x 14): hyenadna-medium-450k's 450560 at N = 917504
+                                                    // instead of 1048576
     p->L = L;
     p->M = M;
     p->M1 = M / 1024;
@@ -86,6 +88,7 @@ int launch_col_dt(int M1, const ColArgs& a, int rows, void* stream) {
         HY_COL_CASE(128)
         HY_COL_CASE(160)
         HY_COL_CASE(256)
+        HY_COL_CASE(448)
         HY_COL_CASE(512)
         HY_COL_CASE(1024)
         default: return HYENA_ERR_UNSUPPORTED_L;

@@ -395,10 +395,54 @@ __device__ __forceinline__ void dft5_reg(c32 (&v)[5]) {
     v[2] = INV ? b2 : a2;
     v[3] = INV ? a2 : b2;
 }
+// 7-point DFT and, on top of it, the 14-point DFT (one radix-2 DIF step + two 7-point DFTs): the odd factor of
+// M1 = 448 = 32 x 14, which serves 262144 < L <= 458752 (L = 450560: N = 917504 instead of 1048576)
+template <bool INV>
+__device__ __forceinline__ void dft7_reg(c32 (&v)[7]) {
+    const float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
+    const float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
+    const c32 t1 = cadd(v[1], v[6]), t2 = cadd(v[2], v[5]), t3 = cadd(v[3], v[4]);
+    const c32 d1 = csub(v[1], v[6]), d2 = csub(v[2], v[5]), d3 = csub(v[3], v[4]);
+    const c32 x0 = v[0];
+    v[0] = cadd(x0, cadd(t1, cadd(t2, t3)));
+    const c32 a1 = mk(x0.x + c1 * t1.x + c2 * t2.x + c3 * t3.x, x0.y + c1 * t1.y + c2 * t2.y + c3 * t3.y);
+    const c32 a2 = mk(x0.x + c2 * t1.x + c3 * t2.x + c1 * t3.x, x0.y + c2 * t1.y + c3 * t2.y + c1 * t3.y);
+    const c32 a3 = mk(x0.x + c3 * t1.x + c1 * t2.x + c2 * t3.x, x0.y + c3 * t1.y + c1 * t2.y + c2 * t3.y);
+    const c32 b1 = mk(s1 * d1.x + s2 * d2.x + s3 * d3.x, s1 * d1.y + s2 * d2.y + s3 * d3.y);
+    const c32 b2 = mk(s2 * d1.x - s3 * d2.x - s1 * d3.x, s2 * d1.y - s3 * d2.y - s1 * d3.y);
+    const c32 b3 = mk(s3 * d1.x - s1 * d2.x + s2 * d3.x, s3 * d1.y - s1 * d2.y + s2 * d3.y);
+    // forward: X[k] = a_k - i b_k, X[7 - k] = a_k + i b_k;  inverse: signs swapped
+    const c32 m1 = mk(a1.x + b1.y, a1.y - b1.x), p1 = mk(a1.x - b1.y, a1.y + b1.x);
+    const c32 m2 = mk(a2.x + b2.y, a2.y - b2.x), p2 = mk(a2.x - b2.y, a2.y + b2.x);
+    const c32 m3 = mk(a3.x + b3.y, a3.y - b3.x), p3 = mk(a3.x - b3.y, a3.y + b3.x);
+    v[1] = INV ? p1 : m1; v[6] = INV ? m1 : p1;
+    v[2] = INV ? p2 : m2; v[5] = INV ? m2 : p2;
+    v[3] = INV ? p3 : m3; v[4] = INV ? m3 : p3;
+}
+template <bool INV>
+__device__ __forceinline__ void dft14_reg(c32 (&v)[14]) {
+    const float cw[7] = {1.0f, 0.90096886790241912624f, 0.62348980185873353053f, 0.22252093395631440429f,
+                         -0.22252093395631440429f, -0.62348980185873353053f, -0.90096886790241912624f};
+    const float sw[7] = {0.0f, 0.43388373911755812048f, 0.78183148246802980871f, 0.97492791218182360702f,
+                         0.97492791218182360702f, 0.78183148246802980871f, 0.43388373911755812048f};
+    c32 a[7], b[7];
+    HY_UNROLL
+    for (int m = 0; m < 7; ++m) {
+        a[m] = cadd(v[m], v[m + 7]);
+        const c32 d = csub(v[m], v[m + 7]);
+        // d * w_14^m (forward) / d * conj(w_14^m) (inverse)
+        b[m] = INV ? mk(d.x * cw[m] - d.y * sw[m], d.y * cw[m] + d.x * sw[m]) : mk(d.x * cw[m] + d.y * sw[m], d.y * cw[m] - d.x * sw[m]);
+    }
+    dft7_reg<INV>(a);
+    dft7_reg<INV>(b);
+    HY_UNROLL
+    for (int k = 0; k < 7; ++k) { v[2 * k] = a[k]; v[2 * k + 1] = b[k]; }
+}
 // second Stockham stage of a column transform: T points
 template <int T, bool INV>
 __device__ __forceinline__ void dft_stage2(c32 (&y)[T]) {
     if constexpr (T == 5) dft5_reg<INV>(y);
+    else if constexpr (T == 14) dft14_reg<INV>(y);
     else dft_reg<T, INV>(y);
 }
 
@@ -469,10 +513,10 @@ struct Tables {
 template <int M1> struct ColCfg {
     static constexpr int T = M1 >= 32 ? M1 / 32 : 1;
     static constexpr int E = M1 >= 32 ? 32 : M1;
-    static constexpr bool POW2 = (T & (T - 1)) == 0;         // M1 = 160: T = 5 (the only non-power-of-two size)
+    static constexpr bool POW2 = (T & (T - 1)) == 0;         // non-power-of-two sizes: M1 = 160 (T = 5), M1 = 448 (T = 14)
     // (32 columns per workgroup -- 256-byte row pieces, one 1024-thread workgroup per CU -- measured slower at M1 = 1024:
     // 7.3 vs 6.7 ms per step)
-    static constexpr int C = !POW2 ? 64 : (256 / T) > 16 ? (256 / T) : 16;
+    static constexpr int C = T == 5 ? 64 : T == 14 ? 32 : (256 / T) > 16 ? (256 / T) : 16;
     static constexpr int THREADS = C * T;
     static constexpr int NB = (32 + T - 1) / T;              // stage-2 butterflies per thread (T > 1); for T = 5 the
                                                              // 32 of them split 7/7/6/6/6 (jj = r + T i < 32)

@@ -71,7 +71,8 @@ const char* hyena_fftconv_error_string(int status);
 
 /* Complex transform length M used for sequence length L: the padded real transform has N = 2M >= 2L
  * points (M = max(1024, next power of two >= L), except 131072 < L <= 163840, where M = 160 * 1024 -- a 32 x 5 column
- * transform that serves hyenadna-medium-160k's L = 160000 with N = 327680 instead of 524288); the reference uses
+ * transform that serves hyenadna-medium-160k's L = 160000 with N = 327680 instead of 524288 -- and 262144 < L <= 458752,
+ * where M = 448 * 1024 (32 x 14: L = 450560 at N = 917504 instead of 1048576)); the reference uses
  * N = 2L (hyena.py:61), which gives the same causal result.  Returns 0 if L is unsupported. */
 int hyena_fftconv_fft_size(int L);
 

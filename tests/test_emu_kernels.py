@@ -35,7 +35,7 @@ def _inputs(B, D, L, dtype, seed=0):
     (2, 3, 1, 0), (2, 3, 8, 0), (1, 2, 1023, 0), (2, 2, 1024, 1), (1, 3, 1025, 2), (1, 2, 2048, 0),
     (2, 2, 3000, 0), (1, 2, 8191, 0), (1, 1, 16384, 0), (2, 2, 32768, 1), (1, 1, 65536, 0), (1, 2, 100000, 0),
     (1, 1, 160000, 0), (2, 2, 131073, 1), (1, 2, 163839, 0), (1, 1, 163840, 0), (1, 1, 163841, 0), (1, 1, 262144, 0),
-    (1, 1, 450560, 0), (4, 2, 5000, 0), (5, 3, 9000, 2), (8, 1, 40000, 0),
+    (1, 1, 450560, 0), (2, 1, 262145, 0), (1, 1, 460800, 0), (4, 2, 5000, 0), (5, 3, 9000, 2), (8, 1, 40000, 0),
 ])
 def test_fp32_fwd_bwd_vs_oracle(emu_backend, B, D, L, chunk):
     u, k, bias, dout = _inputs(B, D, L, torch.float32, seed=L)
