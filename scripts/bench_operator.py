@@ -34,7 +34,34 @@ def run(fused, n=10):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+def torch_fft_conv(u, k, D, dropout_mask=None, gelu=False, force_fp16_output=False, **kw):
+    """measurement aid: the reference's own long convolution (hyena.py:59-88) in torch ops, for the 'reference' mode"""
+    L = u.shape[-1]
+    n = 2 * L
+    k_f = torch.fft.rfft(k, n=n) / n
+    if u.dim() > 3:
+        k_f = k_f.unsqueeze(1)                                   # (v, 1, n) against (b, h, v, z, n)
+    u_f = torch.fft.rfft(u.to(k.dtype), n=n)
+    y = torch.fft.irfft(u_f * k_f, n=n, norm="forward")[..., :L]
+    return (y + u * D.unsqueeze(-1)).to(u.dtype)
+
+
+def run_reference(n=5):
+    """the whole reference graph on this GPU: PyTorch glue + torch.fft (hipFFT) long convolution"""
+    import hyena_dna_amd.hyena as H
+    saved = H.fftconv_func
+    H.fftconv_func = torch_fft_conv
+    try:
+        return run(False, n)
+    finally:
+        H.fftconv_func = saved
+
+
 mode = sys.argv[3] if len(sys.argv) > 3 else "both"
+if mode == "reference":
+    r = run_reference()
+    print(f"HyenaOperator layer fwd+bwd  L={L} B={B} d={D} bf16 autocast: reference graph in PyTorch ops + torch.fft on this GPU {r:.3f} ms")
+    sys.exit(0)
 a = run(True) if mode in ("both", "fused") else float("nan")
 b = run(False) if mode in ("both", "glue") else float("nan")
 print(f"HyenaOperator layer fwd+bwd  L={L} B={B} d={D} bf16 autocast: fused mixer core {a:.3f} ms, PyTorch-glue path {b:.3f} ms, x{b / a:.2f}")
