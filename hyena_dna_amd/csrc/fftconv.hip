@@ -42,18 +42,23 @@ struct Plan {
     int L, M, M1;
 };
 
+// Column sizes M1 the kernels are instantiated for (M = M1 x 1024 complex points serve L <= M): the powers of two, and
+// 2^a x {3, 5, 7} where the second-stage operands still fit the register budget -- so that the zero padding beyond 2L
+// is at most ~20 % instead of up to 100 % (hyenadna-medium-160k: M1 = 160; -450k: M1 = 448).
+const int SUPPORTED_M1[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 64, 96, 128, 160, 192, 224, 256, 320, 384, 448,
+                            512, 640, 768, 1024};
+
 bool make_plan(int L, Plan* p) {
     if (L < 1 || L > HYENA_MAX_L) return false;
-    int M = 1024;
-    while (M < L) M <<= 1;
-    if (L > 131072 && L <= 163840) M = 163840;      // 160 x 1024 (32 x 5 column transform): hyenadna-medium-160k's
-                                                    // 160000 is served by N = 327680 instead of 524288
-    if (L > 262144 && L <= 458752) M = 458752;      // 448 x 1024 (32 x 14): hyenadna-medium-450k's 450560 at N = 917504
-                                                    // instead of 1048576
-    p->L = L;
-    p->M = M;
-    p->M1 = M / 1024;
-    return true;
+    for (int m1 : SUPPORTED_M1) {
+        if ((long)m1 * 1024 >= L) {
+            p->L = L;
+            p->M1 = m1;
+            p->M = m1 * 1024;
+            return true;
+        }
+    }
+    return false;
 }
 
 // table layout inside d_tables (c32 units): tw_lo[1024] | tw_hi[1024 slots, M1 used] | tw_row[1024] | tw_rowT[1024]
@@ -80,16 +85,33 @@ int launch_col_dt(int M1, const ColArgs& a, int rows, void* stream) {
     switch (M1) {
         HY_COL_CASE(1)
         HY_COL_CASE(2)
+        HY_COL_CASE(3)
         HY_COL_CASE(4)
+        HY_COL_CASE(5)
+        HY_COL_CASE(6)
+        HY_COL_CASE(7)
         HY_COL_CASE(8)
+        HY_COL_CASE(10)
+        HY_COL_CASE(12)
+        HY_COL_CASE(14)
         HY_COL_CASE(16)
+        HY_COL_CASE(20)
+        HY_COL_CASE(24)
+        HY_COL_CASE(28)
         HY_COL_CASE(32)
         HY_COL_CASE(64)
+        HY_COL_CASE(96)
         HY_COL_CASE(128)
         HY_COL_CASE(160)
+        HY_COL_CASE(192)
+        HY_COL_CASE(224)
         HY_COL_CASE(256)
+        HY_COL_CASE(320)
+        HY_COL_CASE(384)
         HY_COL_CASE(448)
         HY_COL_CASE(512)
+        HY_COL_CASE(640)
+        HY_COL_CASE(768)
         HY_COL_CASE(1024)
         default: return HYENA_ERR_UNSUPPORTED_L;
     }
@@ -112,11 +134,16 @@ const size_t ROW_SMEM = 2 * ROW_LDS * sizeof(c32);
 
 const size_t ROW0_SMEM = ROW0_LDS * sizeof(c32);
 
-// rows 0 and M1/2 (self-paired) go through the row0_* kernels, the M1/2 - 1 regular pairs through row_*.
+// rows 0 and (for even M1) M1/2 are their own partners and go through the row0_* kernels; the regular pairs
+// (k1, M1 - k1), k1 = 1 .. (M1 - 1) / 2, through row_*.
+int self_paired_rows(int M1) { return (M1 >= 2 && M1 % 2 == 0) ? 2 : 1; }
+int regular_pairs(int M1) { return (M1 - 1) / 2; }
+
 template <int MODE>
 int launch_row_prod2(const RowArgs& a, void* stream) {
-    HY_LAUNCH((row0_prod2_kernel<MODE>), dim3(a.M1 >= 2 ? 2 : 1, (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, stream, a);
-    if (a.M1 >= 4) HY_LAUNCH((row_prod2_kernel<MODE>), dim3(a.M1 / 2 - 1, a.inner), dim3(64), ROW_SMEM, stream, a);
+    HY_LAUNCH((row0_prod2_kernel<MODE>), dim3(self_paired_rows(a.M1), (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, stream, a);
+    if (regular_pairs(a.M1) > 0)
+        HY_LAUNCH((row_prod2_kernel<MODE>), dim3(regular_pairs(a.M1), a.inner), dim3(64), ROW_SMEM, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
@@ -127,10 +154,10 @@ const int ROW_BWD_SPLIT_BATCH = 2;     // measured: B = 1 fused 6.62 vs split 7.
 
 template <bool DO_DU>
 int launch_row_bwd(const RowArgs& a, void* stream) {
-    HY_LAUNCH((row0_bwd_kernel<DO_DU>), dim3(a.M1 >= 2 ? 2 : 1, (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, stream, a);
-    HY_LAUNCH(row0_dk_reduce_kernel, dim3(a.M1 >= 2 ? 2 : 1, a.inner), dim3(256), 0, stream, a);
-    if (a.M1 >= 4) {
-        const dim3 grid(a.M1 / 2 - 1, a.inner);
+    HY_LAUNCH((row0_bwd_kernel<DO_DU>), dim3(self_paired_rows(a.M1), (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, stream, a);
+    HY_LAUNCH(row0_dk_reduce_kernel, dim3(self_paired_rows(a.M1), a.inner), dim3(256), 0, stream, a);
+    if (regular_pairs(a.M1) > 0) {
+        const dim3 grid(regular_pairs(a.M1), a.inner);
         if (a.B >= ROW_BWD_SPLIT_BATCH) {
             HY_LAUNCH(row_dk_kernel, grid, dim3(64), ROW_SMEM, stream, a);       // reads the dout rows before du replaces them
             if (DO_DU) {

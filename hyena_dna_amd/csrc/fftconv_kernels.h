@@ -438,12 +438,71 @@ __device__ __forceinline__ void dft14_reg(c32 (&v)[14]) {
     HY_UNROLL
     for (int k = 0; k < 7; ++k) { v[2 * k] = a[k]; v[2 * k + 1] = b[k]; }
 }
-// second Stockham stage of a column transform: T points
-template <int T, bool INV>
-__device__ __forceinline__ void dft_stage2(c32 (&y)[T]) {
-    if constexpr (T == 5) dft5_reg<INV>(y);
-    else if constexpr (T == 14) dft14_reg<INV>(y);
-    else dft_reg<T, INV>(y);
+template <bool INV>
+__device__ __forceinline__ void dft3_reg(c32 (&v)[3]) {
+    const float s = 0.86602540378443864676f;                  // sin(2 pi / 3); cos = -1/2
+    const c32 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+    const c32 m = mk(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+    const c32 b = mk(s * d.x, s * d.y);
+    v[0] = cadd(v[0], t);
+    const c32 lo = mk(m.x + b.y, m.y - b.x), hi = mk(m.x - b.y, m.y + b.x);      // m - i b, m + i b
+    v[1] = INV ? hi : lo;
+    v[2] = INV ? lo : hi;
+}
+template <int P, bool INV>
+__device__ __forceinline__ void dft_odd_reg(c32 (&v)[P]) {
+    if constexpr (P == 3) dft3_reg<INV>(v);
+    else if constexpr (P == 5) dft5_reg<INV>(v);
+    else dft7_reg<INV>(v);
+}
+__host__ __device__ constexpr int odd_part(int n) { return (n & 1) ? n : odd_part(n >> 1); }
+__host__ __device__ constexpr bool is_pow2(int n) { return (n & (n - 1)) == 0; }
+
+// N = 2^A * P points (P = 3, 5 or 7): A radix-2 decimation-in-frequency steps with twiddles w_N^j = tw[j * tw_step]
+// (an LDS table of w_M1^j; conjugated for the inverse), then 2^A P-point DFTs; block b of the result holds the outputs
+// k = bitrev_A(b) + 2^A k', which the final permutation puts in natural order.  Serves the column sizes that are not
+// powers of two (M1 = 3 ... 28 in one stage, 32 x {3, 6, 7, 10, 12, 20, 24} as the second stage).
+template <int N, bool INV>
+__device__ __forceinline__ void dft_mixed(c32 (&v)[N], const HY_LDS lc32* tw, int tw_step) {
+    constexpr int P = odd_part(N), NBLK = N / P, A = ilog2(NBLK);
+    HY_UNROLL
+    for (int st = 0; st < A; ++st) {
+        const int len = N >> st, half = len >> 1;
+        HY_UNROLL
+        for (int base = 0; base < N; base += len) {
+            HY_UNROLL
+            for (int j = 0; j < half; ++j) {
+                const c32 a = v[base + j], b = v[base + j + half];
+                v[base + j] = cadd(a, b);
+                const c32 d = csub(a, b);
+                if (j == 0) v[base + j + half] = d;
+                else {
+                    const c32 w = lds_ld(tw + j * (N / len) * tw_step);
+                    v[base + j + half] = INV ? cmulc(d, w) : cmul(d, w);
+                }
+            }
+        }
+    }
+    c32 o[N];
+    HY_UNROLL
+    for (int b = 0; b < NBLK; ++b) {
+        c32 blk[P];
+        HY_UNROLL
+        for (int k = 0; k < P; ++k) blk[k] = v[b * P + k];
+        dft_odd_reg<P, INV>(blk);
+        HY_UNROLL
+        for (int k = 0; k < P; ++k) o[brev(b, A) + NBLK * k] = blk[k];
+    }
+    HY_UNROLL
+    for (int q = 0; q < N; ++q) v[q] = o[q];
+}
+// N-point register DFT of a column stage; `tw[j * tw_step]` = w_N^j (needed for the sizes that are not powers of two)
+template <int N, bool INV>
+__device__ __forceinline__ void dft_any(c32 (&y)[N], const HY_LDS lc32* tw, int tw_step) {
+    if constexpr (is_pow2(N)) dft_reg<N, INV>(y);
+    else if constexpr (N == 3 || N == 5 || N == 7) dft_odd_reg<N, INV>(y);
+    else if constexpr (N == 14) dft14_reg<INV>(y);
+    else dft_mixed<N, INV>(y, tw, tw_step);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -513,14 +572,21 @@ struct Tables {
 template <int M1> struct ColCfg {
     static constexpr int T = M1 >= 32 ? M1 / 32 : 1;
     static constexpr int E = M1 >= 32 ? 32 : M1;
-    static constexpr bool POW2 = (T & (T - 1)) == 0;         // non-power-of-two sizes: M1 = 160 (T = 5), M1 = 448 (T = 14)
+    static_assert(M1 < 32 || M1 % 32 == 0, "two-stage column sizes are 32 x T");
+    static constexpr bool POW2 = is_pow2(T);                 // T = 3, 5, 6, 7, 10, 12, 14, 20, 24: the odd-factor sizes
     // (32 columns per workgroup -- 256-byte row pieces, one 1024-thread workgroup per CU -- measured slower at M1 = 1024:
     // 7.3 vs 6.7 ms per step)
-    static constexpr int C = T == 5 ? 64 : T == 14 ? 32 : (256 / T) > 16 ? (256 / T) : 16;
+    static constexpr int C = T == 1 ? 256 : POW2 ? ((256 / T) > 16 ? (256 / T) : 16)
+                           : (T == 3 || T == 5 || T == 7) ? 64 : (T == 6 || T == 10 || T == 14) ? 32 : 16;
     static constexpr int THREADS = C * T;
+    static_assert(THREADS % 64 == 0, "whole wavefronts");
     static constexpr int NB = (32 + T - 1) / T;              // stage-2 butterflies per thread (T > 1); for T = 5 the
                                                              // 32 of them split 7/7/6/6/6 (jj = r + T i < 32)
     static constexpr int TO = (T + 1) / 2;                   // stage-2 outputs q < TO can lie below M1/2
+    static constexpr int EH = E >= 2 ? (E + 1) / 2 : 1;      // single-stage sizes: inputs / outputs n1 < EH can lie below M1/2
+    // waves per SIMD the register budget is set for: 4 (<= 128 VGPRs) everywhere except the three sizes whose second-stage
+    // operands (NB * T = 40 ... 48 complex values) or 28-point butterflies would spill at that budget
+    static constexpr int MIN_WAVES = (M1 == 28 || M1 == 640 || M1 == 768) ? 3 : 4;
     static constexpr size_t LDS_TABLES = (1024 + (size_t)M1) * sizeof(c32);
     static constexpr size_t LDS_PLANE = T > 1 ? (size_t)M1 * C * sizeof(float) : 0;
     static constexpr size_t LDS = LDS_TABLES + LDS_PLANE;
@@ -598,7 +664,7 @@ __device__ __forceinline__ int col_group(int groups) {
 }
 
 template <int M1, int DT>
-__global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_fwd_kernel(ColArgs a) {
+__global__ void __launch_bounds__(ColCfg<M1>::THREADS, ColCfg<M1>::MIN_WAVES) col_fwd_kernel(ColArgs a) {
     typedef ColCfg<M1> Cfg;
     typedef typename Elem<DT>::type elem_t;
     typedef typename Pair<DT>::raw_t raw_t;
@@ -620,7 +686,7 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_fwd_kernel(ColArgs
 
     // all global loads of the thread back to back: E input pairs (+ the table slice)
     // Rows n1 >= M1/2 (s >= E/2) lie beyond L/2 <= M/2 for every supported L: the zero padding is never loaded.
-    constexpr int EL = E >= 2 ? E / 2 : 1;
+    constexpr int EL = T > 1 ? E / 2 : Cfg::EH;
     raw_t raw[EL];
     if (nfull > 0) {
         HY_UNROLL
@@ -641,10 +707,11 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_fwd_kernel(ColArgs
         for (int s = 0; s < E; ++s)
             if ((r + T * s) * 1024 + n2 == nfull) v[s] = mk(Elem<DT>::ld(xrow + a.L - 1), 0.f);
     }
-    dft_reg<E, false>(v);
+    if constexpr (!is_pow2(E)) __syncthreads();        // the mixed-radix butterflies read their twiddles from the tables
+    dft_any<E, false>(v, thi, 1);
 
     if constexpr (T == 1) {
-        __syncthreads();   // tables
+        if constexpr (is_pow2(E)) __syncthreads();     // tables
         HY_UNROLL
         for (int q = 0; q < E; ++q) {
             const c32 w = outer_tw(tlo, thi, n2, q);
@@ -662,7 +729,7 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_fwd_kernel(ColArgs
             y[0] = x2[i * T];
             HY_UNROLL
             for (int s = 1; s < T; ++s) y[s] = cmul(x2[i * T + s], lds_ld(thi + jj * s));
-            dft_stage2<T, false>(y);
+            dft_any<T, false>(y, thi, 32);
             HY_UNROLL
             for (int q = 0; q < T; ++q) {
                 const int k1 = jj + 32 * q;
@@ -682,7 +749,7 @@ __device__ __forceinline__ void col_store(typename Elem<DT>::type* xrow, int n, 
 
 template <int M1, int DT>
 // <= 128 VGPRs (4 waves per SIMD): at 141 only ONE 512-thread workgroup fits a CU and the kernel ran at 2.5 TB/s
-__global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_inv_kernel(ColArgs a) {
+__global__ void __launch_bounds__(ColCfg<M1>::THREADS, ColCfg<M1>::MIN_WAVES) col_inv_kernel(ColArgs a) {
     typedef ColCfg<M1> Cfg;
     typedef typename Elem<DT>::type elem_t;
     constexpr int T = Cfg::T, C = Cfg::C, E = Cfg::E;
@@ -707,12 +774,12 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_inv_kernel(ColArgs
     __syncthreads();
     HY_UNROLL
     for (int s = 0; s < E; ++s) v[s] = cmulc(v[s], outer_tw(tlo, thi, n2, r + T * s));
-    dft_reg<E, true>(v);
+    dft_any<E, true>(v, thi, 1);
 
     // Outputs n1 >= M1/2 lie beyond L/2 <= M/2 for every supported L: never stored, so never computed (the
     // compiler drops the butterflies that only feed them).
     if constexpr (T == 1) {
-        constexpr int EO = E >= 2 ? E / 2 : 1;
+        constexpr int EO = Cfg::EH;
         HY_UNROLL
         for (int q = 0; q < EO; ++q) col_store<DT>(xrow, q * 1024 + n2, nfull, a.L, v[q], a.aux0, row);
     } else {
@@ -727,7 +794,7 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, 4) col_inv_kernel(ColArgs
             y[0] = x2[i * T];
             HY_UNROLL
             for (int s = 1; s < T; ++s) y[s] = cmulc(x2[i * T + s], lds_ld(thi + jj * s));
-            dft_stage2<T, true>(y);
+            dft_any<T, true>(y, thi, 32);
             // power-of-two T: outputs q >= T/2 are all >= M1/2; T = 5: q = 2 straddles it, col_store drops n >= L/2
             HY_UNROLL
             for (int q = 0; q < Cfg::TO; ++q) col_store<DT>(xrow, (jj + 32 * q) * 1024 + n2, nfull, a.L, y[q], a.aux0, row);

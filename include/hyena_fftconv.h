@@ -70,10 +70,11 @@ int hyena_fftconv_abi_version(void);
 const char* hyena_fftconv_error_string(int status);
 
 /* Complex transform length M used for sequence length L: the padded real transform has N = 2M >= 2L
- * points (M = max(1024, next power of two >= L), except 131072 < L <= 163840, where M = 160 * 1024 -- a 32 x 5 column
- * transform that serves hyenadna-medium-160k's L = 160000 with N = 327680 instead of 524288 -- and 262144 < L <= 458752,
- * where M = 448 * 1024 (32 x 14: L = 450560 at N = 917504 instead of 1048576)); the reference uses
- * N = 2L (hyena.py:61), which gives the same causal result.  Returns 0 if L is unsupported. */
+ * points, M = M1 * 1024 with M1 the smallest supported column size >= L / 1024: the powers of two up to 1024 and
+ * 2^a x {3, 5, 7} (3, 5, 6, 7, 10, 12, 14, 20, 24, 28, 96, 160, 192, 224, 320, 384, 448, 640, 768), so that the
+ * zero padding beyond 2L stays below ~20 % for most lengths (hyenadna-medium-160k: L = 160000 -> M1 = 160, N = 327680;
+ * -450k: L = 450560 -> M1 = 448, N = 917504); the reference uses N = 2L (hyena.py:61), which gives the same causal
+ * result.  Returns 0 if L is unsupported. */
 int hyena_fftconv_fft_size(int L);
 
 /* Bytes of device memory needed for the twiddle tables of sequence length L, and their one-time

@@ -75,10 +75,12 @@ def test_host_only_entry_points(product_lib):
     assert L.hyena_fftconv_saved_bytes(1, 256, 1 << 20) == 2 * 256 * (1 << 20) * 8
     L.hyena_fftconv_error_string.restype = ctypes.c_char_p
     assert L.hyena_fftconv_abi_version() == 2
-    assert L.hyena_fftconv_fft_size(1024) == 1024 and L.hyena_fftconv_fft_size(160000) == 163840 and L.hyena_fftconv_fft_size(163841) == 262144
+    assert L.hyena_fftconv_fft_size(1024) == 1024 and L.hyena_fftconv_fft_size(160000) == 163840 and L.hyena_fftconv_fft_size(163841) == 196608
     assert L.hyena_fftconv_fft_size(131072) == 131072 and L.hyena_fftconv_fft_size(131073) == 163840
     assert L.hyena_fftconv_fft_size(450560) == 458752 and L.hyena_fftconv_fft_size(1 << 20) == 1 << 20
-    assert L.hyena_fftconv_fft_size(262144) == 262144 and L.hyena_fftconv_fft_size(262145) == 458752
+    assert L.hyena_fftconv_fft_size(262144) == 262144 and L.hyena_fftconv_fft_size(262145) == 327680
+    assert L.hyena_fftconv_fft_size(2049) == 3072 and L.hyena_fftconv_fft_size(4776) == 5120 and L.hyena_fftconv_fft_size(33000) == 65536
+    assert L.hyena_fftconv_fft_size(700000) == 786432 and L.hyena_fftconv_fft_size(786433) == 1 << 20
     assert L.hyena_fftconv_fft_size(458753) == 524288
     assert L.hyena_fftconv_fft_size((1 << 20) + 1) == 0
     assert L.hyena_fftconv_table_bytes(1 << 20) == 4096 * 8

@@ -172,3 +172,18 @@ def test_randomised_shapes_vs_oracle(emu_backend):
             assert (du.float() - r_du).abs().max() <= tol * r_du.abs().max() + 1e-6, tag
         assert _rel(dk, r_dk) < 2e-5 if dtype != torch.float32 else _rel(dk, r_dk) < REL_FP32, tag
         assert _rel(dbias, r_db) < 2e-5, tag
+
+
+@pytest.mark.parametrize("m1", [3, 5, 6, 7, 10, 12, 14, 20, 24, 28, 96, 192, 224, 320, 384])
+def test_mixed_radix_column_sizes(emu_backend, m1):
+    """every column size that is not a power of two (2^a x {3, 5, 7}; odd M1 has no self-paired row M1/2), forward + backward
+    vs the fp64 evaluation of the oracle (the fp32 oracle itself is up to 5e-6 off at these non-smooth 2L)"""
+    L = m1 * 1024 - 3
+    assert emu_backend.lib().hyena_fftconv_fft_size(L) == m1 * 1024
+    B, D = (2, 2) if m1 < 32 else (1, 1)
+    u, k, bias, dout = _inputs(B, D, L, torch.float32, seed=L)
+    out = emu_backend.fftconv_fwd(u, k, bias)
+    du, dk, dbias = emu_backend.fftconv_bwd(dout, u, k, bias)
+    r_out, r_du, r_dk, r_db = _oracle(u.double(), k.double(), bias.double(), dout.double())
+    assert _rel(out, r_out) < 1e-6 and _rel(du, r_du) < 1e-6 and _rel(dk, r_dk) < 1e-6
+    assert _rel(dbias, r_db) < 2e-5
