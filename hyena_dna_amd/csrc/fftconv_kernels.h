@@ -569,6 +569,9 @@ struct Tables {
 // column kernels.  One workgroup = C adjacent columns n2 of one row; thread (c, r) with r < T,
 // T = max(1, M1/32).  Each thread owns E = min(M1, 32) points of its column.
 // ---------------------------------------------------------------------------------------------
+#ifndef HY_COLW
+#define HY_COLW(m1) (((m1) == 28 || (m1) == 768) ? 3 : 4)
+#endif
 template <int M1> struct ColCfg {
     static constexpr int T = M1 >= 32 ? M1 / 32 : 1;
     static constexpr int E = M1 >= 32 ? 32 : M1;
@@ -584,9 +587,10 @@ template <int M1> struct ColCfg {
                                                              // 32 of them split 7/7/6/6/6 (jj = r + T i < 32)
     static constexpr int TO = (T + 1) / 2;                   // stage-2 outputs q < TO can lie below M1/2
     static constexpr int EH = E >= 2 ? (E + 1) / 2 : 1;      // single-stage sizes: inputs / outputs n1 < EH can lie below M1/2
-    // waves per SIMD the register budget is set for: 4 (<= 128 VGPRs) everywhere except the three sizes whose second-stage
-    // operands (NB * T = 40 ... 48 complex values) or 28-point butterflies would spill at that budget
-    static constexpr int MIN_WAVES = (M1 == 28 || M1 == 640 || M1 == 768) ? 3 : 4;
+    // waves per SIMD the register budget is set for: 4 (<= 128 VGPRs) everywhere except M1 = 28 and 768, which measured
+    // faster at 3 (28000 x 8: 1.32 vs 1.37 ms; 700000: 6.31 vs 6.51 ms) -- M1 = 640 prefers 4 with a 52-byte spill
+    // (600000: 5.20 vs 5.39 ms)
+    static constexpr int MIN_WAVES = HY_COLW(M1);
     static constexpr size_t LDS_TABLES = (1024 + (size_t)M1) * sizeof(c32);
     static constexpr size_t LDS_PLANE = T > 1 ? (size_t)M1 * C * sizeof(float) : 0;
     static constexpr size_t LDS = LDS_TABLES + LDS_PLANE;

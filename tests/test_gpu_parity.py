@@ -54,6 +54,9 @@ def test_native_library_is_the_one_loaded(gpu_lib):
     (2, 3, 1, None), (2, 3, 8, None), (3, 5, 1023, None), (8, 128, 1024, None), (2, 4, 1025, 3), (2, 3, 2048, None),
     (1, 3, 5000, None), (2, 2, 8191, None), (1, 4, 16384, 1), (2, 8, 32768, None), (1, 2, 65536, None),
     (1, 3, 160000, 2), (1, 2, 450560, None), (1, 2, 1048576, None), (1, 1, 1048575, None),
+    # column sizes that are not powers of two (M1 = 3, 5, 7, 12, 28, 96, 224, 384, 640, 768)
+    (2, 3, 3069, None), (2, 2, 5117, None), (2, 2, 7165, 1), (1, 3, 12285, None), (1, 2, 28669, None), (1, 2, 98301, None),
+    (1, 2, 229373, None), (1, 1, 393213, None), (1, 1, 655357, None), (1, 1, 786429, None),
 ])
 def test_fp32_fwd_bwd_vs_oracle(gpu_lib, B, D, L, chunk):
     u, k, bias, dout = _inputs(B, D, L, torch.float32, seed=L)
