@@ -416,6 +416,8 @@ int hyena_fftconv_bwd_saved(const void* dout, const float* bias, void* du, float
                     saved, saved_bytes, stream);
 }
 
+}  // extern "C"
+
 // ---------------------------------------------------------------------------------------------------------------
 // fused mixer shell (include/hyena_mixer.h)
 // ---------------------------------------------------------------------------------------------------------------
@@ -453,6 +455,7 @@ const size_t MW_SMEM_PRE_BWD = (2 * (MW_TP + 4) * MW_CS + 2 * MW_TC * MW_YS) * s
     } while (0)
 }  // namespace
 
+extern "C" {
 int hyena_mixer_pre_fwd(const void* x, const float* w, const float* b, void* vg, int B, int L, int Lx, int D, int dtype,
                         void* stream) {
     if (!mix_ok(x, w, b, B, L, Lx, D, dtype) || vg == nullptr) return HYENA_ERR_BAD_ARG;
