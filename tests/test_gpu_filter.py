@@ -87,8 +87,9 @@ def test_fused_filter_at_hyenadna_lengths(gpu_lib, D, L):
             assert _rel(got[n], p.grad) < 2e-4, (n, _rel(got[n], p.grad))      # both sum ~1e6 fp32 terms per entry
 
 
-def test_operator_uses_the_fused_filter(gpu_lib):
-    """HyenaOperator in the HyenaDNA configuration under bf16 autocast: filter comes from the fused kernels (fp32)"""
+@pytest.mark.parametrize("amp_dtype", [torch.bfloat16, torch.float16])
+def test_operator_uses_the_fused_filter(gpu_lib, amp_dtype):
+    """HyenaOperator in the HyenaDNA configuration under 16-bit autocast: filter comes from the fused kernels (fp32)"""
     from hyena_dna_amd.hyena import HyenaOperator
     torch.manual_seed(0)
     op = HyenaOperator(d_model=128, l_max=1026, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True,
@@ -97,10 +98,12 @@ def test_operator_uses_the_fused_filter(gpu_lib):
     k_fused = op.filter_fn.filter_dl(1024)
     k_ref = op.filter_fn.filter(1024)[0].transpose(0, 1)
     assert _rel(k_fused, k_ref) < 2e-5
-    with torch.autocast("cuda", dtype=torch.bfloat16):
+    with torch.autocast("cuda", dtype=amp_dtype):
         y = op(u)
     y.float().square().mean().backward()
-    assert y.dtype == torch.bfloat16
+    assert y.dtype == amp_dtype
+    y32 = op(u)                                                  # the same layer without autocast (fp32 end to end)
+    assert _rel(y, y32) < (2e-2 if amp_dtype == torch.bfloat16 else 4e-3)
     for n, p in op.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
 
