@@ -217,53 +217,15 @@ def save_spectra_default(B, D, L):
     return saved_bytes(B, D, L) <= float(os.environ.get("HYENA_FFTCONV_SAVE_LIMIT_GB", "6")) * 2 ** 30
 
 
-# ---- optional: independent channel groups of one call on several streams --------------------------------------------------
-# The kernels of one chain (column transform -> row kernels -> inverse column transform) run back to back on one stream,
-# so a read-heavy kernel never overlaps a write-heavy one and every launch pays its own ramp and tail.  Channels are
-# independent, so for B = 1 (where a channel slice of u is contiguous) a call can be cut into G groups whose chains run
-# concurrently on side streams, forked from and joined back into the caller's stream -- same bits, measured 5-9 % faster
-# at L = 2^20 (scripts/stream_pipeline_probe.py).  Opt-in: HYENA_FFTCONV_STREAMS = G.
-_side_streams = {}
-
-
-class SavedSpectra:
-    """What fftconv_fwd(save=True) returns and fftconv_bwd(saved=...) takes back: one buffer per channel group."""
-
-    def __init__(self, buffers):
-        self.buffers = buffers
-
-    @property
-    def groups(self):
-        return len(self.buffers)
-
-    def numel(self):
-        """total bytes kept"""
-        return sum(b.numel() for b in self.buffers)
-
-
-def _groups_for(t):
-    g = int(os.environ.get("HYENA_FFTCONV_STREAMS", "0") or 0)
-    B, D, L = t.shape
-    if g <= 1 or _backend.name != "hip" or B != 1 or D % g != 0 or D // g < 16:
-        return 1
-    return g
-
-
-def _fork(device, n):
-    main = torch.cuda.current_stream(device)
-    pool = _side_streams.setdefault((device.index, n), [torch.cuda.Stream(device=device) for _ in range(n)])
-    for s in pool:
-        s.wait_stream(main)
-    return main, pool
-
-
-def _join(main, pool):
-    for s in pool:
-        main.wait_stream(s)
-
-
-def _fwd_one(u, k, bias, out, chunk, save):
+def fftconv_fwd(u, k, bias, chunk=None, save=False):
+    """u (B, D, L) contiguous, k (D, L) fp32, bias (D,) fp32 or None -> out like u.
+    save=True additionally returns the saved-spectrum buffer for fftconv_bwd(..., saved=)."""
+    _require_gpu(u, "u")
     B, D, L = u.shape
+    out = torch.empty_like(u)
+    if B == 0:                                   # empty batch: nothing to launch (torch.fft returns an empty tensor too)
+        return (out, torch.empty(0, dtype=torch.uint8, device=u.device)) if save else out
+    chunk = _chunk_override() if chunk is None else int(chunk)
     tables = tables_for(u.device, L)
     nbytes = lib().hyena_fftconv_workspace_bytes(B, D, L, 0, chunk)
     ws, stream = workspace_for(u.device, nbytes)
@@ -274,39 +236,23 @@ def _fwd_one(u, k, bias, out, chunk, save):
             check(lib().hyena_fftconv_fwd_save(u.data_ptr(), k.data_ptr(), bp, out.data_ptr(), B, D, L, dtype_code(u.dtype),
                                                tables.data_ptr(), ws.data_ptr(), ws.numel(), chunk, saved.data_ptr(),
                                                saved.numel(), stream))
-            return saved
+            return out, saved
         check(lib().hyena_fftconv_fwd(u.data_ptr(), k.data_ptr(), bp, out.data_ptr(), B, D, L, dtype_code(u.dtype),
                                       tables.data_ptr(), ws.data_ptr(), ws.numel(), chunk, stream))
-    return None
+    return out
 
 
-def fftconv_fwd(u, k, bias, chunk=None, save=False):
-    """u (B, D, L) contiguous, k (D, L) fp32, bias (D,) fp32 or None -> out like u.
-    save=True additionally returns the saved spectra (opaque) for fftconv_bwd(..., saved=)."""
-    _require_gpu(u, "u")
-    B, D, L = u.shape
-    out = torch.empty_like(u)
-    if B == 0:                                   # empty batch: nothing to launch (torch.fft returns an empty tensor too)
-        return (out, SavedSpectra([])) if save else out
-    chunk = _chunk_override() if chunk is None else int(chunk)
-    G = _groups_for(u)
-    if G == 1:
-        saved = _fwd_one(u, k, bias, out, chunk, save)
-        return (out, SavedSpectra([saved])) if save else out
-    per = D // G
-    tables_for(u.device, L)                      # created (one synchronous copy) before any side stream needs them
-    main, pool = _fork(u.device, G)
-    buffers = []
-    for g, s in enumerate(pool):
-        sl = slice(g * per, (g + 1) * per)
-        with torch.cuda.stream(s):
-            buffers.append(_fwd_one(u[:, sl], k[sl], None if bias is None else bias[sl], out[:, sl], chunk, save))
-    _join(main, pool)
-    return (out, SavedSpectra(buffers)) if save else out
-
-
-def _bwd_one(dout, u, k, bias, du, dk, dbias, chunk, saved):
+def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None, saved=None):
+    """Returns (du like u | None, dk (D, L) fp32 | None, dbias (D,) fp32 | None).
+    With saved= (from fftconv_fwd(save=True)) u and k are not read; pass them for their shapes/dtypes only."""
+    _require_gpu(dout, "dout")
     B, D, L = dout.shape
+    du = torch.empty_like(dout) if need_du else None
+    dk = torch.empty((D, L), dtype=torch.float32, device=dout.device) if need_dk else None
+    dbias = torch.empty((D,), dtype=torch.float32, device=dout.device) if need_dk else None
+    if B == 0:                                   # empty batch: the parameter gradients are sums over nothing
+        return du, None if dk is None else dk.zero_(), None if dbias is None else dbias.zero_()
+    chunk = _chunk_override() if chunk is None else int(chunk)
     tables = tables_for(dout.device, L)
     nbytes = lib().hyena_fftconv_workspace_bytes(B, D, L, 1, chunk)
     ws, stream = workspace_for(dout.device, nbytes)
@@ -321,33 +267,6 @@ def _bwd_one(dout, u, k, bias, du, dk, dbias, chunk, saved):
             check(lib().hyena_fftconv_bwd(dout.data_ptr(), u.data_ptr(), k.data_ptr(), bp, ptr(du), ptr(dk), ptr(dbias),
                                           B, D, L, dtype_code(dout.dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(),
                                           chunk, stream))
-
-
-def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None, saved=None):
-    """Returns (du like u | None, dk (D, L) fp32 | None, dbias (D,) fp32 | None).
-    With saved= (from fftconv_fwd(save=True)) u and k are not read; pass them for their shapes/dtypes only."""
-    _require_gpu(dout, "dout")
-    B, D, L = dout.shape
-    du = torch.empty_like(dout) if need_du else None
-    dk = torch.empty((D, L), dtype=torch.float32, device=dout.device) if need_dk else None
-    dbias = torch.empty((D,), dtype=torch.float32, device=dout.device) if need_dk else None
-    if B == 0:                                   # empty batch: the parameter gradients are sums over nothing
-        return du, None if dk is None else dk.zero_(), None if dbias is None else dbias.zero_()
-    chunk = _chunk_override() if chunk is None else int(chunk)
-    G = saved.groups if saved is not None else _groups_for(dout)          # the forward's grouping decides
-    if G == 1:
-        _bwd_one(dout, u, k, bias, du, dk, dbias, chunk, None if saved is None else saved.buffers[0])
-        return du, dk, dbias
-    per = D // G
-    tables_for(dout.device, L)
-    main, pool = _fork(dout.device, G)
-    cut = lambda t, sl, batched: None if t is None else (t[:, sl] if batched else t[sl])     # noqa: E731
-    for g, s in enumerate(pool):
-        sl = slice(g * per, (g + 1) * per)
-        with torch.cuda.stream(s):
-            _bwd_one(dout[:, sl], cut(u, sl, True), cut(k, sl, False), cut(bias, sl, False), cut(du, sl, True), cut(dk, sl, False),
-                     cut(dbias, sl, False), chunk, None if saved is None else saved.buffers[g])
-    _join(main, pool)
     return du, dk, dbias
 
 

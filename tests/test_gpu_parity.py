@@ -300,33 +300,3 @@ def test_randomised_shapes_vs_oracle_gpu(gpu_lib):
             assert (out.float().cpu() - r_out).abs().max() <= tol * r_out.abs().max() + 1e-6, tag
             assert (du.float().cpu() - r_du).abs().max() <= tol * r_du.abs().max() + 1e-6, tag
         assert _rel(dk, r_dk) < 2e-5 and _rel(dbias, r_db) < 3e-5, tag
-
-
-def test_channel_groups_on_side_streams_give_the_same_bits(gpu_lib, monkeypatch):
-    """HYENA_FFTCONV_STREAMS = G cuts a B = 1 call into G channel groups on side streams (fork/join around the caller's
-    stream): identical results, forward (+ saved spectra) and backward, also inside a hipGraph capture"""
-    dev = torch.device("cuda", 0)
-    u, k, bias, dout = (t.to(dev) for t in _inputs(1, 64, 70000, torch.bfloat16, seed=21))
-    monkeypatch.delenv("HYENA_FFTCONV_STREAMS", raising=False)
-    out0, saved0 = gpu_lib.fftconv_fwd(u, k, bias, save=True)
-    ref = (out0,) + tuple(gpu_lib.fftconv_bwd(dout, u, k, bias, saved=saved0))
-    assert saved0.groups == 1
-    monkeypatch.setenv("HYENA_FFTCONV_STREAMS", "4")
-    out1, saved1 = gpu_lib.fftconv_fwd(u, k, bias, save=True)
-    assert saved1.groups == 4 and saved1.numel() == saved0.numel()
-    got = (out1,) + tuple(gpu_lib.fftconv_bwd(dout, u, k, bias, saved=saved1))
-    got2 = (gpu_lib.fftconv_fwd(u, k, bias),) + tuple(gpu_lib.fftconv_bwd(dout, u, k, bias))      # recomputing path
-    torch.cuda.synchronize()
-    for a, b, c in zip(ref, got, got2):
-        assert torch.equal(a, b) and torch.equal(a, c)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        o, s = gpu_lib.fftconv_fwd(u, k, bias, save=True)
-        cap = (o,) + tuple(gpu_lib.fftconv_bwd(dout, u, k, bias, saved=s))
-    graph.replay()
-    torch.cuda.synchronize()
-    for a, b in zip(ref, cap):
-        assert torch.equal(a, b)
-    # batches > 1 are not grouped (their channel slices are not contiguous)
-    u2 = torch.randn(2, 64, 4096, device=dev).bfloat16()
-    assert gpu_lib.fftconv_fwd(u2, k[:, :4096].contiguous(), bias, save=True)[1].groups == 1
