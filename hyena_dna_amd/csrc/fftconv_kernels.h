@@ -592,8 +592,9 @@ template <int M1> struct ColCfg {
     // (600000: 5.20 vs 5.39 ms)
     static constexpr int MIN_WAVES = HY_COLW(M1);
     static constexpr size_t LDS_TABLES = (1024 + (size_t)M1) * sizeof(c32);
-    // (M1 = 1024: 64 KB plane + 16 KB tables = exactly half a CU's LDS; padding the plane against the 4-way bank conflict of
-    // its writes pushes it to one workgroup per CU: 8.24 vs 6.64 ms per step)
+    // (M1 = 1024: 64 KB plane + 16 KB tables = exactly half a CU's LDS.  The plane's writes have a 4-way bank conflict at
+    // C = 16; both cures measured worse: padding pushes it to one workgroup per CU (8.24 vs 6.64 ms per step), an XOR row
+    // swizzle turns the immediate-offset ds_writes into per-lane address arithmetic in a VALU-tight kernel (7.51 ms))
     static constexpr size_t LDS_PLANE = T > 1 ? (size_t)M1 * C * sizeof(float) : 0;
     static constexpr size_t LDS = LDS_TABLES + LDS_PLANE;
 };
