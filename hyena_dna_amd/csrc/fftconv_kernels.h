@@ -664,7 +664,8 @@ __device__ __forceinline__ void col_exchange(const c32 (&v)[32], c32 (&x2)[NB * 
 // Column group of a workgroup.  Workgroups are dealt to the 8 XCDs round-robin on their flattened index, so with the
 // plain mapping (group = blockIdx.x) the 8 neighbouring column groups of a row -- 8 x 128 B of one W row -- land in 8
 // different L2s.  Here each XCD owns a contiguous eighth of the columns instead (1 KB of every W row at M1 = 1024):
-// measured 6.92 -> 6.58 ms per step at L = 2^20, every column kernel 8-20 % faster (profiles/r1ab).
+// measured 6.92 -> 6.58 ms per step at L = 2^20, every column kernel 8-20 % faster (profiles/r1ab); runs of 2 or 4
+// adjacent groups per XCD instead of the whole eighth: 7.00 / 6.92 ms.
 __device__ __forceinline__ int col_group(int groups) {
     const int bx = blockIdx.x;
     return (groups & 7) == 0 ? (bx & 7) * (groups >> 3) + (bx >> 3) : bx;
