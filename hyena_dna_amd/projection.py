@@ -8,8 +8,8 @@ runs over all B*L positions.  At L = 2^20 hipBLASLt schedules it as N*K / tile =
 fp32 partial results summed in a fixed order (0.5 / 0.25 ms; deterministic), and the bias gradient as one fp32 column
 sum.  Forward and input gradient are the ordinary library GEMMs.
 
-Used by ``hyena_dna_amd.hyena.HyenaOperator`` for 16-bit activations (autocast) when there are at least
-``MIN_ROWS`` positions; everything else goes through ``torch.nn.functional.linear`` unchanged.
+Used by ``hyena_dna_amd.hyena.HyenaOperator`` on the GPU when there are at least ``MIN_ROWS`` positions (16-bit autocast, or
+plain fp32 / 16-bit tensors); everything else goes through ``torch.nn.functional.linear`` unchanged.
 """
 import torch
 import torch.nn.functional as F
@@ -61,10 +61,12 @@ class SplitKLinearFunc(torch.autograd.Function):
 
 def hyena_linear(x, weight, bias):
     """``F.linear(x, weight, bias)`` with the autocast semantics of ``nn.Linear`` and the split-K weight gradient."""
-    if x.is_cuda and torch.is_autocast_enabled():
-        dt = torch.get_autocast_dtype("cuda")
-        rows = x.numel() // x.shape[-1]
-        if dt in (torch.bfloat16, torch.float16) and rows >= MIN_ROWS and x.shape[-1] == weight.shape[1]:
-            with torch.autocast("cuda", enabled=False):
-                return SplitKLinearFunc.apply(x.to(dt).contiguous(), weight.to(dt), None if bias is None else bias.to(dt))
+    if x.is_cuda and x.shape[-1] == weight.shape[1] and x.numel() // x.shape[-1] >= MIN_ROWS:
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda")
+            if dt in (torch.bfloat16, torch.float16):
+                with torch.autocast("cuda", enabled=False):
+                    return SplitKLinearFunc.apply(x.to(dt).contiguous(), weight.to(dt), None if bias is None else bias.to(dt))
+        elif x.dtype == weight.dtype and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
+            return SplitKLinearFunc.apply(x.contiguous(), weight, bias)          # plain fp32 / 16-bit training: same pathology
     return F.linear(x, weight, bias)

@@ -124,3 +124,19 @@ def test_split_k_projection_on_gpu(gpu_lib):
     assert _rel(lin.weight.grad, dyb.t() @ xb) < 4e-3            # one bf16 rounding of the fp32-accumulated result
     assert _rel(lin.bias.grad, dyb.sum(0)) < 4e-3
     assert _rel(x.grad, (dyb @ lin.weight.detach().bfloat16().double())[None]) < 4e-3
+
+
+def test_split_k_projection_fp32_without_autocast(gpu_lib):
+    from hyena_dna_amd.projection import hyena_linear
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(2, 32768, 256, device="cuda", generator=g, requires_grad=True)
+    lin = torch.nn.Linear(256, 768).cuda()
+    dy = torch.randn(2, 32768, 768, device="cuda", generator=g)
+    y = hyena_linear(x, lin.weight, lin.bias)
+    assert y.dtype == torch.float32 and _rel(y, lin(x)) < 1e-6
+    y.backward(dy)
+    got = [x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    lin(x).backward(dy)
+    for a, b in zip(got, (x.grad, lin.weight.grad, lin.bias.grad)):
+        assert _rel(a, b) < 1e-4                                  # hipBLASLt may take TF32-free fp32 paths with other orders
