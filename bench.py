@@ -52,7 +52,7 @@ def measured_traffic(L, D, B, io_dtype, save):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
         c = t["config"]
-        if (c["seq_len"], c["d_model"], c["batch_per_gpu"], c["io_dtype"], c["save_spectra"]) == (L, D, B, io_dtype, bool(save)):
+        if (c["seq_len"], c["channels"], c["batch_per_gpu"], c["io_dtype"], c["save_spectra"]) == (L, D, B, io_dtype, bool(save)):
             return t["traffic_bytes_per_step"]
     except (OSError, KeyError, ValueError):
         pass
@@ -244,7 +244,7 @@ def main():
             "config": {"workload": f"Hyena long-conv layer call (fftconv fwd+bwd), L={L}, d={D}, B={B}/GPU, "
                                    f"{args.dtype} activations, fp32 filter and FFT math" +
                                    (" [FWD ONLY -- diagnostic]" if args.fwd_only else ""),
-                       "seq_len": L, "d_model": D, "batch_per_gpu": B, "io_dtype": args.dtype,
+                       "seq_len": L, "channels": D, "batch_per_gpu": B, "io_dtype": args.dtype,
                        "save_spectra": bool(save),
                        "chunk": int(_lib.lib().hyena_fftconv_default_chunk(B, D, L, 1)) if chunk is None else chunk,
                        "parallelism": f"dp{world} (batch-sharded, RCCL all-reduce of {MODEL_GRAD_ELEMS} fp32 grads/step)"

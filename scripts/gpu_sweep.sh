@@ -20,6 +20,6 @@ print("| L | B | d | fused ms | fused M nt/s | roofline frac | unfused hipFFT ms
 print("|---|---|---|---|---|---|---|---|")
 for a, b in zip(f, u):
     c = a["config"]
-    print(f"| {c['seq_len']} | {c['batch_per_gpu']} | {c['d_model']} | {a['ms_per_step']:.3f} | {a['value']/1e6:.1f} | "
+    print(f"| {c['seq_len']} | {c['batch_per_gpu']} | {c['channels']} | {a['ms_per_step']:.3f} | {a['value']/1e6:.1f} | "
           f"{a['roofline']['frac']:.3f} | {b['ms_per_step']:.2f} | {b['ms_per_step']/a['ms_per_step']:.1f}x |")
 PY
