@@ -11,10 +11,11 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libhyena_fftconv.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 HYENA_F32, HYENA_BF16, HYENA_F16 = 0, 1, 2
 MAX_L = 1048576
+PLAN_NONE, PLAN_ONCHIP, PLAN_TWO_LEVEL = 0, 1, 2
 
 _DTYPES = {torch.float32: HYENA_F32, torch.bfloat16: HYENA_BF16, torch.float16: HYENA_F16}
 
@@ -84,6 +85,8 @@ def lib():
         L.hyena_fftconv_error_string.argtypes = [c_int]
         L.hyena_fftconv_fft_size.restype = c_int
         L.hyena_fftconv_fft_size.argtypes = [c_int]
+        L.hyena_fftconv_plan.restype = c_int
+        L.hyena_fftconv_plan.argtypes = [c_int]
         L.hyena_fftconv_table_bytes.restype = c_size_t
         L.hyena_fftconv_table_bytes.argtypes = [c_int]
         L.hyena_fftconv_init_tables.restype = c_int
@@ -104,7 +107,7 @@ def lib():
         L.hyena_fftconv_fwd_save.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                              c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]
         L.hyena_fftconv_bwd_saved.restype = c_int
-        L.hyena_fftconv_bwd_saved.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+        L.hyena_fftconv_bwd_saved.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                               c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]
         # fused mixer shell (include/hyena_mixer.h)
         L.hyena_mixer_pre_fwd.restype = c_int
@@ -171,7 +174,7 @@ def tables_for(device, L):
     M = lib().hyena_fftconv_fft_size(int(L))
     if M == 0:
         raise HyenaLibraryError(f"hyena fftconv: unsupported sequence length L={L} (1 <= L <= {MAX_L})")
-    key = (device.index, M)
+    key = (device.index, M, lib().hyena_fftconv_plan(int(L)))
     t = _tables.get(key)
     if t is None:
         with _lock:
@@ -212,6 +215,8 @@ def save_spectra_default(B, D, L):
     mode = os.environ.get("HYENA_FFTCONV_SAVE_SPECTRA", "auto").lower()
     if mode in ("0", "off", "false"):
         return False
+    if lib().hyena_fftconv_plan(int(L)) == PLAN_ONCHIP:
+        return False         # nothing worth keeping: the only intermediate is the filter spectrum, one transform per channel
     if mode in ("1", "on", "true"):
         return True
     return saved_bytes(B, D, L) <= float(os.environ.get("HYENA_FFTCONV_SAVE_LIMIT_GB", "6")) * 2 ** 30
@@ -244,7 +249,8 @@ def fftconv_fwd(u, k, bias, chunk=None, save=False):
 
 def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None, saved=None):
     """Returns (du like u | None, dk (D, L) fp32 | None, dbias (D,) fp32 | None).
-    With saved= (from fftconv_fwd(save=True)) u and k are not read; pass them for their shapes/dtypes only."""
+    With saved= (from fftconv_fwd(save=True)) k is not read, and u only on the workspace-free path (L <= 32768, where
+    the saved buffer holds the filter spectrum alone)."""
     _require_gpu(dout, "dout")
     B, D, L = dout.shape
     du = torch.empty_like(dout) if need_du else None
@@ -260,7 +266,7 @@ def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None, saved=
     ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
     with _backend.guard(dout.device):
         if saved is not None:
-            check(lib().hyena_fftconv_bwd_saved(dout.data_ptr(), bp, ptr(du), ptr(dk), ptr(dbias), B, D, L,
+            check(lib().hyena_fftconv_bwd_saved(dout.data_ptr(), ptr(u), bp, ptr(du), ptr(dk), ptr(dbias), B, D, L,
                                                 dtype_code(dout.dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(), chunk,
                                                 saved.data_ptr(), saved.numel(), stream))
         else:

@@ -22,25 +22,22 @@
 
 using namespace hyena;
 
-#ifdef HIPEMU
-#define HY_LAUNCH(kernel, grid, block, smem, stream, ...)                              \
-    do {                                                                                \
-        auto _args = std::make_tuple(__VA_ARGS__);                                      \
-        hipemu::launch(grid, block, smem, [&] { std::apply(kernel, _args); });          \
-    } while (0)
-#include <tuple>
-static inline int hy_launch_error() { return 0; }
-#else
-#define HY_LAUNCH(kernel, grid, block, smem, stream, ...) \
-    hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
-static inline int hy_launch_error() { return hipGetLastError() != hipSuccess; }
-#endif
+#include "launch.h"
+#include "onchip_host.h"
 
 namespace {
 
 struct Plan {
     int L, M, M1;
+    int R;          // > 0: the workspace-free path (onchip_kernels.h), M = 1024 R;  0: the two-level path below
 };
+
+// L <= 32768 runs on the workspace-free path unless HYENA_FFTCONV_ONCHIP=0 (read per call: a test / profiling knob that
+// keeps the two-level kernels reachable at small sizes; it selects between two implementations of the same HIP library)
+bool onchip_enabled() {
+    const char* e = std::getenv("HYENA_FFTCONV_ONCHIP");
+    return !(e != nullptr && e[0] == '0');
+}
 
 // Column sizes M1 the kernels are instantiated for (M = M1 x 1024 complex points serve L <= M): the powers of two, and
 // 2^a x {3, 5, 7} where the second-stage operands still fit the register budget -- so that the zero padding beyond 2L
@@ -50,6 +47,13 @@ const int SUPPORTED_M1[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 
 
 bool make_plan(int L, Plan* p) {
     if (L < 1 || L > HYENA_MAX_L) return false;
+    p->R = onchip_enabled() ? oc::plan_r(L) : 0;
+    if (p->R) {
+        p->L = L;
+        p->M1 = p->R;
+        p->M = 1024 * p->R;
+        return true;
+    }
     for (int m1 : SUPPORTED_M1) {
         if ((long)m1 * 1024 >= L) {
             p->L = L;
@@ -184,7 +188,7 @@ const size_t CACHE_BUDGET = (size_t)8 << 30;
 
 extern "C" {
 
-int hyena_fftconv_abi_version(void) { return 2; }
+int hyena_fftconv_abi_version(void) { return 3; }
 
 const char* hyena_fftconv_error_string(int status) {
     switch (status) {
@@ -197,6 +201,12 @@ const char* hyena_fftconv_error_string(int status) {
     }
 }
 
+int hyena_fftconv_plan(int L) {
+    Plan p;
+    if (!make_plan(L, &p)) return HYENA_PLAN_NONE;
+    return p.R ? HYENA_PLAN_ONCHIP : HYENA_PLAN_TWO_LEVEL;
+}
+
 int hyena_fftconv_fft_size(int L) {
     Plan p;
     return make_plan(L, &p) ? p.M : 0;
@@ -205,6 +215,7 @@ int hyena_fftconv_fft_size(int L) {
 size_t hyena_fftconv_table_bytes(int L) {
     Plan p;
     if (!make_plan(L, &p)) return 0;
+    if (p.R) return oc::table_entries(p.R) * sizeof(c32);
     return (size_t)4096 * sizeof(c32);
 }
 
@@ -212,8 +223,18 @@ int hyena_fftconv_init_tables(void* d_tables, int L) {
     Plan p;
     if (d_tables == nullptr) return HYENA_ERR_BAD_ARG;
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
-    std::vector<c32> h(4096);
+    std::vector<c32> h(p.R ? oc::table_entries(p.R) : 4096);
     for (auto& e : h) { e.x = 1.0f; e.y = 0.0f; }
+    if (p.R) {
+        oc::build_tables(p.R, reinterpret_cast<float*>(h.data()));
+#ifdef HIPEMU
+        memcpy(d_tables, h.data(), h.size() * sizeof(c32));
+#else
+        if (hipMemcpy(d_tables, h.data(), h.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess)
+            return HYENA_ERR_LAUNCH;
+#endif
+        return HYENA_OK;
+    }
     const double tau = 6.283185307179586476925286766559;
     for (int i = 0; i < 1024; ++i) {
         double a = -tau * (double)i / (double)p.M;
@@ -246,6 +267,7 @@ int hyena_fftconv_init_tables(void* d_tables, int L) {
 int hyena_fftconv_default_chunk(int B, int D, int L, int backward) {
     Plan p;
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
+    if (p.R) return D;
     const size_t per_channel = (size_t)(backward ? 2 * B + 2 : B + 1) * p.M * sizeof(c32);
     size_t c = CACHE_BUDGET / per_channel;
     const size_t cmax = ((size_t)1 << 28) / p.M;     // a chunk's [chunk][M] slab stays below 2 GiB (32-bit buffer offsets)
@@ -258,6 +280,7 @@ int hyena_fftconv_default_chunk(int B, int D, int L, int backward) {
 size_t hyena_fftconv_workspace_bytes(int B, int D, int L, int backward, int chunk) {
     Plan p;
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
+    if (p.R) return oc::spectrum_bytes(D, p.R);              // the filter spectrum is this path's only intermediate
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, backward);
     if (chunk > D) chunk = D;
     if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
@@ -272,6 +295,7 @@ static inline c32* saved_wu(void* saved, int D, int M) { return reinterpret_cast
 size_t hyena_fftconv_saved_bytes(int B, int D, int L) {
     Plan p;
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
+    if (p.R) return oc::spectrum_bytes(D, p.R);              // H only: the backward re-transforms u on chip
     return (size_t)(B + 1) * D * p.M * sizeof(c32);
 }
 
@@ -283,6 +307,15 @@ static int fwd_impl(const void* u, const float* k, const float* bias, void* out,
         D < 1 || (dtype != HYENA_F32 && dtype != HYENA_BF16 && dtype != HYENA_F16))
         return HYENA_ERR_BAD_ARG;
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
+    if (p.R) {
+        if ((size_t)D * p.M * sizeof(c32) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;       // 32-bit buffer offsets into H
+        if (workspace_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
+        if (saved != nullptr && saved_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
+        void* H = saved ? saved : workspace;
+        int st = oc::launch_spec(p.R, k, bias, H, d_tables, D, L, stream);
+        if (st) return st;
+        return oc::launch_conv(p.R, u, out, H, d_tables, B, D, L, dtype, 0, stream);
+    }
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, 0);
     if (chunk > D) chunk = D;
     if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
@@ -333,6 +366,23 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
         return HYENA_ERR_BAD_ARG;
     if (dbias != nullptr && dk == nullptr) return HYENA_ERR_BAD_ARG;
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
+    if (p.R) {
+        if (dk != nullptr && u == nullptr) return HYENA_ERR_BAD_ARG;        // this path keeps no spectrum of u: it re-reads u
+        if ((size_t)D * p.M * sizeof(c32) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;
+        if (workspace_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
+        if (saved != nullptr && saved_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
+        int st;
+        if (du != nullptr) {
+            const void* H = saved;
+            if (H == nullptr) {
+                if ((st = oc::launch_spec(p.R, k, bias, workspace, d_tables, D, L, stream))) return st;
+                H = workspace;
+            }
+            if ((st = oc::launch_conv(p.R, dout, du, H, d_tables, B, D, L, dtype, 1, stream))) return st;
+        }
+        if (dk != nullptr && (st = oc::launch_dk(p.R, dout, u, dk, dbias, d_tables, B, D, L, dtype, stream))) return st;
+        return HYENA_OK;
+    }
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, 1);
     if (chunk > D) chunk = D;
     if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
@@ -408,11 +458,11 @@ int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const flo
                     stream);
 }
 
-int hyena_fftconv_bwd_saved(const void* dout, const float* bias, void* du, float* dk, float* dbias, int B, int D, int L,
-                            int dtype, const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
+int hyena_fftconv_bwd_saved(const void* dout, const void* u, const float* bias, void* du, float* dk, float* dbias, int B, int D,
+                            int L, int dtype, const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
                             const void* saved, size_t saved_bytes, void* stream) {
     if (saved == nullptr) return HYENA_ERR_BAD_ARG;
-    return bwd_impl(dout, nullptr, nullptr, bias, du, dk, dbias, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk,
+    return bwd_impl(dout, u, nullptr, bias, du, dk, dbias, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk,
                     saved, saved_bytes, stream);
 }
 

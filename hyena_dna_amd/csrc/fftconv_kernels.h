@@ -47,6 +47,12 @@
 #define HY_UNIFORM_PTR(T, p) hyena::uniform_ptr<T>(p)
 #endif
 
+#ifdef HIPEMU
+#define HY_CONST_TABLE static const
+#else
+#define HY_CONST_TABLE __device__ static const
+#endif
+
 #include <stdint.h>
 
 namespace hyena {
@@ -505,6 +511,7 @@ __device__ __forceinline__ void dft_any(c32 (&y)[N], const HY_LDS lc32* tw, int 
     else dft_mixed<N, INV>(y, tw, tw_step);
 }
 
+#ifndef HY_HELPERS_ONLY      // (onchip_kernels.h takes the helpers above and none of the two-level kernels below)
 // ---------------------------------------------------------------------------------------------
 // 1024-point row transform on a half-wavefront: lane j (0..31) holds v[s] = x[j + 32 s] on entry and
 // X[j + 32 q] on exit (Stockham 32 x 32, natural order).  `xb` = this half's LDS exchange buffer of
@@ -870,11 +877,6 @@ __device__ __forceinline__ c32 packed_product(c32 x, c32 xp, c32 h, c32 hp, c32 
 // w_M^k for k = k1 + M1 (j + 32 q):  (w_M^k1 * w_1024^j) * w_32^q, the last factor from a 32-entry constant table
 // (a plain array, not a chain of conditionals: the loops calling this must stay under hipcc's unroll size limit;
 // the index is a compile-time constant after unrolling, so the loads fold to immediates).
-#ifdef HIPEMU
-#define HY_CONST_TABLE static const
-#else
-#define HY_CONST_TABLE __device__ static const
-#endif
 HY_CONST_TABLE float HY_COS32[32] = {1.0f, 0.98078528040323043058f, 0.92387953251128673848f, 0.83146961230254523567f, 0.70710678118654757274f, 0.55557023301960228867f, 0.38268343236508983729f, 0.19509032201612833135f, 0.0f, -0.19509032201612819257f, -0.38268343236508972627f, -0.5555702330196019556f, -0.70710678118654746172f, -0.83146961230254534669f, -0.92387953251128673848f, -0.98078528040323043058f, -1.0f, -0.98078528040323043058f, -0.92387953251128684951f, -0.83146961230254545772f, -0.70710678118654768376f, -0.55557023301960217765f, -0.38268343236509033689f, -0.19509032201612866442f, 0.0f, 0.19509032201612830359f, 0.38268343236509000382f, 0.55557023301960184458f, 0.70710678118654735069f, 0.83146961230254523567f, 0.92387953251128651644f, 0.98078528040323031956f};
 HY_CONST_TABLE float HY_SIN32[32] = {0.0f, 0.19509032201612824808f, 0.38268343236508978178f, 0.55557023301960217765f, 0.70710678118654746172f, 0.83146961230254523567f, 0.92387953251128673848f, 0.98078528040323043058f, 1.0f, 0.98078528040323043058f, 0.92387953251128673848f, 0.83146961230254545772f, 0.70710678118654757274f, 0.55557023301960217765f, 0.3826834323650898928f, 0.19509032201612860891f, 0.0f, -0.19509032201612835911f, -0.38268343236508967076f, -0.5555702330196019556f, -0.70710678118654746172f, -0.83146961230254523567f, -0.92387953251128651644f, -0.98078528040323031956f, -1.0f, -0.98078528040323043058f, -0.92387953251128662746f, -0.83146961230254545772f, -0.70710678118654768376f, -0.55557023301960217765f, -0.3826834323650903924f, -0.19509032201612871993f};
 __device__ __forceinline__ c32 pw_tw(c32 wkj, int q) {
@@ -1287,5 +1289,7 @@ __global__ void __launch_bounds__(256) row0_dk_reduce_kernel(RowArgs a) {
         O[e] = acc;
     }
 }
+
+#endif  // HY_HELPERS_ONLY
 
 }  // namespace hyena

@@ -1,0 +1,145 @@
+// onchip.hip -- host side of the workspace-free long convolution for L <= 32768 (onchip_kernels.h).  Reached only
+// through the C ABI of fftconv.hip; stateless like it (no allocation, no synchronisation, launches on the caller's stream).
+#include "onchip_kernels.h"
+#include "launch.h"
+#include "onchip_host.h"
+#include "../../include/hyena_fftconv.h"
+
+#include <cmath>
+
+namespace hyena {
+namespace oc {
+
+int plan_r(int L) {
+    if (L < 1 || L > MAX_L) return 0;
+    int r = 1;
+    while (1024 * r < L) r *= 2;
+    return r;
+}
+
+namespace {
+// one table set [tw1[11][T] | tw2[10][R]] of transform size 1024 R with input twist phi
+void fill_set(int R, double phi, float* out) {
+    const int T = 32 * R, M = 1024 * R;
+    const double tau = 6.283185307179586476925286766559;
+    for (int t = 0; t < T; ++t) {
+        for (int b = 0; b < 8; ++b) {                        // tB[b] = w_M^(t (b + phi))
+            const double a = -tau * ((double)t * ((double)b + phi)) / (double)M;
+            out[2 * (b * T + t)] = (float)std::cos(a);
+            out[2 * (b * T + t) + 1] = (float)std::sin(a);
+        }
+        for (int a3 = 1; a3 < 4; ++a3) {                     // tA[a] = w_M^(8 t a)
+            const double a = -tau * (double)(((long)8 * t * a3) % M) / (double)M;
+            out[2 * ((7 + a3) * T + t)] = (float)std::cos(a);
+            out[2 * ((7 + a3) * T + t) + 1] = (float)std::sin(a);
+        }
+    }
+    float* o2 = out + 2 * 11 * T;
+    for (int tp = 0; tp < R; ++tp) {
+        for (int b = 1; b < 8; ++b) {                        // tB[b] = w_T^(t' b)
+            const double a = -tau * (double)(tp * b) / (double)T;
+            o2[2 * ((b - 1) * R + tp)] = (float)std::cos(a);
+            o2[2 * ((b - 1) * R + tp) + 1] = (float)std::sin(a);
+        }
+        for (int a3 = 1; a3 < 4; ++a3) {                     // tA[a] = w_T^(8 t' a)
+            const double a = -tau * (double)((8 * tp * a3) % T) / (double)T;
+            o2[2 * ((6 + a3) * R + tp)] = (float)std::cos(a);
+            o2[2 * ((6 + a3) * R + tp) + 1] = (float)std::sin(a);
+        }
+    }
+}
+size_t set_entries(int R) { return (size_t)11 * 32 * R + (size_t)10 * R; }
+}  // namespace
+
+// layout: the set of size R with phi = 1/4; for R = 32 additionally the two parity sets of size 16 (phi = 1/8, 5/8)
+// that dk_kernel<16, 2> uses
+size_t table_entries(int R) { return set_entries(R) + (R == 32 ? 2 * set_entries(16) : 0); }
+
+void build_tables(int R, float* h) {
+    fill_set(R, 0.25, h);
+    if (R == 32) {
+        fill_set(16, 0.125, h + 2 * set_entries(32));
+        fill_set(16, 0.625, h + 2 * (set_entries(32) + set_entries(16)));
+    }
+}
+
+size_t spectrum_bytes(int D, int R) { return (size_t)D * 1024 * R * sizeof(c32); }
+
+template <int R>
+static int spec_r(const SpecArgs& a, void* stream) {
+    typedef WgCfg<R> W;
+    static thread_local int done = -1;
+    hy_allow_lds(spec_kernel<R>, W::LDS, &done);
+    HY_LAUNCH((spec_kernel<R>), dim3((a.D + W::RPW - 1) / W::RPW), dim3(W::WGT), W::LDS, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+template <int R>
+static int conv_r(const ConvArgs& a, void* stream) {
+    typedef WgCfg<R> W;
+    static thread_local int done = -1;
+    hy_allow_lds(conv_kernel<R>, W::LDS, &done);
+    const int rows = a.B * a.D;
+    HY_LAUNCH((conv_kernel<R>), dim3((rows + W::RPW - 1) / W::RPW), dim3(W::WGT), W::LDS, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+template <int R, int NP>
+static int dk_r(const DkArgs& a, void* stream) {
+    typedef DkCfg<R, NP> K;
+    static thread_local int done = -1;
+    hy_allow_lds(dk_kernel<R, NP>, K::LDS, &done);
+    HY_LAUNCH((dk_kernel<R, NP>), dim3(a.D), dim3(K::WGT), K::LDS, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+#define HY_OC_SWITCH(R, call)                 \
+    switch (R) {                              \
+        case 1: return call(1);               \
+        case 2: return call(2);               \
+        case 4: return call(4);               \
+        case 8: return call(8);               \
+        case 16: return call(16);             \
+        case 32: return call(32);             \
+        default: return HYENA_ERR_UNSUPPORTED_L; \
+    }
+
+int launch_spec(int R, const float* k, const float* bias, void* H, const void* tab, int D, int L, void* stream) {
+    SpecArgs a;
+    a.k = k; a.bias = bias; a.H = reinterpret_cast<c32*>(H); a.tab = reinterpret_cast<const c32*>(tab); a.D = D; a.L = L;
+#define HY_CALL(r) spec_r<r>(a, stream)
+    HY_OC_SWITCH(R, HY_CALL)
+#undef HY_CALL
+}
+
+int launch_conv(int R, const void* x, void* out, const void* H, const void* tab, int B, int D, int L, int dtype, int conj,
+                void* stream) {
+    ConvArgs a;
+    a.x = x; a.out = out; a.H = reinterpret_cast<const c32*>(H); a.tab = reinterpret_cast<const c32*>(tab);
+    a.B = B; a.D = D; a.L = L; a.dtype = dtype; a.conj_sign = conj ? -1.0f : 1.0f;
+#define HY_CALL(r) conv_r<r>(a, stream)
+    HY_OC_SWITCH(R, HY_CALL)
+#undef HY_CALL
+}
+
+int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, const void* tab, int B, int D, int L, int dtype,
+              void* stream) {
+    DkArgs a;
+    a.dout = dout; a.u = u; a.dk = dk; a.dbias = dbias; a.tab = reinterpret_cast<const c32*>(tab);
+    a.B = B; a.D = D; a.L = L; a.dtype = dtype;
+    if (R == 32) {       // two 16384-point parity problems; their tables follow the size-32 set
+        a.tab = reinterpret_cast<const c32*>(tab) + set_entries(32);
+        return dk_r<16, 2>(a, stream);
+    }
+#define HY_CALL(r) dk_r<r, 1>(a, stream)
+    switch (R) {
+        case 1: return HY_CALL(1);
+        case 2: return HY_CALL(2);
+        case 4: return HY_CALL(4);
+        case 8: return HY_CALL(8);
+        case 16: return HY_CALL(16);
+        default: return HYENA_ERR_UNSUPPORTED_L;
+    }
+#undef HY_CALL
+}
+
+}  // namespace oc
+}  // namespace hyena

@@ -1,0 +1,28 @@
+// onchip_host.h -- host-side interface of the workspace-free path (onchip.hip) used by the C ABI in fftconv.hip.
+#pragma once
+#include <stddef.h>
+
+namespace hyena {
+namespace oc {
+
+enum { MAX_L = 32768 };
+
+// R = M / 1024 (1, 2, 4, ..., 32) for a sequence length this path serves, 0 otherwise
+int plan_r(int L);
+// twiddle tables: number of complex64 entries, and their construction on the host (double precision)
+size_t table_entries(int R);
+void build_tables(int R, float* host_c32);
+// device memory for the filter spectrum H [D][M] (the only intermediate of this path)
+size_t spectrum_bytes(int D, int R);
+
+// H = (FFT(k) + bias) / M into `H`
+int launch_spec(int R, const float* k, const float* bias, void* H, const void* tab, int D, int L, void* stream);
+// out = conv(x, H) (conj = 0) or corr(x, H) (conj = 1)
+int launch_conv(int R, const void* x, void* out, const void* H, const void* tab, int B, int D, int L, int dtype, int conj,
+                void* stream);
+// dk (and dbias) from dout and u
+int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, const void* tab, int B, int D, int L, int dtype,
+              void* stream);
+
+}  // namespace oc
+}  // namespace hyena

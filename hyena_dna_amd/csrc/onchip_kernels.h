@@ -1,0 +1,657 @@
+// onchip_kernels.h -- workspace-free long convolution for M <= 32768: one workgroup per (b, d) row, the whole
+// transform lives in registers and LDS, HBM traffic = the operator's algorithmic bytes (+ the filter spectrum).
+//
+// What is computed: the same fftconv_ref (src/models/sequence/hyena.py:59-88) as fftconv_kernels.h, for rows short
+// enough to fit one CU (the reference's own fused kernel has this shape -- one block per (b, h) row, grid (B, H),
+// csrc/fftconv/fftconv_cuda.cu:805 -- but stops at fft_size 16384 / L 8192 and needs even L; nothing of its cuFFTDx
+// structure is used here).
+//
+// Transform: "right-angle" (negacyclic) convolution.  For a real row x of length L <= M put
+//     c[n] = x[n] e^(-i pi n / 2M),  n < M          (zero beyond L),         X = FFT_M(c)
+// X[m] is bin 2m of the odd-frequency DFT of the zero-padded length-2M real row; the remaining (odd) bins are complex
+// conjugates, so X alone carries the whole spectrum and a negacyclic convolution of length 2M -- which IS the linear
+// convolution here, because 2L - 1 <= 2M never wraps -- is the plain elementwise product
+//     out = Re( IFFT_M( X_u .* X_k ) e^(+i pi n / 2M) ),      du, dk: the same with conj(X_k), conj(X_u).
+// There is no real/complex unpacking step, hence no partner index (M - k), no self-paired rows and no exchange for
+// the product: every thread multiplies the 32 spectrum values it already holds.  (Numerically checked against
+// numpy in scratch models and by tests/ against the oracle.)
+//
+// Decomposition M = 32 x 32 x R (R = 1, 2, 4, ..., 32), T = 32 R threads per row, 32 points per thread in every pass:
+//     pass 1   thread t:          radix-32 DFT over s of c[t + T s]            -> index ka;  x w_M^(t (ka + 1/4))
+//     exchange 1 (LDS, workgroup)
+//     pass 2   thread (ka, t'):   radix-32 DFT over s' of y[ka][R s' + t']     -> index kb1; x w_T^(t' kb1)
+//     exchange 2 (LDS, inside groups of R adjacent lanes: no workgroup barrier)
+//     pass 3   thread (ka, g):    32/R radix-R DFTs over t' for kb1 = g + R i  -> index kb2
+// Result X[ka + 32 kb1 + 1024 kb2] sits in register q = i R + kb2 of thread tau = ka R + g; spectra in memory use
+// exactly that order (element q T + tau), so filter loads are coalesced and need no permutation.  The inverse runs
+// the three passes backwards with conjugated twiddles.  The e^(-i pi n / 2M) twist costs nothing in pass 1: its
+// t-part is folded into the twiddle (the "+ 1/4"), its s-part is a compile-time constant per register.
+//
+// LDS: exchange buffer of 32 x 33 R elements per row (complex64, or one float plane at a time for R = 32: 135 KB),
+// padded so that every access is bank-conflict free (see x1_* / x2_*).
+//
+// Compiled by hipcc for gfx950 (product) and, with -DHIPEMU, by g++ against tests/hipemu (tests only).
+#pragma once
+#define HY_HELPERS_ONLY
+#include "fftconv_kernels.h"
+
+namespace hyena {
+namespace oc {
+
+#ifdef HIPEMU
+#define HY_WAVE_SYNC() hipemu::yield(2)
+#else
+// LDS operations of one wavefront execute in order, so data exchanged between lanes of the same wavefront needs no
+// workgroup barrier; this only stops the compiler from moving LDS accesses across the exchange point.
+#define HY_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+// cos / sin (2 pi j / 256): the per-register part of the input twist, e^(-2 pi i s phi / 32) with phi = PHI8 / 8
+HY_CONST_TABLE float OC_COS256[256] = {1.000000000e+00f, 9.996988177e-01f, 9.987954497e-01f, 9.972904325e-01f, 9.951847196e-01f, 9.924795628e-01f, 9.891765118e-01f, 9.852776527e-01f, 9.807852507e-01f, 9.757021070e-01f, 9.700312614e-01f, 9.637760520e-01f, 9.569403529e-01f, 9.495281577e-01f, 9.415440559e-01f, 9.329928160e-01f, 9.238795042e-01f, 9.142097831e-01f, 9.039893150e-01f, 8.932242990e-01f, 8.819212914e-01f, 8.700869679e-01f, 8.577286005e-01f, 8.448535800e-01f, 8.314695954e-01f, 8.175848126e-01f, 8.032075167e-01f, 7.883464098e-01f, 7.730104327e-01f, 7.572088242e-01f, 7.409511209e-01f, 7.242470980e-01f, 7.071067691e-01f, 6.895405650e-01f, 6.715589762e-01f, 6.531728506e-01f, 6.343932748e-01f, 6.152315736e-01f, 5.956993103e-01f, 5.758081675e-01f, 5.555702448e-01f, 5.349976420e-01f, 5.141027570e-01f, 4.928981960e-01f, 4.713967443e-01f, 4.496113360e-01f, 4.275550842e-01f, 4.052413106e-01f, 3.826834261e-01f, 3.598950505e-01f, 3.368898630e-01f, 3.136817515e-01f, 2.902846634e-01f, 2.667127550e-01f, 2.429801822e-01f, 2.191012353e-01f, 1.950903237e-01f, 1.709618866e-01f, 1.467304677e-01f, 1.224106774e-01f, 9.801714122e-02f, 7.356456667e-02f, 4.906767607e-02f, 2.454122901e-02f, 6.123234263e-17f, -2.454122901e-02f, -4.906767607e-02f, -7.356456667e-02f, -9.801714122e-02f, -1.224106774e-01f, -1.467304677e-01f, -1.709618866e-01f, -1.950903237e-01f, -2.191012353e-01f, -2.429801822e-01f, -2.667127550e-01f, -2.902846634e-01f, -3.136817515e-01f, -3.368898630e-01f, -3.598950505e-01f, -3.826834261e-01f, -4.052413106e-01f, -4.275550842e-01f, -4.496113360e-01f, -4.713967443e-01f, -4.928981960e-01f, -5.141027570e-01f, -5.349976420e-01f, -5.555702448e-01f, -5.758081675e-01f, -5.956993103e-01f, -6.152315736e-01f, -6.343932748e-01f, -6.531728506e-01f, -6.715589762e-01f, -6.895405650e-01f, -7.071067691e-01f, -7.242470980e-01f, -7.409511209e-01f, -7.572088242e-01f, -7.730104327e-01f, -7.883464098e-01f, -8.032075167e-01f, -8.175848126e-01f, -8.314695954e-01f, -8.448535800e-01f, -8.577286005e-01f, -8.700869679e-01f, -8.819212914e-01f, -8.932242990e-01f, -9.039893150e-01f, -9.142097831e-01f, -9.238795042e-01f, -9.329928160e-01f, -9.415440559e-01f, -9.495281577e-01f, -9.569403529e-01f, -9.637760520e-01f, -9.700312614e-01f, -9.757021070e-01f, -9.807852507e-01f, -9.852776527e-01f, -9.891765118e-01f, -9.924795628e-01f, -9.951847196e-01f, -9.972904325e-01f, -9.987954497e-01f, -9.996988177e-01f, -1.000000000e+00f, -9.996988177e-01f, -9.987954497e-01f, -9.972904325e-01f, -9.951847196e-01f, -9.924795628e-01f, -9.891765118e-01f, -9.852776527e-01f, -9.807852507e-01f, -9.757021070e-01f, -9.700312614e-01f, -9.637760520e-01f, -9.569403529e-01f, -9.495281577e-01f, -9.415440559e-01f, -9.329928160e-01f, -9.238795042e-01f, -9.142097831e-01f, -9.039893150e-01f, -8.932242990e-01f, -8.819212914e-01f, -8.700869679e-01f, -8.577286005e-01f, -8.448535800e-01f, -8.314695954e-01f, -8.175848126e-01f, -8.032075167e-01f, -7.883464098e-01f, -7.730104327e-01f, -7.572088242e-01f, -7.409511209e-01f, -7.242470980e-01f, -7.071067691e-01f, -6.895405650e-01f, -6.715589762e-01f, -6.531728506e-01f, -6.343932748e-01f, -6.152315736e-01f, -5.956993103e-01f, -5.758081675e-01f, -5.555702448e-01f, -5.349976420e-01f, -5.141027570e-01f, -4.928981960e-01f, -4.713967443e-01f, -4.496113360e-01f, -4.275550842e-01f, -4.052413106e-01f, -3.826834261e-01f, -3.598950505e-01f, -3.368898630e-01f, -3.136817515e-01f, -2.902846634e-01f, -2.667127550e-01f, -2.429801822e-01f, -2.191012353e-01f, -1.950903237e-01f, -1.709618866e-01f, -1.467304677e-01f, -1.224106774e-01f, -9.801714122e-02f, -7.356456667e-02f, -4.906767607e-02f, -2.454122901e-02f, -1.836970147e-16f, 2.454122901e-02f, 4.906767607e-02f, 7.356456667e-02f, 9.801714122e-02f, 1.224106774e-01f, 1.467304677e-01f, 1.709618866e-01f, 1.950903237e-01f, 2.191012353e-01f, 2.429801822e-01f, 2.667127550e-01f, 2.902846634e-01f, 3.136817515e-01f, 3.368898630e-01f, 3.598950505e-01f, 3.826834261e-01f, 4.052413106e-01f, 4.275550842e-01f, 4.496113360e-01f, 4.713967443e-01f, 4.928981960e-01f, 5.141027570e-01f, 5.349976420e-01f, 5.555702448e-01f, 5.758081675e-01f, 5.956993103e-01f, 6.152315736e-01f, 6.343932748e-01f, 6.531728506e-01f, 6.715589762e-01f, 6.895405650e-01f, 7.071067691e-01f, 7.242470980e-01f, 7.409511209e-01f, 7.572088242e-01f, 7.730104327e-01f, 7.883464098e-01f, 8.032075167e-01f, 8.175848126e-01f, 8.314695954e-01f, 8.448535800e-01f, 8.577286005e-01f, 8.700869679e-01f, 8.819212914e-01f, 8.932242990e-01f, 9.039893150e-01f, 9.142097831e-01f, 9.238795042e-01f, 9.329928160e-01f, 9.415440559e-01f, 9.495281577e-01f, 9.569403529e-01f, 9.637760520e-01f, 9.700312614e-01f, 9.757021070e-01f, 9.807852507e-01f, 9.852776527e-01f, 9.891765118e-01f, 9.924795628e-01f, 9.951847196e-01f, 9.972904325e-01f, 9.987954497e-01f, 9.996988177e-01f};
+HY_CONST_TABLE float OC_SIN256[256] = {0.000000000e+00f, 2.454122901e-02f, 4.906767607e-02f, 7.356456667e-02f, 9.801714122e-02f, 1.224106774e-01f, 1.467304677e-01f, 1.709618866e-01f, 1.950903237e-01f, 2.191012353e-01f, 2.429801822e-01f, 2.667127550e-01f, 2.902846634e-01f, 3.136817515e-01f, 3.368898630e-01f, 3.598950505e-01f, 3.826834261e-01f, 4.052413106e-01f, 4.275550842e-01f, 4.496113360e-01f, 4.713967443e-01f, 4.928981960e-01f, 5.141027570e-01f, 5.349976420e-01f, 5.555702448e-01f, 5.758081675e-01f, 5.956993103e-01f, 6.152315736e-01f, 6.343932748e-01f, 6.531728506e-01f, 6.715589762e-01f, 6.895405650e-01f, 7.071067691e-01f, 7.242470980e-01f, 7.409511209e-01f, 7.572088242e-01f, 7.730104327e-01f, 7.883464098e-01f, 8.032075167e-01f, 8.175848126e-01f, 8.314695954e-01f, 8.448535800e-01f, 8.577286005e-01f, 8.700869679e-01f, 8.819212914e-01f, 8.932242990e-01f, 9.039893150e-01f, 9.142097831e-01f, 9.238795042e-01f, 9.329928160e-01f, 9.415440559e-01f, 9.495281577e-01f, 9.569403529e-01f, 9.637760520e-01f, 9.700312614e-01f, 9.757021070e-01f, 9.807852507e-01f, 9.852776527e-01f, 9.891765118e-01f, 9.924795628e-01f, 9.951847196e-01f, 9.972904325e-01f, 9.987954497e-01f, 9.996988177e-01f, 1.000000000e+00f, 9.996988177e-01f, 9.987954497e-01f, 9.972904325e-01f, 9.951847196e-01f, 9.924795628e-01f, 9.891765118e-01f, 9.852776527e-01f, 9.807852507e-01f, 9.757021070e-01f, 9.700312614e-01f, 9.637760520e-01f, 9.569403529e-01f, 9.495281577e-01f, 9.415440559e-01f, 9.329928160e-01f, 9.238795042e-01f, 9.142097831e-01f, 9.039893150e-01f, 8.932242990e-01f, 8.819212914e-01f, 8.700869679e-01f, 8.577286005e-01f, 8.448535800e-01f, 8.314695954e-01f, 8.175848126e-01f, 8.032075167e-01f, 7.883464098e-01f, 7.730104327e-01f, 7.572088242e-01f, 7.409511209e-01f, 7.242470980e-01f, 7.071067691e-01f, 6.895405650e-01f, 6.715589762e-01f, 6.531728506e-01f, 6.343932748e-01f, 6.152315736e-01f, 5.956993103e-01f, 5.758081675e-01f, 5.555702448e-01f, 5.349976420e-01f, 5.141027570e-01f, 4.928981960e-01f, 4.713967443e-01f, 4.496113360e-01f, 4.275550842e-01f, 4.052413106e-01f, 3.826834261e-01f, 3.598950505e-01f, 3.368898630e-01f, 3.136817515e-01f, 2.902846634e-01f, 2.667127550e-01f, 2.429801822e-01f, 2.191012353e-01f, 1.950903237e-01f, 1.709618866e-01f, 1.467304677e-01f, 1.224106774e-01f, 9.801714122e-02f, 7.356456667e-02f, 4.906767607e-02f, 2.454122901e-02f, 1.224646853e-16f, -2.454122901e-02f, -4.906767607e-02f, -7.356456667e-02f, -9.801714122e-02f, -1.224106774e-01f, -1.467304677e-01f, -1.709618866e-01f, -1.950903237e-01f, -2.191012353e-01f, -2.429801822e-01f, -2.667127550e-01f, -2.902846634e-01f, -3.136817515e-01f, -3.368898630e-01f, -3.598950505e-01f, -3.826834261e-01f, -4.052413106e-01f, -4.275550842e-01f, -4.496113360e-01f, -4.713967443e-01f, -4.928981960e-01f, -5.141027570e-01f, -5.349976420e-01f, -5.555702448e-01f, -5.758081675e-01f, -5.956993103e-01f, -6.152315736e-01f, -6.343932748e-01f, -6.531728506e-01f, -6.715589762e-01f, -6.895405650e-01f, -7.071067691e-01f, -7.242470980e-01f, -7.409511209e-01f, -7.572088242e-01f, -7.730104327e-01f, -7.883464098e-01f, -8.032075167e-01f, -8.175848126e-01f, -8.314695954e-01f, -8.448535800e-01f, -8.577286005e-01f, -8.700869679e-01f, -8.819212914e-01f, -8.932242990e-01f, -9.039893150e-01f, -9.142097831e-01f, -9.238795042e-01f, -9.329928160e-01f, -9.415440559e-01f, -9.495281577e-01f, -9.569403529e-01f, -9.637760520e-01f, -9.700312614e-01f, -9.757021070e-01f, -9.807852507e-01f, -9.852776527e-01f, -9.891765118e-01f, -9.924795628e-01f, -9.951847196e-01f, -9.972904325e-01f, -9.987954497e-01f, -9.996988177e-01f, -1.000000000e+00f, -9.996988177e-01f, -9.987954497e-01f, -9.972904325e-01f, -9.951847196e-01f, -9.924795628e-01f, -9.891765118e-01f, -9.852776527e-01f, -9.807852507e-01f, -9.757021070e-01f, -9.700312614e-01f, -9.637760520e-01f, -9.569403529e-01f, -9.495281577e-01f, -9.415440559e-01f, -9.329928160e-01f, -9.238795042e-01f, -9.142097831e-01f, -9.039893150e-01f, -8.932242990e-01f, -8.819212914e-01f, -8.700869679e-01f, -8.577286005e-01f, -8.448535800e-01f, -8.314695954e-01f, -8.175848126e-01f, -8.032075167e-01f, -7.883464098e-01f, -7.730104327e-01f, -7.572088242e-01f, -7.409511209e-01f, -7.242470980e-01f, -7.071067691e-01f, -6.895405650e-01f, -6.715589762e-01f, -6.531728506e-01f, -6.343932748e-01f, -6.152315736e-01f, -5.956993103e-01f, -5.758081675e-01f, -5.555702448e-01f, -5.349976420e-01f, -5.141027570e-01f, -4.928981960e-01f, -4.713967443e-01f, -4.496113360e-01f, -4.275550842e-01f, -4.052413106e-01f, -3.826834261e-01f, -3.598950505e-01f, -3.368898630e-01f, -3.136817515e-01f, -2.902846634e-01f, -2.667127550e-01f, -2.429801822e-01f, -2.191012353e-01f, -1.950903237e-01f, -1.709618866e-01f, -1.467304677e-01f, -1.224106774e-01f, -9.801714122e-02f, -7.356456667e-02f, -4.906767607e-02f, -2.454122901e-02f};
+
+template <int PHI8>
+__device__ __forceinline__ c32 twist_const(int s) {          // e^(-2 pi i s PHI8 / 256)
+    const int j = (s * PHI8) & 255;
+    return mk(OC_COS256[j], -OC_SIN256[j]);
+}
+
+template <int R> struct Cfg {
+    static constexpr int T = 32 * R;                 // threads per row
+    static constexpr int M = 1024 * R;               // complex points per row
+    static constexpr int NB = 32 / R;                // radix-R butterflies per thread in pass 3
+    static constexpr bool PLANES = (R == 32);        // 256 KB of row data do not fit the LDS as complex64
+    static constexpr int XE = 32 * 33 * R;           // exchange buffer elements per row
+    static constexpr size_t XBYTES = (size_t)XE * (PLANES ? 4 : 8);
+    static constexpr int ROW1 = T + R;               // exchange 1: position (ka, t) at ka * ROW1 + t
+    static constexpr int GRP2 = 33 * R;              // exchange 2: group ka at ka * GRP2, (t', kb1) at t' * 33 + kb1
+    // twiddle table layout (c32 units): tw1[11][T] | tw2[10][R]
+    static constexpr int TW1 = 11 * T;
+    static constexpr int TWN = TW1 + 10 * R;
+};
+
+// ---------------------------------------------------------------------------------------------
+// twiddles.  Pass 1: w_M^(t (ka + phi)), ka = 8 a + b, as tA[a] * tB[b] with tB[b] = w_M^(t (b + phi)) (b = 0..7) and
+// tA[a] = w_M^(8 t a) (a = 1..3): 11 table loads per thread instead of 32, one extra rounding in 24 of them.
+// Pass 2: w_T^(t' kb1) likewise from tB[b] = w_T^(t' b) (b = 1..7), tA[a] = w_T^(8 t' a).
+// ---------------------------------------------------------------------------------------------
+struct Tw {
+    c32 tB[8];
+    c32 tA[4];   // [0] unused
+};
+template <int R>
+__device__ __forceinline__ void load_tw1(Tw& w, GBuf tab, int t) {
+    constexpr int T = Cfg<R>::T;
+    HY_UNROLL
+    for (int b = 0; b < 8; ++b) w.tB[b] = gb_ld(tab, (unsigned)t * 8u, (unsigned)(b * T) * 8u);
+    HY_UNROLL
+    for (int a = 1; a < 4; ++a) w.tA[a] = gb_ld(tab, (unsigned)t * 8u, (unsigned)((7 + a) * T) * 8u);
+}
+template <int R>
+__device__ __forceinline__ void load_tw2(Tw& w, GBuf tab, int tp) {
+    constexpr int O = Cfg<R>::TW1;
+    HY_UNROLL
+    for (int b = 1; b < 8; ++b) w.tB[b] = gb_ld(tab, (unsigned)tp * 8u, (unsigned)(O + (b - 1) * R) * 8u);
+    HY_UNROLL
+    for (int a = 1; a < 4; ++a) w.tA[a] = gb_ld(tab, (unsigned)tp * 8u, (unsigned)(O + (6 + a) * R) * 8u);
+}
+// v[s] *= w^(s + phi) (PHI: tB[0] is the phi twist) or w^s (no PHI: s = 0 untouched); INV conjugates.
+template <bool INV, bool PHI>
+__device__ __forceinline__ void apply_tw(c32 (&v)[32], const Tw& w) {
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) {
+        const int a = s >> 3, b = s & 7;
+        if (!PHI && s == 0) continue;
+        c32 ta = w.tA[a & 3], tb = w.tB[b];
+        // opaque copies: keeps hipcc from hoisting the 24 products (48 VGPRs) out of loops / sharing them between passes
+        HY_OPAQUE(ta.x); HY_OPAQUE(ta.y); HY_OPAQUE(tb.x); HY_OPAQUE(tb.y);
+        const c32 f = (a == 0) ? tb : (!PHI && b == 0) ? ta : cmul(ta, tb);
+        v[s] = INV ? cmulc(v[s], f) : cmul(v[s], f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS exchanges.  `xb` = this row's buffer (lc32 or float plane), tid = thread within the row, ka = tid / R,
+// tp = tid % R.  Bank analysis (32 lanes of a group must hit 32 different 8-byte / 4-byte slots mod 32):
+//   exchange 1  write  q ROW1 + tid                      lanes -> consecutive slots
+//               read   ka ROW1 + tp + R s                = ka T + (ka R + tp) + R s = tid + const (mod 32)
+//   exchange 2  write  ka GRP2 + tp 33 + kb1             = tid 33 + kb1: stride 33
+//               read   ka GRP2 + tp + 33 t'' + R i       = ka R + tp + const (mod 32) = tid + const
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void row_sync() {
+    if constexpr (T <= 64) HY_WAVE_SYNC();           // the row lives in one wavefront
+    else __syncthreads();
+}
+
+template <int R, bool INV>
+__device__ __forceinline__ void x1(c32 (&v)[32], HY_LDS lc32* xb, int tid, int ka, int tp) {
+    constexpr int T = Cfg<R>::T, ROW1 = Cfg<R>::ROW1;
+    HY_LDS lc32* const pa = xb + tid;                 // (q, t = tid)
+    HY_LDS lc32* const pb = xb + ka * ROW1 + tp;      // (ka, t = R s + tp)
+    if (!INV) {
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) lds_st(pa + q * ROW1, v[q]);
+        row_sync<T>();
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) v[s] = lds_ld(pb + R * s);
+    } else {
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) lds_st(pb + R * s, v[s]);
+        row_sync<T>();
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) v[q] = lds_ld(pa + q * ROW1);
+    }
+    row_sync<T>();
+}
+template <int R, bool INV>
+__device__ __forceinline__ void x2(c32 (&v)[32], HY_LDS lc32* xb, int ka, int tp) {
+    constexpr int NB = Cfg<R>::NB, GRP2 = Cfg<R>::GRP2;
+    HY_LDS lc32* const pa = xb + ka * GRP2 + tp * 33;   // (t' = tp, kb1)
+    HY_LDS lc32* const pb = xb + ka * GRP2 + tp;        // (t'', kb1 = tp + R i)
+    if (!INV) {
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) lds_st(pa + q, v[q]);
+        HY_WAVE_SYNC();
+        HY_UNROLL
+        for (int i = 0; i < NB; ++i) {
+            HY_UNROLL
+            for (int t2 = 0; t2 < R; ++t2) v[i * R + t2] = lds_ld(pb + 33 * t2 + R * i);
+        }
+    } else {
+        HY_UNROLL
+        for (int i = 0; i < NB; ++i) {
+            HY_UNROLL
+            for (int t2 = 0; t2 < R; ++t2) lds_st(pb + 33 * t2 + R * i, v[i * R + t2]);
+        }
+        HY_WAVE_SYNC();
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) v[q] = lds_ld(pa + q);
+    }
+    HY_WAVE_SYNC();
+}
+// the same through one float plane (real parts, then imaginary parts), for R = 32
+template <int R, bool INV>
+__device__ __forceinline__ void x1p(c32 (&v)[32], HY_LDS float* xb, int tid, int ka, int tp) {
+    constexpr int T = Cfg<R>::T, ROW1 = Cfg<R>::ROW1;
+    HY_LDS float* const pa = xb + tid;
+    HY_LDS float* const pb = xb + ka * ROW1 + tp;
+    HY_UNROLL
+    for (int part = 0; part < 2; ++part) {
+        if (!INV) {
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) pa[q * ROW1] = part ? v[q].y : v[q].x;
+            row_sync<T>();
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) { if (part) v[s].y = pb[R * s]; else v[s].x = pb[R * s]; }
+        } else {
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) pb[R * s] = part ? v[s].y : v[s].x;
+            row_sync<T>();
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) { if (part) v[q].y = pa[q * ROW1]; else v[q].x = pa[q * ROW1]; }
+        }
+        row_sync<T>();
+    }
+}
+template <int R, bool INV>
+__device__ __forceinline__ void x2p(c32 (&v)[32], HY_LDS float* xb, int ka, int tp) {
+    constexpr int NB = Cfg<R>::NB, GRP2 = Cfg<R>::GRP2;
+    HY_LDS float* const pa = xb + ka * GRP2 + tp * 33;
+    HY_LDS float* const pb = xb + ka * GRP2 + tp;
+    HY_UNROLL
+    for (int part = 0; part < 2; ++part) {
+        if (!INV) {
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) pa[q] = part ? v[q].y : v[q].x;
+            HY_WAVE_SYNC();
+            HY_UNROLL
+            for (int i = 0; i < NB; ++i) {
+                HY_UNROLL
+                for (int t2 = 0; t2 < R; ++t2) {
+                    const float f = pb[33 * t2 + R * i];
+                    if (part) v[i * R + t2].y = f; else v[i * R + t2].x = f;
+                }
+            }
+        } else {
+            HY_UNROLL
+            for (int i = 0; i < NB; ++i) {
+                HY_UNROLL
+                for (int t2 = 0; t2 < R; ++t2) pb[33 * t2 + R * i] = part ? v[i * R + t2].y : v[i * R + t2].x;
+            }
+            HY_WAVE_SYNC();
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) { const float f = pa[q]; if (part) v[q].y = f; else v[q].x = f; }
+        }
+        HY_WAVE_SYNC();
+    }
+}
+
+// radix-R butterflies of pass 3 on the 32/R register groups
+template <int R, bool INV>
+__device__ __forceinline__ void pass3(c32 (&v)[32]) {
+    if constexpr (R > 1) {
+        HY_UNROLL
+        for (int i = 0; i < 32 / R; ++i) {
+            c32 y[R];
+            HY_UNROLL
+            for (int q = 0; q < R; ++q) y[q] = v[i * R + q];
+            dft_reg<R, INV>(y);
+            HY_UNROLL
+            for (int q = 0; q < R; ++q) v[i * R + q] = y[q];
+        }
+    }
+}
+
+// Per-row context of a transform: where the row's exchange buffer and twiddle tables are, who the thread is.
+struct Ctx {
+    HY_LDS char* xb;        // exchange buffer of this row
+    GBuf tab;               // twiddle tables of this transform size (tw1 | tw2)
+    int tid, ka, tp;
+};
+
+// v[s] = c[tid + T s] e^(+2 pi i tid phi / M) on entry (i.e. the raw samples times the per-register twist constants);
+// spectrum in the order described at the top on exit.
+template <int R>
+__device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
+    dft_reg<32, false>(v);
+    {
+        Tw w;
+        load_tw1<R>(w, c.tab, c.tid);
+        apply_tw<false, true>(v, w);
+    }
+    if constexpr (Cfg<R>::PLANES) x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
+    else x1<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp);
+    dft_reg<32, false>(v);
+    if constexpr (R > 1) {
+        Tw w;
+        load_tw2<R>(w, c.tab, c.tp);
+        apply_tw<false, false>(v, w);
+        if constexpr (Cfg<R>::PLANES) x2p<R, false>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
+        else x2<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp);
+        pass3<R, false>(v);
+    }
+}
+// inverse (unnormalised); on exit v[s] = result[tid + T s] e^(-2 pi i (tid + T s) phi / M) e^(+2 pi i s phi / 32),
+// i.e. the caller still multiplies by conj(twist_const(s)).
+template <int R>
+__device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
+    if constexpr (R > 1) {
+        pass3<R, true>(v);
+        if constexpr (Cfg<R>::PLANES) x2p<R, true>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
+        else x2<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp);
+        Tw w;
+        load_tw2<R>(w, c.tab, c.tp);
+        apply_tw<true, false>(v, w);
+    }
+    dft_reg<32, true>(v);
+    // exchange 1 writes anywhere in the buffer: every wavefront must be done with its exchange-2 region
+    if constexpr (R > 1) row_sync<Cfg<R>::T>();
+    if constexpr (Cfg<R>::PLANES) x1p<R, true>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
+    else x1<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp);
+    {
+        Tw w;
+        load_tw1<R>(w, c.tab, c.tid);
+        apply_tw<true, true>(v, w);
+    }
+    dft_reg<32, true>(v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// row I/O.  A workgroup's rows are RPW consecutive rows of the (B, D, L) tensor; the buffer descriptor covers them
+// (RPW = 1: hardware bounds checking clips n >= L for free; RPW = 2 -- two rows per wavefront at T = 32 -- adds an
+// explicit predicate).  Element n of the thread's register s is n = tid + T s.
+// ---------------------------------------------------------------------------------------------
+#ifdef HIPEMU
+template <int DT>
+__device__ __forceinline__ float io_ld(GBuf b, unsigned byte_off, unsigned limit) {
+    if (byte_off >= limit) return 0.f;
+    return Elem<DT>::ld(reinterpret_cast<const typename Elem<DT>::type*>(b.p + byte_off));
+}
+template <int DT>
+__device__ __forceinline__ void io_st(GBuf b, unsigned byte_off, unsigned limit, float v) {
+    if (byte_off >= limit) return;
+    Elem<DT>::st(reinterpret_cast<typename Elem<DT>::type*>(b.p + byte_off), v);
+}
+#else
+template <int DT>
+__device__ __forceinline__ float io_ld(GBuf b, unsigned voff, unsigned soff) {
+    if constexpr (DT == DT_F32) return u2f(__builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
+    else {
+        const uint16_t h = __builtin_amdgcn_raw_buffer_load_b16(b.r, voff, soff, 0);
+        return DT == DT_BF16 ? bf16_to_f32(h) : f16_to_f32(h);
+    }
+}
+template <int DT>
+__device__ __forceinline__ void io_st(GBuf b, unsigned voff, unsigned soff, float v) {
+    // offset folded into voffset (see gb_st: stores with an SGPR soffset are avoided on gfx950)
+    if constexpr (DT == DT_F32) __builtin_amdgcn_raw_buffer_store_b32(f2u(v), b.r, voff + soff, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b16(DT == DT_BF16 ? f32_to_bf16(v) : f32_to_f16(v), b.r, voff + soff, 0, 0);
+}
+#endif
+
+__device__ __forceinline__ unsigned esize(int dtype) { return dtype == DT_F32 ? 4u : 2u; }
+
+// x[s] = sample tid + T s (+ extra) of the row at byte offset row_off of the descriptor, zero beyond L.  The dtype switch
+// sits around the whole load batch, so the transform code is instantiated once for all element types.
+template <int T, int DT, bool PRED>
+__device__ __forceinline__ void load_raw_dt(float (&x)[32], GBuf xb, int tid, unsigned row_off, int L, int extra) {
+    constexpr unsigned ES = (DT == DT_F32) ? 4u : 2u;
+#ifdef HIPEMU
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) {
+        const int n = tid + T * s + extra;
+        x[s] = n < L ? io_ld<DT>(xb, row_off + (unsigned)n * ES, 0xffffffffu) : 0.f;
+    }
+#else
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) x[s] = io_ld<DT>(xb, row_off + (unsigned)(tid + extra) * ES, (unsigned)(T * s) * ES);
+    if constexpr (PRED) {            // several rows under one descriptor: its bounds check cannot clip n >= L
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) x[s] = (tid + T * s + extra < L) ? x[s] : 0.f;
+    }
+#endif
+}
+template <int T, bool PRED>
+__device__ __forceinline__ void load_raw(float (&x)[32], GBuf xb, int dtype, int tid, unsigned row_off, int L, int extra) {
+    switch (dtype) {
+        case DT_F32: load_raw_dt<T, DT_F32, PRED>(x, xb, tid, row_off, L, extra); break;
+        case DT_BF16: load_raw_dt<T, DT_BF16, PRED>(x, xb, tid, row_off, L, extra); break;
+        default: load_raw_dt<T, DT_F16, PRED>(x, xb, tid, row_off, L, extra); break;
+    }
+}
+// the row's samples times the per-register input twist: v[s] = x[tid + T s] twist(s)
+template <int R, int PHI8, bool PRED>
+__device__ __forceinline__ void load_row(c32 (&v)[32], GBuf xb, int dtype, int tid, unsigned row_off, int L) {
+    float x[32];
+    load_raw<Cfg<R>::T, PRED>(x, xb, dtype, tid, row_off, L, 0);
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) {
+        const c32 w = twist_const<PHI8>(s);
+        v[s] = mk(x[s] * w.x, x[s] * w.y);
+    }
+}
+template <int T, int DT>
+__device__ __forceinline__ void store_row_dt(GBuf ob, int tid, unsigned row_off, int L, const float (&y)[32]) {
+    constexpr unsigned ES = (DT == DT_F32) ? 4u : 2u;
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) {
+        const int n = tid + T * s;
+#ifdef HIPEMU
+        if (n < L) io_st<DT>(ob, row_off + (unsigned)n * ES, 0xffffffffu, y[s]);
+#else
+        if (n < L) io_st<DT>(ob, row_off + (unsigned)n * ES, 0u, y[s]);
+#endif
+    }
+}
+template <int T>
+__device__ __forceinline__ void store_row(GBuf ob, int dtype, int tid, unsigned row_off, int L, const float (&y)[32]) {
+    switch (dtype) {
+        case DT_F32: store_row_dt<T, DT_F32>(ob, tid, row_off, L, y); break;
+        case DT_BF16: store_row_dt<T, DT_BF16>(ob, tid, row_off, L, y); break;
+        default: store_row_dt<T, DT_F16>(ob, tid, row_off, L, y); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+struct SpecArgs {          // filter spectrum: H[d] = (FFT(c_k) + bias) / M
+    const float* k;        // (D, L) fp32
+    const float* bias;     // (D,) or null
+    c32* H;                // [D][M], register order
+    const c32* tab;
+    int D, L;
+};
+struct ConvArgs {          // out = IFFT(FFT(x) .* H) (conj_sign = +1) or .* conj(H) (conj_sign = -1)
+    const void* x;         // (B, D, L)
+    void* out;             // (B, D, L)
+    const c32* H;          // [D][M]
+    const c32* tab;
+    int B, D, L, dtype;
+    float conj_sign;
+};
+struct DkArgs {            // dk[d] = sum_b corr(dout[b, d], u[b, d]);  dbias[d] = dk[d][0]
+    const void* dout;
+    const void* u;
+    float* dk;             // (D, L) fp32
+    float* dbias;          // (D,) or null
+    const c32* tab;        // tables of the (sub-)transform; NP = 2: the two parity sets of size 16384, one after the other
+    int B, D, L, dtype;
+};
+
+template <int R> struct WgCfg {
+    static constexpr int T = Cfg<R>::T;
+    static constexpr int WGT = T < 64 ? 64 : T;          // workgroup threads of the conv / spectrum kernels
+    static constexpr int RPW = WGT / T;                  // rows per workgroup
+    static constexpr size_t LDS = Cfg<R>::XBYTES * RPW;
+};
+
+template <int R>
+__device__ __forceinline__ Ctx make_ctx(HY_LDS char* smem, int rg, int tid, const c32* tab) {
+    Ctx c;
+    c.xb = smem + (size_t)rg * Cfg<R>::XBYTES;
+    c.tab = make_gbuf(tab, (unsigned)Cfg<R>::TWN * 8u);
+    c.tid = tid;
+    c.ka = tid / R;
+    c.tp = tid % R;
+    return c;
+}
+
+template <int R>
+__global__ void __launch_bounds__(WgCfg<R>::WGT) spec_kernel(SpecArgs a) {
+    typedef Cfg<R> C;
+    constexpr int T = C::T, RPW = WgCfg<R>::RPW;
+    HY_SMEM(smem);
+    const int rg = threadIdx.x / T, tid = threadIdx.x % T;
+    const int d0 = blockIdx.x * RPW;
+    const int d_raw = d0 + rg;
+    const bool valid = d_raw < a.D;
+    const int d = valid ? d_raw : a.D - 1;
+    const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
+    const int nrows = (a.D - d0) < RPW ? (a.D - d0) : RPW;
+    const GBuf kb = make_gbuf(a.k + (size_t)d0 * a.L, (unsigned)nrows * (unsigned)a.L * 4u);
+    c32 v[32];
+    load_row<R, 2, (RPW > 1)>(v, kb, DT_F32, tid, (unsigned)(d - d0) * (unsigned)a.L * 4u, a.L);
+    fft_fwd<R>(v, c);
+    const float bias = (a.bias != nullptr) ? a.bias[d] : 0.f;
+    const float sc = 1.0f / (float)C::M;
+    if (valid) {
+        c32* Hd = a.H + (size_t)d * C::M + tid;
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) Hd[q * T] = mk((v[q].x + bias) * sc, v[q].y * sc);
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(WgCfg<R>::WGT) conv_kernel(ConvArgs a) {
+    typedef Cfg<R> C;
+    constexpr int T = C::T, RPW = WgCfg<R>::RPW;
+    HY_SMEM(smem);
+    const unsigned ES = esize(a.dtype);
+    const int rg = threadIdx.x / T, tid = threadIdx.x % T;
+    const int rows = a.B * a.D;
+    // Row of this workgroup.  One row per workgroup: workgroups are dealt to the 8 XCDs round-robin, so the B rows of a
+    // channel (which read the same 8 M bytes of H) are given consecutive slots of ONE XCD's sequence -- its L2 then
+    // serves B - 1 of the B reads of H.
+    int r0;
+    if (RPW == 1 && (a.D & 7) == 0) {
+        const int w = blockIdx.x, xcd = w & 7, seq = w >> 3;
+        const int cs = seq / a.B, b = seq - cs * a.B;
+        r0 = b * a.D + cs * 8 + xcd;
+    } else {
+        r0 = blockIdx.x * RPW;
+    }
+    const int r_raw = r0 + rg;
+    const bool valid = r_raw < rows;
+    const int r = valid ? r_raw : rows - 1;
+    const int d = r % a.D;
+    const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
+    const int nrows = (rows - r0) < RPW ? (rows - r0) : RPW;
+    const GBuf xb = make_gbuf(reinterpret_cast<const char*>(a.x) + (size_t)r0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
+    const GBuf ob = make_gbuf(reinterpret_cast<char*>(a.out) + (size_t)r0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
+    const unsigned row_off = (unsigned)(r - r0) * (unsigned)a.L * ES;
+    const GBuf hb = make_gbuf(a.H, (unsigned)a.D * (unsigned)C::M * 8u);
+    c32 v[32];
+    load_row<R, 2, (RPW > 1)>(v, xb, a.dtype, tid, row_off, a.L);
+    fft_fwd<R>(v, c);
+    {
+        const unsigned ho = ((unsigned)d * (unsigned)C::M + (unsigned)tid) * 8u;
+        HY_UNROLL
+        for (int q0 = 0; q0 < 32; q0 += 8) {          // 8 at a time: 32 filter values at once do not fit 128 VGPRs at T = 1024
+            c32 h[8];
+            HY_UNROLL
+            for (int q = 0; q < 8; ++q) h[q] = gb_ld(hb, ho, (unsigned)((q0 + q) * T) * 8u);
+            HY_UNROLL
+            for (int q = 0; q < 8; ++q) v[q0 + q] = cmul(v[q0 + q], mk(h[q].x, a.conj_sign * h[q].y));
+            HY_SCHED_FENCE();
+        }
+    }
+    fft_inv<R>(v, c);
+    float y[32];
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) {
+        const c32 w = twist_const<2>(s);
+        y[s] = v[s].x * w.x + v[s].y * w.y;             // Re(v conj(twist))
+    }
+    if (valid) store_row<T>(ob, a.dtype, tid, row_off, a.L, y);
+}
+
+// dk.  A workgroup owns a channel; its BP row groups (T threads each) take the batch items b = g, g + BP, ... and keep
+// their partial sum of G .* conj(U) in 32 registers; the groups' sums are added through LDS in group order and ONE
+// inverse transform per channel produces dk (bitwise reproducible: fixed order, no atomics).
+// NP = 2 (M = 32768: two spectra + the accumulator would need 768 KB of registers): the transform is split by one
+// radix-2 decimation-in-frequency step into the even and the odd bins, two 16384-point problems
+//     y_e[n] = x[n] + (-1)^e e^(-i pi / 4) x[n + M/2],  twist phi_e = (1 + 4 e) / 8,
+// run one after the other; with h_e the untwisted inverse of bin set e,
+//     dk[n] = Re(h_0 + h_1) / M,     dk[n + M/2] = Re(e^(i pi / 4) (h_0 - h_1)) / M,
+// the e = 0 halves are parked in the dk row itself (read back by the same thread in the e = 1 pass).
+// Table layout for NP = 2 (R = 16): [tw1(phi = 1/8) | tw2] [tw1(phi = 5/8) | tw2].
+template <int R, int NP> struct DkCfg {
+    static constexpr int T = Cfg<R>::T;
+    static constexpr int BP = (512 / T > 16) ? 16 : 512 / T;       // row groups per workgroup (T BP <= 512 threads: ~192 VGPRs each)
+    static constexpr int WGT = T * BP;
+    static_assert(WGT == 512 && (NP == 1 || BP == 1), "dk workgroups are 512 threads");
+    static constexpr size_t LDS_X = Cfg<R>::XBYTES * BP;
+    static constexpr size_t LDS_RED = BP > 1 ? (size_t)BP * Cfg<R>::M * 8 : 0;
+    static constexpr size_t LDS = LDS_X > LDS_RED ? LDS_X : LDS_RED;
+};
+
+// spectrum input of sub-problem e (NP = 2) or of the whole row (NP = 1)
+template <int R, int NP, int PHI8>
+__device__ __forceinline__ void dk_load(c32 (&v)[32], GBuf xb, int dtype, int tid, int L, float sigma) {
+    if constexpr (NP == 1) {
+        load_row<R, PHI8, false>(v, xb, dtype, tid, 0u, L);
+    } else {
+        const float r = 0.70710678118654752440f * sigma;
+        float xa[32], xc[32];
+        load_raw<Cfg<R>::T, false>(xa, xb, dtype, tid, 0u, L, 0);
+        load_raw<Cfg<R>::T, false>(xc, xb, dtype, tid, 0u, L, Cfg<R>::M);
+        HY_UNROLL
+        for (int s = 0; s < 32; ++s) {
+            const c32 y = mk(xa[s] + r * xc[s], -r * xc[s]);       // x[n] + sigma e^(-i pi/4) x[n + M/2]
+            v[s] = cmul(y, twist_const<PHI8>(s));
+        }
+    }
+}
+
+template <int R, int NP>
+__global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
+    typedef Cfg<R> C;
+    typedef DkCfg<R, NP> K;
+    constexpr int T = C::T, BP = K::BP;
+    HY_SMEM(smem);
+    const unsigned ES = esize(a.dtype);
+    const int rg = threadIdx.x / T, tid = threadIdx.x % T;
+    const int d = blockIdx.x;
+    Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
+    const unsigned rowbytes = (unsigned)a.L * ES;
+    const float sc = 1.0f / (float)(C::M * NP);
+    float* dkrow = a.dk + (size_t)d * a.L;
+    HY_UNROLL
+    for (int e = 0; e < NP; ++e) {
+        if constexpr (NP == 2) c.tab = make_gbuf(a.tab + e * C::TWN, (unsigned)C::TWN * 8u);
+        c32 acc[32];
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
+        for (int b0 = 0; b0 < a.B; b0 += BP) {        // uniform trip count: the transforms contain workgroup barriers
+            const bool live = b0 + rg < a.B;
+            const int b = live ? b0 + rg : a.B - 1;
+            const size_t row = ((size_t)b * a.D + d) * a.L * ES;
+            const GBuf gb = make_gbuf(reinterpret_cast<const char*>(a.dout) + row, rowbytes);
+            const GBuf ub = make_gbuf(reinterpret_cast<const char*>(a.u) + row, rowbytes);
+            c32 u[32], v[32];
+            if (NP == 1) dk_load<R, NP, 2>(u, ub, a.dtype, tid, a.L, 1.f);
+            else if (e == 0) dk_load<R, NP, 1>(u, ub, a.dtype, tid, a.L, 1.f);
+            else dk_load<R, NP, 5>(u, ub, a.dtype, tid, a.L, -1.f);
+            fft_fwd<R>(u, c);
+            if (NP == 1) dk_load<R, NP, 2>(v, gb, a.dtype, tid, a.L, 1.f);
+            else if (e == 0) dk_load<R, NP, 1>(v, gb, a.dtype, tid, a.L, 1.f);
+            else dk_load<R, NP, 5>(v, gb, a.dtype, tid, a.L, -1.f);
+            fft_fwd<R>(v, c);
+            const float lv = live ? 1.f : 0.f;
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) {
+                const c32 p = cmulc(v[q], u[q]);                                             // G conj(U)
+                acc[q] = mk(acc[q].x + lv * p.x, acc[q].y + lv * p.y);
+            }
+        }
+        if constexpr (BP > 1) {
+            // sum of the groups' partial spectra, in group order, through LDS (the exchange buffers are idle now)
+            __syncthreads();
+            HY_LDS lc32* red = HY_LDS_CAST(lc32, smem);
+            if (rg > 0) {
+                HY_UNROLL
+                for (int q = 0; q < 32; ++q) lds_st(red + rg * C::M + q * T + tid, acc[q]);
+            }
+            __syncthreads();
+            if (rg == 0) {
+                const int ng = a.B < BP ? a.B : BP;
+                for (int o = 1; o < ng; ++o) {
+                    HY_UNROLL
+                    for (int q = 0; q < 32; ++q) acc[q] = cadd(acc[q], lds_ld(red + o * C::M + q * T + tid));
+                }
+            }
+            __syncthreads();
+        }
+        // Only group 0 holds the sum, but every group runs the inverse: its barriers are workgroup-wide (the other
+        // groups transform their stale partial sums inside their own exchange buffers and store nothing).
+        fft_inv<R>(acc, c);
+        if (rg == 0) {
+            if constexpr (NP == 1) {
+                HY_UNROLL
+                for (int s = 0; s < 32; ++s) {
+                    const c32 w = twist_const<2>(s);
+                    const int n = tid + T * s;
+                    const float val = (acc[s].x * w.x + acc[s].y * w.y) * sc;
+                    if (n < a.L) dkrow[n] = val;
+                    if (n == 0 && a.dbias != nullptr) a.dbias[d] = val;
+                }
+            } else {
+                const float rr = 0.70710678118654752440f;
+                HY_UNROLL
+                for (int s = 0; s < 32; ++s) {
+                    const c32 w = e ? twist_const<5>(s) : twist_const<1>(s);
+                    const c32 h = cmulc(acc[s], w);                          // untwisted h_e[n]
+                    const int n = tid + T * s;
+                    const float lo = h.x * sc, hi = (h.x - h.y) * rr * sc;   // Re(h), Re(e^(i pi/4) h)
+                    if (e == 0) {
+                        if (n < a.L) dkrow[n] = lo;
+                        if (n + C::M < a.L) dkrow[n + C::M] = hi;
+                    } else {
+                        if (n < a.L) {
+                            const float val = dkrow[n] + lo;
+                            dkrow[n] = val;
+                            if (n == 0 && a.dbias != nullptr) a.dbias[d] = val;
+                        }
+                        if (n + C::M < a.L) dkrow[n + C::M] -= hi;
+                    }
+                }
+            }
+        }
+        if constexpr (NP == 2) __syncthreads();
+    }
+}
+
+}  // namespace oc
+}  // namespace hyena

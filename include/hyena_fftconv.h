@@ -69,13 +69,25 @@ int hyena_fftconv_abi_version(void);
 /* Human-readable text for a status code. */
 const char* hyena_fftconv_error_string(int status);
 
-/* Complex transform length M used for sequence length L: the padded real transform has N = 2M >= 2L
+/* Two execution plans, chosen by L alone:
+ *   L <= 32768   workspace-free: one workgroup per (b, d) row holds the whole transform in registers and LDS
+ *                (M = 1024, 2048, ..., 32768, the smallest power of two >= L); HBM traffic is u, out and the filter
+ *                spectrum H [D][M] (the workspace).  The reference's own fused kernel has this shape but stops at L = 8192
+ *                (csrc/fftconv/fftconv_cuda.cu:805, fftconv.cpp:114-115).  HYENA_FFTCONV_ONCHIP=0 in the environment
+ *                routes these lengths to the two-level plan instead (testing / profiling).
+ *   L >  32768   two-level (four-step) transform through a workspace, M = M1 x 1024.
+ *
+ * Complex transform length M used for sequence length L: the padded real transform has N = 2M >= 2L
  * points, M = M1 * 1024 with M1 the smallest supported column size >= L / 1024: the powers of two up to 1024 and
  * 2^a x {3, 5, 7} (3, 5, 6, 7, 10, 12, 14, 20, 24, 28, 96, 160, 192, 224, 320, 384, 448, 640, 768), so that the
  * zero padding beyond 2L stays below ~20 % for most lengths (hyenadna-medium-160k: L = 160000 -> M1 = 160, N = 327680;
  * -450k: L = 450560 -> M1 = 448, N = 917504); the reference uses N = 2L (hyena.py:61), which gives the same causal
  * result.  Returns 0 if L is unsupported. */
 int hyena_fftconv_fft_size(int L);
+
+/* Which plan serves sequence length L (tables built for one plan are not valid for the other). */
+enum { HYENA_PLAN_NONE = 0, HYENA_PLAN_ONCHIP = 1, HYENA_PLAN_TWO_LEVEL = 2 };
+int hyena_fftconv_plan(int L);
 
 /* Bytes of device memory needed for the twiddle tables of sequence length L, and their one-time
  * initialisation (host computes in double precision, then a synchronous hipMemcpy to `d_tables`).
@@ -114,13 +126,15 @@ int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const flo
  * k_f): the forward can leave the column-transformed filter and activations in a caller-owned buffer
  *     saved = Wk [D][M] | Wu [B][D][M]   complex64,  hyena_fftconv_saved_bytes(B, D, L) bytes
  * and the backward then skips re-reading u and k and their column transforms (22 of ~150 MB of traffic per row at
- * L = 2^20).  Results are bitwise those of the plain entry points.  The buffer must stay untouched in between. */
+ * L = 2^20).  Results are bitwise those of the plain entry points.  The buffer must stay untouched in between.
+ * For L <= 32768 (the workspace-free path, below) the buffer holds the filter spectrum H [D][M] only and the backward
+ * still needs `u` when dk is requested (it re-transforms u on chip); for longer sequences `u` may be NULL. */
 size_t hyena_fftconv_saved_bytes(int B, int D, int L);
 int hyena_fftconv_fwd_save(const void* u, const float* k, const float* bias, void* out,
                            int B, int D, int L, int dtype,
                            const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
                            void* saved, size_t saved_bytes, void* stream);
-int hyena_fftconv_bwd_saved(const void* dout, const float* bias, void* du, float* dk, float* dbias,
+int hyena_fftconv_bwd_saved(const void* dout, const void* u, const float* bias, void* du, float* dk, float* dbias,
                             int B, int D, int L, int dtype,
                             const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
                             const void* saved, size_t saved_bytes, void* stream);

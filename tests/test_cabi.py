@@ -58,7 +58,7 @@ def test_header_declares_the_expected_entry_points():
     for s in ("hyena_fftconv_fwd", "hyena_fftconv_bwd", "hyena_fftconv_workspace_bytes", "hyena_fftconv_init_tables",
               "hyena_fftconv_table_bytes", "hyena_fftconv_fft_size", "hyena_fftconv_abi_version",
               "hyena_fftconv_error_string", "hyena_fftconv_default_chunk", "hyena_fftconv_saved_bytes",
-              "hyena_fftconv_fwd_save", "hyena_fftconv_bwd_saved"):
+              "hyena_fftconv_fwd_save", "hyena_fftconv_bwd_saved", "hyena_fftconv_plan"):
         assert s in syms
 
 
@@ -74,12 +74,14 @@ def test_host_only_entry_points(product_lib):
     L.hyena_fftconv_saved_bytes.restype = ctypes.c_size_t
     assert L.hyena_fftconv_saved_bytes(1, 256, 1 << 20) == 2 * 256 * (1 << 20) * 8
     L.hyena_fftconv_error_string.restype = ctypes.c_char_p
-    assert L.hyena_fftconv_abi_version() == 2
+    assert L.hyena_fftconv_abi_version() == 3
     assert L.hyena_fftconv_fft_size(1024) == 1024 and L.hyena_fftconv_fft_size(160000) == 163840 and L.hyena_fftconv_fft_size(163841) == 196608
     assert L.hyena_fftconv_fft_size(131072) == 131072 and L.hyena_fftconv_fft_size(131073) == 163840
     assert L.hyena_fftconv_fft_size(450560) == 458752 and L.hyena_fftconv_fft_size(1 << 20) == 1 << 20
     assert L.hyena_fftconv_fft_size(262144) == 262144 and L.hyena_fftconv_fft_size(262145) == 327680
-    assert L.hyena_fftconv_fft_size(2049) == 3072 and L.hyena_fftconv_fft_size(4776) == 5120 and L.hyena_fftconv_fft_size(33000) == 65536
+    # L <= 32768: the workspace-free plan, power-of-two sizes
+    assert L.hyena_fftconv_fft_size(2049) == 4096 and L.hyena_fftconv_fft_size(4776) == 8192 and L.hyena_fftconv_fft_size(33000) == 65536
+    assert L.hyena_fftconv_plan(32768) == 1 and L.hyena_fftconv_plan(32769) == 2 and L.hyena_fftconv_plan(0) == 0
     assert L.hyena_fftconv_fft_size(700000) == 786432 and L.hyena_fftconv_fft_size(786433) == 1 << 20
     assert L.hyena_fftconv_fft_size(458753) == 524288
     assert L.hyena_fftconv_fft_size((1 << 20) + 1) == 0

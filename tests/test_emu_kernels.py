@@ -141,7 +141,9 @@ def test_saved_spectra_backward_is_bitwise_the_recomputing_one(emu_backend, B, D
     du, dk, dbias = emu_backend.fftconv_bwd(dout, u, k, bias, chunk=chunk)
     out2, saved = emu_backend.fftconv_fwd(u, k, bias, chunk=chunk, save=True)
     assert saved.numel() == emu_backend.saved_bytes(B, D, L)
-    du2, dk2, dbias2 = emu_backend.fftconv_bwd(dout, None, None, bias, chunk=chunk, saved=saved)
+    # the workspace-free plan (L <= 32768) saves the filter spectrum only and re-reads u; the two-level plan needs neither
+    u_arg = u if L <= 32768 else None
+    du2, dk2, dbias2 = emu_backend.fftconv_bwd(dout, u_arg, None, bias, chunk=chunk, saved=saved)
     assert torch.equal(out, out2) and torch.equal(du, du2) and torch.equal(dk, dk2) and torch.equal(dbias, dbias2)
     du3, dk3, _ = emu_backend.fftconv_bwd(dout, None, None, bias, need_du=True, need_dk=False, chunk=chunk, saved=saved)
     assert dk3 is None and torch.equal(du3, du)
@@ -175,9 +177,10 @@ def test_randomised_shapes_vs_oracle(emu_backend):
 
 
 @pytest.mark.parametrize("m1", [3, 5, 6, 7, 10, 12, 14, 20, 24, 28, 96, 192, 224, 320, 384])
-def test_mixed_radix_column_sizes(emu_backend, m1):
+def test_mixed_radix_column_sizes(emu_backend, monkeypatch, m1):
     """every column size that is not a power of two (2^a x {3, 5, 7}; odd M1 has no self-paired row M1/2), forward + backward
     vs the fp64 evaluation of the oracle (the fp32 oracle itself is up to 5e-6 off at these non-smooth 2L)"""
+    monkeypatch.setenv("HYENA_FFTCONV_ONCHIP", "0")        # M1 < 32: only the two-level plan has these sizes
     L = m1 * 1024 - 3
     assert emu_backend.lib().hyena_fftconv_fft_size(L) == m1 * 1024
     B, D = (2, 2) if m1 < 32 else (1, 1)

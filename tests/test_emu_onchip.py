@@ -1,0 +1,120 @@
+"""The workspace-free plan (hyena_dna_amd/csrc/onchip_kernels.h, L <= 32768) executed under tests/hipemu, through the C ABI,
+against the oracle: every transform size 1024 R, ragged lengths, batch counts around the dk kernel's group count, channel
+counts with and without the XCD-aware row mapping, all element types -- and bitwise agreement of what must be bitwise."""
+import pytest
+import torch
+
+from oracle import hyena_oracle as O
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def _oracle(u, k, bias, dout):
+    u_ = u.clone().requires_grad_(True)
+    k_ = k.clone().requires_grad_(True)
+    b_ = bias.clone().requires_grad_(True)
+    out = O.fftconv_ref(u_, k_, b_)
+    out.backward(dout)
+    return out.detach(), u_.grad, k_.grad, b_.grad
+
+
+def _inputs(B, D, L, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randn(B, D, L, generator=g).to(dtype)
+    k = torch.randn(D, L, generator=g) * torch.exp(-5.0 * torch.linspace(0, 1, L))[None] * 0.1
+    bias = torch.randn(D, generator=g)
+    dout = torch.randn(B, D, L, generator=g).to(dtype)
+    return u, k, bias, dout
+
+
+# (B, D, L): R = 1 ... 32; B around the dk kernel's row-group counts (16, 8, 4, 2, 1); D = 8 / 16 take the XCD-aware mapping
+CASES = [
+    (1, 1, 1), (3, 2, 2), (17, 3, 700), (16, 8, 1024), (5, 1, 1023), (9, 2, 1025), (8, 8, 2048), (3, 3, 2047),
+    (5, 2, 4096), (4, 1, 4095), (2, 16, 3000), (3, 2, 8192), (2, 1, 8191), (1, 3, 5000), (2, 2, 16384), (3, 1, 16383),
+    (1, 2, 12000), (2, 2, 32768), (1, 1, 32767), (3, 1, 16385), (2, 1, 20000), (1, 8, 32768),
+]
+
+
+@pytest.mark.parametrize("B,D,L", CASES)
+def test_fp32_vs_oracle(emu_backend, B, D, L):
+    assert emu_backend.lib().hyena_fftconv_plan(L) == emu_backend.PLAN_ONCHIP
+    u, k, bias, dout = _inputs(B, D, L, torch.float32, seed=L + B)
+    out = emu_backend.fftconv_fwd(u, k, bias)
+    du, dk, dbias = emu_backend.fftconv_bwd(dout, u, k, bias)
+    r_out, r_du, r_dk, r_db = _oracle(u, k, bias, dout)
+    assert _rel(out, r_out) < 2e-6 and _rel(du, r_du) < 2e-6 and _rel(dk, r_dk) < 2e-6
+    # dbias[d] is one sum of B L products of unit-variance numbers (typical size sqrt(B L), heavy cancellation): compare with
+    # the fp64 value on that scale (the fp32 oracle's own summation error is of the same order)
+    db64 = (dout.double() * u.double()).sum(dim=(0, 2))
+    assert (dbias.double() - db64).abs().max() < 1e-6 * (B * L) ** 0.5 + 1e-6
+    # options: no bias, du only, dk only -- the same bits as the full call
+    du2, dk2, db2 = emu_backend.fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=False)
+    assert dk2 is None and db2 is None and torch.equal(du2, du)
+    du3, dk3, db3 = emu_backend.fftconv_bwd(dout, u, k, bias, need_du=False, need_dk=True)
+    assert du3 is None and torch.equal(dk3, dk) and torch.equal(db3, dbias)
+    out0 = emu_backend.fftconv_fwd(u, k, None)
+    assert _rel(out0, O.fftconv_ref(u, k, torch.zeros(D))) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,D,L", [(3, 2, 37), (2, 3, 1000), (4, 2, 4100), (2, 1, 9000), (1, 2, 32767)])
+def test_half_io(emu_backend, dtype, B, D, L):
+    """16-bit I/O: fp32 math inside, one rounding on store -> within one ulp of the reference, bit-identical almost everywhere."""
+    u, k, bias, dout = _inputs(B, D, L, dtype, seed=L + 1)
+    out = emu_backend.fftconv_fwd(u, k, bias)
+    du, dk, dbias = emu_backend.fftconv_bwd(dout, u, k, bias)
+    r_out, r_du, r_dk, r_db = _oracle(u, k, bias, dout)
+    assert out.dtype == dtype and du.dtype == dtype and dk.dtype == torch.float32
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    diff = (out.float() - r_out.float()).abs()
+    assert (diff <= eps * r_out.float().abs() + 2e-5).all()
+    assert (out != r_out).float().mean() < 0.02
+    # du against the fp32 result on the same 16-bit inputs (the reference rounds three times, we once)
+    _, f_du, f_dk, f_db = _oracle(u.float(), k, bias, dout.float())
+    assert ((du.float() - f_du).abs() <= 0.5 * eps * f_du.abs() * 1.01 + 2e-5).all()
+    assert _rel(dk, f_dk) < 2e-6
+    assert (dbias.double() - (dout.double() * u.double()).sum(dim=(0, 2))).abs().max() < 1e-6 * (B * L) ** 0.5 + 1e-6
+
+
+def test_same_results_from_both_plans(emu_backend, monkeypatch):
+    """L <= 32768 on the two-level plan (HYENA_FFTCONV_ONCHIP=0) and on the workspace-free plan: two implementations of one
+    operator, both within fp32 tolerance of the oracle and of each other."""
+    for (B, D, L) in [(2, 3, 1000), (2, 2, 5000), (1, 2, 20000)]:
+        u, k, bias, dout = _inputs(B, D, L, torch.float32, seed=L)
+        monkeypatch.setenv("HYENA_FFTCONV_ONCHIP", "1")
+        out_a = emu_backend.fftconv_fwd(u, k, bias)
+        g_a = emu_backend.fftconv_bwd(dout, u, k, bias)
+        monkeypatch.setenv("HYENA_FFTCONV_ONCHIP", "0")
+        assert emu_backend.lib().hyena_fftconv_plan(L) == emu_backend.PLAN_TWO_LEVEL
+        out_b = emu_backend.fftconv_fwd(u, k, bias)
+        g_b = emu_backend.fftconv_bwd(dout, u, k, bias)
+        assert _rel(out_a, out_b) < 1e-6
+        for a, b in zip(g_a, g_b):
+            assert _rel(a, b) < 2e-6
+
+
+def test_properties(emu_backend):
+    """Size-independent properties: impulse response = filter (+ bias at lag 0), causality, adjoint identities, determinism."""
+    B, D, L = 2, 2, 6000
+    u, k, bias, dout = _inputs(B, D, L, torch.float32, seed=3)
+    imp = torch.zeros(B, D, L)
+    imp[:, :, 0] = 1.0
+    out = emu_backend.fftconv_fwd(imp, k, bias)
+    ref = k.clone()
+    ref[:, 0] += bias
+    assert (out - ref[None]).abs().max() < 2e-6
+    # causality: changing u from position p on leaves out[:p] unchanged (up to fp32 noise of the transform)
+    p = 4321
+    u2 = u.clone()
+    u2[:, :, p:] = torch.randn(B, D, L - p)
+    o1, o2 = emu_backend.fftconv_fwd(u, k, bias), emu_backend.fftconv_fwd(u2, k, bias)
+    assert (o1[:, :, :p] - o2[:, :, :p]).abs().max() < 5e-5
+    # adjoint: <dout, conv(u)> = <du, u> = <dk, k> + <dbias, bias>
+    du, dk, dbias = emu_backend.fftconv_bwd(dout, u, k, bias)
+    lhs = (dout.double() * o1.double()).sum()
+    assert abs(lhs - (du.double() * u.double()).sum()) < 1e-6 * abs(lhs) + 1e-3
+    assert abs(lhs - ((dk.double() * k.double()).sum() + (dbias.double() * bias.double()).sum())) < 1e-6 * abs(lhs) + 1e-3
+    du_b, dk_b, dbias_b = emu_backend.fftconv_bwd(dout, u, k, bias)
+    assert torch.equal(du, du_b) and torch.equal(dk, dk_b) and torch.equal(dbias, dbias_b)
