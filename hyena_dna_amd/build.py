@@ -16,7 +16,7 @@ HEADERS = [os.path.join(CSRC, "fftconv_kernels.h"), os.path.join(CSRC, "onchip_k
            os.path.join(HERE, "..", "include", "hyena_filter.h"), os.path.join(HERE, "..", "include", "hyena_block.h")]
 # -fno-slp-vectorize: hipcc otherwise packs the butterflies into v_pk_*_f32 (no faster on CDNA4) at the
 # price of ~1000 v_mov per kernel and VGPR spills.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
 
 
 def find_hipcc():
@@ -36,7 +36,22 @@ def up_to_date():
 def build(force=False, verbose=True):
     if not force and up_to_date():
         return LIB
-    cmd = [find_hipcc()] + FLAGS + SOURCES + ["-o", LIB]
+    hipcc = find_hipcc()
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in SOURCES:          # one hipcc process per translation unit, side by side
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print("[hyena_dna_amd.build]", " ".join(cmd), flush=True)
+        jobs.append((subprocess.Popen(cmd), cmd, obj))
+    objs = []
+    for proc, cmd, obj in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
     if verbose:
         print("[hyena_dna_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

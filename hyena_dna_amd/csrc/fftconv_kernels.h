@@ -33,18 +33,23 @@
 #define HY_SMEM(name) char* name = hipemu::S.smem
 #define HY_SHFL_U32(v, lane) hipemu::shfl_u32((v), (lane))
 #define HY_UNROLL
+#define HY_NOUNROLL
 #define HY_SCHED_FENCE() do {} while (0)
 #define HY_UNIFORM_PTR(T, p) (p)
+#define HY_SGPR(x) (x)
 #else
 #include <hip/hip_runtime.h>
 #define HY_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define HY_SHFL_U32(v, lane) ((uint32_t)__shfl((int)(v), (lane), 64))
 #define HY_UNROLL _Pragma("unroll")
+#define HY_NOUNROLL _Pragma("nounroll")
 // stops hipcc from hoisting every load of an unrolled loop to its top (which costs hundreds of VGPRs)
 #define HY_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // pins a wave-uniform pointer into SGPRs (and hides it from loop strength reduction, which otherwise turns
 // base + lane offset into 32 loop-carried 64-bit VGPR address pairs)
 #define HY_UNIFORM_PTR(T, p) hyena::uniform_ptr<T>(p)
+// pins a wave-uniform 32-bit value into an SGPR (integer divisions by run-time values otherwise leave their result in VGPRs)
+#define HY_SGPR(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
 #ifdef HIPEMU
@@ -211,12 +216,22 @@ __device__ __forceinline__ c32 shfl_c32(c32 v, int lane) {
 enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return u2f(((uint32_t)h) << 16); }
+#ifdef HIPEMU
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round to nearest even, quiet NaN
     uint32_t u = f2u(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+#else
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32: round to nearest even, quiet NaN) -- one instruction instead of six
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    const __bf16 h = (__bf16)f;
+    uint16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+#endif
 #ifdef HIPEMU
 __device__ __forceinline__ float f16_to_f32(uint16_t h) {
     uint32_t s = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;

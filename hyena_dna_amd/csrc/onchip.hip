@@ -73,22 +73,35 @@ static int spec_r(const SpecArgs& a, void* stream) {
     HY_LAUNCH((spec_kernel<R>), dim3((a.D + W::RPW - 1) / W::RPW), dim3(W::WGT), W::LDS, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
-template <int R>
-static int conv_r(const ConvArgs& a, void* stream) {
+template <int R, bool HALF>
+static int conv_rh(const ConvArgs& a, void* stream) {
     typedef WgCfg<R> W;
     static thread_local int done = -1;
-    hy_allow_lds(conv_kernel<R>, W::LDS, &done);
+    hy_allow_lds(conv_kernel<R, HALF>, W::LDS, &done);
     const int rows = a.B * a.D;
-    HY_LAUNCH((conv_kernel<R>), dim3((rows + W::RPW - 1) / W::RPW), dim3(W::WGT), W::LDS, stream, a);
+    HY_LAUNCH((conv_kernel<R, HALF>), dim3((rows + W::RPW - 1) / W::RPW), dim3(W::WGT), W::LDS, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+template <int R>
+static int conv_r(const ConvArgs& a, void* stream) {
+    return a.dtype == DT_F32 ? conv_rh<R, false>(a, stream) : conv_rh<R, true>(a, stream);
+}
+template <int R, int NP, bool HALF>
+static int dk_rh(const DkArgs& a, void* stream) {
+    typedef DkCfg<R, NP> K;
+    static thread_local int done = -1;
+    hy_allow_lds(dk_kernel<R, NP, HALF, 0>, K::LDS, &done);
+    HY_LAUNCH((dk_kernel<R, NP, HALF, 0>), dim3(a.D), dim3(K::WGT), K::LDS, stream, a);
+    if constexpr (NP == 2) {       // the odd bins, a second launch (it adds to what the first one left in dk)
+        static thread_local int done1 = -1;
+        hy_allow_lds(dk_kernel<R, NP, HALF, 1>, K::LDS, &done1);
+        HY_LAUNCH((dk_kernel<R, NP, HALF, 1>), dim3(a.D), dim3(K::WGT), K::LDS, stream, a);
+    }
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 template <int R, int NP>
 static int dk_r(const DkArgs& a, void* stream) {
-    typedef DkCfg<R, NP> K;
-    static thread_local int done = -1;
-    hy_allow_lds(dk_kernel<R, NP>, K::LDS, &done);
-    HY_LAUNCH((dk_kernel<R, NP>), dim3(a.D), dim3(K::WGT), K::LDS, stream, a);
-    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+    return a.dtype == DT_F32 ? dk_rh<R, NP, false>(a, stream) : dk_rh<R, NP, true>(a, stream);
 }
 
 #define HY_OC_SWITCH(R, call)                 \

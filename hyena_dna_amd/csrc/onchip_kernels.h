@@ -82,18 +82,24 @@ struct Tw {
 template <int R>
 __device__ __forceinline__ void load_tw1(Tw& w, GBuf tab, int t) {
     constexpr int T = Cfg<R>::T;
+    // opaque offset: the forward and the inverse transform of a kernel must not share one set of loaded twiddles
+    // (kept alive across the product they cost 42 VGPRs -- spills at T = 1024)
+    unsigned o = (unsigned)t * 8u;
+    HY_OPAQUE(o);
     HY_UNROLL
-    for (int b = 0; b < 8; ++b) w.tB[b] = gb_ld(tab, (unsigned)t * 8u, (unsigned)(b * T) * 8u);
+    for (int b = 0; b < 8; ++b) w.tB[b] = gb_ld(tab, o, (unsigned)(b * T) * 8u);
     HY_UNROLL
-    for (int a = 1; a < 4; ++a) w.tA[a] = gb_ld(tab, (unsigned)t * 8u, (unsigned)((7 + a) * T) * 8u);
+    for (int a = 1; a < 4; ++a) w.tA[a] = gb_ld(tab, o, (unsigned)((7 + a) * T) * 8u);
 }
 template <int R>
 __device__ __forceinline__ void load_tw2(Tw& w, GBuf tab, int tp) {
     constexpr int O = Cfg<R>::TW1;
+    unsigned o = (unsigned)tp * 8u;
+    HY_OPAQUE(o);
     HY_UNROLL
-    for (int b = 1; b < 8; ++b) w.tB[b] = gb_ld(tab, (unsigned)tp * 8u, (unsigned)(O + (b - 1) * R) * 8u);
+    for (int b = 1; b < 8; ++b) w.tB[b] = gb_ld(tab, o, (unsigned)(O + (b - 1) * R) * 8u);
     HY_UNROLL
-    for (int a = 1; a < 4; ++a) w.tA[a] = gb_ld(tab, (unsigned)tp * 8u, (unsigned)(O + (6 + a) * R) * 8u);
+    for (int a = 1; a < 4; ++a) w.tA[a] = gb_ld(tab, o, (unsigned)(O + (6 + a) * R) * 8u);
 }
 // v[s] *= w^(s + phi) (PHI: tB[0] is the phi twist) or w^s (no PHI: s = 0 untouched); INV conjugates.
 template <bool INV, bool PHI>
@@ -255,21 +261,30 @@ struct Ctx {
 template <int R>
 __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
     dft_reg<32, false>(v);
+    HY_SCHED_FENCE();
     {
         Tw w;
         load_tw1<R>(w, c.tab, c.tid);
         apply_tw<false, true>(v, w);
     }
+    HY_SCHED_FENCE();
     if constexpr (Cfg<R>::PLANES) x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
     else x1<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp);
+    HY_SCHED_FENCE();
     dft_reg<32, false>(v);
+    HY_SCHED_FENCE();
     if constexpr (R > 1) {
-        Tw w;
-        load_tw2<R>(w, c.tab, c.tp);
-        apply_tw<false, false>(v, w);
+        {
+            Tw w;
+            load_tw2<R>(w, c.tab, c.tp);
+            apply_tw<false, false>(v, w);
+        }
+        HY_SCHED_FENCE();
         if constexpr (Cfg<R>::PLANES) x2p<R, false>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
         else x2<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp);
+        HY_SCHED_FENCE();
         pass3<R, false>(v);
+        HY_SCHED_FENCE();
     }
 }
 // inverse (unnormalised); on exit v[s] = result[tid + T s] e^(-2 pi i (tid + T s) phi / M) e^(+2 pi i s phi / 32),
@@ -278,23 +293,30 @@ template <int R>
 __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
     if constexpr (R > 1) {
         pass3<R, true>(v);
+        HY_SCHED_FENCE();
         if constexpr (Cfg<R>::PLANES) x2p<R, true>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
         else x2<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp);
+        HY_SCHED_FENCE();
         Tw w;
         load_tw2<R>(w, c.tab, c.tp);
         apply_tw<true, false>(v, w);
     }
+    HY_SCHED_FENCE();
     dft_reg<32, true>(v);
+    HY_SCHED_FENCE();
     // exchange 1 writes anywhere in the buffer: every wavefront must be done with its exchange-2 region
     if constexpr (R > 1) row_sync<Cfg<R>::T>();
     if constexpr (Cfg<R>::PLANES) x1p<R, true>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
     else x1<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp);
+    HY_SCHED_FENCE();
     {
         Tw w;
         load_tw1<R>(w, c.tab, c.tid);
         apply_tw<true, true>(v, w);
     }
+    HY_SCHED_FENCE();
     dft_reg<32, true>(v);
+    HY_SCHED_FENCE();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -302,95 +324,86 @@ __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
 // (RPW = 1: hardware bounds checking clips n >= L for free; RPW = 2 -- two rows per wavefront at T = 32 -- adds an
 // explicit predicate).  Element n of the thread's register s is n = tid + T s.
 // ---------------------------------------------------------------------------------------------
+// Element access is specialised on the element SIZE only (template parameter HALF: 16-bit vs fp32); bf16 vs fp16 is a
+// per-element select on the run-time dtype.  (A run-time switch over three typed store loops behind the last butterfly
+// stage made hipcc spill 50 registers at T = 1024.)
+__device__ __forceinline__ float half_to_f32(uint16_t h, bool bf) { return bf ? bf16_to_f32(h) : f16_to_f32(h); }
+__device__ __forceinline__ uint16_t f32_to_half(float f, bool bf) { return bf ? f32_to_bf16(f) : f32_to_f16(f); }
 #ifdef HIPEMU
-template <int DT>
-__device__ __forceinline__ float io_ld(GBuf b, unsigned byte_off, unsigned limit) {
-    if (byte_off >= limit) return 0.f;
-    return Elem<DT>::ld(reinterpret_cast<const typename Elem<DT>::type*>(b.p + byte_off));
+template <bool HALF>
+__device__ __forceinline__ float io_ld(GBuf b, unsigned byte_off, unsigned, bool bf) {
+    if (HALF) return half_to_f32(*reinterpret_cast<const uint16_t*>(b.p + byte_off), bf);
+    return *reinterpret_cast<const float*>(b.p + byte_off);
 }
-template <int DT>
-__device__ __forceinline__ void io_st(GBuf b, unsigned byte_off, unsigned limit, float v) {
-    if (byte_off >= limit) return;
-    Elem<DT>::st(reinterpret_cast<typename Elem<DT>::type*>(b.p + byte_off), v);
+template <bool HALF>
+__device__ __forceinline__ void io_st(GBuf b, unsigned byte_off, float v, bool bf) {
+    if (HALF) *reinterpret_cast<uint16_t*>(b.p + byte_off) = f32_to_half(v, bf);
+    else *reinterpret_cast<float*>(b.p + byte_off) = v;
 }
 #else
-template <int DT>
-__device__ __forceinline__ float io_ld(GBuf b, unsigned voff, unsigned soff) {
-    if constexpr (DT == DT_F32) return u2f(__builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
-    else {
-        const uint16_t h = __builtin_amdgcn_raw_buffer_load_b16(b.r, voff, soff, 0);
-        return DT == DT_BF16 ? bf16_to_f32(h) : f16_to_f32(h);
-    }
+template <bool HALF>
+__device__ __forceinline__ float io_ld(GBuf b, unsigned voff, unsigned soff, bool bf) {
+    if constexpr (!HALF) return u2f(__builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
+    else return half_to_f32(__builtin_amdgcn_raw_buffer_load_b16(b.r, voff, soff, 0), bf);
 }
-template <int DT>
-__device__ __forceinline__ void io_st(GBuf b, unsigned voff, unsigned soff, float v) {
-    // offset folded into voffset (see gb_st: stores with an SGPR soffset are avoided on gfx950)
-    if constexpr (DT == DT_F32) __builtin_amdgcn_raw_buffer_store_b32(f2u(v), b.r, voff + soff, 0, 0);
-    else __builtin_amdgcn_raw_buffer_store_b16(DT == DT_BF16 ? f32_to_bf16(v) : f32_to_f16(v), b.r, voff + soff, 0, 0);
+template <bool HALF>
+__device__ __forceinline__ void io_st(GBuf b, unsigned voff, float v, bool bf) {
+    // no scalar-offset field on stores (see gb_st)
+    if constexpr (!HALF) __builtin_amdgcn_raw_buffer_store_b32(f2u(v), b.r, voff, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b16(f32_to_half(v, bf), b.r, voff, 0, 0);
 }
 #endif
 
-__device__ __forceinline__ unsigned esize(int dtype) { return dtype == DT_F32 ? 4u : 2u; }
-
-// x[s] = sample tid + T s (+ extra) of the row at byte offset row_off of the descriptor, zero beyond L.  The dtype switch
-// sits around the whole load batch, so the transform code is instantiated once for all element types.
-template <int T, int DT, bool PRED>
-__device__ __forceinline__ void load_raw_dt(float (&x)[32], GBuf xb, int tid, unsigned row_off, int L, int extra) {
-    constexpr unsigned ES = (DT == DT_F32) ? 4u : 2u;
+// x[s] = sample tid + T s (+ extra) of the row at byte offset row_off of the descriptor, zero beyond L
+template <int T, bool HALF, bool PRED>
+__device__ __forceinline__ void load_raw(float (&x)[32], GBuf xb, bool bf, int tid, unsigned row_off, int L, int extra) {
+    constexpr unsigned ES = HALF ? 2u : 4u;
 #ifdef HIPEMU
     HY_UNROLL
     for (int s = 0; s < 32; ++s) {
         const int n = tid + T * s + extra;
-        x[s] = n < L ? io_ld<DT>(xb, row_off + (unsigned)n * ES, 0xffffffffu) : 0.f;
+        x[s] = n < L ? io_ld<HALF>(xb, row_off + (unsigned)n * ES, 0u, bf) : 0.f;
     }
 #else
     HY_UNROLL
-    for (int s = 0; s < 32; ++s) x[s] = io_ld<DT>(xb, row_off + (unsigned)(tid + extra) * ES, (unsigned)(T * s) * ES);
+    for (int s = 0; s < 32; ++s) x[s] = io_ld<HALF>(xb, row_off + (unsigned)(tid + extra) * ES, (unsigned)(T * s) * ES, bf);
     if constexpr (PRED) {            // several rows under one descriptor: its bounds check cannot clip n >= L
         HY_UNROLL
         for (int s = 0; s < 32; ++s) x[s] = (tid + T * s + extra < L) ? x[s] : 0.f;
     }
 #endif
 }
-template <int T, bool PRED>
-__device__ __forceinline__ void load_raw(float (&x)[32], GBuf xb, int dtype, int tid, unsigned row_off, int L, int extra) {
-    switch (dtype) {
-        case DT_F32: load_raw_dt<T, DT_F32, PRED>(x, xb, tid, row_off, L, extra); break;
-        case DT_BF16: load_raw_dt<T, DT_BF16, PRED>(x, xb, tid, row_off, L, extra); break;
-        default: load_raw_dt<T, DT_F16, PRED>(x, xb, tid, row_off, L, extra); break;
-    }
-}
 // the row's samples times the per-register input twist: v[s] = x[tid + T s] twist(s)
-template <int R, int PHI8, bool PRED>
-__device__ __forceinline__ void load_row(c32 (&v)[32], GBuf xb, int dtype, int tid, unsigned row_off, int L) {
+template <int R, int PHI8, bool HALF, bool PRED>
+__device__ __forceinline__ void load_row(c32 (&v)[32], GBuf xb, bool bf, int tid, unsigned row_off, int L) {
     float x[32];
-    load_raw<Cfg<R>::T, PRED>(x, xb, dtype, tid, row_off, L, 0);
+    load_raw<Cfg<R>::T, HALF, PRED>(x, xb, bf, tid, row_off, L, 0);
     HY_UNROLL
     for (int s = 0; s < 32; ++s) {
         const c32 w = twist_const<PHI8>(s);
         v[s] = mk(x[s] * w.x, x[s] * w.y);
     }
 }
-template <int T, int DT>
-__device__ __forceinline__ void store_row_dt(GBuf ob, int tid, unsigned row_off, int L, const float (&y)[32]) {
-    constexpr unsigned ES = (DT == DT_F32) ? 4u : 2u;
+// y[s] -> sample tid + T s of the row.  One running address register (32 precomputed voffsets cost 32 VGPRs); with one
+// row per descriptor the hardware bounds check drops n >= L.
+template <int T, bool HALF, bool PRED>
+__device__ __forceinline__ void store_row(GBuf ob, bool bf, int tid, unsigned row_off, int L, const float (&y)[32]) {
+    constexpr unsigned ES = HALF ? 2u : 4u;
+#ifdef HIPEMU
     HY_UNROLL
     for (int s = 0; s < 32; ++s) {
         const int n = tid + T * s;
-#ifdef HIPEMU
-        if (n < L) io_st<DT>(ob, row_off + (unsigned)n * ES, 0xffffffffu, y[s]);
+        if (n < L) io_st<HALF>(ob, row_off + (unsigned)n * ES, y[s], bf);
+    }
 #else
-        if (n < L) io_st<DT>(ob, row_off + (unsigned)n * ES, 0u, y[s]);
+    unsigned vo = row_off + (unsigned)tid * ES;
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) {
+        if (!PRED || tid + T * s < L) io_st<HALF>(ob, vo, y[s], bf);
+        vo += (unsigned)T * ES;
+        HY_OPAQUE(vo);
+    }
 #endif
-    }
-}
-template <int T>
-__device__ __forceinline__ void store_row(GBuf ob, int dtype, int tid, unsigned row_off, int L, const float (&y)[32]) {
-    switch (dtype) {
-        case DT_F32: store_row_dt<T, DT_F32>(ob, tid, row_off, L, y); break;
-        case DT_BF16: store_row_dt<T, DT_BF16>(ob, tid, row_off, L, y); break;
-        default: store_row_dt<T, DT_F16>(ob, tid, row_off, L, y); break;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -443,7 +456,7 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT) spec_kernel(SpecArgs a) {
     typedef Cfg<R> C;
     constexpr int T = C::T, RPW = WgCfg<R>::RPW;
     HY_SMEM(smem);
-    const int rg = threadIdx.x / T, tid = threadIdx.x % T;
+    const int rg = RPW == 1 ? 0 : (int)threadIdx.x / T, tid = RPW == 1 ? (int)threadIdx.x : (int)threadIdx.x % T;
     const int d0 = blockIdx.x * RPW;
     const int d_raw = d0 + rg;
     const bool valid = d_raw < a.D;
@@ -452,7 +465,7 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT) spec_kernel(SpecArgs a) {
     const int nrows = (a.D - d0) < RPW ? (a.D - d0) : RPW;
     const GBuf kb = make_gbuf(a.k + (size_t)d0 * a.L, (unsigned)nrows * (unsigned)a.L * 4u);
     c32 v[32];
-    load_row<R, 2, (RPW > 1)>(v, kb, DT_F32, tid, (unsigned)(d - d0) * (unsigned)a.L * 4u, a.L);
+    load_row<R, 2, false, (RPW > 1)>(v, kb, false, tid, (unsigned)(d - d0) * (unsigned)a.L * 4u, a.L);
     fft_fwd<R>(v, c);
     const float bias = (a.bias != nullptr) ? a.bias[d] : 0.f;
     const float sc = 1.0f / (float)C::M;
@@ -463,13 +476,14 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT) spec_kernel(SpecArgs a) {
     }
 }
 
-template <int R>
+template <int R, bool HALF>
 __global__ void __launch_bounds__(WgCfg<R>::WGT) conv_kernel(ConvArgs a) {
     typedef Cfg<R> C;
     constexpr int T = C::T, RPW = WgCfg<R>::RPW;
+    constexpr unsigned ES = HALF ? 2u : 4u;
     HY_SMEM(smem);
-    const unsigned ES = esize(a.dtype);
-    const int rg = threadIdx.x / T, tid = threadIdx.x % T;
+    const bool bf = a.dtype == DT_BF16;
+    const int rg = RPW == 1 ? 0 : (int)threadIdx.x / T, tid = RPW == 1 ? (int)threadIdx.x : (int)threadIdx.x % T;
     const int rows = a.B * a.D;
     // Row of this workgroup.  One row per workgroup: workgroups are dealt to the 8 XCDs round-robin, so the B rows of a
     // channel (which read the same 8 M bytes of H) are given consecutive slots of ONE XCD's sequence -- its L2 then
@@ -478,14 +492,14 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT) conv_kernel(ConvArgs a) {
     if (RPW == 1 && (a.D & 7) == 0) {
         const int w = blockIdx.x, xcd = w & 7, seq = w >> 3;
         const int cs = seq / a.B, b = seq - cs * a.B;
-        r0 = b * a.D + cs * 8 + xcd;
+        r0 = HY_SGPR(b * a.D + cs * 8 + xcd);
     } else {
         r0 = blockIdx.x * RPW;
     }
     const int r_raw = r0 + rg;
     const bool valid = r_raw < rows;
     const int r = valid ? r_raw : rows - 1;
-    const int d = r % a.D;
+    const int d = RPW == 1 ? HY_SGPR(r % a.D) : r % a.D;
     const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
     const int nrows = (rows - r0) < RPW ? (rows - r0) : RPW;
     const GBuf xb = make_gbuf(reinterpret_cast<const char*>(a.x) + (size_t)r0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
@@ -493,7 +507,7 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT) conv_kernel(ConvArgs a) {
     const unsigned row_off = (unsigned)(r - r0) * (unsigned)a.L * ES;
     const GBuf hb = make_gbuf(a.H, (unsigned)a.D * (unsigned)C::M * 8u);
     c32 v[32];
-    load_row<R, 2, (RPW > 1)>(v, xb, a.dtype, tid, row_off, a.L);
+    load_row<R, 2, HALF, (RPW > 1)>(v, xb, bf, tid, row_off, a.L);
     fft_fwd<R>(v, c);
     {
         const unsigned ho = ((unsigned)d * (unsigned)C::M + (unsigned)tid) * 8u;
@@ -514,7 +528,9 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT) conv_kernel(ConvArgs a) {
         const c32 w = twist_const<2>(s);
         y[s] = v[s].x * w.x + v[s].y * w.y;             // Re(v conj(twist))
     }
-    if (valid) store_row<T>(ob, a.dtype, tid, row_off, a.L, y);
+    // (one row per workgroup: the grid is exactly B D blocks, every block is valid; a conditional epilogue costs hipcc 36
+    // spilled registers at T = 1024)
+    if (RPW == 1 || valid) store_row<T, HALF, (RPW > 1)>(ob, bf, tid, row_off, a.L, y);
 }
 
 // dk.  A workgroup owns a channel; its BP row groups (T threads each) take the batch items b = g, g + BP, ... and keep
@@ -523,9 +539,10 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT) conv_kernel(ConvArgs a) {
 // NP = 2 (M = 32768: two spectra + the accumulator would need 768 KB of registers): the transform is split by one
 // radix-2 decimation-in-frequency step into the even and the odd bins, two 16384-point problems
 //     y_e[n] = x[n] + (-1)^e e^(-i pi / 4) x[n + M/2],  twist phi_e = (1 + 4 e) / 8,
-// run one after the other; with h_e the untwisted inverse of bin set e,
+// run as two launches (E0 = 0, 1: both parities unrolled into one kernel made hipcc spill 126 registers); with h_e the
+// untwisted inverse of bin set e,
 //     dk[n] = Re(h_0 + h_1) / M,     dk[n + M/2] = Re(e^(i pi / 4) (h_0 - h_1)) / M,
-// the e = 0 halves are parked in the dk row itself (read back by the same thread in the e = 1 pass).
+// the e = 0 halves are parked in the dk row itself and the e = 1 launch adds to them.
 // Table layout for NP = 2 (R = 16): [tw1(phi = 1/8) | tw2] [tw1(phi = 5/8) | tw2].
 template <int R, int NP> struct DkCfg {
     static constexpr int T = Cfg<R>::T;
@@ -537,39 +554,58 @@ template <int R, int NP> struct DkCfg {
     static constexpr size_t LDS = LDS_X > LDS_RED ? LDS_X : LDS_RED;
 };
 
-// spectrum input of sub-problem e (NP = 2) or of the whole row (NP = 1)
-template <int R, int NP, int PHI8>
-__device__ __forceinline__ void dk_load(c32 (&v)[32], GBuf xb, int dtype, int tid, int L, float sigma) {
+// spectrum input of sub-problem e (NP = 2: PHI8 = 1 + 4 e, sigma = +-1) or of the whole row (NP = 1)
+template <int R, int NP, bool HALF, int PHI8>
+__device__ __forceinline__ void dk_load(c32 (&v)[32], GBuf xb, bool bf, int tid, int L, float sigma) {
     if constexpr (NP == 1) {
-        load_row<R, PHI8, false>(v, xb, dtype, tid, 0u, L);
+        load_row<R, 2, HALF, false>(v, xb, bf, tid, 0u, L);
     } else {
+        constexpr int T = Cfg<R>::T, MS = Cfg<R>::M;
+        constexpr unsigned ES = HALF ? 2u : 4u;
         const float r = 0.70710678118654752440f * sigma;
-        float xa[32], xc[32];
-        load_raw<Cfg<R>::T, false>(xa, xb, dtype, tid, 0u, L, 0);
-        load_raw<Cfg<R>::T, false>(xc, xb, dtype, tid, 0u, L, Cfg<R>::M);
         HY_UNROLL
-        for (int s = 0; s < 32; ++s) {
-            const c32 y = mk(xa[s] + r * xc[s], -r * xc[s]);       // x[n] + sigma e^(-i pi/4) x[n + M/2]
-            v[s] = cmul(y, twist_const<PHI8>(s));
+        for (int s0 = 0; s0 < 32; s0 += 8) {          // 8 pairs at a time: registers are what this kernel is short of
+            float xa[8], xc[8];
+            HY_UNROLL
+            for (int i = 0; i < 8; ++i) {
+                const int s = s0 + i;
+#ifdef HIPEMU
+                const int n = tid + T * s;
+                xa[i] = n < L ? io_ld<HALF>(xb, (unsigned)n * ES, 0u, bf) : 0.f;
+                xc[i] = n + MS < L ? io_ld<HALF>(xb, (unsigned)(n + MS) * ES, 0u, bf) : 0.f;
+#else
+                xa[i] = io_ld<HALF>(xb, (unsigned)tid * ES, (unsigned)(T * s) * ES, bf);
+                xc[i] = io_ld<HALF>(xb, (unsigned)tid * ES, (unsigned)(T * s + MS) * ES, bf);
+#endif
+            }
+            HY_UNROLL
+            for (int i = 0; i < 8; ++i) {
+                const c32 y = mk(xa[i] + r * xc[i], -r * xc[i]);       // x[n] + sigma e^(-i pi/4) x[n + M/2]
+                v[s0 + i] = cmul(y, twist_const<PHI8>(s0 + i));
+            }
+            HY_SCHED_FENCE();
         }
     }
 }
 
-template <int R, int NP>
+template <int R, int NP, bool HALF, int E0>
 __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
     typedef Cfg<R> C;
     typedef DkCfg<R, NP> K;
     constexpr int T = C::T, BP = K::BP;
+    constexpr unsigned ES = HALF ? 2u : 4u;
     HY_SMEM(smem);
-    const unsigned ES = esize(a.dtype);
-    const int rg = threadIdx.x / T, tid = threadIdx.x % T;
+    const bool bf = a.dtype == DT_BF16;
+    const int rg = BP == 1 ? 0 : (int)threadIdx.x / T, tid = BP == 1 ? (int)threadIdx.x : (int)threadIdx.x % T;
     const int d = blockIdx.x;
     Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
     const unsigned rowbytes = (unsigned)a.L * ES;
     const float sc = 1.0f / (float)(C::M * NP);
     float* dkrow = a.dk + (size_t)d * a.L;
-    HY_UNROLL
-    for (int e = 0; e < NP; ++e) {
+    {
+        constexpr int e = E0;
+        constexpr int PHI_A = NP == 2 ? 1 : 2, PHI_B = 5;       // e = 0 / e = 1
+        const float sigma = e ? -1.f : 1.f;
         if constexpr (NP == 2) c.tab = make_gbuf(a.tab + e * C::TWN, (unsigned)C::TWN * 8u);
         c32 acc[32];
         HY_UNROLL
@@ -581,14 +617,14 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
             const GBuf gb = make_gbuf(reinterpret_cast<const char*>(a.dout) + row, rowbytes);
             const GBuf ub = make_gbuf(reinterpret_cast<const char*>(a.u) + row, rowbytes);
             c32 u[32], v[32];
-            if (NP == 1) dk_load<R, NP, 2>(u, ub, a.dtype, tid, a.L, 1.f);
-            else if (e == 0) dk_load<R, NP, 1>(u, ub, a.dtype, tid, a.L, 1.f);
-            else dk_load<R, NP, 5>(u, ub, a.dtype, tid, a.L, -1.f);
+            if (e == 0) dk_load<R, NP, HALF, PHI_A>(u, ub, bf, tid, a.L, sigma);
+            else dk_load<R, NP, HALF, PHI_B>(u, ub, bf, tid, a.L, sigma);
             fft_fwd<R>(u, c);
-            if (NP == 1) dk_load<R, NP, 2>(v, gb, a.dtype, tid, a.L, 1.f);
-            else if (e == 0) dk_load<R, NP, 1>(v, gb, a.dtype, tid, a.L, 1.f);
-            else dk_load<R, NP, 5>(v, gb, a.dtype, tid, a.L, -1.f);
+            HY_SCHED_FENCE();
+            if (e == 0) dk_load<R, NP, HALF, PHI_A>(v, gb, bf, tid, a.L, sigma);
+            else dk_load<R, NP, HALF, PHI_B>(v, gb, bf, tid, a.L, sigma);
             fft_fwd<R>(v, c);
+            HY_SCHED_FENCE();
             const float lv = live ? 1.f : 0.f;
             HY_UNROLL
             for (int q = 0; q < 32; ++q) {
@@ -631,8 +667,7 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
                 const float rr = 0.70710678118654752440f;
                 HY_UNROLL
                 for (int s = 0; s < 32; ++s) {
-                    const c32 w = e ? twist_const<5>(s) : twist_const<1>(s);
-                    const c32 h = cmulc(acc[s], w);                          // untwisted h_e[n]
+                    const c32 h = cmulc(acc[s], e ? twist_const<PHI_B>(s) : twist_const<PHI_A>(s));          // untwisted h_e[n]
                     const int n = tid + T * s;
                     const float lo = h.x * sc, hi = (h.x - h.y) * rr * sc;   // Re(h), Re(e^(i pi/4) h)
                     if (e == 0) {
@@ -649,7 +684,6 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
                 }
             }
         }
-        if constexpr (NP == 2) __syncthreads();
     }
 }
 

@@ -1,0 +1,120 @@
+// Round-2 redo of scripts/xcd_exchange.hip ("weak" item 10): the 20 us intra-XCD barrier measured there was an
+// artefact of its design -- 64 workgroups polling ONE counter with read-modify-write atomics.  Here every workgroup owns
+// a flag word (one relaxed agent-scope store after its data stores have completed), and a consumer polls all 64 flags of
+// its XCD with ONE 64-lane load (sc1: served by the L2) + a wave ballot:
+//     producer : data stores -> s_waitcnt vmcnt(0) -> __syncthreads -> lane 0: flag[xcd][wg] = epoch   (relaxed, agent)
+//     consumer : wave 0: do { f = load(flag[xcd][lane]) } while (!all(f >= epoch)); -> __syncthreads -> buffer_inv sc1
+// Measured: (1) the barrier alone, (2) a W-like slab exchange (128-byte column pieces written, 8 KB rows read back)
+// for slabs of 1 ... 128 MB per XCD, values checked.  Spins are bounded (a non-resident grid reports an error).
+//   hipcc --offload-arch=gfx950 -O3 scripts/xcd_flags.hip -o build/xcd_flags && ./build/xcd_flags
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define NXCD 8
+#define WG_PER_XCD 64
+#define THREADS 256
+#define SPIN_LIMIT 4000000
+
+template <int SLEEP>
+__device__ __forceinline__ bool flag_barrier(unsigned* flags /* [WG_PER_XCD] of this XCD */, int me, unsigned epoch, int* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores have reached the L2
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flags + me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
+    if (threadIdx.x < 64) {
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned f = __hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_ballot_w64(f >= epoch) == ~0ull) break;
+            if (++spins > SPIN_LIMIT) { ok = false; if (threadIdx.x == 0) atomicExch(err, 1); break; }
+            if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
+        }
+    }
+    __syncthreads();
+    asm volatile("buffer_inv sc1" ::: "memory");           // drop stale L1 lines; the L2 keeps its data
+    return ok;
+}
+
+template <int SLEEP>
+__global__ void __launch_bounds__(THREADS) barrier_only(int iters, unsigned* flags, int* err) {
+    const int xcd = blockIdx.x % NXCD, me = blockIdx.x / NXCD;
+    for (int it = 1; it <= iters; ++it)
+        if (!flag_barrier<SLEEP>(flags + xcd * WG_PER_XCD, me, (unsigned)it, err)) return;
+}
+
+// slab of one XCD: rows x 512 float4 (8 KB rows).  Workgroup r owns float4 columns [8 r, 8 r + 8) (128 bytes of a row).
+__global__ void __launch_bounds__(THREADS) exchange(float4* slabs, size_t slab_f4, int rows, int iters, unsigned* flags, int* err,
+                                                    float* sink) {
+    const int bx = blockIdx.x;
+    const int xcd = bx % NXCD, r = bx / NXCD;
+    float4* slab = slabs + (size_t)xcd * slab_f4;
+    unsigned* fl = flags + xcd * WG_PER_XCD;
+    const int t = threadIdx.x;
+    float acc = 0.f;
+    unsigned phase = 0;
+    for (int it = 0; it < iters; ++it) {
+        for (int row = t >> 3; row < rows; row += THREADS / 8) {
+            const float v = (float)(it + row + r);
+            slab[(size_t)row * 512 + 8 * r + (t & 7)] = make_float4(v, v, v, v);
+        }
+        if (!flag_barrier<1>(fl, r, ++phase, err)) return;
+        for (int row = r; row < rows; row += WG_PER_XCD) {
+            const float4 a = slab[(size_t)row * 512 + t], b = slab[(size_t)row * 512 + 256 + t];
+            acc += a.x + b.x - 2.f * (float)(it + row) - (float)(t >> 3) - (float)((256 + t) >> 3);
+        }
+        if (!flag_barrier<1>(fl, r, ++phase, err)) return;
+    }
+    if (acc != 0.f) atomicExch(err, 2);
+    if (acc == 1234.5f) sink[0] = acc;
+}
+
+int main() {
+    const int grid = NXCD * WG_PER_XCD;
+    unsigned* flags; hipMalloc(&flags, NXCD * WG_PER_XCD * sizeof(unsigned));
+    int* err; hipMalloc(&err, sizeof(int));
+    float* sink; hipMalloc(&sink, 64);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    {
+        const int iters = 2000;
+        float ms; int herr;
+#define RUN_BAR(S, label)                                                                                         \
+        hipMemset(flags, 0, NXCD * WG_PER_XCD * sizeof(unsigned)); hipMemset(err, 0, sizeof(int));                \
+        hipEventRecord(e0); barrier_only<S><<<grid, THREADS>>>(iters, flags, err); hipEventRecord(e1);            \
+        hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);                                                 \
+        hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost);                                                 \
+        printf("flag barrier alone, 64 workgroups per XCD x 8 XCDs (%s): %.2f us%s\n", label, ms * 1e3 / iters, herr ? "  [TIMED OUT]" : "");
+        RUN_BAR(0, "busy poll")
+        RUN_BAR(1, "s_sleep 1")
+        RUN_BAR(4, "s_sleep 4")
+    }
+    const int row_counts[] = {128, 256, 384, 512, 1024, 2048, 16384};    // x 8 KB: 1, 2, 3, 4, 8, 16, 128 MB per XCD
+    printf("%12s %14s %14s\n", "MB per XCD", "exchange GB/s", "us per phase");
+    for (int rows : row_counts) {
+        const size_t slab_f4 = (size_t)rows * 512;
+        float4* slabs;
+        if (hipMalloc(&slabs, slab_f4 * 16 * NXCD) != hipSuccess) { printf("alloc failed\n"); break; }
+        hipMemset(slabs, 0, slab_f4 * 16 * NXCD);
+        const int iters = rows <= 1024 ? 200 : (rows <= 2048 ? 50 : 8);
+        float best = 1e30f;
+        int herr = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipMemset(flags, 0, NXCD * WG_PER_XCD * sizeof(unsigned));
+            hipMemset(err, 0, sizeof(int));
+            hipEventRecord(e0);
+            exchange<<<grid, THREADS>>>(slabs, slab_f4, rows, iters, flags, err, sink);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost);
+            if (herr) break;
+            if (ms < best) best = ms;
+        }
+        if (herr) { printf("%12.1f   ERROR %d (1 = barrier timed out, 2 = stale data)\n", rows * 8.0 / 1024, herr); hipFree(slabs); continue; }
+        const double bytes = (double)slab_f4 * 16 * NXCD * 2 * iters;
+        printf("%12.1f %14.0f %14.2f\n", rows * 8.0 / 1024, bytes / best / 1e6, best * 1e3 / (2.0 * iters));
+        hipFree(slabs);
+    }
+    return 0;
+}
