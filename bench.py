@@ -12,14 +12,17 @@ metric on: L = 1,048,576, d = 256, B = 1 per GPU, bf16 activations, fp32 filter 
 
 Multi-GPU: the path shards on the batch axis (independent sequences): every rank runs the same
 per-GPU workload on its own seeded batch (weak scaling).  The convolution itself has no exchange step; the only
-collective of the training step it belongs to is the DDP gradient all-reduce of the model parameters (6.6 M fp32
-for hyenadna-large-1m), which is reproduced here as one RCCL all-reduce of that size per step on a side stream,
-overlapped with the next step's kernels, so that the N-GPU number carries the real communication of the path.
+collective of the training step it belongs to is the DDP gradient all-reduce of the model parameters.  For N > 1 the
+parameters of a hyenadna-large-1m-shaped stack (8 x [HyenaOperator + MLP + 2 LayerNorm] + embedding, ~6.6 M fp32) are
+wrapped in torch DistributedDataParallel and every step runs a backward that produces a gradient for each of them, so
+that RCCL carries DDP's real buckets and hooks (src/utils/train.py semantics: one all-reduce per bucket, overlapped
+with the rest of the backward) next to the convolution's kernels.
 
 One JSON line on stdout (rank 0).  `roofline` is computed from algorithmic bytes (SURVEY.md 8d:
-5*B*D*L*s + 12*D*L per step) over the HIP-event time of the timed region; `cpu_baseline` is the oracle
-(`oracle/hyena_oracle.py`, a restatement of the reference's torch.fft path) timed on this box's host cores on a
-bounded sample.
+5*B*D*L*s + 12*D*L per step) over the HIP-event time of the timed region; `roofline_valu` is the second roofline of
+SURVEY.md 8d (algorithmic flops vs the fp32 vector peak) together with the LDS bytes the transforms' exchanges move;
+`cpu_baseline` is the oracle (`oracle/hyena_oracle.py`, a restatement of the reference's torch.fft path) timed on this
+box's host cores on a bounded sample.
 """
 import argparse
 import json
@@ -35,7 +38,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
-MODEL_GRAD_ELEMS = 6_600_000     # fp32 parameters of hyenadna-large-1m (8 layers, d_model 256)
+VALU_PEAK_TFLOPS = 157.3         # fp32 vector peak (MI355X_MICROARCH.md; v_fma_f32 measured at 117 TF by scripts/valu_rate.hip)
+LDS_PEAK_TBS = 45.0              # aggregate ds_write rate, the tighter half of an exchange (MI355X_MICROARCH.md: 38-51 TB/s)
 METRIC = "nucleotides/sec fwd+bwd at L=1M d=256; fftconv achieved HBM GB/s vs peak"
 
 
@@ -43,6 +47,49 @@ def algorithmic_bytes(B, D, L, s):
     """SURVEY.md 8d, operator boundary of the reference's fftconv: fwd reads u, k and writes out; bwd reads dout, u,
     k and writes du, dk (+ dbias)."""
     return 5 * B * D * L * s + 12 * D * L + 8 * D
+
+
+def algorithmic_flops(B, D, L, M):
+    """a real FFT of 2M points done as a complex FFT of M points costs ~5 M log2 M flops (nominal radix-2
+    count); transforms per (b, d) row, fwd+bwd: U, y; G, du, U again = 5, plus K and dk once per channel = 2 / B."""
+    import math
+    per = 5.0 * M * math.log2(max(M, 2))
+    return (5 * B + 2) * D * per
+
+
+def lds_exchange_bytes(B, D, M):
+    """Bytes the transforms move through LDS per step: every transform is three (M <= 32768: 32 x 32 x R on chip) or four
+    (two-level: 32 x M1/32 columns, 32 x 32 rows) register passes, i.e. two exchanges, each writing and reading 8 M bytes."""
+    return (5 * B + 2) * D * 2 * 2 * 8 * M
+
+
+class GradCarrier(torch.nn.Module):
+    """Parameters of a hyenadna-large-1m-shaped stack (n_layer x [HyenaOperator + Mlp d -> 4d -> d + 2 LayerNorm] + token
+    embedding; long_conv_lm.py:400-502, hg38_hyena.yaml) whose `forward` is a scalar that gives EVERY parameter a gradient
+    -- the object DistributedDataParallel wraps in the N > 1 leg, so that RCCL carries the model's real gradient buckets."""
+
+    def __init__(self, d_model=256, n_layer=8, l_max=1024, d_inner=1024, vocab=16):
+        super().__init__()
+        from hyena_dna_amd.hyena import HyenaOperator
+        nn = torch.nn
+        self.embed = nn.Embedding(vocab, d_model)
+        self.layers = nn.ModuleList()
+        for _ in range(n_layer):
+            self.layers.append(nn.ModuleDict({
+                "mixer": HyenaOperator(d_model=d_model, l_max=l_max, order=2, filter_order=64, emb_dim=5, short_filter_order=3,
+                                       modulate=True, w=10, lr=6e-4, wd=0.0, lr_pos_emb=0.0),
+                "norm1": nn.LayerNorm(d_model), "norm2": nn.LayerNorm(d_model),
+                "fc1": nn.Linear(d_model, d_inner), "fc2": nn.Linear(d_inner, d_model)}))
+        self.ln_f = nn.LayerNorm(d_model)
+
+    def forward(self, scale):
+        # d/dp of sum(p) * scale = scale for every element: a gradient for each parameter, in reverse registration order
+        # (the order DDP's buckets are built for), at the cost of one tiny reduction per tensor
+        total = None
+        for p in self.parameters():
+            t = p.sum()
+            total = t if total is None else total + t
+        return total * scale
 
 
 def measured_traffic(L, D, B, io_dtype, save):
@@ -93,9 +140,9 @@ def cpu_baseline(L, D, dtype, budget_s=25.0):
     k = torch.randn(Ds, L, generator=g) * torch.exp(-5.0 * torch.linspace(0, 1, L))[None] * 0.1
     bias = torch.randn(Ds, generator=g)
     dout = torch.randn(1, Ds, L, generator=g).to(dtype)
-    best = None
+    best, timed = None, 0
     t_start = time.perf_counter()
-    for rep in range(4):                      # 1 warm-up + best of 3
+    for rep in range(4):                      # 1 warm-up + up to 3 timed repetitions inside the time budget
         u_ = u.clone().requires_grad_(True)
         k_ = k.clone().requires_grad_(True)
         b_ = bias.clone().requires_grad_(True)
@@ -105,12 +152,14 @@ def cpu_baseline(L, D, dtype, budget_s=25.0):
         dt = time.perf_counter() - t0
         if rep > 0:
             best = dt if best is None else min(best, dt)
+            timed += 1
         if time.perf_counter() - t_start > budget_s and best is not None:
             break
     nt_per_s = L * (Ds / D) / best           # a nucleotide = one position through all D channels
     return {"value": nt_per_s, "unit": "nt/s", "cores": cores, "kind": "port",
             "sample": f"oracle fftconv_ref fwd+bwd (torch.fft, fp32 math), B=1, L={L}, {Ds} of {D} channels, "
-                      f"best of 3 after 1 warm-up, {best * 1e3:.0f} ms; scaled by {Ds}/{D} channels"}
+                      f"best of {timed} timed repetition{'s' if timed != 1 else ''} after 1 warm-up ({budget_s:.0f} s budget), "
+                      f"{best * 1e3:.0f} ms; scaled by {Ds}/{D} channels"}
 
 
 def operator_layer(L, D, B, dtype, dev, steps=5, warmup=2):
@@ -177,8 +226,13 @@ def main():
     bias = torch.randn(D, generator=g, device=dev)
     dout = torch.randn(B, D, L, generator=g, device=dev).to(dtype)
     chunk = args.chunk if args.chunk > 0 else None
-    grads = torch.zeros(MODEL_GRAD_ELEMS, dtype=torch.float32, device=dev) if world > 1 and not args.no_allreduce else None
-    comm_stream = torch.cuda.Stream(device=dev) if (grads is not None and not args.emu) else None
+    ddp = None
+    if world > 1 and not args.no_allreduce:
+        from torch.nn.parallel import DistributedDataParallel
+        torch.manual_seed(1234)                                   # identical replicas, as DDP requires
+        carrier = GradCarrier(d_model=D, n_layer=8, l_max=min(L, 4096)).to(dev)
+        ddp = DistributedDataParallel(carrier, device_ids=None if args.emu else [dev.index])
+        n_grad = sum(p.numel() for p in carrier.parameters())
 
     save = not args.no_save_spectra and not args.fwd_only
 
@@ -191,14 +245,11 @@ def main():
             out, saved = _lib.fftconv_fwd(u, k, bias, chunk=chunk), None
         if args.fwd_only:
             return out
+        if ddp is not None:
+            # the model's gradient buckets go out (DDP hooks -> RCCL on its own stream) while the convolution's backward runs
+            ddp.zero_grad(set_to_none=True)
+            ddp(1.0).backward()
         res = _lib.fftconv_bwd(dout, u, k, bias, chunk=chunk, saved=saved)
-        if grads is not None:
-            if comm_stream is not None:
-                comm_stream.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(comm_stream):
-                    dist.all_reduce(grads)
-            else:
-                dist.all_reduce(grads)
         return res
 
     def sync():
@@ -220,8 +271,6 @@ def main():
         step()
     if not args.emu:
         e1.record()
-    if comm_stream is not None:
-        torch.cuda.current_stream(dev).wait_stream(comm_stream)
     sync()
     wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1) if not args.emu else wall * 1e3
@@ -237,6 +286,11 @@ def main():
         abytes = algorithmic_bytes(B, D, L, s)
         ev_ms_step = ev_ms / args.steps
         achieved = abytes / (ev_ms_step * 1e-3) / 1e9
+        M = int(_lib.lib().hyena_fftconv_fft_size(L))
+        onchip = int(_lib.lib().hyena_fftconv_plan(L)) == _lib.PLAN_ONCHIP
+        aflops = algorithmic_flops(B, D, L, M)
+        tflops = aflops / (ev_ms_step * 1e-3) / 1e12
+        lds_b = lds_exchange_bytes(B, D, M)
         line = {
             "metric": METRIC, "value": nt_per_s, "unit": "nt/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -247,13 +301,23 @@ def main():
                        "seq_len": L, "channels": D, "batch_per_gpu": B, "io_dtype": args.dtype,
                        "save_spectra": bool(save),
                        "chunk": int(_lib.lib().hyena_fftconv_default_chunk(B, D, L, 1)) if chunk is None else chunk,
-                       "parallelism": f"dp{world} (batch-sharded, RCCL all-reduce of {MODEL_GRAD_ELEMS} fp32 grads/step)"
+                       "parallelism": (f"dp{world} (batch-sharded; torch DDP over a hyenadna-large-1m-shaped parameter stack, "
+                                       f"{n_grad} fp32 gradients all-reduced per step in DDP's buckets)"
+                                       if ddp is not None else f"dp{world} (batch-sharded, no collective)")
                                       if world > 1 else "single GPU",
                        "unit_of_work": "one nucleotide through one Hyena long-conv layer call (fwd+bwd), all d channels"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(L, D, B, args.dtype, save),
-                         "kernel": "all launches of one fftconv fwd+bwd step (col_fwd/row_*/col_inv chain)",
+                         "kernel": "all launches of one fftconv fwd+bwd step (" +
+                                   ("spec / conv / dk kernels of the workspace-free plan)" if onchip
+                                    else "col_fwd / row_* / col_inv chain of the two-level plan)"),
                          "algorithmic_bytes_per_step": abytes, "event_ms_per_step": ev_ms_step},
+            # the second roofline of SURVEY.md 8d: the fused op sits at / above the fp32 ridge, so VALU (and LDS) co-bind
+            "roofline_valu": {"bound": "valu_fp32", "achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": tflops / VALU_PEAK_TFLOPS, "algorithmic_flops_per_step": aflops, "fft_points": M,
+                              "transforms_per_step": (5 * B + 2) * D,
+                              "lds_bytes_per_step": lds_b, "lds_achieved_TBs": lds_b / (ev_ms_step * 1e-3) / 1e12,
+                              "lds_peak_TBs": LDS_PEAK_TBS},
         }
         if world == 1 and not args.emu and not args.no_operator and not args.fwd_only:
             try:

@@ -60,6 +60,9 @@ class _HipBackend:
     def stream(self, device):
         return torch.cuda.current_stream(device).cuda_stream
 
+    def free_memory(self):
+        return torch.cuda.mem_get_info()[0]
+
 
 _backend = _HipBackend()
 
@@ -90,7 +93,7 @@ def lib():
         L.hyena_fftconv_table_bytes.restype = c_size_t
         L.hyena_fftconv_table_bytes.argtypes = [c_int]
         L.hyena_fftconv_init_tables.restype = c_int
-        L.hyena_fftconv_init_tables.argtypes = [c_void_p, c_int]
+        L.hyena_fftconv_init_tables.argtypes = [c_void_p, c_int, c_void_p]
         L.hyena_fftconv_default_chunk.restype = c_int
         L.hyena_fftconv_default_chunk.argtypes = [c_int, c_int, c_int, c_int]
         L.hyena_fftconv_workspace_bytes.restype = c_size_t
@@ -183,17 +186,24 @@ def tables_for(device, L):
                 nbytes = lib().hyena_fftconv_table_bytes(int(L))
                 t = torch.empty(nbytes, dtype=torch.uint8, device=device)
                 with _backend.guard(device):
-                    check(lib().hyena_fftconv_init_tables(t.data_ptr(), int(L)))
+                    check(lib().hyena_fftconv_init_tables(t.data_ptr(), int(L), _backend.stream(device)))
                 _tables[key] = t
     return t
 
 
+_retired = []     # outgrown workspaces: kept alive, a captured hipGraph may still replay on them
+
+
 def workspace_for(device, nbytes):
-    """A per-(device, stream) scratch buffer, grown on demand and reused across calls."""
+    """A per-(device, stream) scratch buffer, grown on demand (geometrically) and reused across calls.  An outgrown buffer
+    is retired, not freed: launches captured into a hipGraph keep pointing at it."""
     stream = _backend.stream(device)
     key = (device.index, stream)
     w = _workspace.get(key)
     if w is None or w.numel() < nbytes:
+        if w is not None:
+            _retired.append(w)
+            nbytes = max(int(nbytes), int(1.5 * w.numel()))
         w = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _workspace[key] = w
     return w, stream
@@ -219,7 +229,13 @@ def save_spectra_default(B, D, L):
         return False         # nothing worth keeping: the only intermediate is the filter spectrum, one transform per channel
     if mode in ("1", "on", "true"):
         return True
-    return saved_bytes(B, D, L) <= float(os.environ.get("HYENA_FFTCONV_SAVE_LIMIT_GB", "6")) * 2 ** 30
+    need = saved_bytes(B, D, L)
+    if need > float(os.environ.get("HYENA_FFTCONV_SAVE_LIMIT_GB", "6")) * 2 ** 30:
+        return False
+    # per call = per layer: never take more than a quarter of what the device has free right now (the recomputing
+    # backward fits where this buffer would not)
+    free = _backend.free_memory()
+    return free is None or need <= free // 4
 
 
 def fftconv_fwd(u, k, bias, chunk=None, save=False):

@@ -219,7 +219,8 @@ size_t hyena_fftconv_table_bytes(int L) {
     return (size_t)4096 * sizeof(c32);
 }
 
-int hyena_fftconv_init_tables(void* d_tables, int L) {
+int hyena_fftconv_init_tables(void* d_tables, int L, void* stream) {
+    (void)stream;
     Plan p;
     if (d_tables == nullptr) return HYENA_ERR_BAD_ARG;
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
@@ -230,8 +231,10 @@ int hyena_fftconv_init_tables(void* d_tables, int L) {
 #ifdef HIPEMU
         memcpy(d_tables, h.data(), h.size() * sizeof(c32));
 #else
-        if (hipMemcpy(d_tables, h.data(), h.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess)
+        // stream-ordered with the kernels that will read the table (pageable source: staged before the call returns)
+        if (hipMemcpyAsync(d_tables, h.data(), h.size() * sizeof(c32), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
             return HYENA_ERR_LAUNCH;
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return HYENA_ERR_LAUNCH;
 #endif
         return HYENA_OK;
     }
@@ -258,8 +261,9 @@ int hyena_fftconv_init_tables(void* d_tables, int L) {
 #ifdef HIPEMU
     memcpy(d_tables, h.data(), h.size() * sizeof(c32));
 #else
-    if (hipMemcpy(d_tables, h.data(), h.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpyAsync(d_tables, h.data(), h.size() * sizeof(c32), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
         return HYENA_ERR_LAUNCH;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return HYENA_ERR_LAUNCH;
 #endif
     return HYENA_OK;
 }
@@ -368,6 +372,7 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
     if (p.R) {
         if (dk != nullptr && u == nullptr) return HYENA_ERR_BAD_ARG;        // this path keeps no spectrum of u: it re-reads u
+        if (p.R == 1 && (size_t)B * D * L * elem_size(dtype) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;   // 32-bit row offsets (dk, T = 32)
         if ((size_t)D * p.M * sizeof(c32) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;
         if (workspace_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
         if (saved != nullptr && saved_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;

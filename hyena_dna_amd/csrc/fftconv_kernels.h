@@ -163,7 +163,15 @@ __device__ __forceinline__ void stg(c32* base, unsigned idx, c32 v) {
 // the hardware bounds check.
 #ifdef HIPEMU
 struct GBuf { char* p; };
-__device__ __forceinline__ GBuf make_gbuf(const void* base, unsigned) { GBuf b; b.p = (char*)base; return b; }
+// Like the hardware descriptor (built from SGPRs via readfirstlane), the emulated one takes the base of the wavefront's
+// FIRST lane for every lane: a kernel that hands per-lane bases to make_gbuf fails here as it would on the GPU.
+__device__ __forceinline__ GBuf make_gbuf(const void* base, unsigned) {
+    const uintptr_t v = (uintptr_t)base;
+    const uint32_t lo = hipemu::shfl_u32((uint32_t)v, 0), hi = hipemu::shfl_u32((uint32_t)(v >> 32), 0);
+    GBuf b;
+    b.p = (char*)(((uintptr_t)hi << 32) | lo);
+    return b;
+}
 __device__ __forceinline__ c32 gb_ld(GBuf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const c32*>(b.p + voff + soff); }
 __device__ __forceinline__ void gb_st(GBuf b, unsigned voff, unsigned soff, c32 v) { *reinterpret_cast<c32*>(b.p + voff + soff) = v; }
 struct __attribute__((aligned(16))) c32x2 { c32 a, b; };

@@ -556,34 +556,22 @@ template <int R, int NP> struct DkCfg {
 
 // spectrum input of sub-problem e (NP = 2: PHI8 = 1 + 4 e, sigma = +-1) or of the whole row (NP = 1)
 template <int R, int NP, bool HALF, int PHI8>
-__device__ __forceinline__ void dk_load(c32 (&v)[32], GBuf xb, bool bf, int tid, int L, float sigma) {
+__device__ __forceinline__ void dk_load(c32 (&v)[32], GBuf xb, bool bf, int tid, unsigned row_off, int L, float sigma) {
     if constexpr (NP == 1) {
-        load_row<R, 2, HALF, false>(v, xb, bf, tid, 0u, L);
+        // T = 32: two row groups share a wavefront, hence one descriptor (the whole tensor) and a per-lane row offset
+        load_row<R, PHI8, HALF, (Cfg<R>::T < 64)>(v, xb, bf, tid, row_off, L);
     } else {
         constexpr int T = Cfg<R>::T, MS = Cfg<R>::M;
-        constexpr unsigned ES = HALF ? 2u : 4u;
         const float r = 0.70710678118654752440f * sigma;
+        // all 64 loads of the thread in one batch (one memory round trip; 8-pair batches measured 4x slower on MI355X:
+        // with 2 wavefronts per SIMD nothing hides the latency between batches)
+        float xa[32], xc[32];
+        load_raw<T, HALF, false>(xa, xb, bf, tid, 0u, L, 0);
+        load_raw<T, HALF, false>(xc, xb, bf, tid, 0u, L, MS);
         HY_UNROLL
-        for (int s0 = 0; s0 < 32; s0 += 8) {          // 8 pairs at a time: registers are what this kernel is short of
-            float xa[8], xc[8];
-            HY_UNROLL
-            for (int i = 0; i < 8; ++i) {
-                const int s = s0 + i;
-#ifdef HIPEMU
-                const int n = tid + T * s;
-                xa[i] = n < L ? io_ld<HALF>(xb, (unsigned)n * ES, 0u, bf) : 0.f;
-                xc[i] = n + MS < L ? io_ld<HALF>(xb, (unsigned)(n + MS) * ES, 0u, bf) : 0.f;
-#else
-                xa[i] = io_ld<HALF>(xb, (unsigned)tid * ES, (unsigned)(T * s) * ES, bf);
-                xc[i] = io_ld<HALF>(xb, (unsigned)tid * ES, (unsigned)(T * s + MS) * ES, bf);
-#endif
-            }
-            HY_UNROLL
-            for (int i = 0; i < 8; ++i) {
-                const c32 y = mk(xa[i] + r * xc[i], -r * xc[i]);       // x[n] + sigma e^(-i pi/4) x[n + M/2]
-                v[s0 + i] = cmul(y, twist_const<PHI8>(s0 + i));
-            }
-            HY_SCHED_FENCE();
+        for (int s = 0; s < 32; ++s) {
+            const c32 y = mk(xa[s] + r * xc[s], -r * xc[s]);           // x[n] + sigma e^(-i pi/4) x[n + M/2]
+            v[s] = cmul(y, twist_const<PHI8>(s));
         }
     }
 }
@@ -614,15 +602,19 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
             const bool live = b0 + rg < a.B;
             const int b = live ? b0 + rg : a.B - 1;
             const size_t row = ((size_t)b * a.D + d) * a.L * ES;
-            const GBuf gb = make_gbuf(reinterpret_cast<const char*>(a.dout) + row, rowbytes);
-            const GBuf ub = make_gbuf(reinterpret_cast<const char*>(a.u) + row, rowbytes);
+            // one descriptor per row (hardware bounds check clips n >= L) -- except at T = 32, where the two row groups of
+            // a wavefront need a common one: the whole tensor (< 4 GB, checked by the host) + a per-lane row offset
+            constexpr bool WHOLE = T < 64;
+            const GBuf gb = WHOLE ? make_gbuf(a.dout, (unsigned)((size_t)a.B * a.D * a.L * ES)) : make_gbuf(reinterpret_cast<const char*>(a.dout) + row, rowbytes);
+            const GBuf ub = WHOLE ? make_gbuf(a.u, (unsigned)((size_t)a.B * a.D * a.L * ES)) : make_gbuf(reinterpret_cast<const char*>(a.u) + row, rowbytes);
+            const unsigned row_off = WHOLE ? (unsigned)row : 0u;
             c32 u[32], v[32];
-            if (e == 0) dk_load<R, NP, HALF, PHI_A>(u, ub, bf, tid, a.L, sigma);
-            else dk_load<R, NP, HALF, PHI_B>(u, ub, bf, tid, a.L, sigma);
+            if (e == 0) dk_load<R, NP, HALF, PHI_A>(u, ub, bf, tid, row_off, a.L, sigma);
+            else dk_load<R, NP, HALF, PHI_B>(u, ub, bf, tid, row_off, a.L, sigma);
             fft_fwd<R>(u, c);
             HY_SCHED_FENCE();
-            if (e == 0) dk_load<R, NP, HALF, PHI_A>(v, gb, bf, tid, a.L, sigma);
-            else dk_load<R, NP, HALF, PHI_B>(v, gb, bf, tid, a.L, sigma);
+            if (e == 0) dk_load<R, NP, HALF, PHI_A>(v, gb, bf, tid, row_off, a.L, sigma);
+            else dk_load<R, NP, HALF, PHI_B>(v, gb, bf, tid, row_off, a.L, sigma);
             fft_fwd<R>(v, c);
             HY_SCHED_FENCE();
             const float lv = live ? 1.f : 0.f;

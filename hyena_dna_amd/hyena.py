@@ -251,7 +251,7 @@ class HyenaOperator(nn.Module):
         """The fused HIP mixer core covers exactly the HyenaDNA operator configuration."""
         return (self.order == 2 and self.num_heads == 1 and self.num_blocks == 1 and self.inner_factor == 1
                 and not self.outer_mixing and not self.post_order_ffn and self.short_filter_order == 3
-                and (self.dropout.p == 0.0 or not self.training) and self.filter_fn.use_bias is not None)
+                and (self.dropout.p == 0.0 or not self.training))
 
     def forward(self, u, *args, **kwargs):
         l = u.size(-2)

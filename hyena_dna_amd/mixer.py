@@ -52,15 +52,23 @@ class HyenaMixerFunc(torch.autograd.Function):
         part = _lib.mixer_partials(xc, L)
         dy = _lib.mixer_post_bwd(dz, y, xc, w, b, dx, part)
         vg = None if ctx.spectra is not None else _lib.mixer_pre_fwd(xc, w, b, L)      # recompute the conv's input
-        dvg, dk, dbias = _lib.fftconv_bwd(dy, vg, kf, bf, need_du=True, need_dk=True, saved=ctx.spectra)
+        need_dk = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]          # a frozen filter skips the dk path entirely
+        dvg, dk, dbias = _lib.fftconv_bwd(dy, vg, kf, bf, need_du=True, need_dk=need_dk, saved=ctx.spectra)
         ctx.spectra = None
         _lib.mixer_pre_bwd(dvg, xc, w, b, dx, part)
         red = part.sum(dim=(0, 1))                                  # (3D, 4): deterministic two-stage reduction
         dw = red[:, :3].reshape(w_shape).to(w_dtype)
         db = red[:, 3].to(b_dtype)
-        return dx, dw, db, dk.to(k_dtype), dbias.reshape(bias_shape).to(bias_dtype), None
+        return (dx, dw, db, dk.to(k_dtype) if dk is not None else None,
+                dbias.reshape(bias_shape).to(bias_dtype) if dbias is not None else None, None)
 
 
 def hyena_mixer_core(x, sf_weight, sf_bias, k, bias, L):
     """z = ((fftconv(v * x1, k, bias)) * x0)^T with (x0, x1, v) = short_conv(x^T)[..., :L].split(D)."""
+    if x.shape[0] == 0 or L == 0:
+        # empty batch (or length): nothing to launch.  Like the reference's PyTorch ops this returns an empty tensor that
+        # is still connected to every input (their gradients are zeros, not None).
+        D = x.shape[-1] // 3
+        zero = 0 * (sf_weight.sum() + sf_bias.sum() + k.sum() + bias.sum())
+        return x[:, :L, :D] * 0 + zero.to(x.dtype)
     return HyenaMixerFunc.apply(x, sf_weight, sf_bias, k, bias, L)

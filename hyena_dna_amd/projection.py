@@ -14,7 +14,7 @@ plain fp32 / 16-bit tensors); everything else goes through ``torch.nn.functional
 import torch
 import torch.nn.functional as F
 
-__all__ = ["hyena_linear", "SplitKLinearFunc", "split_count"]
+__all__ = ["hyena_linear", "SplitKLinearFunc", "split_count", "split_k_weight_grad"]
 
 MIN_ROWS = 32768          # below this the library's own schedule is fine
 MAX_SPLITS = 64
@@ -22,11 +22,31 @@ MIN_SLICE = 4096
 
 
 def split_count(rows):
-    """Largest power-of-two number of slices <= MAX_SPLITS that divides ``rows`` with slices of >= MIN_SLICE rows."""
+    """Number of equal position slices of the batched weight-gradient GEMM: the largest power of two <= MAX_SPLITS with
+    slices of >= MIN_SLICE rows.  ``rows`` need not be divisible by it: the ``rows % S`` leftover rows go through one small
+    tail GEMM (the reference dataset yields L = max_length - 1 -- 999,999 / 449,999 / 159,999 / 32,767,
+    hg38_dataset.py:220 -- so B*L is odd in real training)."""
     s = 1
-    while s < MAX_SPLITS and rows % (2 * s) == 0 and rows // (2 * s) >= MIN_SLICE:
+    while s < MAX_SPLITS and rows // (2 * s) >= MIN_SLICE:
         s *= 2
     return s
+
+
+def split_k_weight_grad(dy2, x2):
+    """dy2^T x2 (fp32) as S batched slices + a tail, partial sums added in a fixed order (deterministic)."""
+    rows, n = dy2.shape
+    k = x2.shape[1]
+    s = split_count(rows)
+    body = (rows // s) * s
+    a, b = dy2[:body].view(s, rows // s, n).transpose(1, 2), x2[:body].view(s, rows // s, k)
+    if dy2.is_cuda:
+        part = torch.bmm(a, b, out_dtype=torch.float32)             # fp32 partial sums straight out of the MFMA accumulators
+    else:
+        part = torch.bmm(a.float(), b.float())                      # host tensors (unit tests): bmm has no out_dtype there
+    dw = part.sum(0)
+    if body < rows:                                                 # < S leftover rows
+        dw = dw + torch.mm(dy2[body:].t().float(), x2[body:].float())
+    return dw
 
 
 class SplitKLinearFunc(torch.autograd.Function):
@@ -46,14 +66,7 @@ class SplitKLinearFunc(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dy2, weight).view(x.shape)
         if ctx.needs_input_grad[1]:
-            rows = x2.shape[0]
-            s = split_count(rows)
-            a, b = dy2.view(s, rows // s, n).transpose(1, 2), x2.view(s, rows // s, k)
-            if dy2.is_cuda:
-                part = torch.bmm(a, b, out_dtype=torch.float32)     # fp32 partial sums straight out of the MFMA accumulators
-            else:
-                part = torch.bmm(a.float(), b.float())              # host tensors (unit tests): bmm has no out_dtype there
-            dw = part.sum(0).to(weight.dtype)
+            dw = split_k_weight_grad(dy2, x2).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(0, dtype=torch.float32).to(dy.dtype)
         return dx, dw, db

@@ -90,10 +90,12 @@ enum { HYENA_PLAN_NONE = 0, HYENA_PLAN_ONCHIP = 1, HYENA_PLAN_TWO_LEVEL = 2 };
 int hyena_fftconv_plan(int L);
 
 /* Bytes of device memory needed for the twiddle tables of sequence length L, and their one-time
- * initialisation (host computes in double precision, then a synchronous hipMemcpy to `d_tables`).
- * The same tables serve every call with the same hyena_fftconv_fft_size(L). */
+ * initialisation: the host computes them in double precision and copies them on `stream` (the stream the compute
+ * entry points will be given), then waits for that copy -- the ONE synchronising call of this ABI.  It must not
+ * run inside a hipGraph capture: initialise the tables of every length you will use before capturing.
+ * The same tables serve every call with the same hyena_fftconv_fft_size(L) and hyena_fftconv_plan(L). */
 size_t hyena_fftconv_table_bytes(int L);
-int hyena_fftconv_init_tables(void* d_tables, int L);
+int hyena_fftconv_init_tables(void* d_tables, int L, void* stream);
 
 /* Channels processed per pass through the kernel chain ("chunk").  Intermediate spectra of one chunk
  * live in the workspace; the default takes as many channels as an 8 GiB workspace holds (all of them at

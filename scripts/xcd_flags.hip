@@ -17,7 +17,10 @@
 #define THREADS 256
 #define SPIN_LIMIT 4000000
 
-template <int SLEEP>
+// INV: how the consumer side drops stale L1 lines after the barrier.  2 = every wavefront issues buffer_inv sc1 (first
+// attempt: 21 us per barrier -- each invalidate costs ~2 us and the 8 wavefronts of a CU's two workgroups serialise);
+// 1 = wavefront 0 only; 0 = none (the consumer then reads the exchanged data with sc1 loads, which bypass the L1).
+template <int SLEEP, int INV>
 __device__ __forceinline__ bool flag_barrier(unsigned* flags /* [WG_PER_XCD] of this XCD */, int me, unsigned epoch, int* err) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores have reached the L2
     __syncthreads();
@@ -32,19 +35,28 @@ __device__ __forceinline__ bool flag_barrier(unsigned* flags /* [WG_PER_XCD] of 
             if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
         }
     }
+    if (INV == 1 && threadIdx.x < 64) asm volatile("buffer_inv sc1" ::: "memory");
     __syncthreads();
-    asm volatile("buffer_inv sc1" ::: "memory");           // drop stale L1 lines; the L2 keeps its data
+    if (INV == 2) asm volatile("buffer_inv sc1" ::: "memory");           // drop stale L1 lines; the L2 keeps its data
     return ok;
 }
 
-template <int SLEEP>
+template <int SLEEP, int INV>
 __global__ void __launch_bounds__(THREADS) barrier_only(int iters, unsigned* flags, int* err) {
     const int xcd = blockIdx.x % NXCD, me = blockIdx.x / NXCD;
     for (int it = 1; it <= iters; ++it)
-        if (!flag_barrier<SLEEP>(flags + xcd * WG_PER_XCD, me, (unsigned)it, err)) return;
+        if (!flag_barrier<SLEEP, INV>(flags + xcd * WG_PER_XCD, me, (unsigned)it, err)) return;
+}
+
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_sc1(const float4* p) {       // 16-byte load that bypasses the L1 (served by the XCD's L2)
+    u4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
 }
 
 // slab of one XCD: rows x 512 float4 (8 KB rows).  Workgroup r owns float4 columns [8 r, 8 r + 8) (128 bytes of a row).
+template <int INV>
 __global__ void __launch_bounds__(THREADS) exchange(float4* slabs, size_t slab_f4, int rows, int iters, unsigned* flags, int* err,
                                                     float* sink) {
     const int bx = blockIdx.x;
@@ -59,12 +71,14 @@ __global__ void __launch_bounds__(THREADS) exchange(float4* slabs, size_t slab_f
             const float v = (float)(it + row + r);
             slab[(size_t)row * 512 + 8 * r + (t & 7)] = make_float4(v, v, v, v);
         }
-        if (!flag_barrier<1>(fl, r, ++phase, err)) return;
+        if (!flag_barrier<1, INV>(fl, r, ++phase, err)) return;
         for (int row = r; row < rows; row += WG_PER_XCD) {
-            const float4 a = slab[(size_t)row * 512 + t], b = slab[(size_t)row * 512 + 256 + t];
+            float4 a, b;
+            if (INV == 0) { a = ld_sc1(slab + (size_t)row * 512 + t); b = ld_sc1(slab + (size_t)row * 512 + 256 + t); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            else { a = slab[(size_t)row * 512 + t]; b = slab[(size_t)row * 512 + 256 + t]; }
             acc += a.x + b.x - 2.f * (float)(it + row) - (float)(t >> 3) - (float)((256 + t) >> 3);
         }
-        if (!flag_barrier<1>(fl, r, ++phase, err)) return;
+        if (!flag_barrier<1, 0>(fl, r, ++phase, err)) return;      // write-after-read: nothing to invalidate
     }
     if (acc != 0.f) atomicExch(err, 2);
     if (acc == 1234.5f) sink[0] = acc;
@@ -79,18 +93,20 @@ int main() {
     {
         const int iters = 2000;
         float ms; int herr;
-#define RUN_BAR(S, label)                                                                                         \
+#define RUN_BAR(S, I, label)                                                                                         \
         hipMemset(flags, 0, NXCD * WG_PER_XCD * sizeof(unsigned)); hipMemset(err, 0, sizeof(int));                \
-        hipEventRecord(e0); barrier_only<S><<<grid, THREADS>>>(iters, flags, err); hipEventRecord(e1);            \
+        hipEventRecord(e0); barrier_only<S, I><<<grid, THREADS>>>(iters, flags, err); hipEventRecord(e1);            \
         hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);                                                 \
         hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost);                                                 \
         printf("flag barrier alone, 64 workgroups per XCD x 8 XCDs (%s): %.2f us%s\n", label, ms * 1e3 / iters, herr ? "  [TIMED OUT]" : "");
-        RUN_BAR(0, "busy poll")
-        RUN_BAR(1, "s_sleep 1")
-        RUN_BAR(4, "s_sleep 4")
+        RUN_BAR(1, 2, "s_sleep 1, buffer_inv by all 4 wavefronts")
+        RUN_BAR(1, 1, "s_sleep 1, buffer_inv by wavefront 0")
+        RUN_BAR(1, 0, "s_sleep 1, no invalidate")
+        RUN_BAR(0, 0, "busy poll, no invalidate")
     }
     const int row_counts[] = {128, 256, 384, 512, 1024, 2048, 16384};    // x 8 KB: 1, 2, 3, 4, 8, 16, 128 MB per XCD
-    printf("%12s %14s %14s\n", "MB per XCD", "exchange GB/s", "us per phase");
+    for (int inv = 1; inv >= 0; --inv) {
+    printf("consumer: %s\n%12s %14s %14s\n", inv ? "buffer_inv sc1 by wavefront 0 + plain loads" : "no invalidate, sc1 loads", "MB per XCD", "exchange GB/s", "us per phase");
     for (int rows : row_counts) {
         const size_t slab_f4 = (size_t)rows * 512;
         float4* slabs;
@@ -103,7 +119,8 @@ int main() {
             hipMemset(flags, 0, NXCD * WG_PER_XCD * sizeof(unsigned));
             hipMemset(err, 0, sizeof(int));
             hipEventRecord(e0);
-            exchange<<<grid, THREADS>>>(slabs, slab_f4, rows, iters, flags, err, sink);
+            if (inv) exchange<1><<<grid, THREADS>>>(slabs, slab_f4, rows, iters, flags, err, sink);
+            else exchange<0><<<grid, THREADS>>>(slabs, slab_f4, rows, iters, flags, err, sink);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -115,6 +132,7 @@ int main() {
         const double bytes = (double)slab_f4 * 16 * NXCD * 2 * iters;
         printf("%12.1f %14.0f %14.2f\n", rows * 8.0 / 1024, bytes / best / 1e6, best * 1e3 / (2.0 * iters));
         hipFree(slabs);
+    }
     }
     return 0;
 }

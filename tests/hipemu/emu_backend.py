@@ -20,3 +20,6 @@ class EmuBackend:
 
     def stream(self, device):
         return None
+
+    def free_memory(self):
+        return None

@@ -200,7 +200,8 @@ def test_saved_spectra_path_is_bitwise_the_recomputing_one(gpu_lib, B, D, L, dty
     out = gpu_lib.fftconv_fwd(u, k, bias)
     du, dk, dbias = gpu_lib.fftconv_bwd(dout, u, k, bias)
     out2, saved = gpu_lib.fftconv_fwd(u, k, bias, save=True)
-    du2, dk2, dbias2 = gpu_lib.fftconv_bwd(dout, None, None, bias, saved=saved)
+    # the workspace-free plan (L <= 32768) keeps the filter spectrum only and re-reads u; the two-level plan needs neither
+    du2, dk2, dbias2 = gpu_lib.fftconv_bwd(dout, u if L <= 32768 else None, None, bias, saved=saved)
     torch.cuda.synchronize()
     assert torch.equal(out, out2) and torch.equal(du, du2) and torch.equal(dk, dk2) and torch.equal(dbias, dbias2)
 
@@ -324,8 +325,11 @@ def test_contract_configs_all_channels_vs_oracle(gpu_lib, B, D, L, dtype):
     else:
         eps = 2.0 ** -7
         # forward: fp32 math and ONE rounding on both sides -> at most one bf16 ulp apart, bit-identical almost everywhere
+        # (absolute slack: the fp32 noise floor of a transform whose row peaks at |r|max is ~1e-6 |r|max on BOTH sides, which
+        # decides the rounding of the few samples that sit near zero -- 2.7e8 samples here)
         diff = (out.float() - r_out.float()).abs()
-        assert (diff <= eps * r_out.float().abs() + 2e-5).all()
+        slack = 2e-5 + 2e-6 * r_out.float().abs().amax(dim=2, keepdim=True)
+        assert (diff <= eps * r_out.float().abs() + slack).all()
         assert (out != r_out).float().mean() < 0.02
         # per channel too: a defect confined to a few channels must not hide in a global average
         per_ch = (out != r_out).float().mean(dim=(0, 2))

@@ -154,9 +154,11 @@ def test_split_k_linear_gradients_match_linear():
     """hyena_dna_amd/projection.py: the slice-batched weight gradient equals autograd's dy^T x (hyena.py:391,440)"""
     from hyena_dna_amd.projection import SplitKLinearFunc, split_count
     assert split_count(1 << 20) == 64 and split_count(32768) == 8 and split_count(160000) == 32 and split_count(8191) == 1
-    for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-2)):
+    # the lengths the reference dataset really yields are max_length - 1 (hg38_dataset.py:220): odd row counts split too
+    assert split_count(999999) == 64 and split_count(449999) == 64 and split_count(159999) == 32 and split_count(2 * 32767) == 8
+    for dt, tol, rows in ((torch.float32, 1e-6, 8192), (torch.bfloat16, 1e-2, 8192), (torch.float32, 1e-6, 16383), (torch.bfloat16, 1e-2, 9999)):
         g = torch.Generator().manual_seed(0)
-        x = torch.randn(2, 8192, 16, generator=g).to(dt).requires_grad_()
+        x = torch.randn(2, rows, 16, generator=g).to(dt).requires_grad_()
         w = (torch.randn(24, 16, generator=g) * 0.1).to(dt).requires_grad_()
         b = torch.randn(24, generator=g).to(dt).requires_grad_()
         y = SplitKLinearFunc.apply(x, w, b)
@@ -187,6 +189,14 @@ def test_empty_batch_and_oversize_length(emu_backend):
     assert torch.count_nonzero(k.grad) == 0 and torch.count_nonzero(bias.grad) == 0 and u.grad.shape == u.shape
     with pytest.raises(HyenaLibraryError):
         emu_backend.fftconv_fwd(torch.zeros(1, 1, (1 << 20) + 1), torch.zeros(1, (1 << 20) + 1), None)
+    # the fused operator path too: an empty batch returns an empty tensor, parameter gradients are zeros
+    from hyena_dna_amd.hyena import HyenaOperator
+    op = HyenaOperator(d_model=64, l_max=102, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10)
+    x = torch.randn(0, 100, 64, requires_grad=True)
+    y = op(x)
+    assert y.shape == (0, 100, 64)
+    y.sum().backward()
+    assert x.grad.shape == x.shape and all(p.grad is None or torch.count_nonzero(p.grad) == 0 for p in op.parameters())
 
 
 def test_tiny_lm_trains_on_the_emulated_kernels(emu_backend):
