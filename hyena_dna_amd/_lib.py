@@ -46,7 +46,7 @@ class _HipBackend:
     tensors + libhyena_fftconv.so); tests/ substitute a CPU-emulation double to exercise the host logic without
     a GPU (tests/hipemu/emu_backend.py) -- nothing in this package ever selects another backend."""
     name = "hip"
-    path = LIB_PATH
+    path = os.environ.get("HYENA_FFTCONV_LIB", LIB_PATH)      # (development: A/B builds of the same HIP library)
 
     def require(self, t, name):
         if not t.is_cuda:

@@ -108,9 +108,9 @@ __device__ __forceinline__ void apply_tw(c32 (&v)[32], const Tw& w) {
     for (int s = 0; s < 32; ++s) {
         const int a = s >> 3, b = s & 7;
         if (!PHI && s == 0) continue;
-        c32 ta = w.tA[a & 3], tb = w.tB[b];
-        // opaque copies: keeps hipcc from hoisting the 24 products (48 VGPRs) out of loops / sharing them between passes
-        HY_OPAQUE(ta.x); HY_OPAQUE(ta.y); HY_OPAQUE(tb.x); HY_OPAQUE(tb.y);
+        // (no opaque copies needed here: the table LOADS are opaque, so no product can be hoisted out of a batch loop or
+        // shared between the forward and the inverse pass -- and the copies cost 90 v_mov per pass)
+        const c32 ta = w.tA[a & 3], tb = w.tB[b];
         const c32 f = (a == 0) ? tb : (!PHI && b == 0) ? ta : cmul(ta, tb);
         v[s] = INV ? cmulc(v[s], f) : cmul(v[s], f);
     }
@@ -250,6 +250,13 @@ __device__ __forceinline__ void pass3(c32 (&v)[32]) {
 }
 
 // Per-row context of a transform: where the row's exchange buffer and twiddle tables are, who the thread is.
+// scheduling fences between the phases of a transform (exchange | butterflies | twiddles)
+#ifdef OC_NO_PHASE_FENCES
+#define OC_FENCE() do {} while (0)
+#else
+#define OC_FENCE() HY_SCHED_FENCE()
+#endif
+
 struct Ctx {
     HY_LDS char* xb;        // exchange buffer of this row
     GBuf tab;               // twiddle tables of this transform size (tw1 | tw2)
@@ -261,30 +268,30 @@ struct Ctx {
 template <int R>
 __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
     dft_reg<32, false>(v);
-    HY_SCHED_FENCE();
+    OC_FENCE();
     {
         Tw w;
         load_tw1<R>(w, c.tab, c.tid);
         apply_tw<false, true>(v, w);
     }
-    HY_SCHED_FENCE();
+    OC_FENCE();
     if constexpr (Cfg<R>::PLANES) x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
     else x1<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp);
-    HY_SCHED_FENCE();
+    OC_FENCE();
     dft_reg<32, false>(v);
-    HY_SCHED_FENCE();
+    OC_FENCE();
     if constexpr (R > 1) {
         {
             Tw w;
             load_tw2<R>(w, c.tab, c.tp);
             apply_tw<false, false>(v, w);
         }
-        HY_SCHED_FENCE();
+        OC_FENCE();
         if constexpr (Cfg<R>::PLANES) x2p<R, false>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
         else x2<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp);
-        HY_SCHED_FENCE();
+        OC_FENCE();
         pass3<R, false>(v);
-        HY_SCHED_FENCE();
+        OC_FENCE();
     }
 }
 // inverse (unnormalised); on exit v[s] = result[tid + T s] e^(-2 pi i (tid + T s) phi / M) e^(+2 pi i s phi / 32),
@@ -293,30 +300,30 @@ template <int R>
 __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
     if constexpr (R > 1) {
         pass3<R, true>(v);
-        HY_SCHED_FENCE();
+        OC_FENCE();
         if constexpr (Cfg<R>::PLANES) x2p<R, true>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
         else x2<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp);
-        HY_SCHED_FENCE();
+        OC_FENCE();
         Tw w;
         load_tw2<R>(w, c.tab, c.tp);
         apply_tw<true, false>(v, w);
     }
-    HY_SCHED_FENCE();
+    OC_FENCE();
     dft_reg<32, true>(v);
-    HY_SCHED_FENCE();
+    OC_FENCE();
     // exchange 1 writes anywhere in the buffer: every wavefront must be done with its exchange-2 region
     if constexpr (R > 1) row_sync<Cfg<R>::T>();
     if constexpr (Cfg<R>::PLANES) x1p<R, true>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
     else x1<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp);
-    HY_SCHED_FENCE();
+    OC_FENCE();
     {
         Tw w;
         load_tw1<R>(w, c.tab, c.tid);
         apply_tw<true, true>(v, w);
     }
-    HY_SCHED_FENCE();
+    OC_FENCE();
     dft_reg<32, true>(v);
-    HY_SCHED_FENCE();
+    OC_FENCE();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,323 @@
+"""Model glue around the Hyena mixer, MI355X-side: what the reference's backbone imports from ``flash_attn``
+(``src/models/sequence/long_conv_lm.py:18-33``) and, on top of it, a Lightning-free language model of the same structure.
+
+The reference's ``ConvLMHeadModel`` (``long_conv_lm.py:400-502``) is built from flash_attn's ``GPT2Embeddings``,
+``Block``, ``Mlp``, ``MHA`` and ``GenerationMixin`` -- CUDA-only in the pinned flash_attn, and restated in plain PyTorch
+by the reference itself at ``src/models/sequence/simple_lm.py:26-305`` / ``standalone_hyenadna.py:302-561``.  The classes
+below follow those restatements' semantics (same constructor arguments, attribute / state-dict names and forward
+contracts), so that the unmodified reference backbone builds on ROCm once ``overlay/flash_attn`` (thin re-exports of
+this module) is on ``sys.path`` -- INTEGRATION.md section 4.  What is MI355X-specific:
+
+* ``Block`` routes its two (dropout ->) add -> LayerNorm steps through the fused HIP kernels of
+  ``hyena_dna_amd.block.dropout_add_layer_norm`` when ``fused_dropout_add_ln=True``;
+* ``Mlp`` keeps its two products on the library GEMMs (hipBLASLt MFMA kernels) with the split-K weight gradient of
+  ``hyena_dna_amd.projection`` (the same B*L-long contraction pathology as the operator's projections); the tanh-GELU
+  the backbone asks for (``long_conv_lm.py:117-123``) is PyTorch's fused elementwise kernel;
+* the mixer is whatever ``mixer_cls`` builds -- ``hyena_dna_amd.hyena.HyenaOperator`` through the registry swap.
+
+``HyenaDNALM`` = embedding -> n_layer x Block -> (dropout, add,) LayerNorm -> tied LM head, the hyenadna-* model family
+(``hg38_hyena.yaml``), with ``loss()`` = next-token cross entropy: the full-model step ``bench.py`` times as a secondary
+figure (north_star configuration 5).
+"""
+import math
+from collections import namedtuple
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .block import dropout_add_layer_norm
+from .projection import hyena_linear
+
+__all__ = ["Mlp", "Block", "GPT2Embeddings", "MHA", "GenerationMixin", "HyenaDNALM", "sync_shared_params", "all_gather_raw"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flash_attn.modules.mlp.Mlp  (semantics: simple_lm.py:192-212)
+# ---------------------------------------------------------------------------------------------------------------------
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, activation=F.gelu, return_residual=False,
+                 device=None, dtype=None):
+        factory_kwargs = {"device": device, "dtype": dtype}
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.return_residual = return_residual
+        self.fc1 = nn.Linear(in_features, hidden_features, **factory_kwargs)
+        self.activation = activation
+        self.fc2 = nn.Linear(hidden_features, out_features, **factory_kwargs)
+
+    def forward(self, x):
+        y = hyena_linear(x, self.fc1.weight, self.fc1.bias)
+        y = self.activation(y)
+        y = hyena_linear(y, self.fc2.weight, self.fc2.bias)
+        return y if not self.return_residual else (y, x)
+
+
+def _refuse(name):
+    class _Missing(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f"flash_attn.{name} (tensor / sequence parallel or fused-dense variants) is not part of the "
+                                      "HyenaDNA path: every hg38 configuration builds the plain module (process_group=None)")
+    _Missing.__name__ = name.rsplit(".", 1)[-1]
+    return _Missing
+
+
+FusedMLP = _refuse("modules.mlp.FusedMLP")
+ParallelFusedMLP = _refuse("modules.mlp.ParallelFusedMLP")
+ParallelMHA = _refuse("modules.mha.ParallelMHA")
+ParallelGPT2Embeddings = _refuse("modules.embedding.ParallelGPT2Embeddings")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flash_attn.modules.mha.MHA  (semantics: simple_lm.py:26-150; HyenaDNA sets attn_layer_idx = None, so this is only
+# ever built by hybrid configurations)
+# ---------------------------------------------------------------------------------------------------------------------
+class MHA(nn.Module):
+    def __init__(self, embed_dim, num_heads, bias=True, dropout=0.0, softmax_scale=None, causal=False, layer_idx=None,
+                 dwconv=False, return_residual=False, device=None, dtype=None, **unused):
+        factory_kwargs = {"device": device, "dtype": dtype}
+        super().__init__()
+        assert embed_dim % num_heads == 0, "self.kdim must be divisible by num_heads"
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.causal, self.layer_idx, self.dwconv, self.return_residual = causal, layer_idx, dwconv, return_residual
+        self.softmax_scale, self.dropout_p = softmax_scale, dropout
+        self.Wqkv = nn.Linear(embed_dim, 3 * embed_dim, bias=bias, **factory_kwargs)
+        if dwconv:
+            self.dwconv_qkv = nn.Conv1d(3 * embed_dim, 3 * embed_dim, kernel_size=3, padding=2, groups=3 * embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, **factory_kwargs)
+
+    def forward(self, x, key_padding_mask=None, **kwargs):
+        qkv = self.Wqkv(x)
+        if self.dwconv:
+            qkv = self.dwconv_qkv(qkv.transpose(1, 2))[..., :-2].transpose(1, 2).contiguous()
+        B, S, _ = qkv.shape
+        q, k, v = qkv.view(B, S, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)      # (3, B, H, S, d)
+        mask = None
+        if key_padding_mask is not None:
+            mask = key_padding_mask[:, None, None, :]
+            if self.causal:
+                mask = mask & torch.ones(S, S, dtype=torch.bool, device=x.device).tril()
+        ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=self.dropout_p if self.training else 0.0,
+                                             is_causal=self.causal and mask is None, scale=self.softmax_scale)
+        out = self.out_proj(ctx.transpose(1, 2).reshape(B, S, self.embed_dim))
+        return out if not self.return_residual else (out, x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flash_attn.modules.embedding.GPT2Embeddings  (semantics: simple_lm.py:153-190)
+# ---------------------------------------------------------------------------------------------------------------------
+class GPT2Embeddings(nn.Module):
+    def __init__(self, embed_dim, vocab_size, max_position_embeddings, padding_idx=None, word_embed_proj_dim=None,
+                 device=None, dtype=None):
+        factory_kwargs = {"device": device, "dtype": dtype}
+        super().__init__()
+        if word_embed_proj_dim is None:
+            self.word_embeddings = nn.Embedding(vocab_size, embed_dim, padding_idx=padding_idx, **factory_kwargs)
+            self.project_in = None
+        else:
+            self.word_embeddings = nn.Embedding(vocab_size, word_embed_proj_dim, padding_idx=padding_idx, **factory_kwargs)
+            self.project_in = nn.Linear(word_embed_proj_dim, embed_dim, bias=False, **factory_kwargs)
+        self.max_position_embeddings = max_position_embeddings
+        if self.max_position_embeddings > 0:
+            self.position_embeddings = nn.Embedding(max_position_embeddings, embed_dim, **factory_kwargs)
+
+    def forward(self, input_ids, position_ids=None):
+        batch_size, seqlen = input_ids.shape
+        embeddings = self.word_embeddings(input_ids)
+        if self.project_in is not None:
+            embeddings = self.project_in(embeddings)
+        if self.max_position_embeddings > 0:
+            if position_ids is None:
+                position_ids = torch.arange(seqlen, dtype=torch.long, device=input_ids.device)
+            embeddings = embeddings + self.position_embeddings(position_ids)
+        return embeddings
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flash_attn.modules.block.Block  (semantics: simple_lm.py:214-305; constructor as long_conv_lm.py:171-185 calls it)
+# ---------------------------------------------------------------------------------------------------------------------
+class Block(nn.Module):
+    def __init__(self, dim, mixer_cls=None, mlp_cls=None, norm_cls=nn.LayerNorm, dropout_cls=nn.Dropout, prenorm=True,
+                 resid_dropout1=0.0, resid_dropout2=0.0, drop_path1=0.0, drop_path2=0.0, fused_dropout_add_ln=False,
+                 return_residual=False, residual_in_fp32=False, sequence_parallel=False, mark_shared_params=False):
+        super().__init__()
+        if drop_path1 or drop_path2:
+            raise NotImplementedError("stochastic depth is not used by any HyenaDNA configuration")
+        if sequence_parallel or mark_shared_params:
+            raise NotImplementedError("tensor / sequence parallelism is not part of the HyenaDNA path (north_star: data parallel only)")
+        self.prenorm = prenorm
+        self.fused_dropout_add_ln = fused_dropout_add_ln
+        self.return_residual = return_residual
+        self.residual_in_fp32 = residual_in_fp32
+        if self.residual_in_fp32:
+            assert self.prenorm, "residual_in_fp32 is only compatible with prenorm=True"
+        if mixer_cls is None:
+            mixer_cls = partial(MHA, num_heads=dim // 64)
+        if mlp_cls is None:
+            mlp_cls = partial(Mlp, hidden_features=4 * dim)
+        self.mixer = mixer_cls(dim)
+        self.dropout1 = dropout_cls(resid_dropout1)
+        self.norm1 = norm_cls(dim)
+        self.mlp = mlp_cls(dim)
+        if not isinstance(self.mlp, nn.Identity):
+            self.dropout2 = dropout_cls(resid_dropout2)
+            self.norm2 = norm_cls(dim)
+
+    def _add_norm(self, hidden_states, residual, drop, norm):
+        if self.fused_dropout_add_ln:
+            return dropout_add_layer_norm(hidden_states, residual, norm.weight, norm.bias, drop.p if self.training else 0.0,
+                                          norm.eps, prenorm=True, residual_in_fp32=self.residual_in_fp32)
+        dropped = drop(hidden_states)
+        residual = (dropped + residual) if residual is not None else dropped
+        hidden_states = norm(residual.to(dtype=norm.weight.dtype))
+        if self.residual_in_fp32:
+            residual = residual.to(torch.float32)
+        return hidden_states, residual
+
+    def forward(self, hidden_states, residual=None, mixer_subset=None, mixer_kwargs=None):
+        if self.prenorm:
+            hidden_states, residual = self._add_norm(hidden_states, residual, self.dropout1, self.norm1)
+            mixer_kwargs = {} if mixer_kwargs is None else mixer_kwargs
+            if mixer_subset is not None:
+                mixer_kwargs["mixer_subset"] = mixer_subset
+            hidden_states = self.mixer(hidden_states, **mixer_kwargs)
+            if mixer_subset is not None:
+                residual = residual[:, mixer_subset]
+            if not isinstance(self.mlp, nn.Identity):
+                hidden_states, residual = self._add_norm(hidden_states, residual, self.dropout2, self.norm2)
+                hidden_states = self.mlp(hidden_states)
+            return hidden_states, residual
+        assert residual is None
+        mixer_out = self.mixer(hidden_states, **(mixer_kwargs if mixer_kwargs is not None else {}))
+        if self.return_residual:
+            mixer_out, hidden_states = mixer_out
+        hidden_states = self.norm1((self.dropout1(mixer_out) + hidden_states).to(dtype=self.norm1.weight.dtype))
+        if not isinstance(self.mlp, nn.Identity):
+            mlp_out = self.mlp(hidden_states)
+            if self.return_residual:
+                mlp_out, hidden_states = mlp_out
+            hidden_states = self.norm2((self.dropout2(mlp_out) + hidden_states).to(dtype=self.norm2.weight.dtype))
+        return hidden_states
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flash_attn.utils.generation.GenerationMixin / flash_attn.utils.distributed
+# ---------------------------------------------------------------------------------------------------------------------
+class GenerationMixin:
+    """Greedy / top-k sampling by re-running the causal model on the growing prefix (the convolutional mixer has no
+    incremental state in the reference either: HyenaOperator ignores ``inference_params``)."""
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        return None
+
+    @torch.no_grad()
+    def generate(self, input_ids, max_length, top_k=1, temperature=1.0, return_dict_in_generate=False, output_scores=False, **kwargs):
+        ids, scores = input_ids, []
+        while ids.shape[1] < max_length:
+            out = self(ids)
+            logits = (out[0] if isinstance(out, tuple) else out)
+            logits = (logits.logits if hasattr(logits, "logits") else logits)[:, -1] / max(temperature, 1e-6)
+            if top_k <= 1:
+                nxt = logits.argmax(-1, keepdim=True)
+            else:
+                v, i = logits.topk(top_k, dim=-1)
+                nxt = i.gather(-1, torch.multinomial(torch.softmax(v.float(), -1), 1))
+            scores.append(logits)
+            ids = torch.cat([ids, nxt], dim=1)
+        if return_dict_in_generate:
+            return namedtuple("GreedySearchDecoderOnlyOutput", ["sequences", "scores"])(ids, tuple(scores) if output_scores else None)
+        return ids
+
+
+def sync_shared_params(model, process_group):
+    """Broadcast parameters marked ``_shared_params`` from rank 0 of the group (flash_attn.utils.distributed)."""
+    import torch.distributed as dist
+    for _, p in sorted(model.named_parameters()):
+        if getattr(p, "_shared_params", False):
+            with torch.no_grad():
+                dist.broadcast(p, src=dist.get_global_rank(process_group, 0), group=process_group)
+
+
+def all_gather_raw(input_, process_group, async_op=False):
+    import torch.distributed as dist
+    world = dist.get_world_size(process_group)
+    out = torch.empty(world * input_.shape[0], *input_.shape[1:], dtype=input_.dtype, device=input_.device)
+    handle = dist.all_gather_into_tensor(out, input_.contiguous(), group=process_group, async_op=async_op)
+    return out, handle
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The hyenadna-* language model without Lightning / Hydra (structure: long_conv_lm.py:249-502, hg38_hyena.yaml)
+# ---------------------------------------------------------------------------------------------------------------------
+def _init_weights(module, n_layer, initializer_range=0.02, rescale_prenorm_residual=True):
+    """long_conv_lm.py:204-246 (GPT-2 scheme: out_proj / fc2 scaled by 1 / sqrt(2 n_layer))."""
+    if isinstance(module, nn.Linear):
+        nn.init.normal_(module.weight, std=initializer_range)
+        if module.bias is not None:
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, nn.Embedding):
+        nn.init.normal_(module.weight, std=initializer_range)
+    if rescale_prenorm_residual:
+        for name, p in module.named_parameters():
+            if name in ("out_proj.weight", "fc2.weight"):
+                nn.init.normal_(p, mean=0.0, std=initializer_range / math.sqrt(2 * n_layer))
+
+
+class HyenaDNALM(nn.Module, GenerationMixin):
+    """``ConvLMHeadModel`` with the Hyena mixer in every block (the hg38 pre-training model): same sub-module names as the
+    reference (``backbone.embeddings.word_embeddings``, ``backbone.layers.N.{mixer,norm1,norm2,mlp.fc1,mlp.fc2}``,
+    ``backbone.ln_f``, ``lm_head``), so a reference checkpoint's state dict loads."""
+
+    def __init__(self, d_model, n_layer, d_inner, vocab_size, layer=None, max_position_embeddings=0, resid_dropout=0.0,
+                 embed_dropout=0.1, layer_norm_epsilon=1e-5, initializer_cfg=None, fused_dropout_add_ln=True,
+                 residual_in_fp32=True, pad_vocab_size_multiple=1, checkpoint_mixer=False, checkpoint_mlp=False, **unused):
+        super().__init__()
+        from .hyena import HyenaOperator
+        if vocab_size % pad_vocab_size_multiple != 0:
+            vocab_size += pad_vocab_size_multiple - (vocab_size % pad_vocab_size_multiple)
+        layer = dict(layer or {})
+        layer.pop("_name_", None)
+        self.d_model, self.residual_in_fp32, self.fused_dropout_add_ln = d_model, residual_in_fp32, fused_dropout_add_ln
+        backbone = nn.Module()
+        backbone.embeddings = GPT2Embeddings(d_model, vocab_size, max_position_embeddings)
+        mlp_cls = partial(Mlp, hidden_features=d_inner if d_inner is not None else 4 * d_model,
+                          activation=partial(F.gelu, approximate="tanh"))
+        norm_cls = partial(nn.LayerNorm, eps=layer_norm_epsilon)
+        backbone.layers = nn.ModuleList([
+            Block(d_model, partial(HyenaOperator, **layer), mlp_cls, norm_cls=norm_cls, prenorm=True,
+                  resid_dropout1=embed_dropout if i == 0 else resid_dropout, resid_dropout2=resid_dropout,
+                  fused_dropout_add_ln=fused_dropout_add_ln, residual_in_fp32=residual_in_fp32) for i in range(n_layer)])
+        backbone.drop_f = nn.Dropout(resid_dropout)
+        backbone.ln_f = nn.LayerNorm(d_model, eps=layer_norm_epsilon)
+        self.backbone = backbone
+        self.checkpoint_mixer, self.checkpoint_mlp = checkpoint_mixer, checkpoint_mlp
+        self.lm_head = nn.Linear(d_model, vocab_size, bias=False)
+        self.apply(partial(_init_weights, n_layer=n_layer, **(initializer_cfg or {})))
+        self.tie_weights()
+
+    def tie_weights(self):
+        self.lm_head.weight = self.backbone.embeddings.word_embeddings.weight
+
+    def hidden(self, input_ids, position_ids=None):
+        bb = self.backbone
+        hidden_states, residual = bb.embeddings(input_ids, position_ids=position_ids), None
+        for blk in bb.layers:
+            hidden_states, residual = blk(hidden_states, residual)
+        if self.fused_dropout_add_ln:
+            return dropout_add_layer_norm(hidden_states, residual, bb.ln_f.weight, bb.ln_f.bias,
+                                          bb.drop_f.p if self.training else 0.0, bb.ln_f.eps, prenorm=False,
+                                          residual_in_fp32=self.residual_in_fp32)
+        dropped = bb.drop_f(hidden_states)
+        residual = (dropped + residual) if residual is not None else dropped
+        return bb.ln_f(residual.to(dtype=bb.ln_f.weight.dtype))
+
+    def forward(self, input_ids, position_ids=None, inference_params=None, state=None):
+        lm_logits = self.lm_head(self.hidden(input_ids, position_ids))
+        return namedtuple("CausalLMOutput", ["logits"])(logits=lm_logits), None
+
+    def loss(self, input_ids, targets, ignore_index=-100):
+        """next-token cross entropy (src/tasks/metrics.py cross_entropy over the flattened logits), logits in fp32"""
+        logits = self.forward(input_ids)[0].logits
+        return F.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), targets.reshape(-1), ignore_index=ignore_index)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B builds of the HIP library: scripts/build_variant.sh <name> [-D...]  ->  build/libhyena_<name>.so
+# (fftconv.hip object is reused from the regular build; only onchip.hip is recompiled unless FULL=1)
+set -e
+NAME=$1; shift
+R=$(cd $(dirname $0)/.. && pwd)
+mkdir -p $R/build/var_$NAME
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize"
+/opt/rocm/bin/hipcc $FL "$@" -c $R/hyena_dna_amd/csrc/onchip.hip -o $R/build/var_$NAME/onchip.o &
+if [ "$FULL" = "1" ]; then /opt/rocm/bin/hipcc $FL "$@" -c $R/hyena_dna_amd/csrc/fftconv.hip -o $R/build/var_$NAME/fftconv.o & else cp $R/hyena_dna_amd/csrc/_obj/fftconv.hip.o $R/build/var_$NAME/fftconv.o; fi
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $R/build/var_$NAME/fftconv.o $R/build/var_$NAME/onchip.o -o $R/build/libhyena_$NAME.so
+echo built build/libhyena_$NAME.so

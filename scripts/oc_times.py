@@ -4,7 +4,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hyena_dna_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda", 0)

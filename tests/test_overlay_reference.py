@@ -24,3 +24,17 @@ def test_reference_operator_runs_through_the_overlay(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
     assert "OVERLAY_OK" in p.stdout and "REGISTRY_OK" in p.stdout, p.stdout[-1500:]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "models", "sequence")), reason="reference checkout not present")
+def test_reference_backbone_builds_on_the_flash_attn_surface(tmp_path):
+    """the unmodified reference ``ConvLMHeadModel`` imports (``flash_attn.modules.*``,
+    ``flash_attn.utils.*``, ``flash_attn.ops.layer_norm`` served by ``overlay/flash_attn``), builds this package's operator
+    through the registry, loads the state dict of the reference's own ``SimpleLMHeadModel`` (strict) and matches its logits,
+    loss and every parameter gradient; so does the Lightning-free ``hyena_dna_amd.lm.HyenaDNALM``."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.pop("PYTHONPATH", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_lm_worker.py")], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    assert "LM_OK" in p.stdout, p.stdout[-1500:]
