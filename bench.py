@@ -194,6 +194,46 @@ def operator_layer(L, D, B, dtype, dev, steps=5, warmup=2):
                         f"L={L}, d={D}, B={B}, {str(dtype).split('.')[-1]} autocast; secondary figure, not `value`"}
 
 
+def model_step(L, D, B, dtype, dev, rank=0, n_layer=8, steps=3, warmup=1):
+    """Secondary figure (not `value`): the full hyenadna pre-training step of north_star configuration 5 on synthetic tokens --
+    embedding -> n_layer x [add+LayerNorm -> HyenaOperator -> add+LayerNorm -> MLP (d -> 4d -> d, tanh-GELU)] -> LayerNorm ->
+    tied LM head -> cross entropy, backward, AdamW step -- random init, autocast (hg38_hyena.yaml: d_model 256, n_layer 8,
+    d_inner 1024, vocab 12 padded to 16)."""
+    from hyena_dna_amd.lm import HyenaDNALM
+    torch.manual_seed(0)
+    layer = dict(l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10, lr=6e-4, wd=0.0,
+                 lr_pos_emb=0.0)
+    model = HyenaDNALM(d_model=D, n_layer=n_layer, d_inner=4 * D, vocab_size=12, layer=layer, resid_dropout=0.0, embed_dropout=0.1,
+                       pad_vocab_size_multiple=8, fused_dropout_add_ln=True, residual_in_fp32=True).to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=6e-4, weight_decay=0.1, betas=(0.9, 0.999))
+    g = torch.Generator(device=dev).manual_seed(2222 + rank)
+    ids = torch.randint(7, 11, (B, L), generator=g, device=dev)           # A, C, G, T (hg38_char_tokenizer.py:59-66)
+    tgt = torch.roll(ids, -1, 1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
+            loss = model.loss(ids, tgt)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        loss = step()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / steps
+    return {"ms_per_step": ms, "value": B * L / ms * 1e3, "unit": "nt/s", "steps": steps, "loss": float(loss),
+            "params": sum(p.numel() for p in model.parameters()), "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+            "workload": f"full model step (fwd + bwd + AdamW): hyenadna d_model={D}, n_layer={n_layer}, d_inner={4 * D}, L={L}, B={B}, "
+                        f"{str(dtype).split('.')[-1]} autocast, synthetic tokens; secondary figure, not `value`"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -324,6 +364,10 @@ def main():
                 line["operator_layer"] = operator_layer(L, D, B, dtype, dev)
             except Exception as e:                                   # secondary: never lose the contract line over it
                 line["operator_layer"] = {"error": repr(e)[:200]}
+            try:
+                line["model_step"] = model_step(L, D, B, dtype, dev)
+            except Exception as e:
+                line["model_step"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline and not args.emu:
             line["cpu_baseline"] = cpu_baseline(L, D, dtype)          # rank 0 at N = 1 only (other ranks would idle at the barrier)
         else:

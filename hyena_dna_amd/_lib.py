@@ -226,7 +226,9 @@ def save_spectra_default(B, D, L):
     if mode in ("0", "off", "false"):
         return False
     if lib().hyena_fftconv_plan(int(L)) == PLAN_ONCHIP:
-        return False         # nothing worth keeping: the only intermediate is the filter spectrum, one transform per channel
+        # the only intermediate is the filter spectrum H [D][M]: small, and keeping it saves the backward one launch
+        # (one transform per channel) -- worth it whenever there is a batch to amortise it over
+        return B >= 2 and saved_bytes(B, D, L) <= 256 * 2 ** 20
     if mode in ("1", "on", "true"):
         return True
     need = saved_bytes(B, D, L)

@@ -51,7 +51,9 @@ class HyenaMixerFunc(torch.autograd.Function):
         dx = torch.zeros_like(xc) if Lx > L else torch.empty_like(xc)
         part = _lib.mixer_partials(xc, L)
         dy = _lib.mixer_post_bwd(dz, y, xc, w, b, dx, part)
-        vg = None if ctx.spectra is not None else _lib.mixer_pre_fwd(xc, w, b, L)      # recompute the conv's input
+        # the conv's input v * x1 is recomputed from x -- unless the saved spectra hold its transform (two-level plan)
+        need_vg = ctx.spectra is None or _lib.lib().hyena_fftconv_plan(int(L)) == _lib.PLAN_ONCHIP
+        vg = _lib.mixer_pre_fwd(xc, w, b, L) if need_vg else None
         need_dk = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]          # a frozen filter skips the dk path entirely
         dvg, dk, dbias = _lib.fftconv_bwd(dy, vg, kf, bf, need_du=True, need_dk=need_dk, saved=ctx.spectra)
         ctx.spectra = None

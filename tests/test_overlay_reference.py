@@ -38,3 +38,16 @@ def test_reference_backbone_builds_on_the_flash_attn_surface(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
     assert "LM_OK" in p.stdout, p.stdout[-1500:]
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "src", "ops", "fftconv.py")), reason="reference checkout not present")
+def test_reference_python_op_runs_on_the_native_seam(tmp_path):
+    """the reference's own ``src/ops/fftconv.py`` -- unmodified ``FFTConvFunc`` with its
+    14-argument ``fftconv_fwd`` / ``fftconv_bwd`` calls (csrc/fftconv/fftconv.cpp:53-61,134-142) -- on top of this repository's
+    ``fftconv`` module (overlay/fftconv.py over the C ABI) equals the reference's torch.fft path, values and gradients."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.pop("PYTHONPATH", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_b3_worker.py")], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    assert "B3_OK" in p.stdout, p.stdout[-1500:]
