@@ -108,6 +108,34 @@ class MHA(nn.Module):
 # ---------------------------------------------------------------------------------------------------------------------
 # flash_attn.modules.embedding.GPT2Embeddings  (semantics: simple_lm.py:153-190)
 # ---------------------------------------------------------------------------------------------------------------------
+class SmallVocabEmbeddingFunc(torch.autograd.Function):
+    """``F.embedding`` whose weight gradient is a dense product ``onehot(ids)^T @ dh``.  PyTorch's embedding backward sorts /
+    scatters per token; with the 16-row DNA vocabulary and 10^6 tokens per sequence every token collides with 2.6e5 others
+    and that kernel alone took 10.5 ms of a 212 ms model step (profiles/r2h).  The one-hot product is one slice-batched
+    GEMM (``projection.split_k_weight_grad``), deterministic."""
+
+    @staticmethod
+    def forward(ctx, ids, weight):
+        ctx.save_for_backward(ids)
+        ctx.vocab = weight.shape[0]
+        return F.embedding(ids, weight)
+
+    @staticmethod
+    def backward(ctx, dh):
+        from .projection import split_k_weight_grad
+        (ids,) = ctx.saved_tensors
+        dh2 = dh.reshape(-1, dh.shape[-1])
+        onehot = F.one_hot(ids.reshape(-1), ctx.vocab).to(dh2.dtype)
+        return None, split_k_weight_grad(onehot, dh2).to(dh.dtype)
+
+
+def small_vocab_embedding(ids, emb):
+    if (ids.is_cuda and emb.padding_idx is None and emb.max_norm is None and not emb.sparse and emb.num_embeddings <= 64
+            and ids.numel() >= 32768):
+        return SmallVocabEmbeddingFunc.apply(ids, emb.weight)
+    return emb(ids)
+
+
 class GPT2Embeddings(nn.Module):
     def __init__(self, embed_dim, vocab_size, max_position_embeddings, padding_idx=None, word_embed_proj_dim=None,
                  device=None, dtype=None):
@@ -125,7 +153,7 @@ class GPT2Embeddings(nn.Module):
 
     def forward(self, input_ids, position_ids=None):
         batch_size, seqlen = input_ids.shape
-        embeddings = self.word_embeddings(input_ids)
+        embeddings = small_vocab_embedding(input_ids, self.word_embeddings)
         if self.project_in is not None:
             embeddings = self.project_in(embeddings)
         if self.max_position_embeddings > 0:

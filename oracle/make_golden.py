@@ -49,10 +49,10 @@ def decaying_filter(D, L, gen):
     return torch.randn(D, L, generator=gen) * torch.exp(-5.0 * t) * 0.1
 
 
-def fftconv_cases(ref):
+def fftconv_cases(ref, specs=None):
     """Op-level vectors: reference fftconv_ref (hyena.py:59-88) fwd + autograd grads."""
     cases = {}
-    specs = [
+    specs = specs or [
         # name,        B, D, L,    dtype,          five_d
         ("b2d4l8",      2, 4, 8,    torch.float32,  False),
         ("b2d3l37",     2, 3, 37,   torch.float32,  False),
@@ -113,6 +113,10 @@ def main():
     ref = import_reference()
     os.makedirs(OUT, exist_ok=True)
     torch.save(fftconv_cases(ref), os.path.join(OUT, "fftconv_ref_cases.pt"))
+    # sizes beyond one 1024-point column: a two-stage column transform (L = 40000 -> M1 = 64) and a mixed-radix one
+    # (L = 160000 -> M1 = 160 = 32 x 5, the hyenadna-medium-160k length), kept small by D and the 16-bit I/O
+    large = [("b1d2l40000", 1, 2, 40000, torch.float32, False), ("b1d1l160000_bf16", 1, 1, 160000, torch.bfloat16, False)]
+    torch.save(fftconv_cases(ref, large), os.path.join(OUT, "fftconv_ref_large.pt"))
     torch.save(operator_cases(ref), os.path.join(OUT, "hyena_operator_cases.pt"))
     meta = dict(torch=torch.__version__, reference=REF,
                 note="generated by oracle/make_golden.py from the reference's own classes")

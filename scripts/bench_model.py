@@ -1,0 +1,12 @@
+"""The full hyenadna model step alone (bench.model_step), for profiling: python scripts/bench_model.py L B D [steps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+L, B, D = (int(x) for x in sys.argv[1:4])
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+r = bench.model_step(L, D, B, torch.bfloat16, torch.device("cuda", 0), steps=steps)
+print(r)

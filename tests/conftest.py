@@ -21,6 +21,13 @@ def golden_fftconv():
 
 
 @pytest.fixture(scope="session")
+def golden_fftconv_large():
+    """reference-minted vectors at a two-stage column size (L = 40000) and a mixed-radix one (L = 160000)"""
+    import torch
+    return torch.load(os.path.join(GOLDEN, "fftconv_ref_large.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="session")
 def golden_operator():
     import torch
     return torch.load(os.path.join(GOLDEN, "hyena_operator_cases.pt"), weights_only=False)

@@ -85,6 +85,22 @@ def test_half_io_matches_reference_rounding(emu_backend, dtype, L):
     assert _rel(dk, r_dk) < REL_FP32 and _rel(dbias, r_db) < 5e-6
 
 
+@pytest.mark.parametrize("name", ["b1d2l40000", "b1d1l160000_bf16"])
+def test_golden_vectors_from_reference_large(emu_backend, golden_fftconv_large, name):
+    """reference-minted vectors beyond one column: L = 40000 (two-stage columns, M1 = 64), L = 160000 (mixed radix, M1 = 160)"""
+    c = golden_fftconv_large[name]
+    out = emu_backend.fftconv_fwd(c["u"], c["k"], c["bias"])
+    du, dk, dbias = emu_backend.fftconv_bwd(c["dout"], c["u"], c["k"], c["bias"])
+    if c["u"].dtype == torch.float32:
+        assert _rel(out, c["out"]) < REL_FP32 and _rel(du, c["du"]) < REL_FP32
+    else:
+        eps = 2.0 ** -7
+        diff = (out.float() - c["out"].float()).abs()
+        assert (diff <= eps * c["out"].float().abs() + 2e-5).all() and (out != c["out"]).float().mean() < 0.02
+        assert _rel(du.float(), c["du"].float()) < 1.5 * eps
+    assert _rel(dk, c["dk"]) < REL_FP32 and _rel(dbias, c["dbias"]) < 2e-5
+
+
 @pytest.mark.parametrize("name", ["b2d4l8", "b2d3l37", "b1d4l1023", "b2d4l1024", "b2d4l1024_5d", "b2d4l1000_bf16",
                                   "b1d2l4100"])
 def test_golden_vectors_from_reference(emu_backend, golden_fftconv, name):

@@ -99,6 +99,21 @@ def test_golden_vectors_from_reference(gpu_lib, golden_fftconv, name):
     assert _rel(dk, c["dk"]) < REL_FP32 and _rel(dbias, c["dbias"]) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["b1d2l40000", "b1d1l160000_bf16"])
+def test_golden_vectors_from_reference_large(gpu_lib, golden_fftconv_large, name):
+    """reference-minted vectors at a two-stage column size (L = 40000, M1 = 64) and a mixed-radix one (L = 160000, M1 = 160)"""
+    c = golden_fftconv_large[name]
+    out, du, dk, dbias = _gpu(gpu_lib, c["u"], c["k"], c["bias"], c["dout"])
+    if c["u"].dtype == torch.float32:
+        assert _rel(out, c["out"]) < REL_FP32 and _rel(du, c["du"]) < REL_FP32
+    else:
+        eps = 2.0 ** -7
+        diff = (out.float() - c["out"].float()).abs()
+        assert (diff <= eps * c["out"].float().abs() + 2e-5).all() and (out != c["out"]).float().mean() < 0.02
+        assert _rel(du.float(), c["du"].float()) < 1.5 * eps
+    assert _rel(dk, c["dk"]) < REL_FP32 and _rel(dbias, c["dbias"]) < 2e-5
+
+
 def test_autograd_function_5d_on_gpu(gpu_lib):
     from hyena_dna_amd.fftconv import fftconv_func
     dev = torch.device("cuda", 0)

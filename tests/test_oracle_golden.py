@@ -26,6 +26,19 @@ def test_fftconv_oracle_matches_reference_vectors(golden_fftconv, name):
     assert torch.equal(b.grad, c["dbias"])
 
 
+@pytest.mark.parametrize("name", ["b1d2l40000", "b1d1l160000_bf16"])
+def test_fftconv_oracle_matches_reference_vectors_large(golden_fftconv_large, name):
+    """the same at sizes with a two-stage (L = 40000) and a mixed-radix (L = 160000, hyenadna-medium-160k) column transform"""
+    c = golden_fftconv_large[name]
+    u = c["u"].clone().requires_grad_(True)
+    k = c["k"].clone().requires_grad_(True)
+    b = c["bias"].clone().requires_grad_(True)
+    out = O.fftconv_ref(u, k, b)
+    out.backward(c["dout"])
+    assert torch.equal(out.detach(), c["out"]) and torch.equal(u.grad, c["du"])
+    assert torch.equal(k.grad, c["dk"]) and torch.equal(b.grad, c["dbias"])
+
+
 @pytest.mark.parametrize("name", ["b2d4l8", "b2d3l37"])
 def test_fftconv_oracle_vs_direct_f64(golden_fftconv, name):
     """The FFT formulation equals the O(L^2) causal convolution (no-FFT float64 truth)."""
