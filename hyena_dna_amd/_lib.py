@@ -126,6 +126,20 @@ def lib():
         L.hyena_mixer_pre_bwd.restype = c_int
         L.hyena_mixer_pre_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_int, c_int, c_int, c_int, c_void_p]
+        # the same shell in channel-major layout (csrc/cm_kernels.h)
+        L.hyena_cm_partial_floats.restype = c_size_t
+        L.hyena_cm_partial_floats.argtypes = [c_int, c_int, c_int]
+        L.hyena_cm_pre_fwd.restype = c_int
+        L.hyena_cm_pre_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_cm_post_fwd.restype = c_int
+        L.hyena_cm_post_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p]
+        L.hyena_cm_post_bwd.restype = c_int
+        L.hyena_cm_post_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_cm_pre_bwd.restype = c_int
+        L.hyena_cm_pre_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_int, c_int, c_int, c_int, c_void_p]
         # fused implicit filter (include/hyena_filter.h)
         L.hyena_filter_supported.restype = c_int
         L.hyena_filter_supported.argtypes = [c_int, c_int, c_int, c_int]
@@ -342,6 +356,55 @@ def mixer_pre_bwd(dvg, x, w, b, dx, part):
         check(lib().hyena_mixer_pre_bwd(dvg.data_ptr(), x.data_ptr(), w.data_ptr(), b.data_ptr(), dx.data_ptr(),
                                         part.data_ptr(), B, L, x.shape[1], D, dtype_code(x.dtype),
                                         _backend.stream(x.device)))
+
+
+# ---- the shell in channel-major layout (include/hyena_mixer.h, hyena_cm_*) ------------------------------------------------
+def cm_pre_fwd(xT, bin_, w, b, L):
+    """xT (3D, B, Lx) [in_proj output without bias], bin_ (3D,) fp32 or None -> vg (B, D, L)."""
+    _require_gpu(xT, "xT")
+    D3, B, Lx = xT.shape
+    D = D3 // 3
+    vg = torch.empty((B, D, L), dtype=xT.dtype, device=xT.device)
+    with _backend.guard(xT.device):
+        check(lib().hyena_cm_pre_fwd(xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(), vg.data_ptr(),
+                                     B, L, Lx, D, dtype_code(xT.dtype), _backend.stream(xT.device)))
+    return vg
+
+
+def cm_post_fwd(y, xT, bin_, w, b):
+    """y (B, D, L), xT (3D, B, Lx) -> zT (D, B, L)."""
+    B, D, L = y.shape
+    zT = torch.empty((D, B, L), dtype=xT.dtype, device=xT.device)
+    with _backend.guard(xT.device):
+        check(lib().hyena_cm_post_fwd(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                      zT.data_ptr(), B, L, xT.shape[2], D, dtype_code(xT.dtype), _backend.stream(xT.device)))
+    return zT
+
+
+def cm_partials(xT, L):
+    D3, B, Lx = xT.shape
+    n = lib().hyena_cm_partial_floats(B, L, D3 // 3)
+    return torch.empty(n, dtype=torch.float32, device=xT.device).view(D3, -1, 8)
+
+
+def cm_post_bwd(dzT, y, xT, bin_, w, b, dxT, part):
+    """-> dy (B, D, L); fills dxT[0:D] (positions < L) and part[0:D]."""
+    B, D, L = y.shape
+    dy = torch.empty_like(y)
+    with _backend.guard(xT.device):
+        check(lib().hyena_cm_post_bwd(dzT.data_ptr(), y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(),
+                                      b.data_ptr(), dy.data_ptr(), dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D,
+                                      dtype_code(xT.dtype), _backend.stream(xT.device)))
+    return dy
+
+
+def cm_pre_bwd(dvg, xT, bin_, w, b, dxT, part):
+    """fills dxT[D:3D] (positions < L) and part[D:3D]."""
+    B, D, L = dvg.shape
+    with _backend.guard(xT.device):
+        check(lib().hyena_cm_pre_bwd(dvg.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                     dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D, dtype_code(xT.dtype),
+                                     _backend.stream(xT.device)))
 
 
 # ---- fused implicit filter (include/hyena_filter.h) ---------------------------------------------------------------------

@@ -1,0 +1,76 @@
+// cm.hip -- host side of the channel-major operator shell (cm_kernels.h; C ABI in include/hyena_mixer.h).
+#include "cm_kernels.h"
+#include "launch.h"
+#include "../../include/hyena_fftconv.h"
+#include "../../include/hyena_mixer.h"
+
+using namespace hyena;
+
+namespace {
+bool cm_ok(const void* xT, const float* w, const float* b, int B, int L, int Lx, int D, int dtype) {
+    return xT != nullptr && w != nullptr && b != nullptr && B >= 1 && L >= 1 && Lx >= L && D >= 1 &&
+           (dtype == HYENA_F32 || dtype == HYENA_BF16 || dtype == HYENA_F16);
+}
+int cm_tiles(int L) { return (L + CM_TILE - 1) / CM_TILE; }
+dim3 cm_grid(int B, int L, int D) { return dim3(cm_tiles(L), D, B); }
+const size_t CM_SMEM = 5 * 4 * sizeof(float);
+
+#define HY_CM_DISPATCH(kernel, smem)                                                                                      \
+    do {                                                                                                                  \
+        switch (dtype) {                                                                                                  \
+            case HYENA_F32: HY_LAUNCH((kernel<DT_F32>), cm_grid(B, L, D), dim3(CM_THREADS), smem, stream, a); break;      \
+            case HYENA_BF16: HY_LAUNCH((kernel<DT_BF16>), cm_grid(B, L, D), dim3(CM_THREADS), smem, stream, a); break;    \
+            default: HY_LAUNCH((kernel<DT_F16>), cm_grid(B, L, D), dim3(CM_THREADS), smem, stream, a); break;             \
+        }                                                                                                                 \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+size_t hyena_cm_partial_floats(int B, int L, int D) {
+    if (B < 1 || L < 1 || D < 1) return 0;
+    return (size_t)3 * D * B * cm_tiles(L) * CM_NP;
+}
+
+int hyena_cm_pre_fwd(const void* xT, const float* bin, const float* w, const float* b, void* vg, int B, int L, int Lx, int D, int dtype,
+                     void* stream) {
+    if (!cm_ok(xT, w, b, B, L, Lx, D, dtype) || vg == nullptr) return HYENA_ERR_BAD_ARG;
+    CmArgs a;
+    a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = nullptr; a.a1 = nullptr; a.o0 = vg; a.dxT = nullptr; a.part = nullptr;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    HY_CM_DISPATCH(cm_pre_fwd_kernel, 0);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+int hyena_cm_post_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, void* zT, int B, int L, int Lx,
+                      int D, int dtype, void* stream) {
+    if (!cm_ok(xT, w, b, B, L, Lx, D, dtype) || y == nullptr || zT == nullptr) return HYENA_ERR_BAD_ARG;
+    CmArgs a;
+    a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = y; a.a1 = nullptr; a.o0 = zT; a.dxT = nullptr; a.part = nullptr;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    HY_CM_DISPATCH(cm_post_fwd_kernel, 0);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+int hyena_cm_post_bwd(const void* dzT, const void* y, const void* xT, const float* bin, const float* w, const float* b, void* dy,
+                      void* dxT, float* part, int B, int L, int Lx, int D, int dtype, void* stream) {
+    if (!cm_ok(xT, w, b, B, L, Lx, D, dtype) || dzT == nullptr || y == nullptr || dy == nullptr || dxT == nullptr || part == nullptr)
+        return HYENA_ERR_BAD_ARG;
+    CmArgs a;
+    a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = y; a.a1 = dzT; a.o0 = dy; a.dxT = dxT; a.part = part;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    HY_CM_DISPATCH(cm_post_bwd_kernel, CM_SMEM);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+int hyena_cm_pre_bwd(const void* dvg, const void* xT, const float* bin, const float* w, const float* b, void* dxT, float* part, int B,
+                     int L, int Lx, int D, int dtype, void* stream) {
+    if (!cm_ok(xT, w, b, B, L, Lx, D, dtype) || dvg == nullptr || dxT == nullptr || part == nullptr) return HYENA_ERR_BAD_ARG;
+    CmArgs a;
+    a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = dvg; a.a1 = nullptr; a.o0 = nullptr; a.dxT = dxT; a.part = part;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    HY_CM_DISPATCH(cm_pre_bwd_kernel, CM_SMEM);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+}  // extern "C"

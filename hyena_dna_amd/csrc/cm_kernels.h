@@ -1,0 +1,236 @@
+// cm_kernels.h -- the element-wise shell of the Hyena operator in CHANNEL-MAJOR layout.
+//
+// Reference: src/models/sequence/hyena.py:391-440 (order 2, one head / block, inner factor 1, dropout 0, activation id).
+// The reference computes x = in_proj(u) as (B, L, 3D) and immediately rearranges it to (B, 3D, L) for the depthwise
+// short convolution, the gates and the long convolution, then rearranges back for out_proj -- two transposing copies.
+// mixer_kernels.h (round 1) fuses those copies into its four kernels through 64 x 64 LDS tiles.  Here the projections
+// themselves produce / consume the transposed tensors (the GEMM library takes transposed operands at no cost --
+// measured in profiles/gemm_layout_r2.txt), so every tensor between in_proj and out_proj is a set of rows contiguous
+// along L and the shell is four 1-D streaming kernels with 16-byte accesses, no LDS tiles, no transposes:
+//
+//     xT  = W_in u^T                               (3D, B, Lx)    [GEMM; the bias b_in is added here, on load]
+//     xc[c, b, t] = b_sc[c] + sum_j w[c, j] (xT[c, b, t-2+j] + b_in[c])  for t-2+j >= 0      hyena.py:394 (Conv1d k=3, padding 2)
+//     vg[b, d, t] = xc[2D+d, b, t] xc[D+d, b, t]                     cm_pre_fwd            hyena.py:404,420
+//     y           = fftconv(vg, k, bias)                             (hyena_fftconv_*)      hyena.py:423
+//     zT[d, b, t] = y[b, d, t] xc[d, b, t]                           cm_post_fwd           hyena.py:432
+//     out         = zT^T W_out^T + b_out                             [GEMM]                hyena.py:440
+// and the gradients: cm_post_bwd (dzT, y, xT -> dy, dxT rows [0, D)), cm_pre_bwd (dvg, xT -> dxT rows [D, 3D)); both leave
+// per-workgroup partial sums of the short filter's weight / bias gradients and of db_in (deterministic two-stage sums).
+//
+// A workgroup = 256 threads x 8 consecutive positions = one 2048-position tile of one (channel, batch) row.
+#pragma once
+#define HY_HELPERS_ONLY
+#include "fftconv_kernels.h"
+
+namespace hyena {
+
+enum { CM_THREADS = 256, CM_V = 8, CM_TILE = CM_THREADS * CM_V, CM_NP = 8 /* floats per partial record */ };
+
+struct CmArgs {
+    const void* xT;     // (3D, B, Lx) in_proj output WITHOUT its bias, elements of DT
+    const float* bin;   // (3D,) in_proj bias (fp32), added on load
+    const float* w;     // (3D, 3) short-filter taps
+    const float* b;     // (3D,)   short-filter bias
+    const void* a0;     // pre_fwd: -           post_fwd: y (B, D, L)   post_bwd: y (B, D, L)     pre_bwd: dvg (B, D, L)
+    const void* a1;     // post_bwd: dzT (D, B, L)
+    void* o0;           // pre_fwd: vg (B, D, L)   post_fwd: zT (D, B, L)   post_bwd: dy (B, D, L)
+    void* dxT;          // bwd: (3D, B, Lx) gradient of xT (post_bwd writes rows [0, D), pre_bwd rows [D, 3D)); positions >= L untouched
+    float* part;        // bwd: [3D][B * tiles][CM_NP] partial sums (dw0, dw1, dw2, db_sc, db_in, 0, 0, 0)
+    int B, L, D, Lx;
+};
+
+// v[i] = row[l0 + i] for i in [LO, HI), zero outside [0, L).  Interior vectors move as 16-byte (8 x 16-bit) or 2 x 16-byte
+// accesses (rows of odd length start under-aligned: gfx950 global memory handles that).
+template <int DT, int N>
+__device__ __forceinline__ void cm_ld(const void* row, int l0, int L, float (&v)[N]) {
+    typedef typename Elem<DT>::type elem_t;
+    const elem_t* p = reinterpret_cast<const elem_t*>(row);
+    if (l0 >= 0 && l0 + N <= L) {
+        elem_t raw[N];
+        __builtin_memcpy(raw, p + l0, sizeof(raw));
+        HY_UNROLL
+        for (int i = 0; i < N; ++i) v[i] = Elem<DT>::ld(&raw[i]);
+    } else {
+        HY_UNROLL
+        for (int i = 0; i < N; ++i) {
+            const int l = l0 + i;
+            const bool ok = l >= 0 && l < L;
+            const float f = Elem<DT>::ld(p + (ok ? l : 0));
+            v[i] = ok ? f : 0.f;
+        }
+    }
+}
+template <int DT, int N>
+__device__ __forceinline__ void cm_st(void* row, int l0, int L, const float (&v)[N]) {
+    typedef typename Elem<DT>::type elem_t;
+    elem_t* p = reinterpret_cast<elem_t*>(row);
+    if (l0 + N <= L) {
+        elem_t raw[N];
+        HY_UNROLL
+        for (int i = 0; i < N; ++i) Elem<DT>::st(&raw[i], v[i]);
+        __builtin_memcpy(p + l0, raw, sizeof(raw));
+    } else {
+        HY_UNROLL
+        for (int i = 0; i < N; ++i)
+            if (l0 + i < L) Elem<DT>::st(p + l0 + i, v[i]);
+    }
+}
+
+struct CmTap { float w0, w1, w2, bsc, bin; };
+__device__ __forceinline__ CmTap cm_tap(const CmArgs& a, int c) {
+    CmTap t;
+    t.w0 = a.w[c * 3]; t.w1 = a.w[c * 3 + 1]; t.w2 = a.w[c * 3 + 2];
+    t.bsc = a.b[c];
+    t.bin = a.bin != nullptr ? a.bin[c] : 0.f;
+    return t;
+}
+// xs[i] = raw xT[l0 - 2 + i]; out[i] = short-conv output at l0 + i (taps that fall before position 0 are zero padding)
+template <int N>
+__device__ __forceinline__ void cm_sc(const float (&xs)[N + 2], int l0, const CmTap& t, float (&out)[N]) {
+    HY_UNROLL
+    for (int i = 0; i < N; ++i) {
+        const int l = l0 + i;
+        const float x0 = l >= 2 ? xs[i] + t.bin : 0.f, x1 = l >= 1 ? xs[i + 1] + t.bin : 0.f, x2 = xs[i + 2] + t.bin;
+        out[i] = t.bsc + t.w0 * x0 + t.w1 * x1 + t.w2 * x2;
+    }
+}
+__device__ __forceinline__ const char* cm_row(const void* base, size_t row, int len, size_t es) {
+    return reinterpret_cast<const char*>(base) + row * (size_t)len * es;
+}
+template <int DT> struct CmEs { static constexpr size_t V = (DT == DT_F32) ? 4 : 2; };
+
+// vg[b, d, :] = xc[2D + d, b, :] * xc[D + d, b, :]                grid (tiles, D, B)
+template <int DT>
+__global__ void __launch_bounds__(CM_THREADS) cm_pre_fwd_kernel(CmArgs a) {
+    constexpr size_t ES = CmEs<DT>::V;
+    const int d = blockIdx.y, b = blockIdx.z;
+    const int l0 = (blockIdx.x * CM_THREADS + threadIdx.x) * CM_V;
+    if (l0 >= a.L) return;
+    const CmTap t1 = cm_tap(a, a.D + d), tv = cm_tap(a, 2 * a.D + d);
+    float x1[CM_V + 2], xv[CM_V + 2], c1[CM_V], cv[CM_V], o[CM_V];
+    cm_ld<DT, CM_V + 2>(cm_row(a.xT, (size_t)(a.D + d) * a.B + b, a.Lx, ES), l0 - 2, a.Lx, x1);
+    cm_ld<DT, CM_V + 2>(cm_row(a.xT, (size_t)(2 * a.D + d) * a.B + b, a.Lx, ES), l0 - 2, a.Lx, xv);
+    cm_sc<CM_V>(x1, l0, t1, c1);
+    cm_sc<CM_V>(xv, l0, tv, cv);
+    HY_UNROLL
+    for (int i = 0; i < CM_V; ++i) o[i] = c1[i] * cv[i];
+    cm_st<DT, CM_V>(const_cast<char*>(cm_row(a.o0, (size_t)b * a.D + d, a.L, ES)), l0, a.L, o);
+}
+
+// zT[d, b, :] = y[b, d, :] * xc[d, b, :]
+template <int DT>
+__global__ void __launch_bounds__(CM_THREADS) cm_post_fwd_kernel(CmArgs a) {
+    constexpr size_t ES = CmEs<DT>::V;
+    const int d = blockIdx.y, b = blockIdx.z;
+    const int l0 = (blockIdx.x * CM_THREADS + threadIdx.x) * CM_V;
+    if (l0 >= a.L) return;
+    const CmTap t0 = cm_tap(a, d);
+    float x0[CM_V + 2], c0[CM_V], y[CM_V], o[CM_V];
+    cm_ld<DT, CM_V + 2>(cm_row(a.xT, (size_t)d * a.B + b, a.Lx, ES), l0 - 2, a.Lx, x0);
+    cm_ld<DT, CM_V>(cm_row(a.a0, (size_t)b * a.D + d, a.L, ES), l0, a.L, y);
+    cm_sc<CM_V>(x0, l0, t0, c0);
+    HY_UNROLL
+    for (int i = 0; i < CM_V; ++i) o[i] = y[i] * c0[i];
+    cm_st<DT, CM_V>(const_cast<char*>(cm_row(a.o0, (size_t)d * a.B + b, a.L, ES)), l0, a.L, o);
+}
+
+// sum of `v` over the 256 threads of the workgroup, in a fixed order; valid in thread 0
+__device__ __forceinline__ float cm_block_sum(float v, HY_LDS float* red, int slot) {
+    HY_UNROLL
+    for (int off = 32; off > 0; off >>= 1) v += u2f(HY_SHFL_U32(f2u(v), (threadIdx.x & 63) ^ off));
+    if ((threadIdx.x & 63) == 0) red[slot * 4 + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    const float s = (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
+    __syncthreads();
+    return s;
+}
+
+// Back through one short-conv channel.  da[i] = gradient w.r.t. the conv OUTPUT at l0 + i, i in [0, V + 2) (zero beyond L);
+// xs[i] = raw xT[l0 - 2 + i], i in [0, V + 2).  Writes dx[l0 .. l0 + V) and returns this thread's partial sums.
+struct CmPart { float dw0, dw1, dw2, dbsc, dbin; };
+template <int DT>
+__device__ __forceinline__ CmPart cm_sc_bwd(const float (&da)[CM_V + 2], const float (&xs)[CM_V + 2], int l0, int L, const CmTap& t,
+                                            void* dx_row, int Lx) {
+    CmPart p = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float dx[CM_V];
+    HY_UNROLL
+    for (int i = 0; i < CM_V; ++i) {
+        const int m = l0 + i;
+        // x[m] feeds outputs m (tap 2), m + 1 (tap 1), m + 2 (tap 0); da is already zero beyond L
+        dx[i] = t.w2 * da[i] + t.w1 * da[i + 1] + t.w0 * da[i + 2];
+        if (m < L) p.dbin += dx[i];
+        // the outputs this thread owns (l = m): dw[j] += da[l] x_true[l - 2 + j]
+        const float x0 = m >= 2 ? xs[i] + t.bin : 0.f, x1 = m >= 1 ? xs[i + 1] + t.bin : 0.f, x2 = xs[i + 2] + t.bin;
+        p.dw0 += da[i] * x0;
+        p.dw1 += da[i] * x1;
+        p.dw2 += da[i] * x2;
+        p.dbsc += da[i];
+    }
+    cm_st<DT, CM_V>(dx_row, l0, L < Lx ? L : Lx, dx);
+    return p;
+}
+__device__ __forceinline__ void cm_store_part(const CmArgs& a, int c, int rec, int nrec, const CmPart& p, HY_LDS float* red) {
+    const float s0 = cm_block_sum(p.dw0, red, 0), s1 = cm_block_sum(p.dw1, red, 1), s2 = cm_block_sum(p.dw2, red, 2);
+    const float s3 = cm_block_sum(p.dbsc, red, 3), s4 = cm_block_sum(p.dbin, red, 4);
+    if (threadIdx.x == 0) {
+        float* o = a.part + ((size_t)c * nrec + rec) * CM_NP;
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
+// dy[b, d, :] = dzT[d, b, :] * xc[d, b, :];   g = dzT * y  -> dxT[d, b, :] and the partials of channel d
+template <int DT>
+__global__ void __launch_bounds__(CM_THREADS) cm_post_bwd_kernel(CmArgs a) {
+    constexpr size_t ES = CmEs<DT>::V;
+    HY_SMEM(smem);
+    HY_LDS float* red = HY_LDS_CAST(float, smem);
+    const int d = blockIdx.y, b = blockIdx.z;
+    const int l0 = (blockIdx.x * CM_THREADS + threadIdx.x) * CM_V;      // (threads beyond L still take part in the sums)
+    const CmTap t0 = cm_tap(a, d);
+    float x0[CM_V + 2], dz[CM_V + 2], y[CM_V + 2], c0[CM_V], dy[CM_V], da[CM_V + 2];
+    cm_ld<DT, CM_V + 2>(cm_row(a.xT, (size_t)d * a.B + b, a.Lx, ES), l0 - 2, a.Lx, x0);
+    cm_ld<DT, CM_V + 2>(cm_row(a.a1, (size_t)d * a.B + b, a.L, ES), l0, a.L, dz);
+    cm_ld<DT, CM_V + 2>(cm_row(a.a0, (size_t)b * a.D + d, a.L, ES), l0, a.L, y);
+    cm_sc<CM_V>(x0, l0, t0, c0);
+    HY_UNROLL
+    for (int i = 0; i < CM_V; ++i) dy[i] = dz[i] * c0[i];
+    HY_UNROLL
+    for (int i = 0; i < CM_V + 2; ++i) da[i] = dz[i] * y[i];            // zero beyond L: dz is
+    if (l0 < a.L) cm_st<DT, CM_V>(const_cast<char*>(cm_row(a.o0, (size_t)b * a.D + d, a.L, ES)), l0, a.L, dy);
+    CmPart p = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (l0 < a.L)
+        p = cm_sc_bwd<DT>(da, x0, l0, a.L, t0, const_cast<char*>(cm_row(a.dxT, (size_t)d * a.B + b, a.Lx, ES)), a.Lx);
+    cm_store_part(a, d, b * gridDim.x + blockIdx.x, a.B * gridDim.x, p, red);
+}
+
+// dvg -> dxT rows D + d (through x1c: gradient dvg * vc) and 2D + d (through vc: gradient dvg * x1c), and their partials
+template <int DT>
+__global__ void __launch_bounds__(CM_THREADS) cm_pre_bwd_kernel(CmArgs a) {
+    constexpr size_t ES = CmEs<DT>::V;
+    HY_SMEM(smem);
+    HY_LDS float* red = HY_LDS_CAST(float, smem);
+    const int d = blockIdx.y, b = blockIdx.z;
+    const int l0 = (blockIdx.x * CM_THREADS + threadIdx.x) * CM_V;
+    const CmTap t1 = cm_tap(a, a.D + d), tv = cm_tap(a, 2 * a.D + d);
+    // conv outputs are needed at l0 .. l0 + V + 1, hence raw inputs at l0 - 2 .. l0 + V + 1
+    float x1[CM_V + 4], xv[CM_V + 4], g[CM_V + 2], c1[CM_V + 2], cv[CM_V + 2], da1[CM_V + 2], dav[CM_V + 2];
+    cm_ld<DT, CM_V + 4>(cm_row(a.xT, (size_t)(a.D + d) * a.B + b, a.Lx, ES), l0 - 2, a.Lx, x1);
+    cm_ld<DT, CM_V + 4>(cm_row(a.xT, (size_t)(2 * a.D + d) * a.B + b, a.Lx, ES), l0 - 2, a.Lx, xv);
+    cm_ld<DT, CM_V + 2>(cm_row(a.a0, (size_t)b * a.D + d, a.L, ES), l0, a.L, g);
+    cm_sc<CM_V + 2>(x1, l0, t1, c1);
+    cm_sc<CM_V + 2>(xv, l0, tv, cv);
+    HY_UNROLL
+    for (int i = 0; i < CM_V + 2; ++i) { da1[i] = g[i] * cv[i]; dav[i] = g[i] * c1[i]; }      // zero beyond L: dvg is
+    float xs1[CM_V + 2], xsv[CM_V + 2];
+    HY_UNROLL
+    for (int i = 0; i < CM_V + 2; ++i) { xs1[i] = x1[i]; xsv[i] = xv[i]; }
+    CmPart p1 = {0.f, 0.f, 0.f, 0.f, 0.f}, pv = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (l0 < a.L) {
+        p1 = cm_sc_bwd<DT>(da1, xs1, l0, a.L, t1, const_cast<char*>(cm_row(a.dxT, (size_t)(a.D + d) * a.B + b, a.Lx, ES)), a.Lx);
+        pv = cm_sc_bwd<DT>(dav, xsv, l0, a.L, tv, const_cast<char*>(cm_row(a.dxT, (size_t)(2 * a.D + d) * a.B + b, a.Lx, ES)), a.Lx);
+    }
+    cm_store_part(a, a.D + d, b * gridDim.x + blockIdx.x, a.B * gridDim.x, p1, red);
+    cm_store_part(a, 2 * a.D + d, b * gridDim.x + blockIdx.x, a.B * gridDim.x, pv, red);
+}
+
+}  // namespace hyena

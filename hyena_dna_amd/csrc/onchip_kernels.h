@@ -265,9 +265,27 @@ struct Ctx {
 
 // v[s] = c[tid + T s] e^(+2 pi i tid phi / M) on entry (i.e. the raw samples times the per-register twist constants);
 // spectrum in the order described at the top on exit.
+// OC_DBG_* (profiling builds only, scripts/build_variant.sh; results are wrong by construction): leave out the
+// workgroup-wide exchange, the wave-local exchange or the butterflies to see what each costs on the hardware
+#ifdef OC_DBG_NO_X1
+#define OC_X1(...) do {} while (0)
+#else
+#define OC_X1(...) __VA_ARGS__
+#endif
+#ifdef OC_DBG_NO_X2
+#define OC_X2(...) do {} while (0)
+#else
+#define OC_X2(...) __VA_ARGS__
+#endif
+#ifdef OC_DBG_NO_DFT
+#define OC_DFT(...) do {} while (0)
+#else
+#define OC_DFT(...) __VA_ARGS__
+#endif
+
 template <int R>
 __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
-    dft_reg<32, false>(v);
+    OC_DFT((dft_reg<32, false>(v)));
     OC_FENCE();
     {
         Tw w;
@@ -275,10 +293,10 @@ __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
         apply_tw<false, true>(v, w);
     }
     OC_FENCE();
-    if constexpr (Cfg<R>::PLANES) x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
-    else x1<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp);
+    OC_X1(if constexpr (Cfg<R>::PLANES) x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
+          else x1<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp));
     OC_FENCE();
-    dft_reg<32, false>(v);
+    OC_DFT((dft_reg<32, false>(v)));
     OC_FENCE();
     if constexpr (R > 1) {
         {
@@ -287,10 +305,10 @@ __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
             apply_tw<false, false>(v, w);
         }
         OC_FENCE();
-        if constexpr (Cfg<R>::PLANES) x2p<R, false>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
-        else x2<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp);
+        OC_X2(if constexpr (Cfg<R>::PLANES) x2p<R, false>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
+              else x2<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp));
         OC_FENCE();
-        pass3<R, false>(v);
+        OC_DFT((pass3<R, false>(v)));
         OC_FENCE();
     }
 }
@@ -299,22 +317,22 @@ __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
 template <int R>
 __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
     if constexpr (R > 1) {
-        pass3<R, true>(v);
+        OC_DFT((pass3<R, true>(v)));
         OC_FENCE();
-        if constexpr (Cfg<R>::PLANES) x2p<R, true>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
-        else x2<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp);
+        OC_X2(if constexpr (Cfg<R>::PLANES) x2p<R, true>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
+              else x2<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp));
         OC_FENCE();
         Tw w;
         load_tw2<R>(w, c.tab, c.tp);
         apply_tw<true, false>(v, w);
     }
     OC_FENCE();
-    dft_reg<32, true>(v);
+    OC_DFT((dft_reg<32, true>(v)));
     OC_FENCE();
     // exchange 1 writes anywhere in the buffer: every wavefront must be done with its exchange-2 region
     if constexpr (R > 1) row_sync<Cfg<R>::T>();
-    if constexpr (Cfg<R>::PLANES) x1p<R, true>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
-    else x1<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp);
+    OC_X1(if constexpr (Cfg<R>::PLANES) x1p<R, true>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
+          else x1<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp));
     OC_FENCE();
     {
         Tw w;
@@ -322,7 +340,7 @@ __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
         apply_tw<true, true>(v, w);
     }
     OC_FENCE();
-    dft_reg<32, true>(v);
+    OC_DFT((dft_reg<32, true>(v)));
     OC_FENCE();
 }
 
@@ -372,8 +390,13 @@ __device__ __forceinline__ void load_raw(float (&x)[32], GBuf xb, bool bf, int t
         x[s] = n < L ? io_ld<HALF>(xb, row_off + (unsigned)n * ES, 0u, bf) : 0.f;
     }
 #else
+#ifdef OC_DBG_NO_IO
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) { x[s] = (float)(tid * 3 + s); HY_OPAQUE(x[s]); }
+#else
     HY_UNROLL
     for (int s = 0; s < 32; ++s) x[s] = io_ld<HALF>(xb, row_off + (unsigned)(tid + extra) * ES, (unsigned)(T * s) * ES, bf);
+#endif
     if constexpr (PRED) {            // several rows under one descriptor: its bounds check cannot clip n >= L
         HY_UNROLL
         for (int s = 0; s < 32; ++s) x[s] = (tid + T * s + extra < L) ? x[s] : 0.f;
@@ -404,12 +427,19 @@ __device__ __forceinline__ void store_row(GBuf ob, bool bf, int tid, unsigned ro
     }
 #else
     unsigned vo = row_off + (unsigned)tid * ES;
+#ifdef OC_DBG_NO_IO
+    float acc = 0.f;
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) acc += y[s];
+    io_st<HALF>(ob, vo, acc, bf);
+#else
     HY_UNROLL
     for (int s = 0; s < 32; ++s) {
         if (!PRED || tid + T * s < L) io_st<HALF>(ob, vo, y[s], bf);
         vo += (unsigned)T * ES;
         HY_OPAQUE(vo);
     }
+#endif
 #endif
 }
 
@@ -521,8 +551,13 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT) conv_kernel(ConvArgs a) {
         HY_UNROLL
         for (int q0 = 0; q0 < 32; q0 += 8) {          // 8 at a time: 32 filter values at once do not fit 128 VGPRs at T = 1024
             c32 h[8];
+#ifdef OC_DBG_NO_H
+            HY_UNROLL
+            for (int q = 0; q < 8; ++q) { h[q] = mk((float)(tid + q), 0.5f); HY_OPAQUE(h[q].x); }
+#else
             HY_UNROLL
             for (int q = 0; q < 8; ++q) h[q] = gb_ld(hb, ho, (unsigned)((q0 + q) * T) * 8u);
+#endif
             HY_UNROLL
             for (int q = 0; q < 8; ++q) v[q0 + q] = cmul(v[q0 + q], mk(h[q].x, a.conj_sign * h[q].y));
             HY_SCHED_FENCE();

@@ -18,8 +18,15 @@ import torch.nn.functional as F
 
 from .fftconv import fftconv_func
 from .filter import fused_filter_ok, hyena_filter_dl
-from .mixer import hyena_mixer_core
-from .projection import hyena_linear
+import os
+
+from .mixer import hyena_mixer_core, hyena_mixer_core_cm
+from .projection import hyena_linear, in_proj_cm, out_proj_cm
+
+# Layout of the tensors between the operator's two projections: channel-major (x^T written by the in_proj GEMM, z^T read by
+# the out_proj GEMM, no transposes anywhere: csrc/cm_kernels.h) or the reference's position-major (B, L, 3D) with the
+# transposes fused into the shell kernels (csrc/mixer_kernels.h).  HYENA_MIXER_LAYOUT=position selects the latter (A/B).
+CHANNEL_MAJOR = os.environ.get("HYENA_MIXER_LAYOUT", "channel").lower() != "position"
 
 __all__ = ["HyenaOperator", "HyenaFilter", "PositionalEmbedding", "ExponentialModulation", "Sin"]
 
@@ -257,11 +264,17 @@ class HyenaOperator(nn.Module):
         l = u.size(-2)
         l_filter = min(l, self.l_max)
         if self._fused_ok():
-            x = hyena_linear(u, self.in_proj.weight, self.in_proj.bias)         # (B, L, 3D), hipBLASLt GEMM
             k = self.filter_fn.filter_dl(l_filter)                              # (D, l), rows contiguous along l
             fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
-            z = hyena_mixer_core(x, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter)
-            y = hyena_linear(self.activation(z), self.out_proj.weight, self.out_proj.bias)
+            if CHANNEL_MAJOR:
+                # x^T = W_in u^T straight out of the GEMM (3D, B, L): nothing between the projections is ever transposed
+                xT = in_proj_cm(u, self.in_proj.weight)
+                zT = hyena_mixer_core_cm(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter)
+                y = out_proj_cm(zT, self.out_proj.weight, self.out_proj.bias)   # activation is the identity (_fused_ok)
+            else:
+                x = hyena_linear(u, self.in_proj.weight, self.in_proj.bias)     # (B, L, 3D), hipBLASLt GEMM
+                z = hyena_mixer_core(x, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter)
+                y = hyena_linear(self.activation(z), self.out_proj.weight, self.out_proj.bias)
             return (y, None) if self.return_state else y
         u = self.in_proj(u).transpose(1, 2)                                     # b l d -> b d l
         uc = self.short_filter(u)[..., :l_filter]

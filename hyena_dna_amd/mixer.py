@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["hyena_mixer_core", "HyenaMixerFunc"]
+__all__ = ["hyena_mixer_core", "HyenaMixerFunc", "hyena_mixer_core_cm", "HyenaMixerCMFunc"]
 
 
 class HyenaMixerFunc(torch.autograd.Function):
@@ -74,3 +74,62 @@ def hyena_mixer_core(x, sf_weight, sf_bias, k, bias, L):
         zero = 0 * (sf_weight.sum() + sf_bias.sum() + k.sum() + bias.sum())
         return x[:, :L, :D] * 0 + zero.to(x.dtype)
     return HyenaMixerFunc.apply(x, sf_weight, sf_bias, k, bias, L)
+
+
+class HyenaMixerCMFunc(torch.autograd.Function):
+    """The same core in channel-major layout (``csrc/cm_kernels.h``): ``xT`` (3D, B, Lx) = W_in u^T without the in_proj bias,
+    result ``zT`` (D, B, L) for ``projection.out_proj_cm``.  No tensor between the two projections is ever transposed."""
+
+    @staticmethod
+    def forward(ctx, xT, b_in, sf_weight, sf_bias, k, bias, L):
+        D3, B, Lx = xT.shape
+        D = D3 // 3
+        xc = xT.contiguous()
+        bi = b_in.detach().to(torch.float32).contiguous()
+        w = sf_weight.detach().to(torch.float32).reshape(D3, 3).contiguous()
+        b = sf_bias.detach().to(torch.float32).contiguous()
+        kf = k.detach().to(torch.float32).contiguous()
+        bf = bias.detach().to(torch.float32).reshape(D).contiguous()
+        vg = _lib.cm_pre_fwd(xc, bi, w, b, L)
+        want_grad = any(ctx.needs_input_grad[:6])
+        spectra = None
+        if want_grad and _lib.save_spectra_default(B, D, L):
+            y, spectra = _lib.fftconv_fwd(vg, kf, bf, save=True)
+        else:
+            y = _lib.fftconv_fwd(vg, kf, bf)
+        zT = _lib.cm_post_fwd(y, xc, bi, w, b)
+        ctx.save_for_backward(xc, bi, w, b, kf, bf, y)
+        ctx.spectra = spectra
+        ctx.meta = (b_in.dtype, sf_weight.shape, sf_weight.dtype, sf_bias.dtype, k.dtype, bias.shape, bias.dtype, L)
+        return zT
+
+    @staticmethod
+    def backward(ctx, dzT):
+        xc, bi, w, b, kf, bf, y = ctx.saved_tensors
+        bin_dtype, w_shape, w_dtype, b_dtype, k_dtype, bias_shape, bias_dtype, L = ctx.meta
+        D3, B, Lx = xc.shape
+        dzT = dzT.to(xc.dtype).contiguous()
+        dxT = torch.zeros_like(xc) if Lx > L else torch.empty_like(xc)
+        part = _lib.cm_partials(xc, L)
+        dy = _lib.cm_post_bwd(dzT, y, xc, bi, w, b, dxT, part)
+        need_vg = ctx.spectra is None or _lib.lib().hyena_fftconv_plan(int(L)) == _lib.PLAN_ONCHIP
+        vg = _lib.cm_pre_fwd(xc, bi, w, b, L) if need_vg else None                 # recompute the conv's input
+        need_dk = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
+        dvg, dk, dbias = _lib.fftconv_bwd(dy, vg, kf, bf, need_du=True, need_dk=need_dk, saved=ctx.spectra)
+        ctx.spectra = None
+        _lib.cm_pre_bwd(dvg, xc, bi, w, b, dxT, part)
+        red = part.sum(dim=1)                                        # (3D, 8): deterministic two-stage reduction
+        dw = red[:, :3].reshape(w_shape).to(w_dtype)
+        db = red[:, 3].to(b_dtype)
+        dbin = red[:, 4].to(bin_dtype)
+        return (dxT, dbin, dw, db, dk.to(k_dtype) if dk is not None else None,
+                dbias.reshape(bias_shape).to(bias_dtype) if dbias is not None else None, None)
+
+
+def hyena_mixer_core_cm(xT, b_in, sf_weight, sf_bias, k, bias, L):
+    """zT (D, B, L) = fftconv(v * x1, k, bias) * x0 with (x0, x1, v) = short_conv(xT + b_in)[..., :L].split(D) (channel-major)."""
+    if xT.shape[1] == 0 or L == 0:
+        D = xT.shape[0] // 3
+        zero = 0 * (b_in.sum() + sf_weight.sum() + sf_bias.sum() + k.sum() + bias.sum())
+        return xT[:D, :, :L] * 0 + zero.to(xT.dtype)
+    return HyenaMixerCMFunc.apply(xT, b_in, sf_weight, sf_bias, k, bias, L)

@@ -14,7 +14,7 @@ plain fp32 / 16-bit tensors); everything else goes through ``torch.nn.functional
 import torch
 import torch.nn.functional as F
 
-__all__ = ["hyena_linear", "SplitKLinearFunc", "split_count", "split_k_weight_grad"]
+__all__ = ["hyena_linear", "SplitKLinearFunc", "split_count", "split_k_weight_grad", "in_proj_cm", "out_proj_cm"]
 
 MIN_ROWS = 32768          # below this the library's own schedule is fine
 MAX_SPLITS = 64
@@ -83,3 +83,104 @@ def hyena_linear(x, weight, bias):
         elif x.dtype == weight.dtype and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
             return SplitKLinearFunc.apply(x.contiguous(), weight, bias)          # plain fp32 / 16-bit training: same pathology
     return F.linear(x, weight, bias)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Channel-major projections (what hyena_dna_amd.mixer's channel-major core sits between).  The GEMM library takes transposed
+# operands at no cost (profiles/gemm_layout_r2.txt), so in_proj can WRITE x^T = W u^T (3D, B L) and out_proj can READ z^T
+# (D, B L): the two rearranging copies of hyena.py:392 and hyena.py:432-439 are never made.
+# ---------------------------------------------------------------------------------------------------------------------
+def _bmm_f32(a, b):
+    if a.is_cuda:
+        return torch.bmm(a, b, out_dtype=torch.float32)
+    return torch.bmm(a.float(), b.float())
+
+
+class InProjCMFunc(torch.autograd.Function):
+    """xT (N, B, L) = W (N, K) u^T, WITHOUT the bias (the shell kernels add it on load and return its gradient)."""
+
+    @staticmethod
+    def forward(ctx, u, weight):
+        B, L, K = u.shape
+        u2 = u.reshape(B * L, K)
+        ctx.save_for_backward(u2, weight)
+        ctx.ushape = u.shape
+        return torch.mm(weight, u2.t()).view(weight.shape[0], B, L)
+
+    @staticmethod
+    def backward(ctx, dxT):
+        u2, weight = ctx.saved_tensors
+        n, k = weight.shape
+        rows = u2.shape[0]
+        d2 = dxT.reshape(n, rows)
+        du = dw = None
+        if ctx.needs_input_grad[0]:
+            du = torch.mm(d2.t(), weight).view(ctx.ushape)
+        if ctx.needs_input_grad[1]:
+            s = split_count(rows)
+            body = (rows // s) * s
+            dw = _bmm_f32(d2[:, :body].reshape(n, s, rows // s).permute(1, 0, 2), u2[:body].view(s, rows // s, k)).sum(0)
+            if body < rows:
+                dw = dw + torch.mm(d2[:, body:].float(), u2[body:].float())
+            dw = dw.to(weight.dtype)
+        return du, dw
+
+
+class OutProjCMFunc(torch.autograd.Function):
+    """y (B, L, N) = zT^T W^T + b for zT (K, B, L)."""
+
+    @staticmethod
+    def forward(ctx, zT, weight, bias):
+        K, B, L = zT.shape
+        z2 = zT.reshape(K, B * L)
+        ctx.save_for_backward(z2, weight)
+        ctx.has_bias = bias is not None
+        ctx.zshape = zT.shape
+        y = torch.mm(z2.t(), weight.t()) if bias is None else torch.addmm(bias, z2.t(), weight.t())
+        return y.view(B, L, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        z2, weight = ctx.saved_tensors
+        n, k = weight.shape
+        rows = z2.shape[1]
+        dy2 = dy.reshape(rows, n)
+        dz = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dz = torch.mm(weight.t(), dy2.t()).view(ctx.zshape)               # (K, B L): channel-major, straight from the GEMM
+        if ctx.needs_input_grad[1]:
+            s = split_count(rows)
+            body = (rows // s) * s
+            dw = _bmm_f32(dy2[:body].view(s, rows // s, n).transpose(1, 2), z2[:, :body].reshape(k, s, rows // s).permute(1, 2, 0)).sum(0)
+            if body < rows:
+                dw = dw + torch.mm(dy2[body:].t().float(), z2[:, body:].t().float())
+            dw = dw.to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0, dtype=torch.float32).to(dy.dtype)
+        return dz, dw, db
+
+
+def _autocast_dtype(x):
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda" if x.is_cuda else "cpu")
+        if dt in (torch.bfloat16, torch.float16):
+            return dt
+    return None
+
+
+def in_proj_cm(u, weight):
+    """(B, L, K) -> xT (N, B, L) = W u^T with nn.Linear's autocast semantics (bias NOT added: see InProjCMFunc)."""
+    dt = _autocast_dtype(u)
+    if dt is not None:
+        with torch.autocast("cuda" if u.is_cuda else "cpu", enabled=False):
+            return InProjCMFunc.apply(u.to(dt).contiguous(), weight.to(dt))
+    return InProjCMFunc.apply(u.contiguous(), weight.to(u.dtype))
+
+
+def out_proj_cm(zT, weight, bias):
+    """zT (K, B, L) -> (B, L, N) = zT^T W^T + b with nn.Linear's autocast semantics."""
+    dt = _autocast_dtype(zT)
+    if dt is not None:
+        with torch.autocast("cuda" if zT.is_cuda else "cpu", enabled=False):
+            return OutProjCMFunc.apply(zT.to(dt).contiguous(), weight.to(dt), None if bias is None else bias.to(dt))
+    return OutProjCMFunc.apply(zT.contiguous(), weight.to(zT.dtype), None if bias is None else bias.to(zT.dtype))

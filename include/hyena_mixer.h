@@ -42,6 +42,23 @@ int hyena_mixer_post_bwd(const void* dz, const void* y, const void* x, const flo
 int hyena_mixer_pre_bwd(const void* dvg, const void* x, const float* w, const float* b,
                         void* dx, float* part, int B, int L, int Lx, int D, int dtype, void* stream);
 
+/* ---- the same shell in CHANNEL-MAJOR layout (csrc/cm_kernels.h) -------------------------------------------------------
+ * The projections produce / consume transposed tensors (the GEMM library takes transposed operands at no cost), so nothing
+ * between in_proj and out_proj is ever rearranged ('b l d -> b d l' at hyena.py:392 and back at hyena.py:432-439 disappear):
+ *   xT  : (3D, B, Lx)  = W_in u^T, WITHOUT the in_proj bias `bin` (3D, fp32; may be NULL) -- the kernels add it on load
+ *   zT, dzT : (D, B, L);   dxT : (3D, B, Lx) (positions >= L are not written);   vg, y, dy, dvg : (B, D, L) as above
+ *   part: hyena_cm_partial_floats(B, L, D) floats, [3D][B * tiles][8] = per-workgroup partial sums of
+ *         (dw[c][0], dw[c][1], dw[c][2], db_sc[c], db_in[c], 0, 0, 0); summing axis 1 gives the gradients. */
+size_t hyena_cm_partial_floats(int B, int L, int D);
+int hyena_cm_pre_fwd(const void* xT, const float* bin, const float* w, const float* b, void* vg,
+                     int B, int L, int Lx, int D, int dtype, void* stream);
+int hyena_cm_post_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, void* zT,
+                      int B, int L, int Lx, int D, int dtype, void* stream);
+int hyena_cm_post_bwd(const void* dzT, const void* y, const void* xT, const float* bin, const float* w, const float* b,
+                      void* dy, void* dxT, float* part, int B, int L, int Lx, int D, int dtype, void* stream);
+int hyena_cm_pre_bwd(const void* dvg, const void* xT, const float* bin, const float* w, const float* b,
+                     void* dxT, float* part, int B, int L, int Lx, int D, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ from hyena_dna_amd import _lib  # noqa: E402
 dev = torch.device("cuda", 0)
 
 
-def timeit(fn, n=20, w=3):
+def timeit(fn, n=50, w=10):
     for _ in range(w):
         fn()
     torch.cuda.synchronize()
