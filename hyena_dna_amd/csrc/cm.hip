@@ -13,7 +13,7 @@ bool cm_ok(const void* xT, const float* w, const float* b, int B, int L, int Lx,
 }
 int cm_tiles(int L) { return (L + CM_TILE - 1) / CM_TILE; }
 dim3 cm_grid(int B, int L, int D) { return dim3(cm_tiles(L), D, B); }
-const size_t CM_SMEM = 5 * 4 * sizeof(float);
+const size_t CM_SMEM = 2 * 5 * 4 * sizeof(float);
 
 #define HY_CM_DISPATCH(kernel, smem)                                                                                      \
     do {                                                                                                                  \

@@ -35,7 +35,7 @@ struct CmArgs {
     const void* a1;     // post_bwd: dzT (D, B, L)
     void* o0;           // pre_fwd: vg (B, D, L)   post_fwd: zT (D, B, L)   post_bwd: dy (B, D, L)
     void* dxT;          // bwd: (3D, B, Lx) gradient of xT (post_bwd writes rows [0, D), pre_bwd rows [D, 3D)); positions >= L untouched
-    float* part;        // bwd: [3D][B * tiles][CM_NP] partial sums (dw0, dw1, dw2, db_sc, db_in, 0, 0, 0)
+    float* part;        // bwd: [3D][B * tiles][CM_NP] partial sums (dw0, dw1, dw2, db_sc, db_in, -, -, -): the host reads [:5]
     int B, L, D, Lx;
 };
 
@@ -134,15 +134,11 @@ __global__ void __launch_bounds__(CM_THREADS) cm_post_fwd_kernel(CmArgs a) {
     cm_st<DT, CM_V>(const_cast<char*>(cm_row(a.o0, (size_t)d * a.B + b, a.L, ES)), l0, a.L, o);
 }
 
-// sum of `v` over the 256 threads of the workgroup, in a fixed order; valid in thread 0
-__device__ __forceinline__ float cm_block_sum(float v, HY_LDS float* red, int slot) {
+// wavefront sum (xor butterfly: every lane ends with the total, fixed order)
+__device__ __forceinline__ float cm_wave_sum(float v) {
     HY_UNROLL
     for (int off = 32; off > 0; off >>= 1) v += u2f(HY_SHFL_U32(f2u(v), (threadIdx.x & 63) ^ off));
-    if ((threadIdx.x & 63) == 0) red[slot * 4 + (threadIdx.x >> 6)] = v;
-    __syncthreads();
-    const float s = (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
-    __syncthreads();
-    return s;
+    return v;
 }
 
 // Back through one short-conv channel.  da[i] = gradient w.r.t. the conv OUTPUT at l0 + i, i in [0, V + 2) (zero beyond L);
@@ -169,12 +165,26 @@ __device__ __forceinline__ CmPart cm_sc_bwd(const float (&da)[CM_V + 2], const f
     cm_st<DT, CM_V>(dx_row, l0, L < Lx ? L : Lx, dx);
     return p;
 }
-__device__ __forceinline__ void cm_store_part(const CmArgs& a, int c, int rec, int nrec, const CmPart& p, HY_LDS float* red) {
-    const float s0 = cm_block_sum(p.dw0, red, 0), s1 = cm_block_sum(p.dw1, red, 1), s2 = cm_block_sum(p.dw2, red, 2);
-    const float s3 = cm_block_sum(p.dbsc, red, 3), s4 = cm_block_sum(p.dbin, red, 4);
-    if (threadIdx.x == 0) {
-        float* o = a.part + ((size_t)c * nrec + rec) * CM_NP;
-        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
+// The workgroup's sums of NC channels' partial records -> part[c][rec][:], ONE barrier for all 5 NC values: wavefront sums
+// by shuffles, the four wavefronts' results through LDS, added in a fixed order (deterministic).
+template <int NC>
+__device__ __forceinline__ void cm_store_parts(const CmArgs& a, const int (&c)[NC], int rec, int nrec, const CmPart (&p)[NC],
+                                               HY_LDS float* red) {
+    float v[NC * 5];
+    HY_UNROLL
+    for (int i = 0; i < NC; ++i) {
+        v[i * 5] = cm_wave_sum(p[i].dw0); v[i * 5 + 1] = cm_wave_sum(p[i].dw1); v[i * 5 + 2] = cm_wave_sum(p[i].dw2);
+        v[i * 5 + 3] = cm_wave_sum(p[i].dbsc); v[i * 5 + 4] = cm_wave_sum(p[i].dbin);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        HY_UNROLL
+        for (int i = 0; i < NC * 5; ++i) red[i * 4 + (threadIdx.x >> 6)] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < NC * 5) {
+        const int i = threadIdx.x, ch = i / 5, f = i % 5;
+        const float s = (red[i * 4] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
+        a.part[((size_t)c[ch] * nrec + rec) * CM_NP + f] = s;
     }
 }
 
@@ -200,7 +210,9 @@ __global__ void __launch_bounds__(CM_THREADS) cm_post_bwd_kernel(CmArgs a) {
     CmPart p = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (l0 < a.L)
         p = cm_sc_bwd<DT>(da, x0, l0, a.L, t0, const_cast<char*>(cm_row(a.dxT, (size_t)d * a.B + b, a.Lx, ES)), a.Lx);
-    cm_store_part(a, d, b * gridDim.x + blockIdx.x, a.B * gridDim.x, p, red);
+    const int cs[1] = {d};
+    const CmPart ps[1] = {p};
+    cm_store_parts<1>(a, cs, b * gridDim.x + blockIdx.x, a.B * gridDim.x, ps, red);
 }
 
 // dvg -> dxT rows D + d (through x1c: gradient dvg * vc) and 2D + d (through vc: gradient dvg * x1c), and their partials
@@ -229,8 +241,9 @@ __global__ void __launch_bounds__(CM_THREADS) cm_pre_bwd_kernel(CmArgs a) {
         p1 = cm_sc_bwd<DT>(da1, xs1, l0, a.L, t1, const_cast<char*>(cm_row(a.dxT, (size_t)(a.D + d) * a.B + b, a.Lx, ES)), a.Lx);
         pv = cm_sc_bwd<DT>(dav, xsv, l0, a.L, tv, const_cast<char*>(cm_row(a.dxT, (size_t)(2 * a.D + d) * a.B + b, a.Lx, ES)), a.Lx);
     }
-    cm_store_part(a, a.D + d, b * gridDim.x + blockIdx.x, a.B * gridDim.x, p1, red);
-    cm_store_part(a, 2 * a.D + d, b * gridDim.x + blockIdx.x, a.B * gridDim.x, pv, red);
+    const int cs[2] = {a.D + d, 2 * a.D + d};
+    const CmPart ps[2] = {p1, pv};
+    cm_store_parts<2>(a, cs, b * gridDim.x + blockIdx.x, a.B * gridDim.x, ps, red);
 }
 
 }  // namespace hyena

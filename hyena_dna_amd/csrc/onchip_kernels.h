@@ -86,6 +86,13 @@ __device__ __forceinline__ void load_tw1(Tw& w, GBuf tab, int t) {
     // (kept alive across the product they cost 42 VGPRs -- spills at T = 1024)
     unsigned o = (unsigned)t * 8u;
     HY_OPAQUE(o);
+#if defined(OC_DBG_NO_TW) || defined(OC_DBG_NO_TW1)
+    HY_UNROLL
+    for (int b = 0; b < 8; ++b) { w.tB[b] = mk(1.f - 1e-6f * (float)(o + b), 1e-3f * (float)b); HY_OPAQUE(w.tB[b].x); }
+    HY_UNROLL
+    for (int a = 1; a < 4; ++a) { w.tA[a] = mk(1.f - 1e-6f * (float)(o + a), 1e-3f * (float)a); HY_OPAQUE(w.tA[a].x); }
+    return;
+#endif
     HY_UNROLL
     for (int b = 0; b < 8; ++b) w.tB[b] = gb_ld(tab, o, (unsigned)(b * T) * 8u);
     HY_UNROLL
@@ -96,6 +103,13 @@ __device__ __forceinline__ void load_tw2(Tw& w, GBuf tab, int tp) {
     constexpr int O = Cfg<R>::TW1;
     unsigned o = (unsigned)tp * 8u;
     HY_OPAQUE(o);
+#if defined(OC_DBG_NO_TW) || defined(OC_DBG_NO_TW2)
+    HY_UNROLL
+    for (int b = 1; b < 8; ++b) { w.tB[b] = mk(1.f - 1e-6f * (float)(o + b), 1e-3f * (float)b); HY_OPAQUE(w.tB[b].x); }
+    HY_UNROLL
+    for (int a = 1; a < 4; ++a) { w.tA[a] = mk(1.f - 1e-6f * (float)(o + a), 1e-3f * (float)a); HY_OPAQUE(w.tA[a].x); }
+    return;
+#endif
     HY_UNROLL
     for (int b = 1; b < 8; ++b) w.tB[b] = gb_ld(tab, o, (unsigned)(O + (b - 1) * R) * 8u);
     HY_UNROLL
@@ -283,6 +297,8 @@ struct Ctx {
 #define OC_DFT(...) __VA_ARGS__
 #endif
 
+// (Issuing the twiddle-table loads of a pass ahead of the butterflies that precede their use was tried -- no gain on the
+// conv kernels, more spills in the 256-register dk kernels; profiles/r2_attribution.txt.)
 template <int R>
 __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
     OC_DFT((dft_reg<32, false>(v)));

@@ -118,7 +118,7 @@ class HyenaMixerCMFunc(torch.autograd.Function):
         dvg, dk, dbias = _lib.fftconv_bwd(dy, vg, kf, bf, need_du=True, need_dk=need_dk, saved=ctx.spectra)
         ctx.spectra = None
         _lib.cm_pre_bwd(dvg, xc, bi, w, b, dxT, part)
-        red = part.sum(dim=1)                                        # (3D, 8): deterministic two-stage reduction
+        red = part[:, :, :5].sum(dim=1)                              # (3D, 5): deterministic two-stage reduction
         dw = red[:, :3].reshape(w_shape).to(w_dtype)
         db = red[:, 3].to(b_dtype)
         dbin = red[:, 4].to(bin_dtype)

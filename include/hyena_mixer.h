@@ -48,7 +48,8 @@ int hyena_mixer_pre_bwd(const void* dvg, const void* x, const float* w, const fl
  *   xT  : (3D, B, Lx)  = W_in u^T, WITHOUT the in_proj bias `bin` (3D, fp32; may be NULL) -- the kernels add it on load
  *   zT, dzT : (D, B, L);   dxT : (3D, B, Lx) (positions >= L are not written);   vg, y, dy, dvg : (B, D, L) as above
  *   part: hyena_cm_partial_floats(B, L, D) floats, [3D][B * tiles][8] = per-workgroup partial sums of
- *         (dw[c][0], dw[c][1], dw[c][2], db_sc[c], db_in[c], 0, 0, 0); summing axis 1 gives the gradients. */
+ *         (dw[c][0], dw[c][1], dw[c][2], db_sc[c], db_in[c]) in the first five of eight floats (the rest is padding, not
+ *         written); summing axis 1 gives the gradients. */
 size_t hyena_cm_partial_floats(int B, int L, int D);
 int hyena_cm_pre_fwd(const void* xT, const float* bin, const float* w, const float* b, void* vg,
                      int B, int L, int Lx, int D, int dtype, void* stream);
