@@ -97,10 +97,11 @@ def measured_traffic(L, D, B, io_dtype, save):
     taken on this exact configuration; None otherwise (rocprofv3 cannot run inside this process)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        c = t["config"]
-        if (c["seq_len"], c["channels"], c["batch_per_gpu"], c["io_dtype"], c["save_spectra"]) == (L, D, B, io_dtype, bool(save)):
-            return t["traffic_bytes_per_step"]
+            doc = json.load(f)
+        for t in doc["configs"]:
+            c = t["config"]
+            if (c["seq_len"], c["channels"], c["batch_per_gpu"], c["io_dtype"], c["save_spectra"]) == (L, D, B, io_dtype, bool(save)):
+                return t["traffic_bytes_per_step"]
     except (OSError, KeyError, ValueError):
         pass
     return None
