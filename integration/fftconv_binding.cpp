@@ -16,8 +16,9 @@
 //        "-Wl,-rpath,$ORIGIN"], with_cuda=False, is_python_module=True)
 //   PY
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
 
 #include <map>
 #include <mutex>
@@ -75,8 +76,10 @@ torch::Tensor fftconv_fwd(torch::Tensor u, torch::Tensor filter, torch::Tensor D
     const int B = u.size(0), H = u.size(1), L = u.size(2);
     TORCH_CHECK(filter.dim() == 2 && filter.size(0) == H && filter.size(1) == fft_size / 2 + 1 && L <= fft_size / 2);
     TORCH_CHECK(D.scalar_type() == torch::kFloat32 && D.numel() == H);
-    c10::hip::HIPGuard guard(u.device());
-    void* stream = (void*)c10::hip::getCurrentHIPStream().stream();
+    // PyTorch-ROCm tensors carry the device type "cuda" (HIP masquerading as CUDA): the generic guard and the masquerading
+    // stream accessor are the ones that accept it
+    c10::DeviceGuard guard(u.device());
+    void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(u.get_device()).stream();
     u = u.contiguous();
     auto k = time_domain_filter(filter, fft_size, L);
     auto out = torch::empty_like(u);
@@ -95,8 +98,10 @@ fftconv_bwd(torch::Tensor dout, torch::Tensor u, torch::Tensor filter, torch::Te
     TORCH_CHECK(dout.is_cuda() && u.is_cuda() && filter.is_cuda() && D.is_cuda(), "fftconv: tensors must live on the ROCm device");
     refuse_options(v, head_dim, q, dropout_mask, gelu, gelu_inp, gelu_q, output_hbl_layout, fftfp16);
     const int B = u.size(0), H = u.size(1), L = u.size(2);
-    c10::hip::HIPGuard guard(u.device());
-    void* stream = (void*)c10::hip::getCurrentHIPStream().stream();
+    // PyTorch-ROCm tensors carry the device type "cuda" (HIP masquerading as CUDA): the generic guard and the masquerading
+    // stream accessor are the ones that accept it
+    c10::DeviceGuard guard(u.device());
+    void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(u.get_device()).stream();
     u = u.contiguous();
     dout = dout.to(u.scalar_type()).contiguous();
     auto k = time_domain_filter(filter, fft_size, L);
