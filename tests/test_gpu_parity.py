@@ -360,3 +360,32 @@ def test_contract_configs_all_channels_vs_oracle(gpu_lib, B, D, L, dtype):
     # dbias[d] is one sum of B L products (size ~ sqrt(B L), heavy cancellation): compare with the fp64 value on that scale
     db64 = (dout.double() * u.double()).sum(dim=(0, 2))
     assert (dbias.double() - db64).abs().max() < 3e-6 * (B * L) ** 0.5 + 1e-6       # ~3 fp32 ulps of sqrt(B L)
+
+
+@pytest.mark.parametrize("B,D,L", [(4, 64, 4096), (2, 16, 32768), (1, 8, 100000)])
+def test_entry_points_are_graph_capturable(gpu_lib, B, D, L):
+    """include/hyena_fftconv.h promises no allocation / synchronisation inside the compute entry points: after one warm-up call
+    (twiddle tables, workspace, LDS attributes) forward + backward of both plans are captured into a hipGraph and replayed
+    on new data -- results equal the eager ones bit for bit."""
+    dev = torch.device("cuda", 0)
+    u, k, bias, dout = (t.to(dev) for t in _inputs(B, D, L, torch.bfloat16, seed=L))
+    out_e = gpu_lib.fftconv_fwd(u, k, bias)                       # warm-up + eager reference
+    du_e, dk_e, db_e = gpu_lib.fftconv_bwd(dout, u, k, bias)
+    torch.cuda.synchronize()
+    su, sd = torch.zeros_like(u), torch.zeros_like(dout)          # static inputs of the graph
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        gpu_lib.fftconv_fwd(su, k, bias)                          # warm-up on the capture stream (its own workspace)
+        gpu_lib.fftconv_bwd(sd, su, k, bias)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            out_g = gpu_lib.fftconv_fwd(su, k, bias)
+            du_g, dk_g, db_g = gpu_lib.fftconv_bwd(sd, su, k, bias)
+    torch.cuda.current_stream().wait_stream(s)
+    su.copy_(u)
+    sd.copy_(dout)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, out_e) and torch.equal(du_g, du_e) and torch.equal(dk_g, dk_e) and torch.equal(db_g, db_e)
