@@ -389,3 +389,33 @@ def test_entry_points_are_graph_capturable(gpu_lib, B, D, L):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out_g, out_e) and torch.equal(du_g, du_e) and torch.equal(dk_g, dk_e) and torch.equal(db_g, db_e)
+
+
+def test_randomised_shapes_workspace_free_plan(gpu_lib):
+    """60 seeded random (B, D, L, dtype, bias?) cases with L <= 32768 (every transform size 1024 ... 32768, ragged everything,
+    channel counts with and without the XCD-aware row mapping) against the oracle"""
+    rng = torch.Generator().manual_seed(20260924)
+    dts = [torch.float32, torch.bfloat16, torch.float16]
+    for case in range(60):
+        r = int(torch.randint(0, 6, (1,), generator=rng))                       # transform size 1024 << r
+        hi = 1024 << r
+        L = int(torch.randint(hi // 2 + 1 if r else 1, hi + 1, (1,), generator=rng))
+        B = int(torch.randint(1, 20, (1,), generator=rng))
+        D = [1, 3, 8, 16, 24, 7][int(torch.randint(0, 6, (1,), generator=rng))]
+        if B * D * L > 6_000_000:
+            B = max(1, 6_000_000 // (D * L))
+        dtype = dts[int(torch.randint(0, 3, (1,), generator=rng))]
+        u, k, bias, dout = _inputs(B, D, L, dtype, seed=3000 + case)
+        use_bias = bool(torch.randint(0, 4, (1,), generator=rng))
+        dev = torch.device("cuda", 0)
+        ud, kd, gd = u.to(dev), k.to(dev), dout.to(dev)
+        bd = bias.to(dev) if use_bias else None
+        out = gpu_lib.fftconv_fwd(ud, kd, bd)
+        du, dk, dbias = gpu_lib.fftconv_bwd(gd, ud, kd, bd)
+        r_out, r_du, r_dk, r_db = _oracle(u.float(), k, bias if use_bias else torch.zeros(D), dout.float())
+        tag = (case, B, D, L, dtype, use_bias)
+        tol = REL_FP32 if dtype == torch.float32 else (6e-3 if dtype == torch.bfloat16 else 8e-4)
+        assert _rel(out.float(), r_out) < tol and _rel(du.float(), r_du) < tol, tag
+        assert _rel(dk, r_dk) < REL_FP32, tag
+        db64 = (dout.double() * u.double()).sum(dim=(0, 2))
+        assert (dbias.double().cpu() - db64).abs().max() < 3e-6 * (B * L) ** 0.5 + 1e-5, tag
