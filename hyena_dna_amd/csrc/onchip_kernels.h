@@ -27,8 +27,8 @@
 // the three passes backwards with conjugated twiddles.  The e^(-i pi n / 2M) twist costs nothing in pass 1: its
 // t-part is folded into the twiddle (the "+ 1/4"), its s-part is a compile-time constant per register.
 //
-// LDS: exchange buffer of 32 x 33 R elements per row (complex64, or one float plane at a time for R = 32: 135 KB),
-// padded so that every access is bank-conflict free (see x1_* / x2_*).
+// LDS: exchange buffer of 32 x 33 R floats per row (one plane at a time -- real parts, then imaginary parts: 135 KB at
+// R = 32), padded so that every access is bank-conflict free (see x1p / x2p).
 //
 // Compiled by hipcc for gfx950 (product) and, with -DHIPEMU, by g++ against tests/hipemu (tests only).
 #pragma once
@@ -60,9 +60,12 @@ template <int R> struct Cfg {
     static constexpr int T = 32 * R;                 // threads per row
     static constexpr int M = 1024 * R;               // complex points per row
     static constexpr int NB = 32 / R;                // radix-R butterflies per thread in pass 3
-    static constexpr bool PLANES = (R == 32);        // 256 KB of row data do not fit the LDS as complex64
-    static constexpr int XE = 32 * 33 * R;           // exchange buffer elements per row
-    static constexpr size_t XBYTES = (size_t)XE * (PLANES ? 4 : 8);
+    // The exchanges move one float plane at a time (real parts, then imaginary parts).  At R = 32 there is no choice (256 KB
+    // of row data vs 160 KB of LDS); below that it halves the LDS per row and, measured, the registers the compiler needs
+    // around an exchange -- the kernels then fit 128 VGPRs = 4 wavefronts per SIMD, worth 13-21 % at M = 4096 ... 16384
+    // over complex64 exchanges at 2 wavefronts per SIMD (gpurun_out/r2v).
+    static constexpr int XE = 32 * 33 * R;           // exchange buffer elements (floats) per row
+    static constexpr size_t XBYTES = (size_t)XE * 4;
     static constexpr int ROW1 = T + R;               // exchange 1: position (ka, t) at ka * ROW1 + t
     static constexpr int GRP2 = 33 * R;              // exchange 2: group ka at ka * GRP2, (t', kb1) at t' * 33 + kb1
     // twiddle table layout (c32 units): tw1[11][T] | tw2[10][R]
@@ -144,53 +147,7 @@ __device__ __forceinline__ void row_sync() {
     else __syncthreads();
 }
 
-template <int R, bool INV>
-__device__ __forceinline__ void x1(c32 (&v)[32], HY_LDS lc32* xb, int tid, int ka, int tp) {
-    constexpr int T = Cfg<R>::T, ROW1 = Cfg<R>::ROW1;
-    HY_LDS lc32* const pa = xb + tid;                 // (q, t = tid)
-    HY_LDS lc32* const pb = xb + ka * ROW1 + tp;      // (ka, t = R s + tp)
-    if (!INV) {
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) lds_st(pa + q * ROW1, v[q]);
-        row_sync<T>();
-        HY_UNROLL
-        for (int s = 0; s < 32; ++s) v[s] = lds_ld(pb + R * s);
-    } else {
-        HY_UNROLL
-        for (int s = 0; s < 32; ++s) lds_st(pb + R * s, v[s]);
-        row_sync<T>();
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) v[q] = lds_ld(pa + q * ROW1);
-    }
-    row_sync<T>();
-}
-template <int R, bool INV>
-__device__ __forceinline__ void x2(c32 (&v)[32], HY_LDS lc32* xb, int ka, int tp) {
-    constexpr int NB = Cfg<R>::NB, GRP2 = Cfg<R>::GRP2;
-    HY_LDS lc32* const pa = xb + ka * GRP2 + tp * 33;   // (t' = tp, kb1)
-    HY_LDS lc32* const pb = xb + ka * GRP2 + tp;        // (t'', kb1 = tp + R i)
-    if (!INV) {
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) lds_st(pa + q, v[q]);
-        HY_WAVE_SYNC();
-        HY_UNROLL
-        for (int i = 0; i < NB; ++i) {
-            HY_UNROLL
-            for (int t2 = 0; t2 < R; ++t2) v[i * R + t2] = lds_ld(pb + 33 * t2 + R * i);
-        }
-    } else {
-        HY_UNROLL
-        for (int i = 0; i < NB; ++i) {
-            HY_UNROLL
-            for (int t2 = 0; t2 < R; ++t2) lds_st(pb + 33 * t2 + R * i, v[i * R + t2]);
-        }
-        HY_WAVE_SYNC();
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) v[q] = lds_ld(pa + q);
-    }
-    HY_WAVE_SYNC();
-}
-// the same through one float plane (real parts, then imaginary parts), for R = 32
+// (every exchange moves one float plane at a time: real parts, then imaginary parts)
 template <int R, bool INV>
 __device__ __forceinline__ void x1p(c32 (&v)[32], HY_LDS float* xb, int tid, int ka, int tp) {
     constexpr int T = Cfg<R>::T, ROW1 = Cfg<R>::ROW1;
@@ -309,8 +266,7 @@ __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
         apply_tw<false, true>(v, w);
     }
     OC_FENCE();
-    OC_X1(if constexpr (Cfg<R>::PLANES) x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
-          else x1<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp));
+    OC_X1(x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp));
     OC_FENCE();
     OC_DFT((dft_reg<32, false>(v)));
     OC_FENCE();
@@ -321,8 +277,7 @@ __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
             apply_tw<false, false>(v, w);
         }
         OC_FENCE();
-        OC_X2(if constexpr (Cfg<R>::PLANES) x2p<R, false>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
-              else x2<R, false>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp));
+        OC_X2(x2p<R, false>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp));
         OC_FENCE();
         OC_DFT((pass3<R, false>(v)));
         OC_FENCE();
@@ -335,8 +290,7 @@ __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
     if constexpr (R > 1) {
         OC_DFT((pass3<R, true>(v)));
         OC_FENCE();
-        OC_X2(if constexpr (Cfg<R>::PLANES) x2p<R, true>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp);
-              else x2<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.ka, c.tp));
+        OC_X2(x2p<R, true>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp));
         OC_FENCE();
         Tw w;
         load_tw2<R>(w, c.tab, c.tp);
@@ -347,8 +301,7 @@ __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
     OC_FENCE();
     // exchange 1 writes anywhere in the buffer: every wavefront must be done with its exchange-2 region
     if constexpr (R > 1) row_sync<Cfg<R>::T>();
-    OC_X1(if constexpr (Cfg<R>::PLANES) x1p<R, true>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp);
-          else x1<R, true>(v, HY_LDS_CAST(lc32, c.xb), c.tid, c.ka, c.tp));
+    OC_X1(x1p<R, true>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp));
     OC_FENCE();
     {
         Tw w;
@@ -486,6 +439,12 @@ struct DkArgs {            // dk[d] = sum_b corr(dout[b, d], u[b, d]);  dbias[d]
     int B, D, L, dtype;
 };
 
+// Wavefronts per SIMD the conv / spectrum kernels are compiled for (-> at most 128 VGPRs): a wavefront issues one VALU
+// instruction per ~4.4 cycles, so a SIMD needs 3-4 of them to stay busy (profiles/r2d_pmc_sq_onchip.csv)
+#ifndef OC_MINW
+#define OC_MINW 4
+#endif
+
 template <int R> struct WgCfg {
     static constexpr int T = Cfg<R>::T;
     static constexpr int WGT = T < 64 ? 64 : T;          // workgroup threads of the conv / spectrum kernels
@@ -505,7 +464,7 @@ __device__ __forceinline__ Ctx make_ctx(HY_LDS char* smem, int rg, int tid, cons
 }
 
 template <int R>
-__global__ void __launch_bounds__(WgCfg<R>::WGT) spec_kernel(SpecArgs a) {
+__global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) spec_kernel(SpecArgs a) {
     typedef Cfg<R> C;
     constexpr int T = C::T, RPW = WgCfg<R>::RPW;
     HY_SMEM(smem);
@@ -530,7 +489,7 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT) spec_kernel(SpecArgs a) {
 }
 
 template <int R, bool HALF>
-__global__ void __launch_bounds__(WgCfg<R>::WGT) conv_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a) {
     typedef Cfg<R> C;
     constexpr int T = C::T, RPW = WgCfg<R>::RPW;
     constexpr unsigned ES = HALF ? 2u : 4u;
