@@ -49,14 +49,14 @@ __device__ __forceinline__ void blk_load(const void* base, size_t off, float (&v
     struct __attribute__((aligned(sizeof(elem_t) * (E > 4 ? 4 : E)))) Raw { elem_t e[E]; } raw;
     raw = *reinterpret_cast<const Raw*>(reinterpret_cast<const elem_t*>(base) + off);
     HY_UNROLL
-    for (int e = 0; e < E; ++e) v[e] = Elem<DT>::ld(&raw.e[e]);
+    for (int e = 0; e < E; ++e) v[e] = Elem<DT>::dec(raw.e[e]);
 }
 template <int DT, int E>
 __device__ __forceinline__ void blk_store(void* base, size_t off, const float (&v)[E]) {
     typedef typename Elem<DT>::type elem_t;
     struct __attribute__((aligned(sizeof(elem_t) * (E > 4 ? 4 : E)))) Raw { elem_t e[E]; } raw;
     HY_UNROLL
-    for (int e = 0; e < E; ++e) Elem<DT>::st(&raw.e[e], v[e]);
+    for (int e = 0; e < E; ++e) raw.e[e] = Elem<DT>::cvt(v[e]);
     *reinterpret_cast<Raw*>(reinterpret_cast<elem_t*>(base) + off) = raw;
 }
 

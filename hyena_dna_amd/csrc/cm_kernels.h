@@ -41,6 +41,13 @@ struct CmArgs {
 
 // v[i] = row[l0 + i] for i in [LO, HI), zero outside [0, L).  Interior vectors move as 16-byte (8 x 16-bit) or 2 x 16-byte
 // accesses (rows of odd length start under-aligned: gfx950 global memory handles that).
+// HY_POL_CM: cache policy of the shell's output streams (2 = nt; every output is written once and read by a later launch)
+#ifndef HY_POL_CM
+#define HY_POL_CM 2
+#endif
+#if !defined(HIPEMU)
+typedef unsigned cm_vec16 __attribute__((ext_vector_type(4), aligned(2)));   // rows start at any even byte offset
+#endif
 template <int DT, int N>
 __device__ __forceinline__ void cm_ld(const void* row, int l0, int L, float (&v)[N]) {
     typedef typename Elem<DT>::type elem_t;
@@ -49,7 +56,7 @@ __device__ __forceinline__ void cm_ld(const void* row, int l0, int L, float (&v)
         elem_t raw[N];
         __builtin_memcpy(raw, p + l0, sizeof(raw));
         HY_UNROLL
-        for (int i = 0; i < N; ++i) v[i] = Elem<DT>::ld(&raw[i]);
+        for (int i = 0; i < N; ++i) v[i] = Elem<DT>::dec(raw[i]);
     } else {
         HY_UNROLL
         for (int i = 0; i < N; ++i) {
@@ -67,7 +74,18 @@ __device__ __forceinline__ void cm_st(void* row, int l0, int L, const float (&v)
     if (l0 + N <= L) {
         elem_t raw[N];
         HY_UNROLL
-        for (int i = 0; i < N; ++i) Elem<DT>::st(&raw[i], v[i]);
+        for (int i = 0; i < N; ++i) raw[i] = Elem<DT>::cvt(v[i]);
+#if !defined(HIPEMU)
+        if constexpr ((HY_POL_CM & 2) != 0 && sizeof(raw) % 16 == 0) {      // write-once stream: non-temporal 16-byte stores
+            HY_UNROLL
+            for (int j = 0; j < (int)(sizeof(raw) / 16); ++j) {
+                cm_vec16 t;
+                __builtin_memcpy(&t, reinterpret_cast<const char*>(raw) + 16 * j, 16);
+                __builtin_nontemporal_store(t, reinterpret_cast<cm_vec16*>(p + l0) + j);
+            }
+            return;
+        }
+#endif
         __builtin_memcpy(p + l0, raw, sizeof(raw));
     } else {
         HY_UNROLL

@@ -150,10 +150,37 @@ __device__ __forceinline__ void lds_st(HY_LDS lc32* p, c32 v) { lc32 t; t.x = v.
 
 // Global access as wave-uniform base + 32-bit BYTE offset: lets hipcc use the SGPR-base/VGPR-offset form of
 // global_load/store instead of materialising a 64-bit address pair per access (which spills).
+// HY_POL_LD / HY_POL_ST: cache-policy bits of the accesses to the workspace W (gfx950: 1 = sc0, 2 = nt, 16 = sc1).
+// Non-temporal STORES are worth 3 % at every two-level length (write-once streams stop displacing the lines the
+// next kernel reads); non-temporal LOADS read 14 % faster in isolation (7.2 vs 6.3 TB/s) but gain < 1 % here at
+// L = 2^20 and lose 3 % at L = 160000, where part of W is served by the Infinity Cache
+// (profiles/cpol_bw_r2.txt, gpurun_out/r2z_pol2).
+#ifndef HY_POL_LD
+#define HY_POL_LD 0
+#endif
+#ifndef HY_POL_ST
+#define HY_POL_ST 2
+#endif
+#if !defined(HIPEMU)
+typedef float hy_f2 __attribute__((ext_vector_type(2)));
+#endif
 __device__ __forceinline__ c32 ldg(const c32* base, unsigned idx) {
+#if !defined(HIPEMU)
+    if constexpr ((HY_POL_LD & 2) != 0) {
+        const hy_f2 t = __builtin_nontemporal_load(reinterpret_cast<const hy_f2*>(reinterpret_cast<const char*>(base) + (size_t)(idx * 8u)));
+        return mk(t.x, t.y);
+    }
+#endif
     return *reinterpret_cast<const c32*>(reinterpret_cast<const char*>(base) + (size_t)(idx * 8u));
 }
 __device__ __forceinline__ void stg(c32* base, unsigned idx, c32 v) {
+#if !defined(HIPEMU)
+    if constexpr ((HY_POL_ST & 2) != 0) {
+        hy_f2 t; t.x = v.x; t.y = v.y;
+        __builtin_nontemporal_store(t, reinterpret_cast<hy_f2*>(reinterpret_cast<char*>(base) + (size_t)(idx * 8u)));
+        return;
+    }
+#endif
     *reinterpret_cast<c32*>(reinterpret_cast<char*>(base) + (size_t)(idx * 8u)) = v;
 }
 
@@ -174,6 +201,7 @@ __device__ __forceinline__ GBuf make_gbuf(const void* base, unsigned) {
 }
 __device__ __forceinline__ c32 gb_ld(GBuf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const c32*>(b.p + voff + soff); }
 __device__ __forceinline__ void gb_st(GBuf b, unsigned voff, unsigned soff, c32 v) { *reinterpret_cast<c32*>(b.p + voff + soff) = v; }
+__device__ __forceinline__ c32 gb_ldt(GBuf b, unsigned voff, unsigned soff) { return gb_ld(b, voff, soff); }
 struct __attribute__((aligned(16))) c32x2 { c32 a, b; };
 __device__ __forceinline__ c32x2 gb_ld2(GBuf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const c32x2*>(b.p + voff + soff); }
 __device__ __forceinline__ void gb_st2(GBuf b, unsigned voff, unsigned soff, c32x2 v) { *reinterpret_cast<c32x2*>(b.p + voff + soff) = v; }
@@ -187,6 +215,10 @@ __device__ __forceinline__ GBuf make_gbuf(const void* base, unsigned bytes) {
     return b;
 }
 __device__ __forceinline__ c32 gb_ld(GBuf b, unsigned voff, unsigned soff) {
+    const hy_u2 w = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, HY_POL_LD);
+    return mk(u2f(w.x), u2f(w.y));
+}
+__device__ __forceinline__ c32 gb_ldt(GBuf b, unsigned voff, unsigned soff) {      // tables: re-used, default policy
     const hy_u2 w = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0);
     return mk(u2f(w.x), u2f(w.y));
 }
@@ -198,12 +230,12 @@ __device__ __forceinline__ void gb_st(GBuf b, unsigned voff, unsigned soff, c32 
     // offset folded into voffset/immediate the store is an ordinary one.  Found by
     // tests/test_gpu_parity.py::test_properties_at_baseline_sizes (causality / determinism at D = 256).
     hy_u2 w; w.x = f2u(v.x); w.y = f2u(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(w, b.r, voff + soff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(w, b.r, voff + soff, 0, HY_POL_ST);
 }
 struct __attribute__((aligned(16))) c32x2 { c32 a, b; };
 typedef unsigned hy_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ c32x2 gb_ld2(GBuf b, unsigned voff, unsigned soff) {
-    const hy_u4 w = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, 0);
+    const hy_u4 w = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, HY_POL_LD);
     c32x2 r; r.a = mk(u2f(w.x), u2f(w.y)); r.b = mk(u2f(w.z), u2f(w.w)); return r;
 }
 __device__ __forceinline__ void gb_st2(GBuf b, unsigned voff, unsigned soff, c32x2 v) {
@@ -278,36 +310,63 @@ __device__ __forceinline__ uint16_t f32_to_f16(float f) {
 }
 #endif
 
+// HY_POL_IO: cache policy of the operator's own tensors (u, k, dout read once; out, du, dk written once)
+#ifndef HY_POL_IO
+#define HY_POL_IO 2
+#endif
+template <class T> __device__ __forceinline__ T io_ldp(const T* p) {
+#if !defined(HIPEMU)
+    if constexpr ((HY_POL_IO & 2) != 0) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
+template <class T> __device__ __forceinline__ void io_stp(T* p, T v) {
+#if !defined(HIPEMU)
+    if constexpr ((HY_POL_IO & 2) != 0) { __builtin_nontemporal_store(v, p); return; }
+#endif
+    *p = v;
+}
 template <int DT> struct Elem;
 template <> struct Elem<DT_F32> {
     typedef float type;
-    static __device__ __forceinline__ float ld(const float* p) { return *p; }
-    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ float cvt(float v) { return v; }
+    static __device__ __forceinline__ float dec(float r) { return r; }
+    static __device__ __forceinline__ float ld(const float* p) { return io_ldp(p); }
+    static __device__ __forceinline__ void st(float* p, float v) { io_stp(p, v); }
+#if defined(HIPEMU)
     static __device__ __forceinline__ c32 ld2(const float* p) { return *reinterpret_cast<const c32*>(p); }
     static __device__ __forceinline__ void st2(float* p, c32 v) { *reinterpret_cast<c32*>(p) = v; }
+#else
+    static __device__ __forceinline__ c32 ld2(const float* p) { const hy_f2 t = io_ldp(reinterpret_cast<const hy_f2*>(p)); return mk(t.x, t.y); }
+    static __device__ __forceinline__ void st2(float* p, c32 v) { hy_f2 t; t.x = v.x; t.y = v.y; io_stp(reinterpret_cast<hy_f2*>(p), t); }
+#endif
 };
 template <> struct Elem<DT_BF16> {
     typedef uint16_t type;
-    static __device__ __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(*p); }
-    static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+    static __device__ __forceinline__ uint16_t cvt(float v) { return f32_to_bf16(v); }
+    static __device__ __forceinline__ float dec(uint16_t r) { return bf16_to_f32(r); }
+    static __device__ __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(io_ldp(p)); }
+    static __device__ __forceinline__ void st(uint16_t* p, float v) { io_stp(p, f32_to_bf16(v)); }
     static __device__ __forceinline__ c32 ld2(const uint16_t* p) {
-        uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+        uint32_t w = io_ldp(reinterpret_cast<const uint32_t*>(p));
         return mk(u2f(w << 16), u2f(w & 0xffff0000u));
     }
     static __device__ __forceinline__ void st2(uint16_t* p, c32 v) {
-        *reinterpret_cast<uint32_t*>(p) = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+        io_stp(reinterpret_cast<uint32_t*>(p), (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16));
     }
 };
 template <> struct Elem<DT_F16> {
     typedef uint16_t type;
-    static __device__ __forceinline__ float ld(const uint16_t* p) { return f16_to_f32(*p); }
-    static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_f16(v); }
+    static __device__ __forceinline__ uint16_t cvt(float v) { return f32_to_f16(v); }
+    static __device__ __forceinline__ float dec(uint16_t r) { return f16_to_f32(r); }
+    static __device__ __forceinline__ float ld(const uint16_t* p) { return f16_to_f32(io_ldp(p)); }
+    static __device__ __forceinline__ void st(uint16_t* p, float v) { io_stp(p, f32_to_f16(v)); }
     static __device__ __forceinline__ c32 ld2(const uint16_t* p) {
-        uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+        uint32_t w = io_ldp(reinterpret_cast<const uint32_t*>(p));
         return mk(f16_to_f32((uint16_t)(w & 0xffffu)), f16_to_f32((uint16_t)(w >> 16)));
     }
     static __device__ __forceinline__ void st2(uint16_t* p, c32 v) {
-        *reinterpret_cast<uint32_t*>(p) = (uint32_t)f32_to_f16(v.x) | ((uint32_t)f32_to_f16(v.y) << 16);
+        io_stp(reinterpret_cast<uint32_t*>(p), (uint32_t)f32_to_f16(v.x) | ((uint32_t)f32_to_f16(v.y) << 16));
     }
 };
 
@@ -554,9 +613,9 @@ struct RowTw {
 };
 __device__ __forceinline__ void load_row_tw(RowTw& t, GBuf twT, int j) {
     HY_UNROLL
-    for (int b = 1; b < 8; ++b) t.tB[b] = gb_ld(twT, (unsigned)j * 8u, (unsigned)b * 256u);
+    for (int b = 1; b < 8; ++b) t.tB[b] = gb_ldt(twT, (unsigned)j * 8u, (unsigned)b * 256u);
     HY_UNROLL
-    for (int a = 1; a < 4; ++a) t.tA[a] = gb_ld(twT, (unsigned)j * 8u, (unsigned)(8 * a) * 256u);
+    for (int a = 1; a < 4; ++a) t.tA[a] = gb_ldt(twT, (unsigned)j * 8u, (unsigned)(8 * a) * 256u);
 }
 
 template <bool INV>
@@ -981,7 +1040,7 @@ __global__ void __launch_bounds__(64, 2) row_prod2_kernel(RowArgs a) {
     const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
     RowTw rtw;
     load_row_tw(rtw, twT, j);
-    const c32 tj = gb_ld(twR, (unsigned)j * 8u, 0u);
+    const c32 tj = gb_ldt(twR, (unsigned)j * 8u, 0u);
     const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
 
     HY_LDS lc32* xb = lds + half * ROW_LDS;
@@ -1027,7 +1086,7 @@ __global__ void __launch_bounds__(64, 2) row_bwd_kernel(RowArgs a) {
     const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
     RowTw rtw;
     load_row_tw(rtw, twT, j);
-    const c32 tj = gb_ld(twR, (unsigned)j * 8u, 0u);
+    const c32 tj = gb_ldt(twR, (unsigned)j * 8u, 0u);
     const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
 
     HY_LDS lc32* xb = lds + half * ROW_LDS;
@@ -1106,7 +1165,7 @@ __global__ void __launch_bounds__(64, 2) row_dk_kernel(RowArgs a) {
     const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
     RowTw rtw;
     load_row_tw(rtw, twT, j);
-    const c32 tj = gb_ld(twR, (unsigned)j * 8u, 0u);
+    const c32 tj = gb_ldt(twR, (unsigned)j * 8u, 0u);
     HY_LDS lc32* xb = lds + half * ROW_LDS;
     HY_LDS lc32* xl = xb + j;
     const HY_LDS lc32* pl = lds + (1 - half) * ROW_LDS + (31 - j);
@@ -1202,7 +1261,7 @@ __global__ void __launch_bounds__(64, 2) row0_prod2_kernel(RowArgs a) {
     const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
     RowTw rtw;
     load_row_tw(rtw, twT, j);
-    const c32 wkj = cmul(a.tab.tw_lo[myrow], gb_ld(twR, (unsigned)j * 8u, 0u));
+    const c32 wkj = cmul(a.tab.tw_lo[myrow], gb_ldt(twR, (unsigned)j * 8u, 0u));
     const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
     const unsigned vo = ((unsigned)ch * (unsigned)M1 * 1024u + (unsigned)(myrow * 1024 + j)) * 8u;
 
@@ -1245,7 +1304,7 @@ __global__ void __launch_bounds__(64, 2) row0_bwd_kernel(RowArgs a) {
     const GBuf twT = make_gbuf(a.tab.tw_rowT, 8192), twR = make_gbuf(a.tab.tw_row, 8192);
     RowTw rtw;
     load_row_tw(rtw, twT, j);
-    const c32 wkj = cmul(a.tab.tw_lo[myrow], gb_ld(twR, (unsigned)j * 8u, 0u));
+    const c32 wkj = cmul(a.tab.tw_lo[myrow], gb_ldt(twR, (unsigned)j * 8u, 0u));
     const float bias = (a.bias != nullptr) ? a.bias[ch] : 0.f;
     const unsigned vo = ((unsigned)ch * (unsigned)M1 * 1024u + (unsigned)(myrow * 1024 + j)) * 8u;
 

@@ -8,7 +8,7 @@ mkdir -p $R/build/var_$NAME
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $FL "$@" -c $R/hyena_dna_amd/csrc/onchip.hip -o $R/build/var_$NAME/onchip.o &
 if [ "$FULL" = "1" ]; then /opt/rocm/bin/hipcc $FL "$@" -c $R/hyena_dna_amd/csrc/fftconv.hip -o $R/build/var_$NAME/fftconv.o & else cp $R/hyena_dna_amd/csrc/_obj/fftconv.hip.o $R/build/var_$NAME/fftconv.o; fi
-cp $R/hyena_dna_amd/csrc/_obj/cm.hip.o $R/build/var_$NAME/cm.o
+if [ "$FULL" = "1" ]; then /opt/rocm/bin/hipcc $FL "$@" -c $R/hyena_dna_amd/csrc/cm.hip -o $R/build/var_$NAME/cm.o & else cp $R/hyena_dna_amd/csrc/_obj/cm.hip.o $R/build/var_$NAME/cm.o; fi
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $R/build/var_$NAME/fftconv.o $R/build/var_$NAME/onchip.o $R/build/var_$NAME/cm.o -o $R/build/libhyena_$NAME.so
 echo built build/libhyena_$NAME.so
