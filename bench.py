@@ -27,6 +27,7 @@ box's host cores on a bounded sample.
 import argparse
 import json
 import os
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime starts: see hyena_dna_amd/__init__.py
 import sys
 import time
 
@@ -195,7 +196,7 @@ def operator_layer(L, D, B, dtype, dev, steps=5, warmup=2):
                         f"L={L}, d={D}, B={B}, {str(dtype).split('.')[-1]} autocast; secondary figure, not `value`"}
 
 
-def model_step(L, D, B, dtype, dev, rank=0, n_layer=8, steps=3, warmup=1):
+def model_step(L, D, B, dtype, dev, rank=0, n_layer=8, steps=3, warmup=2):
     """Secondary figure (not `value`): the full hyenadna pre-training step of north_star configuration 5 on synthetic tokens --
     embedding -> n_layer x [add+LayerNorm -> HyenaOperator -> add+LayerNorm -> MLP (d -> 4d -> d, tanh-GELU)] -> LayerNorm ->
     tied LM head -> cross entropy, backward, AdamW step -- random init, autocast (hg38_hyena.yaml: d_model 256, n_layer 8,
@@ -229,7 +230,30 @@ def model_step(L, D, B, dtype, dev, rank=0, n_layer=8, steps=3, warmup=1):
     e1.record()
     torch.cuda.synchronize(dev)
     ms = e0.elapsed_time(e1) / steps
-    return {"ms_per_step": ms, "value": B * L / ms * 1e3, "unit": "nt/s", "steps": steps, "loss": float(loss),
+    loss = float(loss)                               # (also drops the last autograd graph before the capture below)
+    graphed = None
+    if L <= 65536:
+        try:
+            # launch-bound regime: the same step captured into one hipGraph (lm.GraphedTrainStep) and replayed
+            from hyena_dna_amd.lm import GraphedTrainStep
+            del opt
+            opt_g = torch.optim.AdamW(model.parameters(), lr=6e-4, weight_decay=0.1, betas=(0.9, 0.999), capturable=True)
+            gstep = GraphedTrainStep(model, opt_g, ids, tgt, autocast_dtype=dtype, warmup=2)
+            for _ in range(2):
+                gstep()
+            torch.cuda.synchronize(dev)
+            n = max(steps, 10)
+            e0.record()
+            for _ in range(n):
+                gl = gstep()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            gms = e0.elapsed_time(e1) / n
+            graphed = {"ms_per_step": gms, "value": B * L / gms * 1e3, "unit": "nt/s", "steps": n, "loss": float(gl),
+                       "how": "forward + loss + backward + AdamW captured into one hipGraph (hyena_dna_amd.lm.GraphedTrainStep)"}
+        except Exception as e:                                     # never lose the eager figure over the capture
+            graphed = {"error": repr(e)[:200]}
+    return {"ms_per_step": ms, "value": B * L / ms * 1e3, "unit": "nt/s", "steps": steps, "loss": float(loss), "graphed": graphed,
             "params": sum(p.numel() for p in model.parameters()), "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
             "workload": f"full model step (fwd + bwd + AdamW): hyenadna d_model={D}, n_layer={n_layer}, d_inner={4 * D}, L={L}, B={B}, "
                         f"{str(dtype).split('.')[-1]} autocast, synthetic tokens; secondary figure, not `value`"}

@@ -14,7 +14,20 @@ HazyResearch/hyena-dna, nothing else.
 
 There is no CPU or PyTorch fallback for the convolution: without the compiled gfx950 library the ops raise.
 """
-from . import _lib  # noqa: F401
+import os as _os
+
+import torch as _torch
+
+# hipGraph replays on ROCm 7.2: with the runtime's "graph packet capture" optimisation (pre-built AQL packets) a replayed graph
+# of ~1 000 kernels reads clobbered kernel arguments once a few hundred eager launches have run between two replays -- NaNs,
+# or HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION; reproduced with plain torch.nn.Linear, none of this package's kernels
+# (scripts/graph_bisect.py, scripts/graph_debug3.py; gpurun_out/r2g*).  The knob is read when the HIP runtime initialises,
+# so it is set here, at import, unless the user has decided otherwise; lm.GraphedTrainStep refuses to capture when it could
+# not take effect.  Eager launches are not affected by it.
+GRAPH_SAFE = (_os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0") or not _torch.cuda.is_initialized()
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+from . import _lib  # noqa: F401,E402
 
 __all__ = ["fftconv", "hyena", "mixer", "filter", "projection", "block", "tokenizer", "build"]
 __version__ = "0.1.0"

@@ -61,6 +61,8 @@ class _HipBackend:
         return torch.cuda.current_stream(device).cuda_stream
 
     def free_memory(self):
+        if torch.cuda.is_current_stream_capturing():      # no driver queries inside a hipGraph capture
+            return None
         return torch.cuda.mem_get_info()[0]
 
 

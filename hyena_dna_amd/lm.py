@@ -20,6 +20,7 @@ this module) is on ``sys.path`` -- INTEGRATION.md section 4.  What is MI355X-spe
 figure (north_star configuration 5).
 """
 import math
+import os
 from collections import namedtuple
 from functools import partial
 
@@ -349,3 +350,75 @@ class HyenaDNALM(nn.Module, GenerationMixin):
         """next-token cross entropy (src/tasks/metrics.py cross_entropy over the flattened logits), logits in fp32"""
         logits = self.forward(input_ids)[0].logits
         return F.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), targets.reshape(-1), ignore_index=ignore_index)
+
+
+class GraphedTrainStep:
+    """One whole training step -- forward, loss, backward, optimizer step -- captured into ONE hipGraph and replayed.
+
+    Below L ~ 32k the eager step of the 8-layer model is bound by the ~1 500 kernel launches Python issues, not by the GPU
+    (DESIGN.md section 5); a replay costs one launch.  Everything on this path is stream-ordered and allocation-free after the
+    warm-up (include/hyena_fftconv.h), so the capture needs nothing special: static input buffers, gradients that live inside
+    the graph's memory pool, and an optimizer built with ``capturable=True`` (its step counters are device tensors).
+
+        opt  = torch.optim.AdamW(model.parameters(), lr=6e-4, weight_decay=0.1, capturable=True)
+        step = GraphedTrainStep(model, opt, input_ids, targets)      # warms up (3 eager steps) and captures
+        loss = step(next_ids, next_targets)                           # copies into the static buffers, replays
+
+    The captured step always sees batches of the captured shape; to change the learning rate between replays make it a
+    device tensor (``lr=torch.tensor(6e-4, device=...)``) and update it in place.  Drop the loss / outputs of earlier eager
+    steps before constructing this (their autograd graphs pin gradient accumulators to another stream), and see
+    ``hyena_dna_amd/__init__.py`` for the ROCm runtime setting whole-step replays need (applied at import).
+    """
+
+    def __init__(self, model, optimizer, input_ids, targets, autocast_dtype=torch.bfloat16, warmup=3, ignore_index=-100):
+        if not input_ids.is_cuda:
+            raise RuntimeError("GraphedTrainStep captures a hipGraph: model and batch must live on a ROCm device")
+        for group in optimizer.param_groups:
+            if not group.get("capturable", False):
+                raise RuntimeError("GraphedTrainStep needs an optimizer built with capturable=True")
+        import hyena_dna_amd
+        if not hyena_dna_amd.GRAPH_SAFE or os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+            raise RuntimeError("GraphedTrainStep: hipGraph replays of a whole step are only reliable on this ROCm runtime with "
+                               "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP runtime initialises "
+                               "(import hyena_dna_amd before the first torch.cuda call, or export the variable); see "
+                               "hyena_dna_amd/__init__.py")
+        self.model, self.optimizer = model, optimizer
+        self.ids, self.targets = input_ids.clone(), targets.clone()
+        self.autocast_dtype, self.ignore_index = autocast_dtype, ignore_index
+        # Gradient-accumulation nodes remember the stream they were created on.  Nodes left over from eager steps on another
+        # stream (kept alive by a retained loss tensor, or by not-yet-collected reference cycles of autograd contexts) would run
+        # OUTSIDE the capture: drop them, and warm up on the very stream the capture uses.
+        import gc
+        gc.collect()
+        side = torch.cuda.Stream(input_ids.device)
+        side.wait_stream(torch.cuda.current_stream(input_ids.device))
+        with torch.cuda.stream(side):                 # twiddle tables, workspaces, optimizer state, GEMM heuristics: all created here
+            for _ in range(max(1, int(warmup))):
+                optimizer.zero_grad(set_to_none=True)
+                self._fwd_bwd()
+                optimizer.step()
+            optimizer.zero_grad(set_to_none=True)      # the gradients of the captured step live in the graph's pool
+            gc.collect()
+            side.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                self.loss = self._fwd_bwd().detach()
+                optimizer.step()
+        torch.cuda.current_stream(input_ids.device).wait_stream(side)
+
+    def _fwd_bwd(self):
+        enabled = self.autocast_dtype is not None and self.autocast_dtype != torch.float32
+        with torch.autocast("cuda", dtype=self.autocast_dtype if enabled else torch.bfloat16, enabled=enabled):
+            loss = self.model.loss(self.ids, self.targets, ignore_index=self.ignore_index)
+        loss.backward()
+        return loss
+
+    def __call__(self, input_ids=None, targets=None):
+        """Replays the step on (input_ids, targets) -- or on the batch already in the static buffers -- and returns the
+        (static, device-resident) loss tensor; read it with .item() only when you need the number."""
+        if input_ids is not None:
+            self.ids.copy_(input_ids, non_blocking=True)
+        if targets is not None:
+            self.targets.copy_(targets, non_blocking=True)
+        self.graph.replay()
+        return self.loss

@@ -1,4 +1,5 @@
 import os
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime starts: see hyena_dna_amd/__init__.py
 import sys
 
 import pytest

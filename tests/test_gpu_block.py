@@ -93,3 +93,49 @@ def test_tiny_lm_trains_on_the_gpu(gpu_lib):
     losses = train("cuda", steps=40, d=128, L=2048, B=4, n_layer=2, autocast_dtype=torch.bfloat16)
     assert all(l == l for l in losses)
     assert losses[-1] < 0.35 * losses[0], (losses[0], losses[-1])
+
+
+def test_graphed_train_step_matches_eager(gpu_lib):
+    """lm.GraphedTrainStep: forward + loss + backward + AdamW of the whole model captured into ONE hipGraph and replayed on new
+    batches gives the eager step's losses and parameters (same kernels, same order; dropout off so no RNG is involved),
+    with eager work interleaved between the replays."""
+    from hyena_dna_amd.lm import GraphedTrainStep, HyenaDNALM
+    dev = torch.device("cuda", 0)
+    L, B, D = 2048, 2, 128
+    layer = dict(l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10)
+
+    def make():
+        torch.manual_seed(7)
+        m = HyenaDNALM(d_model=D, n_layer=2, d_inner=4 * D, vocab_size=12, layer=layer, resid_dropout=0.0, embed_dropout=0.0,
+                       pad_vocab_size_multiple=8).to(dev)
+        return m, torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.1, capturable=True)
+
+    g = torch.Generator(device=dev).manual_seed(3)
+    batches = [torch.randint(7, 11, (B, L), generator=g, device=dev) for _ in range(6)]
+    warm = 2
+
+    m_e, o_e = make()
+    eager = []
+    for i, ids in enumerate([batches[0]] * warm + batches):         # the graphed step's warm-up trains on its first batch too
+        o_e.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = m_e.loss(ids, torch.roll(ids, -1, 1))
+        loss.backward()
+        o_e.step()
+        if i >= warm:
+            eager.append(float(loss))
+
+    m_g, o_g = make()
+    step = GraphedTrainStep(m_g, o_g, batches[0], torch.roll(batches[0], -1, 1), warmup=warm)
+    graphed = []
+    for ids in batches:
+        graphed.append(float(step(ids, torch.roll(ids, -1, 1))))
+        # a few hundred eager launches between two replays: what broke replays under the runtime's default graph
+        # "packet capture" mode (hyena_dna_amd/__init__.py) -- gradients must stay finite and the losses on track
+        assert all(bool(torch.isfinite(p.grad).all()) and bool(torch.isfinite(p).all()) for p in m_g.parameters())
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(eager, graphed)), (eager, graphed)
+    for (n, p), q in zip(m_e.named_parameters(), m_g.parameters()):
+        assert torch.allclose(p, q, rtol=2e-2, atol=2e-4), n
+
+    with pytest.raises(RuntimeError, match="capturable"):
+        GraphedTrainStep(m_g, torch.optim.AdamW(m_g.parameters(), lr=1e-3), batches[0], batches[0])
