@@ -335,16 +335,22 @@ __device__ __forceinline__ void io_st(GBuf b, unsigned byte_off, float v, bool b
     else *reinterpret_cast<float*>(b.p + byte_off) = v;
 }
 #else
+#ifndef OC_POL_LD
+#define OC_POL_LD 0
+#endif
+#ifndef OC_POL_ST
+#define OC_POL_ST 2          // outputs are written once: non-temporal stores, 1 - 2.5 % at every size (gpurun_out/r2z_oc)
+#endif
 template <bool HALF>
 __device__ __forceinline__ float io_ld(GBuf b, unsigned voff, unsigned soff, bool bf) {
-    if constexpr (!HALF) return u2f(__builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
-    else return half_to_f32(__builtin_amdgcn_raw_buffer_load_b16(b.r, voff, soff, 0), bf);
+    if constexpr (!HALF) return u2f(__builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, OC_POL_LD));
+    else return half_to_f32(__builtin_amdgcn_raw_buffer_load_b16(b.r, voff, soff, OC_POL_LD), bf);
 }
 template <bool HALF>
 __device__ __forceinline__ void io_st(GBuf b, unsigned voff, float v, bool bf) {
     // no scalar-offset field on stores (see gb_st)
-    if constexpr (!HALF) __builtin_amdgcn_raw_buffer_store_b32(f2u(v), b.r, voff, 0, 0);
-    else __builtin_amdgcn_raw_buffer_store_b16(f32_to_half(v, bf), b.r, voff, 0, 0);
+    if constexpr (!HALF) __builtin_amdgcn_raw_buffer_store_b32(f2u(v), b.r, voff, 0, OC_POL_ST);
+    else __builtin_amdgcn_raw_buffer_store_b16(f32_to_half(v, bf), b.r, voff, 0, OC_POL_ST);
 }
 #endif
 
