@@ -214,3 +214,17 @@ def test_block_glue_refuses_cpu_tensors_without_the_test_double():
     from hyena_dna_amd._lib import HyenaLibraryError
     with pytest.raises(HyenaLibraryError):
         dropout_add_layer_norm(torch.randn(2, 3, 64), None, torch.ones(64), torch.zeros(64), 0.0, 1e-5, residual_in_fp32=True)
+
+
+def test_graphed_train_step_refuses_what_it_cannot_capture():
+    """lm.GraphedTrainStep fails loudly, before touching the device, on a CPU batch and on a non-capturable optimizer; the
+    package sets the ROCm graph knob at import (hyena_dna_amd/__init__.py)."""
+    import os
+
+    import hyena_dna_amd
+    from hyena_dna_amd.lm import GraphedTrainStep
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and isinstance(hyena_dna_amd.GRAPH_SAFE, bool)
+    lin = torch.nn.Linear(4, 4)
+    ids = torch.zeros(1, 8, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        GraphedTrainStep(lin, torch.optim.AdamW(lin.parameters(), lr=1e-3), ids, ids)
