@@ -24,7 +24,10 @@
 
 namespace hyena {
 
-enum { CM_THREADS = 256, CM_V = 8, CM_TILE = CM_THREADS * CM_V, CM_NP = 8 /* floats per partial record */ };
+#ifndef HY_CM_V
+#define HY_CM_V 8
+#endif
+enum { CM_THREADS = 256, CM_V = HY_CM_V, CM_TILE = CM_THREADS * CM_V, CM_NP = 8 /* floats per partial record */ };
 
 struct CmArgs {
     const void* xT;     // (3D, B, Lx) in_proj output WITHOUT its bias, elements of DT
