@@ -84,13 +84,32 @@ class GradCarrier(torch.nn.Module):
         self.ln_f = nn.LayerNorm(d_model)
 
     def forward(self, scale):
-        # d/dp of sum(p) * scale = scale for every element: a gradient for each parameter, in reverse registration order
-        # (the order DDP's buckets are built for), at the cost of one tiny reduction per tensor
-        total = None
-        for p in self.parameters():
-            t = p.sum()
-            total = t if total is None else total + t
-        return total * scale
+        # every parameter gets a gradient (a view of one constant buffer) from ONE autograd node: what reaches RCCL is exactly what
+        # DDP does with a real model's gradients -- per-parameter hooks, bucket copies, bucketed all-reduce -- without ~1 000 tiny
+        # reduction kernels of a sum-of-sums on the compute stream
+        params = list(self.parameters())
+        flat = getattr(self, "_flat", None)
+        if flat is None or flat.device != params[0].device:
+            flat = self._flat = torch.ones(sum(p.numel() for p in params), device=params[0].device)
+        return _AllGrads.apply(flat[:1], flat, *params)                  # (`scale` is the constant 1: no host-to-device copy per step)
+
+
+class _AllGrads(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale, flat, *params):
+        ctx.flat, ctx.shapes = flat, [p.shape for p in params]
+        return scale.sum() * 0.0
+
+    @staticmethod
+    def backward(ctx, g):
+        grads, o = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            grads.append(ctx.flat[o:o + n].view(shp))
+            o += n
+        return (None, None, *grads)
 
 
 def measured_traffic(L, D, B, io_dtype, save):
