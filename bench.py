@@ -143,6 +143,8 @@ def parse():
     ap.add_argument("--no-save-spectra", action="store_true",
                     help="backward recomputes the column spectra of u and k instead of reusing the forward's")
     ap.add_argument("--fwd-only", action="store_true", help="diagnostic; the reported metric needs fwd+bwd")
+    ap.add_argument("--share-gpu0", action="store_true",
+                    help="TEST ONLY: every rank on cuda:0 with the gloo backend (exercises the N > 1 GPU leg on a 1-GPU box)")
     ap.add_argument("--emu", action="store_true",
                     help="TEST ONLY: run the host logic on the CPU emulation of the kernels with the gloo backend")
     return ap.parse_args()
@@ -295,12 +297,15 @@ def main():
         dev = torch.device("cpu")
     else:
         assert torch.cuda.is_available(), "bench.py needs a ROCm device (there is no CPU fallback)"
+        if args.share_gpu0:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if args.emu else "nccl", rank=rank, world_size=world,
-                                **({} if args.emu else {"device_id": dev}))
+        cpu_backend = args.emu or args.share_gpu0
+        dist.init_process_group("gloo" if cpu_backend else "nccl", rank=rank, world_size=world,
+                                **({} if cpu_backend else {"device_id": dev}))
 
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     B, D, L = args.batch, args.d_model, args.seq_len
