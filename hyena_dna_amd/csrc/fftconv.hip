@@ -284,7 +284,8 @@ int hyena_fftconv_default_chunk(int B, int D, int L, int backward) {
 size_t hyena_fftconv_workspace_bytes(int B, int D, int L, int backward, int chunk) {
     Plan p;
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
-    if (p.R) return oc::spectrum_bytes(D, p.R);              // the filter spectrum is this path's only intermediate
+    if (p.R)      // the filter spectrum is this path's only intermediate (+ dk's per-slice partial rows when D < number of CUs)
+        return oc::spectrum_bytes(D, p.R) + (backward ? oc::dk_partial_bytes(p.R, B, D, L) : 0);
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, backward);
     if (chunk > D) chunk = D;
     if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
@@ -374,8 +375,9 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
         if (dk != nullptr && u == nullptr) return HYENA_ERR_BAD_ARG;        // this path keeps no spectrum of u: it re-reads u
         if (p.R == 1 && (size_t)B * D * L * elem_size(dtype) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;   // 32-bit row offsets (dk, T = 32)
         if ((size_t)D * p.M * sizeof(c32) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;
-        if (workspace_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
+        if (workspace_bytes < hyena_fftconv_workspace_bytes(B, D, L, 1, chunk)) return HYENA_ERR_WORKSPACE;
         if (saved != nullptr && saved_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
+        void* partials = reinterpret_cast<char*>(workspace) + oc::spectrum_bytes(D, p.R);
         int st;
         if (du != nullptr) {
             const void* H = saved;
@@ -385,7 +387,7 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
             }
             if ((st = oc::launch_conv(p.R, dout, du, H, d_tables, B, D, L, dtype, 1, stream))) return st;
         }
-        if (dk != nullptr && (st = oc::launch_dk(p.R, dout, u, dk, dbias, d_tables, B, D, L, dtype, stream))) return st;
+        if (dk != nullptr && (st = oc::launch_dk(p.R, dout, u, dk, dbias, partials, d_tables, B, D, L, dtype, stream))) return st;
         return HYENA_OK;
     }
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, 1);

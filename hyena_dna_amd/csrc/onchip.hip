@@ -65,6 +65,26 @@ void build_tables(int R, float* h) {
 
 size_t spectrum_bytes(int D, int R) { return (size_t)D * 1024 * R * sizeof(c32); }
 
+// dk owns one workgroup (512 threads, the whole register file of a CU) per channel; with fewer channels than the MI355X has CUs
+// the batch of a channel is cut into slices so that D S workgroups fill the chip.
+static int dk_row_groups(int R) { const int bp = 512 / (32 * R); return R == 32 ? 1 : (bp > 16 ? 16 : (bp < 1 ? 1 : bp)); }
+int dk_slices(int R, int B, int D, int* nb_out) {
+    const int CUS = 256;
+    const int iters = (B + dk_row_groups(R) - 1) / dk_row_groups(R);          // sequential steps of an unsliced workgroup
+    int S = (CUS + D - 1) / D;
+    if (S > iters) S = iters;
+    if (S < 1) S = 1;
+    int nb = (B + S - 1) / S;
+    nb = (nb + dk_row_groups(R) - 1) / dk_row_groups(R) * dk_row_groups(R);    // whole steps per slice
+    S = (B + nb - 1) / nb;
+    if (nb_out) *nb_out = nb;
+    return S;
+}
+size_t dk_partial_bytes(int R, int B, int D, int L) {
+    const int S = dk_slices(R, B, D, nullptr);
+    return S > 1 ? (size_t)S * D * L * sizeof(float) : 0;
+}
+
 template <int R>
 static int spec_r(const SpecArgs& a, void* stream) {
     typedef WgCfg<R> W;
@@ -91,12 +111,13 @@ static int dk_rh(const DkArgs& a, void* stream) {
     typedef DkCfg<R, NP> K;
     static thread_local int done = -1;
     hy_allow_lds(dk_kernel<R, NP, HALF, 0>, K::LDS, &done);
-    HY_LAUNCH((dk_kernel<R, NP, HALF, 0>), dim3(a.D), dim3(K::WGT), K::LDS, stream, a);
+    HY_LAUNCH((dk_kernel<R, NP, HALF, 0>), dim3(a.D, a.S), dim3(K::WGT), K::LDS, stream, a);
     if constexpr (NP == 2) {       // the odd bins, a second launch (it adds to what the first one left in dk)
         static thread_local int done1 = -1;
         hy_allow_lds(dk_kernel<R, NP, HALF, 1>, K::LDS, &done1);
-        HY_LAUNCH((dk_kernel<R, NP, HALF, 1>), dim3(a.D), dim3(K::WGT), K::LDS, stream, a);
+        HY_LAUNCH((dk_kernel<R, NP, HALF, 1>), dim3(a.D, a.S), dim3(K::WGT), K::LDS, stream, a);
     }
+    if (a.S > 1) HY_LAUNCH(dk_sum_kernel, dim3((a.L + 255) / 256, a.D), dim3(256), 0, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 template <int R, int NP>
@@ -133,11 +154,14 @@ int launch_conv(int R, const void* x, void* out, const void* H, const void* tab,
 #undef HY_CALL
 }
 
-int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, const void* tab, int B, int D, int L, int dtype,
-              void* stream) {
+int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, void* partials, const void* tab, int B, int D, int L,
+              int dtype, void* stream) {
     DkArgs a;
     a.dout = dout; a.u = u; a.dk = dk; a.dbias = dbias; a.tab = reinterpret_cast<const c32*>(tab);
     a.B = B; a.D = D; a.L = L; a.dtype = dtype;
+    a.S = dk_slices(R, B, D, &a.nb);
+    a.part = reinterpret_cast<float*>(partials);
+    if (a.S > 1 && partials == nullptr) return HYENA_ERR_WORKSPACE;
     if (R == 32) {       // two 16384-point parity problems; their tables follow the size-32 set
         a.tab = reinterpret_cast<const c32*>(tab) + set_entries(32);
         return dk_r<16, 2>(a, stream);

@@ -20,9 +20,11 @@ int launch_spec(int R, const float* k, const float* bias, void* H, const void* t
 // out = conv(x, H) (conj = 0) or corr(x, H) (conj = 1)
 int launch_conv(int R, const void* x, void* out, const void* H, const void* tab, int B, int D, int L, int dtype, int conj,
                 void* stream);
-// dk (and dbias) from dout and u
-int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, const void* tab, int B, int D, int L, int dtype,
-              void* stream);
+// dk (and dbias) from dout and u; `partials` = dk_partial_bytes(...) bytes of scratch (may be null when that is 0)
+size_t dk_partial_bytes(int R, int B, int D, int L);
+int dk_slices(int R, int B, int D, int* nb_out);
+int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, void* partials, const void* tab, int B, int D, int L,
+              int dtype, void* stream);
 
 }  // namespace oc
 }  // namespace hyena

@@ -442,7 +442,9 @@ struct DkArgs {            // dk[d] = sum_b corr(dout[b, d], u[b, d]);  dbias[d]
     float* dk;             // (D, L) fp32
     float* dbias;          // (D,) or null
     const c32* tab;        // tables of the (sub-)transform; NP = 2: the two parity sets of size 16384, one after the other
+    float* part;           // S > 1: [S][D][L] fp32, the slices' partial dk rows (summed in slice order by dk_sum_kernel)
     int B, D, L, dtype;
+    int S, nb;             // batch slices per channel (grid.y) and batch items per slice: slice s owns b in [s nb, min(B, (s + 1) nb))
 };
 
 // Wavefronts per SIMD the conv / spectrum kernels are compiled for (-> at most 128 VGPRs): a wavefront issues one VALU
@@ -609,10 +611,16 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
     const bool bf = a.dtype == DT_BF16;
     const int rg = BP == 1 ? 0 : (int)threadIdx.x / T, tid = BP == 1 ? (int)threadIdx.x : (int)threadIdx.x % T;
     const int d = blockIdx.x;
+    // With fewer channels than CUs a channel's batch is cut into S slices (blockIdx.y), each a workgroup of its own that leaves
+    // its partial dk row in `part`; the transform is linear, so the rows are simply added afterwards (dk_sum_kernel, slice order).
+    const int sl = blockIdx.y;
+    const int b_lo = sl * a.nb, b_hi = (b_lo + a.nb < a.B) ? b_lo + a.nb : a.B;
+    const bool sliced = a.S > 1;
     Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
     const unsigned rowbytes = (unsigned)a.L * ES;
     const float sc = 1.0f / (float)(C::M * NP);
-    float* dkrow = a.dk + (size_t)d * a.L;
+    float* dkrow = sliced ? a.part + ((size_t)sl * a.D + d) * a.L : a.dk + (size_t)d * a.L;
+    float* dbias = sliced ? nullptr : a.dbias;
     {
         constexpr int e = E0;
         constexpr int PHI_A = NP == 2 ? 1 : 2, PHI_B = 5;       // e = 0 / e = 1
@@ -621,9 +629,9 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
         c32 acc[32];
         HY_UNROLL
         for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
-        for (int b0 = 0; b0 < a.B; b0 += BP) {        // uniform trip count: the transforms contain workgroup barriers
-            const bool live = b0 + rg < a.B;
-            const int b = live ? b0 + rg : a.B - 1;
+        for (int b0 = b_lo; b0 < b_hi; b0 += BP) {    // uniform trip count: the transforms contain workgroup barriers
+            const bool live = b0 + rg < b_hi;
+            const int b = live ? b0 + rg : b_hi - 1;
             const size_t row = ((size_t)b * a.D + d) * a.L * ES;
             // one descriptor per row (hardware bounds check clips n >= L) -- except at T = 32, where the two row groups of
             // a wavefront need a common one: the whole tensor (< 4 GB, checked by the host) + a per-lane row offset
@@ -657,7 +665,7 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
             }
             __syncthreads();
             if (rg == 0) {
-                const int ng = a.B < BP ? a.B : BP;
+                const int ng = (b_hi - b_lo) < BP ? (b_hi - b_lo) : BP;
                 for (int o = 1; o < ng; ++o) {
                     HY_UNROLL
                     for (int q = 0; q < 32; ++q) acc[q] = cadd(acc[q], lds_ld(red + o * C::M + q * T + tid));
@@ -676,7 +684,7 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
                     const int n = tid + T * s;
                     const float val = (acc[s].x * w.x + acc[s].y * w.y) * sc;
                     if (n < a.L) dkrow[n] = val;
-                    if (n == 0 && a.dbias != nullptr) a.dbias[d] = val;
+                    if (n == 0 && dbias != nullptr) dbias[d] = val;
                 }
             } else {
                 const float rr = 0.70710678118654752440f;
@@ -692,7 +700,7 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
                         if (n < a.L) {
                             const float val = dkrow[n] + lo;
                             dkrow[n] = val;
-                            if (n == 0 && a.dbias != nullptr) a.dbias[d] = val;
+                            if (n == 0 && dbias != nullptr) dbias[d] = val;
                         }
                         if (n + C::M < a.L) dkrow[n + C::M] -= hi;
                     }
@@ -700,6 +708,17 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
             }
         }
     }
+}
+
+// dk[d][n] = sum over the S batch slices of part[s][d][n], in slice order (deterministic); dbias[d] = dk[d][0]
+__global__ void __launch_bounds__(256) dk_sum_kernel(DkArgs a) {
+    const int d = blockIdx.y;
+    const int n = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (n >= a.L) return;
+    float acc = a.part[(size_t)d * a.L + n];
+    for (int s = 1; s < a.S; ++s) acc += a.part[((size_t)s * a.D + d) * a.L + n];
+    a.dk[(size_t)d * a.L + n] = acc;
+    if (n == 0 && a.dbias != nullptr) a.dbias[d] = acc;
 }
 
 }  // namespace oc

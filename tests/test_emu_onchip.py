@@ -34,6 +34,8 @@ CASES = [
     (1, 1, 1), (3, 2, 2), (17, 3, 700), (16, 8, 1024), (5, 1, 1023), (9, 2, 1025), (8, 8, 2048), (3, 3, 2047),
     (5, 2, 4096), (4, 1, 4095), (2, 16, 3000), (3, 2, 8192), (2, 1, 8191), (1, 3, 5000), (2, 2, 16384), (3, 1, 16383),
     (1, 2, 12000), (2, 2, 32768), (1, 1, 32767), (3, 1, 16385), (2, 1, 20000), (1, 8, 32768),
+    # D far below the CU count: dk cuts the batch of a channel into slices (3 / 5 / 4 / 5 of them here, the last one ragged)
+    (40, 3, 700), (9, 4, 5000), (7, 2, 2100), (5, 2, 20000),
 ]
 
 
@@ -118,3 +120,23 @@ def test_properties(emu_backend):
     assert abs(lhs - ((dk.double() * k.double()).sum() + (dbias.double() * bias.double()).sum())) < 1e-6 * abs(lhs) + 1e-3
     du_b, dk_b, dbias_b = emu_backend.fftconv_bwd(dout, u, k, bias)
     assert torch.equal(du, du_b) and torch.equal(dk, dk_b) and torch.equal(dbias, dbias_b)
+
+
+def test_dk_batch_slices_cover_the_batch_exactly():
+    """host logic of the sliced dk (csrc/onchip.hip dk_slices), read back through the C ABI: the backward's workspace is the filter
+    spectrum + S D L floats of partial rows (S = 1: none).  A channel count >= the CU count is never sliced, the slice count never
+    exceeds the sequential steps an unsliced workgroup would take, and D S stays within ~2x the CUs."""
+    from hyena_dna_amd import _lib
+    L_ = _lib.lib()
+    for L, R in ((700, 1), (2000, 2), (4000, 4), (8000, 8), (16000, 16), (32000, 32)):
+        bp = 1 if R == 32 else min(16, 512 // (32 * R))
+        for B in (1, 2, 7, 8, 16, 17, 64, 250):
+            for D in (1, 3, 64, 128, 200, 256, 768):
+                extra = L_.hyena_fftconv_workspace_bytes(B, D, L, 1, 0) - L_.hyena_fftconv_workspace_bytes(B, D, L, 0, 0)
+                assert extra % (D * L * 4) == 0
+                S = extra // (D * L * 4) or 1
+                assert extra == (S * D * L * 4 if S > 1 else 0)
+                steps = -(-B // bp)
+                assert 1 <= S <= steps and (S == 1 if D >= 256 else S * D < 2 * 256 + D)
+                if D < 256 and steps >= 2:
+                    assert S >= 2                        # the case this exists for
