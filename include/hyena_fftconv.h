@@ -72,8 +72,9 @@ const char* hyena_fftconv_error_string(int status);
 /* Two execution plans, chosen by L alone:
  *   L <= 32768   workspace-free: one workgroup per (b, d) row holds the whole transform in registers and LDS
  *                (M = 1024, 2048, ..., 32768, the smallest power of two >= L); HBM traffic is u, out and the filter
- *                spectrum H [D][M] (the workspace).  The reference's own fused kernel has this shape but stops at L = 8192
- *                (csrc/fftconv/fftconv_cuda.cu:805, fftconv.cpp:114-115).  HYENA_FFTCONV_ONCHIP=0 in the environment
+ *                spectrum H [D][M] (the workspace; the backward adds S D L floats of per-slice dk rows when D is below the
+ *                number of CUs and the batch of a channel is split over S workgroups).  The reference's own fused kernel has
+ *                this shape but stops at L = 8192 (csrc/fftconv/fftconv_cuda.cu:805, fftconv.cpp:114-115).  HYENA_FFTCONV_ONCHIP=0 in the environment
  *                routes these lengths to the two-level plan instead (testing / profiling).
  *   L >  32768   two-level (four-step) transform through a workspace, M = M1 x 1024.
  *
