@@ -24,8 +24,16 @@ import torch as _torch
 # (scripts/graph_bisect.py, scripts/graph_debug3.py; gpurun_out/r2g*).  The knob is read when the HIP runtime initialises,
 # so it is set here, at import, unless the user has decided otherwise; lm.GraphedTrainStep refuses to capture when it could
 # not take effect.  Eager launches are not affected by it.
-GRAPH_SAFE = (_os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0") or not _torch.cuda.is_initialized()
-_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# Side effect, stated: this sets a PROCESS-WIDE ROCm runtime knob for every hipGraph user in the process (graphs stay
+# correct, launches inside a replay are dispatched the ordinary way); export DEBUG_CLR_GRAPH_PACKET_CAPTURE=1 before the
+# import to keep the runtime's default -- GraphedTrainStep then refuses to capture.
+_K = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+_was_init = _torch.cuda.is_initialized()
+_prev = _os.environ.get(_K)
+_os.environ.setdefault(_K, "0")
+# safe = the variable reads "0" AND the HIP runtime reads it after it was set: either it was not initialised yet, or the
+# user had exported "0" before starting the process (a value placed in os.environ after initialisation is never seen).
+GRAPH_SAFE = _os.environ[_K] == "0" and ((not _was_init) or _prev == "0")
 
 from . import _lib  # noqa: F401,E402
 

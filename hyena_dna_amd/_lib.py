@@ -60,10 +60,16 @@ class _HipBackend:
     def stream(self, device):
         return torch.cuda.current_stream(device).cuda_stream
 
-    def free_memory(self):
+    def capturing(self):
+        return torch.cuda.is_current_stream_capturing()
+
+    def free_memory(self, device=None):
+        """Bytes a new allocation on `device` can take: what the driver reports free plus what PyTorch's caching
+        allocator holds but is not using (it hands those blocks out again without asking the driver)."""
         if torch.cuda.is_current_stream_capturing():      # no driver queries inside a hipGraph capture
             return None
-        return torch.cuda.mem_get_info()[0]
+        return (torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device)
+                - torch.cuda.memory_allocated(device))
 
 
 _backend = _HipBackend()
@@ -207,21 +213,28 @@ def tables_for(device, L):
     return t
 
 
-_retired = []     # outgrown workspaces: kept alive, a captured hipGraph may still replay on them
+_retired = []     # outgrown workspaces a captured hipGraph may still replay on: kept alive
+_captured = set() # (device index, stream) keys whose workspace was handed out during a hipGraph capture
 
 
 def workspace_for(device, nbytes):
     """A per-(device, stream) scratch buffer, grown on demand (geometrically) and reused across calls.  An outgrown buffer
-    is retired, not freed: launches captured into a hipGraph keep pointing at it."""
+    is freed (stream-ordered, through the caching allocator) unless launches captured into a hipGraph point at it -- only
+    then is it retired instead, for the life of the process."""
     stream = _backend.stream(device)
     key = (device.index, stream)
     w = _workspace.get(key)
+    capturing = getattr(_backend, "capturing", lambda: False)()
     if w is None or w.numel() < nbytes:
         if w is not None:
-            _retired.append(w)
+            if key in _captured:
+                _retired.append(w)
+                _captured.discard(key)
             nbytes = max(int(nbytes), int(1.5 * w.numel()))
         w = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _workspace[key] = w
+    if capturing:
+        _captured.add(key)
     return w, stream
 
 
@@ -235,7 +248,10 @@ def saved_bytes(B, D, L):
     return int(lib().hyena_fftconv_saved_bytes(int(B), int(D), int(L)))
 
 
-def save_spectra_default(B, D, L):
+_save_decision = {}   # (device index, B, D, L) -> bool
+
+
+def save_spectra_default(B, D, L, device=None):
     """Keep the forward's column spectra for the backward?  HYENA_FFTCONV_SAVE_SPECTRA = 0 | 1 | auto (default:
     on while the buffer stays below HYENA_FFTCONV_SAVE_LIMIT_GB, default 6 GiB per call)."""
     mode = os.environ.get("HYENA_FFTCONV_SAVE_SPECTRA", "auto").lower()
@@ -250,15 +266,24 @@ def save_spectra_default(B, D, L):
     need = saved_bytes(B, D, L)
     if need > float(os.environ.get("HYENA_FFTCONV_SAVE_LIMIT_GB", "6")) * 2 ** 30:
         return False
-    # per call = per layer: never take more than a quarter of what the device has free right now (the recomputing
-    # backward fits where this buffer would not)
-    free = _backend.free_memory()
-    return free is None or need <= free // 4
+    # per call = per layer: never take more than a quarter of what the device can still give (the recomputing backward
+    # fits where this buffer would not).  Decided ONCE per (device, B, D, L): the answer must not flip between steps, nor
+    # between an eager warm-up and the hipGraph capture that follows it, with the state of the allocator's cache.
+    key = (getattr(device, "index", None), int(B), int(D), int(L))
+    hit = _save_decision.get(key)
+    if hit is None:
+        free = _backend.free_memory(device) if device is not None else _backend.free_memory()
+        if free is None:                         # capturing and never decided eagerly: keep the spectra, do not cache
+            return True
+        hit = _save_decision[key] = bool(need <= free // 4)
+    return hit
 
 
-def fftconv_fwd(u, k, bias, chunk=None, save=False):
+def fftconv_fwd(u, k, bias, chunk=None, save=False, grad=None):
     """u (B, D, L) contiguous, k (D, L) fp32, bias (D,) fp32 or None -> out like u.
-    save=True additionally returns the saved-spectrum buffer for fftconv_bwd(..., saved=)."""
+    save=True additionally returns the saved-spectrum buffer for fftconv_bwd(..., saved=).
+    grad: a backward of the same shape will follow (default: save or autograd's grad mode) -- the workspace is then sized
+    for it right away instead of being outgrown at the first backward."""
     _require_gpu(u, "u")
     B, D, L = u.shape
     out = torch.empty_like(u)
@@ -267,6 +292,9 @@ def fftconv_fwd(u, k, bias, chunk=None, save=False):
     chunk = _chunk_override() if chunk is None else int(chunk)
     tables = tables_for(u.device, L)
     nbytes = lib().hyena_fftconv_workspace_bytes(B, D, L, 0, chunk)
+    if (save or torch.is_grad_enabled()) if grad is None else grad:
+        # a backward of the same shape follows and needs the larger buffer: take it now instead of outgrowing this one
+        nbytes = max(nbytes, lib().hyena_fftconv_workspace_bytes(B, D, L, 1, chunk))
     ws, stream = workspace_for(u.device, nbytes)
     bp = bias.data_ptr() if bias is not None else None
     with _backend.guard(u.device):

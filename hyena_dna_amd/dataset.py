@@ -52,12 +52,40 @@ class FastaIndex:
 
     def __init__(self, fasta_file):
         self.path = str(fasta_file)
+        self._open()
+        # pyfaidx rebuilds a .fai that is older than its FASTA; a stale or foreign index would silently shift every
+        # training sequence.  Use the index only when it is not older than the file AND every record it lists lies inside
+        # the file; otherwise index the file itself (one numpy pass).
+        fai = self.path + ".fai"
+        self.records = None
+        if os.path.exists(fai) and os.path.getmtime(fai) >= os.path.getmtime(self.path):
+            rec = self._read_fai(fai)
+            if rec and all(self._inside(r) for r in rec.values()):
+                self.records = rec
+        if self.records is None:
+            self.records = self._scan()
+
+    def _open(self):
         self._fh = open(self.path, "rb")
         size = os.fstat(self._fh.fileno()).st_size
         self._mm = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ) if size else b""
         self._buf = np.frombuffer(self._mm, dtype=np.uint8) if size else np.zeros(0, np.uint8)
-        fai = self.path + ".fai"
-        self.records = self._read_fai(fai) if os.path.exists(fai) else self._scan()
+
+    def _inside(self, rec):
+        length, off, lb, lw = rec
+        if length < 0 or off < 0 or lb <= 0 or lw < lb:
+            return False
+        last = off + ((length - 1) // lb) * lw + (length - 1) % lb + 1 if length else off
+        return last <= self._buf.shape[0]
+
+    # DataLoader workers started with spawn / forkserver pickle the dataset: the open file, the mmap and the numpy view
+    # are per-process state, re-created from the path
+    def __getstate__(self):
+        return {"path": self.path, "records": self.records}
+
+    def __setstate__(self, state):
+        self.path, self.records = state["path"], state["records"]
+        self._open()
 
     @staticmethod
     def _read_fai(path):

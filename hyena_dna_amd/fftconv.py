@@ -84,10 +84,10 @@ class FFTConvFunc(torch.autograd.Function):
         # _lib.save_spectra_default); otherwise the backward recomputes them from (u, k)
         want_grad = any(ctx.needs_input_grad[:3])
         saved = None
-        if want_grad and _lib.save_spectra_default(*rows.shape):
+        if want_grad and _lib.save_spectra_default(*rows.shape, device=rows.device):
             out, saved = _lib.fftconv_fwd(rows, kf, bias, save=True)
         else:
-            out = _lib.fftconv_fwd(rows, kf, bias)
+            out = _lib.fftconv_fwd(rows, kf, bias, grad=want_grad)
         ctx.spectra = saved
         ctx.save_for_backward(rows, kf, bias if bias is not None else torch.empty(0, device=u.device))
         ctx.has_bias = bias is not None

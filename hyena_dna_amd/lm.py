@@ -304,6 +304,18 @@ class HyenaDNALM(nn.Module, GenerationMixin):
                  residual_in_fp32=True, pad_vocab_size_multiple=1, checkpoint_mixer=False, checkpoint_mlp=False, **unused):
         super().__init__()
         from .hyena import HyenaOperator
+        # Keywords of ConvLMHeadModel / LMBackbone (long_conv_lm.py:249-272, 402-424) this single-process, Hyena-only model has
+        # no counterpart for are accepted at their "off" values only: a config asking for attention layers, tensor parallelism
+        # or flash_attn's FusedMLP must not silently get a different model.
+        off = {"attn_layer_idx": None, "attn_cfg": None, "process_group": None, "fused_mlp": False, "identity_mlp": False,
+               "sequence_parallel": (True, False), "device": None, "dtype": None, "return_hidden_state": False}
+        for key, val in unused.items():
+            allowed = off.get(key, KeyError)
+            if allowed is KeyError:
+                raise TypeError(f"HyenaDNALM: unknown keyword {key!r}")
+            if not (val in allowed if isinstance(allowed, tuple) else val == allowed):
+                raise NotImplementedError(f"HyenaDNALM: {key}={val!r} is not supported (Hyena mixers, one process per GPU, "
+                                          "library-GEMM MLP only)")
         if vocab_size % pad_vocab_size_multiple != 0:
             vocab_size += pad_vocab_size_multiple - (vocab_size % pad_vocab_size_multiple)
         layer = dict(layer or {})
@@ -318,6 +330,13 @@ class HyenaDNALM(nn.Module, GenerationMixin):
             Block(d_model, partial(HyenaOperator, **layer), mlp_cls, norm_cls=norm_cls, prenorm=True,
                   resid_dropout1=embed_dropout if i == 0 else resid_dropout, resid_dropout2=resid_dropout,
                   fused_dropout_add_ln=fused_dropout_add_ln, residual_in_fp32=residual_in_fp32) for i in range(n_layer)])
+        # long_conv_lm.py:196-199: activation checkpointing wraps the sub-module, which also moves its state-dict keys under
+        # `.layer` -- a checkpoint saved with these flags loads only into a model built with them
+        for blk in backbone.layers:
+            if checkpoint_mlp:
+                blk.mlp = CheckpointedModule(blk.mlp)
+            if checkpoint_mixer:
+                blk.mixer = CheckpointedModule(blk.mixer)
         backbone.drop_f = nn.Dropout(resid_dropout)
         backbone.ln_f = nn.LayerNorm(d_model, eps=layer_norm_epsilon)
         self.backbone = backbone
@@ -350,6 +369,18 @@ class HyenaDNALM(nn.Module, GenerationMixin):
         """next-token cross entropy (src/tasks/metrics.py cross_entropy over the flattened logits), logits in fp32"""
         logits = self.forward(input_ids)[0].logits
         return F.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), targets.reshape(-1), ignore_index=ignore_index)
+
+
+class CheckpointedModule(nn.Module):
+    """long_conv_lm.py:39-45: the wrapped module under the attribute `layer`, its forward recomputed in the backward."""
+
+    def __init__(self, layer):
+        super().__init__()
+        self.layer = layer
+
+    def forward(self, x):
+        from torch.utils.checkpoint import checkpoint
+        return checkpoint(self.layer, x, use_reentrant=False)
 
 
 class GraphedTrainStep:

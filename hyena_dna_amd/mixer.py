@@ -32,10 +32,10 @@ class HyenaMixerFunc(torch.autograd.Function):
         vg = _lib.mixer_pre_fwd(xc, w, b, L)
         want_grad = any(ctx.needs_input_grad[:5])
         spectra = None
-        if want_grad and _lib.save_spectra_default(B, D, L):
+        if want_grad and _lib.save_spectra_default(B, D, L, device=vg.device):
             y, spectra = _lib.fftconv_fwd(vg, kf, bf, save=True)
         else:
-            y = _lib.fftconv_fwd(vg, kf, bf)
+            y = _lib.fftconv_fwd(vg, kf, bf, grad=want_grad)
         z = _lib.mixer_post_fwd(y, xc, w, b)
         ctx.save_for_backward(xc, w, b, kf, bf, y)
         ctx.spectra = spectra
@@ -93,10 +93,10 @@ class HyenaMixerCMFunc(torch.autograd.Function):
         vg = _lib.cm_pre_fwd(xc, bi, w, b, L)
         want_grad = any(ctx.needs_input_grad[:6])
         spectra = None
-        if want_grad and _lib.save_spectra_default(B, D, L):
+        if want_grad and _lib.save_spectra_default(B, D, L, device=vg.device):
             y, spectra = _lib.fftconv_fwd(vg, kf, bf, save=True)
         else:
-            y = _lib.fftconv_fwd(vg, kf, bf)
+            y = _lib.fftconv_fwd(vg, kf, bf, grad=want_grad)
         zT = _lib.cm_post_fwd(y, xc, bi, w, b)
         ctx.save_for_backward(xc, bi, w, b, kf, bf, y)
         ctx.spectra = spectra

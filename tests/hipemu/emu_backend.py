@@ -21,5 +21,8 @@ class EmuBackend:
     def stream(self, device):
         return None
 
-    def free_memory(self):
+    def capturing(self):
+        return False
+
+    def free_memory(self, device=None):
         return None

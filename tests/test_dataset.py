@@ -81,3 +81,38 @@ def test_reverse_complement_and_interval_call(genome):
     assert isinstance(s, str) and len(s) == 64 and s.startswith("." * 17) and not s.endswith(".")
     with pytest.raises(NotImplementedError):
         HG38Dataset("train", genome[2], fa, 64, tokenizer_name="bpe")
+
+
+def test_stale_or_foreign_fai_is_not_trusted_and_index_pickles(genome, tmp_path):
+    """pyfaidx rebuilds an index older than its FASTA; spawn-started DataLoader workers pickle the dataset."""
+    import pickle
+    import shutil
+    import time
+    g, fa, _ = genome
+    fa2 = str(tmp_path / "g.fa")
+    shutil.copy(fa, fa2)
+    good = FastaIndex(fa2)
+    name = next(iter(good.keys()))
+    length, off, lb, lw = good.records[name]
+    want = good.fetch(name, 3, 200)
+    # (a) an index that points outside the file (foreign)
+    with open(fa2 + ".fai", "w") as f:
+        f.write(f"{name}\t{length}\t{off + 10 ** 9}\t{lb}\t{lw}\n")
+    assert FastaIndex(fa2).fetch(name, 3, 200) == want
+    # (b) an index older than the FASTA with plausible but wrong offsets (stale)
+    with open(fa2 + ".fai", "w") as f:
+        f.write(f"{name}\t{length}\t{off + 1}\t{lb}\t{lw}\n")
+    past = time.time() - 1000
+    os.utime(fa2 + ".fai", (past, past))
+    assert FastaIndex(fa2).fetch(name, 3, 200) == want
+    # (c) a fresh, correct index is used as is
+    with open(fa2 + ".fai", "w") as f:
+        for n, r in good.records.items():
+            f.write("\t".join([n] + [str(x) for x in r]) + "\n")
+    idx = FastaIndex(fa2)
+    assert idx.records == good.records and idx.fetch(name, 3, 200) == want
+    # pickling re-opens the file in the receiving process
+    clone = pickle.loads(pickle.dumps(idx))
+    assert clone.fetch(name, 3, 200) == want and clone.records == idx.records
+    ds = FastaInterval(fasta_file=fa2, return_seq_indices=False, shift_augs=None, rc_aug=False)
+    assert pickle.loads(pickle.dumps(ds)).seqs.fetch(name, 3, 200) == want

@@ -228,3 +228,60 @@ def test_graphed_train_step_refuses_what_it_cannot_capture():
     ids = torch.zeros(1, 8, dtype=torch.long)
     with pytest.raises(RuntimeError, match="ROCm device"):
         GraphedTrainStep(lin, torch.optim.AdamW(lin.parameters(), lr=1e-3), ids, ids)
+
+
+def test_workspace_growth_frees_unless_captured_and_save_decision_is_cached(emu_backend, monkeypatch):
+    """ADVICE r2: (a) an outgrown workspace is dropped, not retired forever, unless a hipGraph capture was handed the buffer;
+    (b) a forward that a backward will follow takes the backward's (larger) workspace right away; (c) the two-level plan's
+    keep-the-spectra decision is made once per (device, B, D, L), not re-derived from the allocator's state every step."""
+    _lib = emu_backend
+    monkeypatch.setattr(_lib, "_retired", [])
+    monkeypatch.setattr(_lib, "_captured", set())
+    dev = torch.device("cpu")
+    w1, _ = _lib.workspace_for(dev, 1000)
+    w2, _ = _lib.workspace_for(dev, 5000)
+    assert w2.numel() >= 5000 and _lib._retired == []
+    monkeypatch.setattr(_lib._backend, "capturing", lambda: True, raising=False)
+    w3, _ = _lib.workspace_for(dev, 100)                      # handed out during a capture
+    assert w3 is w2
+    monkeypatch.setattr(_lib._backend, "capturing", lambda: False, raising=False)
+    w4, _ = _lib.workspace_for(dev, 50000)
+    assert _lib._retired == [w2] and w4.numel() >= 50000
+    # (b)
+    B, D, L = 2, 4, 40000                                       # two-level plan
+    u, k = torch.randn(B, D, L), torch.randn(D, L) * 0.01
+    monkeypatch.setattr(_lib, "_workspace", {})
+    _lib.fftconv_fwd(u, k, None, grad=True)
+    need_bwd = _lib.lib().hyena_fftconv_workspace_bytes(B, D, L, 1, 0)
+    assert next(iter(_lib._workspace.values())).numel() >= need_bwd
+    # (c)
+    monkeypatch.setattr(_lib, "_save_decision", {})
+    calls = []
+
+    def free(device=None):
+        calls.append(1)
+        return 1 << 40
+    monkeypatch.setattr(_lib._backend, "free_memory", free, raising=False)
+    assert _lib.save_spectra_default(B, D, L, device=dev) and _lib.save_spectra_default(B, D, L, device=dev)
+    assert len(calls) == 1
+
+
+def test_lm_checkpoint_flags_wrap_like_the_reference_and_unknown_keywords_raise():
+    """checkpoint_mixer / checkpoint_mlp wrap the sub-modules under `.layer` (long_conv_lm.py:39-45, 196-199: the
+    state-dict keys move), everything the model has no counterpart for raises instead of being swallowed."""
+    from hyena_dna_amd.lm import CheckpointedModule, HyenaDNALM
+    layer = dict(l_max=66, order=2, filter_order=16, emb_dim=5, short_filter_order=3, modulate=True, w=10, lr=6e-4, wd=0.0, lr_pos_emb=0.0)
+    kw = dict(d_model=16, n_layer=2, d_inner=32, vocab_size=12, layer=layer, pad_vocab_size_multiple=8)
+    m = HyenaDNALM(checkpoint_mixer=True, checkpoint_mlp=True, **kw)
+    assert isinstance(m.backbone.layers[0].mixer, CheckpointedModule) and isinstance(m.backbone.layers[1].mlp, CheckpointedModule)
+    keys = set(m.state_dict())
+    assert "backbone.layers.0.mixer.layer.in_proj.weight" in keys and "backbone.layers.1.mlp.layer.fc1.weight" in keys
+    plain = HyenaDNALM(**kw)
+    assert "backbone.layers.0.mixer.in_proj.weight" in set(plain.state_dict())
+    HyenaDNALM(attn_layer_idx=None, fused_mlp=False, process_group=None, **kw)            # reference keywords at "off": fine
+    with pytest.raises(NotImplementedError):
+        HyenaDNALM(attn_layer_idx=[1], **kw)
+    with pytest.raises(NotImplementedError):
+        HyenaDNALM(fused_mlp=True, **kw)
+    with pytest.raises(TypeError):
+        HyenaDNALM(no_such_option=1, **kw)
