@@ -11,12 +11,13 @@ metric on: L = 1,048,576, d = 256, B = 1 per GPU, bf16 activations, fp32 filter 
         bench.py --gpus N --steps K --warmup W
 
 Multi-GPU: the path shards on the batch axis (independent sequences): every rank runs the same
-per-GPU workload on its own seeded batch (weak scaling).  The convolution itself has no exchange step; the only
-collective of the training step it belongs to is the DDP gradient all-reduce of the model parameters.  For N > 1 the
-parameters of a hyenadna-large-1m-shaped stack (8 x [HyenaOperator + MLP + 2 LayerNorm] + embedding, ~6.6 M fp32) are
-wrapped in torch DistributedDataParallel and every step runs a backward that produces a gradient for each of them, so
-that RCCL carries DDP's real buckets and hooks (src/utils/train.py semantics: one all-reduce per bucket, overlapped
-with the rest of the backward) next to the convolution's kernels.
+per-GPU workload on its own seeded batch (weak scaling).  The convolution itself has no exchange step, so the timed
+region (`value`) carries no collective.  The only collective of the training step this path belongs to is DDP's gradient
+all-reduce, and that is measured where it lives: at every N the line also carries `model_step` -- the REAL
+hyenadna model (hyena_dna_amd.lm.HyenaDNALM, north_star configuration 5: d_model 256, n_layer 8, d_inner 1024) on this
+rank's synthetic token batch, forward + backward + AdamW, for N > 1 wrapped in torch DistributedDataParallel exactly as
+the reference's trainer does (train.py:611-620: find_unused_parameters=False, gradient_as_bucket_view=True; RCCL carries
+the model's ~6.6 M fp32 gradients in DDP's buckets, overlapped with the backward), barrier-bracketed, max over ranks.
 
 One JSON line on stdout (rank 0).  `roofline` is computed from algorithmic bytes (SURVEY.md 8d:
 5*B*D*L*s + 12*D*L per step) over the HIP-event time of the timed region; `roofline_valu` is the second roofline of
@@ -64,54 +65,6 @@ def lds_exchange_bytes(B, D, M):
     return (5 * B + 2) * D * 2 * 2 * 8 * M
 
 
-class GradCarrier(torch.nn.Module):
-    """Parameters of a hyenadna-large-1m-shaped stack (n_layer x [HyenaOperator + Mlp d -> 4d -> d + 2 LayerNorm] + token
-    embedding; long_conv_lm.py:400-502, hg38_hyena.yaml) whose `forward` is a scalar that gives EVERY parameter a gradient
-    -- the object DistributedDataParallel wraps in the N > 1 leg, so that RCCL carries the model's real gradient buckets."""
-
-    def __init__(self, d_model=256, n_layer=8, l_max=1024, d_inner=1024, vocab=16):
-        super().__init__()
-        from hyena_dna_amd.hyena import HyenaOperator
-        nn = torch.nn
-        self.embed = nn.Embedding(vocab, d_model)
-        self.layers = nn.ModuleList()
-        for _ in range(n_layer):
-            self.layers.append(nn.ModuleDict({
-                "mixer": HyenaOperator(d_model=d_model, l_max=l_max, order=2, filter_order=64, emb_dim=5, short_filter_order=3,
-                                       modulate=True, w=10, lr=6e-4, wd=0.0, lr_pos_emb=0.0),
-                "norm1": nn.LayerNorm(d_model), "norm2": nn.LayerNorm(d_model),
-                "fc1": nn.Linear(d_model, d_inner), "fc2": nn.Linear(d_inner, d_model)}))
-        self.ln_f = nn.LayerNorm(d_model)
-
-    def forward(self, scale):
-        # every parameter gets a gradient (a view of one constant buffer) from ONE autograd node: what reaches RCCL is exactly what
-        # DDP does with a real model's gradients -- per-parameter hooks, bucket copies, bucketed all-reduce -- without ~1 000 tiny
-        # reduction kernels of a sum-of-sums on the compute stream
-        params = list(self.parameters())
-        flat = getattr(self, "_flat", None)
-        if flat is None or flat.device != params[0].device:
-            flat = self._flat = torch.ones(sum(p.numel() for p in params), device=params[0].device)
-        return _AllGrads.apply(flat[:1], flat, *params)                  # (`scale` is the constant 1: no host-to-device copy per step)
-
-
-class _AllGrads(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, scale, flat, *params):
-        ctx.flat, ctx.shapes = flat, [p.shape for p in params]
-        return scale.sum() * 0.0
-
-    @staticmethod
-    def backward(ctx, g):
-        grads, o = [], 0
-        for shp in ctx.shapes:
-            n = 1
-            for d in shp:
-                n *= d
-            grads.append(ctx.flat[o:o + n].view(shp))
-            o += n
-        return (None, None, *grads)
-
-
 def measured_traffic(L, D, B, io_dtype, save):
     """HBM bytes per step from the committed PMC run (profiles/pmc_traffic.json, made by scripts/gpu_pmc.sh) if it was
     taken on this exact configuration; None otherwise (rocprofv3 cannot run inside this process)."""
@@ -138,7 +91,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--chunk", type=int, default=0, help="channels per kernel-chain pass (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-allreduce", action="store_true")
+    ap.add_argument("--no-model", action="store_true", help="skip the secondary full-model step (for N > 1: the DDP-wrapped model)")
+    ap.add_argument("--model-layers", type=int, default=8, help="n_layer of the secondary full-model step (hyenadna-large-1m: 8)")
     ap.add_argument("--no-operator", action="store_true", help="skip the secondary whole-layer measurement")
     ap.add_argument("--no-save-spectra", action="store_true",
                     help="backward recomputes the column spectra of u and k instead of reusing the forward's")
@@ -217,7 +171,7 @@ def operator_layer(L, D, B, dtype, dev, steps=5, warmup=2):
                         f"L={L}, d={D}, B={B}, {str(dtype).split('.')[-1]} autocast; secondary figure, not `value`"}
 
 
-def model_step(L, D, B, dtype, dev, rank=0, n_layer=8, steps=3, warmup=2):
+def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=3, warmup=2, emu=False, graphed_ok=True):
     """Secondary figure (not `value`): the full hyenadna pre-training step of north_star configuration 5 on synthetic tokens --
     embedding -> n_layer x [add+LayerNorm -> HyenaOperator -> add+LayerNorm -> MLP (d -> 4d -> d, tanh-GELU)] -> LayerNorm ->
     tied LM head -> cross entropy, backward, AdamW step -- random init, autocast (hg38_hyena.yaml: d_model 256, n_layer 8,
@@ -228,32 +182,52 @@ def model_step(L, D, B, dtype, dev, rank=0, n_layer=8, steps=3, warmup=2):
                  lr_pos_emb=0.0)
     model = HyenaDNALM(d_model=D, n_layer=n_layer, d_inner=4 * D, vocab_size=12, layer=layer, resid_dropout=0.0, embed_dropout=0.1,
                        pad_vocab_size_multiple=8, fused_dropout_add_ln=True, residual_in_fp32=True).to(dev)
+    net = model
+    if world > 1:
+        # train.py:611-620 (DDPStrategy(find_unused_parameters=False, gradient_as_bucket_view=True)): identical replicas
+        # (same seed above), gradients averaged over the ranks bucket by bucket while the backward still runs
+        from torch.nn.parallel import DistributedDataParallel
+        net = DistributedDataParallel(model, device_ids=None if emu else [dev.index], find_unused_parameters=False,
+                                      gradient_as_bucket_view=True)
     opt = torch.optim.AdamW(model.parameters(), lr=6e-4, weight_decay=0.1, betas=(0.9, 0.999))
     g = torch.Generator(device=dev).manual_seed(2222 + rank)
     ids = torch.randint(7, 11, (B, L), generator=g, device=dev)           # A, C, G, T (hg38_char_tokenizer.py:59-66)
     tgt = torch.roll(ids, -1, 1)
+    dev_type = "cpu" if emu else "cuda"
 
     def step():
         opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
-            loss = model.loss(ids, tgt)
+        with torch.autocast(dev_type, dtype=dtype, enabled=dtype != torch.float32 and not emu):   # (the CPU test double runs fp32)
+            logits = net(ids)[0].logits              # through DDP's forward, so that its reducer is armed for the backward
+            loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), tgt.reshape(-1))
         loss.backward()
         opt.step()
         return loss
 
+    def sync():
+        if not emu:
+            torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        if not emu:
+            torch.cuda.synchronize(dev)
+
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    sync()
+    t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / steps
+    sync()
+    wall = time.perf_counter() - t0
+    if world > 1:                                    # the step ends when the slowest rank's does
+        tm = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        wall = tm.item()
+    ms = wall * 1e3 / steps
     loss = float(loss)                               # (also drops the last autograd graph before the capture below)
     graphed = None
-    if L <= 65536:
+    if L <= 65536 and world == 1 and graphed_ok and not emu:
         try:
             # launch-bound regime: the same step captured into one hipGraph (lm.GraphedTrainStep) and replayed
             from hyena_dna_amd.lm import GraphedTrainStep
@@ -274,10 +248,15 @@ def model_step(L, D, B, dtype, dev, rank=0, n_layer=8, steps=3, warmup=2):
                        "how": "forward + loss + backward + AdamW captured into one hipGraph (hyena_dna_amd.lm.GraphedTrainStep)"}
         except Exception as e:                                     # never lose the eager figure over the capture
             graphed = {"error": repr(e)[:200]}
-    return {"ms_per_step": ms, "value": B * L / ms * 1e3, "unit": "nt/s", "steps": steps, "loss": float(loss), "graphed": graphed,
-            "params": sum(p.numel() for p in model.parameters()), "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
-            "workload": f"full model step (fwd + bwd + AdamW): hyenadna d_model={D}, n_layer={n_layer}, d_inner={4 * D}, L={L}, B={B}, "
-                        f"{str(dtype).split('.')[-1]} autocast, synthetic tokens; secondary figure, not `value`"}
+    return {"ms_per_step": ms, "value": B * L * world / ms * 1e3, "unit": "nt/s", "n_gpus": world, "steps": steps, "loss": float(loss),
+            "graphed": graphed, "params": sum(p.numel() for p in model.parameters()),
+            "peak_mem_GB": None if emu else torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+            "parallelism": "single GPU" if world == 1 else
+                           f"dp{world}: torch DDP (find_unused_parameters=False, gradient_as_bucket_view=True), one sequence batch per "
+                           f"rank, gradients all-reduced in DDP's buckets over {'gloo (test)' if emu else 'RCCL'}",
+            "workload": f"full model step (fwd + bwd + AdamW): hyenadna d_model={D}, n_layer={n_layer}, d_inner={4 * D}, L={L}, B={B}/GPU, "
+                        f"{str(dtype).split('.')[-1]} autocast, synthetic tokens; whole-job nt/s, barrier-bracketed, max over ranks; "
+                        f"secondary figure, not `value`"}
 
 
 def main():
@@ -315,14 +294,6 @@ def main():
     bias = torch.randn(D, generator=g, device=dev)
     dout = torch.randn(B, D, L, generator=g, device=dev).to(dtype)
     chunk = args.chunk if args.chunk > 0 else None
-    ddp = None
-    if world > 1 and not args.no_allreduce:
-        from torch.nn.parallel import DistributedDataParallel
-        torch.manual_seed(1234)                                   # identical replicas, as DDP requires
-        carrier = GradCarrier(d_model=D, n_layer=8, l_max=min(L, 4096)).to(dev)
-        ddp = DistributedDataParallel(carrier, device_ids=None if args.emu else [dev.index])
-        n_grad = sum(p.numel() for p in carrier.parameters())
-
     save = not args.no_save_spectra and not args.fwd_only
 
     def step():
@@ -334,10 +305,6 @@ def main():
             out, saved = _lib.fftconv_fwd(u, k, bias, chunk=chunk), None
         if args.fwd_only:
             return out
-        if ddp is not None:
-            # the model's gradient buckets go out (DDP hooks -> RCCL on its own stream) while the convolution's backward runs
-            ddp.zero_grad(set_to_none=True)
-            ddp(1.0).backward()
         res = _lib.fftconv_bwd(dout, u, k, bias, chunk=chunk, saved=saved)
         return res
 
@@ -368,6 +335,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = tmax.item()
 
+    model_res = None
+    if not args.no_model and not args.fwd_only and (world > 1 or not args.emu):
+        # every rank takes part (DDP's collectives); a failure must not lose the contract line, nor leave the other ranks
+        # inside a collective: the exception is reported and every rank then moves on to the final barrier
+        try:
+            model_res = model_step(L, D, B, dtype, dev, rank=rank, world=world, n_layer=args.model_layers, emu=args.emu)
+        except Exception as e:
+            model_res = {"error": repr(e)[:300]}
+
     if rank == 0:
         s = 4 if dtype == torch.float32 else 2
         ms_per_step = wall * 1e3 / args.steps
@@ -390,9 +366,8 @@ def main():
                        "seq_len": L, "channels": D, "batch_per_gpu": B, "io_dtype": args.dtype,
                        "save_spectra": bool(save),
                        "chunk": int(_lib.lib().hyena_fftconv_default_chunk(B, D, L, 1)) if chunk is None else chunk,
-                       "parallelism": (f"dp{world} (batch-sharded; torch DDP over a hyenadna-large-1m-shaped parameter stack, "
-                                       f"{n_grad} fp32 gradients all-reduced per step in DDP's buckets)"
-                                       if ddp is not None else f"dp{world} (batch-sharded, no collective)")
+                       "parallelism": f"dp{world} (batch-sharded replicas: the convolution has no exchange step, so no collective in the "
+                                      f"timed region; the DDP gradient all-reduce is measured in `model_step`)"
                                       if world > 1 else "single GPU",
                        "unit_of_work": "one nucleotide through one Hyena long-conv layer call (fwd+bwd), all d channels"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -413,10 +388,7 @@ def main():
                 line["operator_layer"] = operator_layer(L, D, B, dtype, dev)
             except Exception as e:                                   # secondary: never lose the contract line over it
                 line["operator_layer"] = {"error": repr(e)[:200]}
-            try:
-                line["model_step"] = model_step(L, D, B, dtype, dev)
-            except Exception as e:
-                line["model_step"] = {"error": repr(e)[:200]}
+        line["model_step"] = model_res
         if world == 1 and not args.no_cpu_baseline and not args.emu:
             line["cpu_baseline"] = cpu_baseline(L, D, dtype)          # rank 0 at N = 1 only (other ranks would idle at the barrier)
         else:

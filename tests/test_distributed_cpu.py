@@ -1,5 +1,5 @@
-"""The N > 1 path of bench.py (batch-sharded replicas + the DDP-sized gradient all-reduce, barrier + max-over-ranks
-timing, one JSON line from rank 0) with world_size 2 on CPU: gloo backend, kernels under tests/hipemu."""
+"""The N > 1 path of bench.py (batch-sharded replicas, barrier + max-over-ranks timing, one JSON line from rank 0, the
+DDP-wrapped real model as `model_step`) with world_size 2 on CPU: gloo backend, kernels under tests/hipemu."""
 import json
 import os
 import subprocess
@@ -13,8 +13,8 @@ def _run(nproc, port):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--emu", "--seq-len", "3000", "--d-model", "4",
-           "--batch", "1", "--dtype", "bf16"]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+           "--batch", "1", "--dtype", "bf16", "--model-layers", "2"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout          # exactly one JSON line, from rank 0
@@ -29,6 +29,11 @@ def test_bench_world_size_2_gloo():
     # whole-job aggregate: 2 ranks x 1 sequence x 3000 nt per step
     assert abs(r["value"] - 2 * 3000 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
     assert r["roofline"]["bound"] == "hbm" and r["roofline"]["algorithmic_bytes_per_step"] == 5 * 4 * 3000 * 2 + 12 * 4 * 3000 + 32
+    # the N > 1 leg's real collective: HyenaDNALM under DDP (train.py:611-620), whole-job nt/s over both ranks
+    m = r["model_step"]
+    assert "error" not in m, m
+    assert m["n_gpus"] == 2 and "DDP" in m["parallelism"] and "gradient_as_bucket_view=True" in m["parallelism"]
+    assert abs(m["value"] - 2 * 3000 / (m["ms_per_step"] * 1e-3)) / m["value"] < 1e-6 and m["loss"] == m["loss"]
 
 
 def test_bench_single_process_line_shape():
@@ -53,3 +58,14 @@ def test_ddp_operator_world_size_2():
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
     assert "DDP_OK world=2" in p.stdout, p.stdout[-1500:]
+
+
+def test_ddp_lm_world_size_2():
+    """bench.py's N > 1 model: HyenaDNALM under DDP(find_unused_parameters=False, gradient_as_bucket_view=True) -- all-reduced
+    gradients of every parameter == single-process gradients over the whole batch"""
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29615", os.path.join(ROOT, "tests", "_ddp_lm_worker.py")]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    assert "DDP_LM_OK world=2" in p.stdout, p.stdout[-1500:]

@@ -1,0 +1,171 @@
+"""Operator- and model-level parity AT THE CONTRACT SHAPES on a real MI355X:
+
+* the fused mixer core (channel-major shell + long convolution, ``hyena_mixer_core_cm``) and the whole ``HyenaOperator``
+  (fused filter + ``in_proj_cm`` / ``out_proj_cm`` + shell + long conv) against the oracle ``O.hyena_operator`` /
+  its pieces at (B, L, D) = (8, 32768, 256), (2, 160000, 256), (1, 2^20, 256) -- forward, input gradient and every
+  parameter gradient; in fp32 (tight tolerance: this is the index-map check -- round 1's only hardware bug showed up at
+  D = 256 at scale and nowhere else) and under bf16 autocast (the training configuration, 16-bit tolerance);
+* ``HyenaDNALM`` against the golden minted from the reference's ``SimpleLMHeadModel`` (oracle/make_golden_lm.py,
+  simple_lm.py:26-305): logits, loss and every gradient.
+
+The oracle runs on the host cores in fp32 (tens of seconds at L = 2^20)."""
+import os
+
+import pytest
+import torch
+
+from oracle import hyena_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SHAPES = [(8, 32768, 256), (2, 160000, 256), (1, 1048576, 256)]
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _per_channel_rel(a, b, dim):
+    """worst relative L2 error over the slices along `dim` (a per-channel bound: one bad channel cannot hide in the norm)"""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    dims = [d for d in range(a.dim()) if d != dim]
+    num = (a - b).pow(2).sum(dim=dims).sqrt()
+    den = b.pow(2).sum(dim=dims).sqrt().clamp_min(1e-30)
+    return (num / den).max().item()
+
+
+def _ref_core_cm(xT, b_in, w, b, k, bias, L):
+    D = xT.shape[0] // 3
+    x = (xT + b_in[:, None, None]).permute(1, 0, 2)
+    xc = O.short_conv(x, w, b, L)
+    x0, x1, v = xc.split(D, dim=1)
+    return (O.fftconv_ref(v * x1, k, bias) * x0).permute(1, 0, 2)
+
+
+@pytest.mark.parametrize("B,L,D", SHAPES)
+def test_mixer_core_cm_at_contract_shapes_vs_oracle(gpu_lib, B, L, D):
+    """hyena.py:392-439 between the projections, bf16 tensors as under autocast; oracle in fp32 on the same bf16 inputs"""
+    from hyena_dna_amd.mixer import hyena_mixer_core_cm
+    dev = torch.device("cuda", 0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    g = torch.Generator(device=dev).manual_seed(L + D)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
+    xT = rn(3 * D, B, L).to(torch.bfloat16)
+    b_in = rn(3 * D) * 0.3
+    w = rn(3 * D, 1, 3) * 0.5
+    b = rn(3 * D) * 0.2
+    k = rn(D, L) * torch.exp(-5.0 * torch.linspace(0, 1, L, device=dev))[None] * 0.1
+    bias = rn(D)
+    dz = rn(D, B, L).to(torch.bfloat16)
+    leaves = [t.clone().requires_grad_(True) for t in (xT, b_in, w, b, k, bias)]
+    z = hyena_mixer_core_cm(*leaves, L)
+    z.backward(dz)
+    ref_leaves = [t.detach().float().cpu().requires_grad_(True) for t in (xT, b_in, w, b, k, bias)]
+    zr = _ref_core_cm(*ref_leaves, L)
+    zr.backward(dz.float().cpu())
+    # 16-bit storage of vg, y, z and of the gradients between the kernels: ~3 roundings of 2^-9 on each path
+    assert _rel(z.float(), zr) < 8e-3 and _per_channel_rel(z.float(), zr, 0) < 1.2e-2
+    assert _rel(leaves[0].grad.float(), ref_leaves[0].grad) < 1.2e-2
+    assert _per_channel_rel(leaves[0].grad.float(), ref_leaves[0].grad, 0) < 2e-2
+    for n, a, r in zip(["db_in", "dw_sc", "db_sc", "dk", "dbias"], leaves[1:], ref_leaves[1:]):
+        e = _rel(a.grad.float(), r.grad)
+        assert e < 1.2e-2, (n, e)
+    assert _per_channel_rel(leaves[4].grad.float(), ref_leaves[4].grad, 0) < 2e-2
+
+
+def _operator_and_oracle(B, L, D, seed):
+    from hyena_dna_amd.hyena import HyenaOperator
+    torch.manual_seed(seed)
+    op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
+                       lr=6e-4, wd=0.0, lr_pos_emb=0.0)
+    with torch.no_grad():                       # biases are zero-initialised by the LM; give them values here
+        for n, p in op.named_parameters():
+            if n.endswith("bias") and n != "filter_fn.bias":
+                p.normal_(0, 0.1)
+    sd = {k_: v.detach().clone() for k_, v in op.state_dict().items()}
+    g = torch.Generator().manual_seed(seed + 1)
+    u = torch.randn(B, L, D, generator=g)
+    dy = torch.randn(B, L, D, generator=g)
+    # oracle: the reference's forward restated (hyena.py:388-444), fp32 on the host, autograd for the gradients
+    leaves = {k_: v.clone().requires_grad_(v.is_floating_point() and k_ in dict(op.named_parameters())) for k_, v in sd.items()}
+    for i in (3, 5):                            # hyena.py:199: ONE freq parameter shared by the three activations
+        leaves[f"filter_fn.implicit_filter.{i}.freq"] = leaves["filter_fn.implicit_filter.1.freq"]
+    u_ref = u.clone().requires_grad_(True)
+    y_ref = O.hyena_operator(leaves, u_ref, l_max=L + 2)
+    y_ref.backward(dy)
+    ref = dict(y=y_ref.detach(), du=u_ref.grad, grads={n: leaves[n].grad for n, _ in op.named_parameters()})
+    return op, u, dy, ref
+
+
+@pytest.mark.parametrize("B,L,D", SHAPES)
+def test_operator_at_contract_shapes_vs_oracle(gpu_lib, B, L, D):
+    """The whole HyenaOperator.forward (hyena.py:388-444) on the fused path, fp32 and bf16 autocast, vs the oracle."""
+    dev = torch.device("cuda", 0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    op, u, dy, ref = _operator_and_oracle(B, L, D, seed=L // 7 + B)
+    op = op.to(dev)
+    assert op._fused_ok()
+    for mode in ("fp32", "bf16"):
+        op.zero_grad(set_to_none=True)
+        ud = u.to(dev).requires_grad_(True)
+        if mode == "fp32":
+            y = op(ud)
+            y.backward(dy.to(dev))
+            # fp32 everywhere (library GEMMs in fp32, fused filter, exact-fp32 transforms): rounding noise only.  The
+            # filter's sin(10 x) chain amplifies one fp32 rounding to ~1e-6, the GEMMs sum 256-768 terms.
+            ty, tg = 2e-5, 2e-4
+        else:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = op(ud.to(torch.bfloat16))
+            y.float().backward(dy.to(dev))
+            ty, tg = 1.5e-2, 3e-2
+        assert y.shape == ref["y"].shape
+        e = _rel(y.float(), ref["y"])
+        assert e < ty, (mode, "y", e)
+        assert _per_channel_rel(y.float(), ref["y"], 2) < 3 * ty, (mode, "y per channel")
+        e = _rel(ud.grad.float(), ref["du"])
+        assert e < tg, (mode, "du", e)
+        for n, p in op.named_parameters():
+            r = ref["grads"][n]
+            if r is None:
+                assert p.grad is None or torch.count_nonzero(p.grad) == 0, n
+                continue
+            e = _rel(p.grad.float(), r)
+            assert e < tg, (mode, n, e)
+        del y, ud
+        torch.cuda.empty_cache()
+
+
+def test_lm_vs_reference_simple_lm_golden(gpu_lib):
+    """HyenaDNALM (2 layers, d_model 128, L = 4096) vs SimpleLMHeadModel's logits, loss and every gradient (the golden is the
+    reference's own model on the CPU in fp32)."""
+    from hyena_dna_amd.lm import HyenaDNALM
+    dev = torch.device("cuda", 0)
+    c = torch.load(os.path.join(GOLDEN, "lm_simple_d128_l4096.pt"), weights_only=False)
+    for fused_ln in (True, False):
+        model = HyenaDNALM(layer=dict(c["layer"]), fused_dropout_add_ln=fused_ln, **c["cfg"])
+        model.load_state_dict(c["state_dict"], strict=True)
+        model = model.to(dev)
+        ids, tgt = c["ids"].to(dev), c["targets"].to(dev)
+        logits = model(ids)[0].logits
+        loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), tgt.reshape(-1))
+        loss.backward()
+        assert _rel(logits, c["logits"]) < 2e-5
+        assert abs(loss.item() - c["loss"]) < 1e-5 * abs(c["loss"]) + 1e-6
+        grads = {n: p.grad for n, p in model.named_parameters()}
+        assert set(grads) == set(c["grads"])
+        for n, gref in c["grads"].items():
+            e = _rel(grads[n], gref)
+            assert e < 5e-4, (fused_ln, n, e)
+    # the training configuration: bf16 autocast, same weights -- 16-bit tolerance on the logits and the loss
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = model(ids)[0].logits
+    loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), tgt.reshape(-1))
+    loss.backward()
+    assert _rel(logits.float(), c["logits"]) < 3e-2 and abs(loss.item() - c["loss"]) < 2e-2 * abs(c["loss"])
+    for n, p in model.named_parameters():
+        e = _rel(p.grad.float(), c["grads"][n])
+        assert e < 0.1, (n, e)
