@@ -401,7 +401,8 @@ class GraphedTrainStep:
     ``hyena_dna_amd/__init__.py`` for the ROCm runtime setting whole-step replays need (applied at import).
     """
 
-    def __init__(self, model, optimizer, input_ids, targets, autocast_dtype=torch.bfloat16, warmup=3, ignore_index=-100):
+    def __init__(self, model, optimizer, input_ids, targets, autocast_dtype=torch.bfloat16, warmup=3, ignore_index=-100,
+                 clip_grad_norm=0.0):
         if not input_ids.is_cuda:
             raise RuntimeError("GraphedTrainStep captures a hipGraph: model and batch must live on a ROCm device")
         for group in optimizer.param_groups:
@@ -416,6 +417,7 @@ class GraphedTrainStep:
         self.model, self.optimizer = model, optimizer
         self.ids, self.targets = input_ids.clone(), targets.clone()
         self.autocast_dtype, self.ignore_index = autocast_dtype, ignore_index
+        self.clip_grad_norm = float(clip_grad_norm or 0.0)           # trainer.gradient_clip_val (hg38_hyena.yaml:41), inside the graph
         # Gradient-accumulation nodes remember the stream they were created on.  Nodes left over from eager steps on another
         # stream (kept alive by a retained loss tensor, or by not-yet-collected reference cycles of autograd contexts) would run
         # OUTSIDE the capture: drop them, and warm up on the very stream the capture uses.
@@ -442,6 +444,8 @@ class GraphedTrainStep:
         with torch.autocast("cuda", dtype=self.autocast_dtype if enabled else torch.bfloat16, enabled=enabled):
             loss = self.model.loss(self.ids, self.targets, ignore_index=self.ignore_index)
         loss.backward()
+        if self.clip_grad_norm > 0:                                   # device-side norm and scale: no host sync, capturable
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad_norm)
         return loss
 
     def __call__(self, input_ids=None, targets=None):
