@@ -49,14 +49,28 @@ __global__ void __launch_bounds__(THREADS) barrier_only(int iters, unsigned* fla
 }
 
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_sc1(const float4* p) {       // 16-byte load that bypasses the L1 (served by the XCD's L2)
+// 16-byte loads with an explicit cache policy.  MODE 0: sc1 (agent scope; round 2: returned stale lines), 3: sc0 sc1 (system scope),
+// 4: nt, 5: sc0 sc1 nt -- round 3's one follow-up: can the consumer skip the L1 invalidate with a load that
+// cannot hit the L1?
+template <int MODE>
+__device__ __forceinline__ float4 ld_pol(const float4* p) {
     u4 r;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+    if (MODE == 0) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+    else if (MODE == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(r) : "v"(p) : "memory");
+    else if (MODE == 4) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(r) : "v"(p) : "memory");
     return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+// producer side of the same question: stores at agent scope (PST = 1: `sc1`) instead of plain write-through stores
+template <int PST>
+__device__ __forceinline__ void st_pol(float4* p, float v) {
+    if (PST == 0) { *p = make_float4(v, v, v, v); return; }
+    u4 d; d.x = d.y = d.z = d.w = __float_as_uint(v);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(d) : "memory");
 }
 
 // slab of one XCD: rows x 512 float4 (8 KB rows).  Workgroup r owns float4 columns [8 r, 8 r + 8) (128 bytes of a row).
-template <int INV>
+template <int INV, int PST>
 __global__ void __launch_bounds__(THREADS) exchange(float4* slabs, size_t slab_f4, int rows, int iters, unsigned* flags, int* err,
                                                     float* sink) {
     const int bx = blockIdx.x;
@@ -69,12 +83,12 @@ __global__ void __launch_bounds__(THREADS) exchange(float4* slabs, size_t slab_f
     for (int it = 0; it < iters; ++it) {
         for (int row = t >> 3; row < rows; row += THREADS / 8) {
             const float v = (float)(it + row + r);
-            slab[(size_t)row * 512 + 8 * r + (t & 7)] = make_float4(v, v, v, v);
+            st_pol<PST>(slab + (size_t)row * 512 + 8 * r + (t & 7), v);
         }
-        if (!flag_barrier<1, INV>(fl, r, ++phase, err)) return;
+        if (!flag_barrier<1, (INV == 1 ? 1 : 0)>(fl, r, ++phase, err)) return;
         for (int row = r; row < rows; row += WG_PER_XCD) {
             float4 a, b;
-            if (INV == 0) { a = ld_sc1(slab + (size_t)row * 512 + t); b = ld_sc1(slab + (size_t)row * 512 + 256 + t); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (INV != 1) { a = ld_pol<INV>(slab + (size_t)row * 512 + t); b = ld_pol<INV>(slab + (size_t)row * 512 + 256 + t); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             else { a = slab[(size_t)row * 512 + t]; b = slab[(size_t)row * 512 + 256 + t]; }
             acc += a.x + b.x - 2.f * (float)(it + row) - (float)(t >> 3) - (float)((256 + t) >> 3);
         }
@@ -105,8 +119,13 @@ int main() {
         RUN_BAR(0, 0, "busy poll, no invalidate")
     }
     const int row_counts[] = {128, 256, 384, 512, 1024, 2048, 16384};    // x 8 KB: 1, 2, 3, 4, 8, 16, 128 MB per XCD
-    for (int inv = 1; inv >= 0; --inv) {
-    printf("consumer: %s\n%12s %14s %14s\n", inv ? "buffer_inv sc1 by wavefront 0 + plain loads" : "no invalidate, sc1 loads", "MB per XCD", "exchange GB/s", "us per phase");
+    const int modes[][2] = {{1, 0}, {0, 0}, {3, 0}, {4, 0}, {5, 0}, {0, 1}, {3, 1}};
+    const char* names[] = {"?", "buffer_inv sc1 by wavefront 0 + plain loads", "", "no invalidate, sc0 sc1 loads", "no invalidate, nt loads",
+                           "no invalidate, sc0 sc1 nt loads"};
+    for (const auto& md : modes) {
+    const int inv = md[0], pst = md[1];
+    printf("consumer: %s; producer: %s stores\n%12s %14s %14s\n", inv == 0 ? "no invalidate, sc1 loads" : names[inv], pst ? "sc1" : "plain",
+           "MB per XCD", "exchange GB/s", "us per phase");
     for (int rows : row_counts) {
         const size_t slab_f4 = (size_t)rows * 512;
         float4* slabs;
@@ -119,8 +138,9 @@ int main() {
             hipMemset(flags, 0, NXCD * WG_PER_XCD * sizeof(unsigned));
             hipMemset(err, 0, sizeof(int));
             hipEventRecord(e0);
-            if (inv) exchange<1><<<grid, THREADS>>>(slabs, slab_f4, rows, iters, flags, err, sink);
-            else exchange<0><<<grid, THREADS>>>(slabs, slab_f4, rows, iters, flags, err, sink);
+#define XRUN(I, P) exchange<I, P><<<grid, THREADS>>>(slabs, slab_f4, rows, iters, flags, err, sink)
+            if (inv == 1) XRUN(1, 0); else if (inv == 0 && !pst) XRUN(0, 0); else if (inv == 3 && !pst) XRUN(3, 0);
+            else if (inv == 4) XRUN(4, 0); else if (inv == 5) XRUN(5, 0); else if (inv == 0) XRUN(0, 1); else XRUN(3, 1);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
