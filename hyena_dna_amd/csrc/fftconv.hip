@@ -316,6 +316,8 @@ static int fwd_impl(const void* u, const float* k, const float* bias, void* out,
         if ((size_t)D * p.M * sizeof(c32) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;       // 32-bit buffer offsets into H
         if (workspace_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
         if (saved != nullptr && saved_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
+        if (oc::small_ok(p.R, B, D, L, dtype))          // one launch: the filter transform rides in the convolution kernel
+            return oc::launch_small_fwd(p.R, u, out, k, bias, saved, d_tables, B, D, L, dtype, stream);
         void* H = saved ? saved : workspace;
         int st = oc::launch_spec(p.R, k, bias, H, d_tables, D, L, stream);
         if (st) return st;
@@ -379,6 +381,8 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
         if (saved != nullptr && saved_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
         void* partials = reinterpret_cast<char*>(workspace) + oc::spectrum_bytes(D, p.R);
         int st;
+        if (saved != nullptr && (du != nullptr || dk != nullptr) && oc::small_ok(p.R, B, D, L, dtype))
+            return oc::launch_small_bwd(p.R, dout, u, du, dk, dbias, saved, d_tables, B, D, L, dtype, stream);   // du and dk from one launch
         if (du != nullptr) {
             const void* H = saved;
             if (H == nullptr) {

@@ -6,6 +6,7 @@
 #include "../../include/hyena_fftconv.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace hyena {
 namespace oc {
@@ -123,6 +124,58 @@ static int dk_rh(const DkArgs& a, void* stream) {
 template <int R, int NP>
 static int dk_r(const DkArgs& a, void* stream) {
     return a.dtype == DT_F32 ? dk_rh<R, NP, false>(a, stream) : dk_rh<R, NP, true>(a, stream);
+}
+
+// ---- short rows, small batch: one launch per direction (small_fwd_kernel / small_bwd_kernel) --------------------------------
+// HYENA_FFTCONV_SMALL=0 keeps the general kernels reachable at these sizes (A/B, tests).
+static bool small_enabled() {
+    const char* e = std::getenv("HYENA_FFTCONV_SMALL");
+    return !(e != nullptr && e[0] == '0');
+}
+bool small_ok(int R, int B, int D, int L, int dtype) {
+    if (R > 2 || !small_enabled()) return false;
+    const int G = 256 / (32 * R);
+    // every row group takes at most two rows: beyond that the general kernels (one row per workgroup, the batch of a channel
+    // sharing an XCD's L2) fill the chip better than D workgroups would
+    if (B > 2 * G) return false;
+    const size_t es = dtype == DT_F32 ? 4 : 2;
+    return (size_t)B * D * L * es < ((size_t)1 << 32) && (size_t)D * L * 4 < ((size_t)1 << 32);       // 32-bit buffer offsets
+}
+template <int R, bool HALF>
+static int small_fwd_rh(const SmallFwdArgs& a, void* stream) {
+    typedef SmallCfg<R> S;
+    static thread_local int done = -1;
+    hy_allow_lds(small_fwd_kernel<R, HALF>, S::LDS_FWD, &done);
+    HY_LAUNCH((small_fwd_kernel<R, HALF>), dim3(a.D, 1), dim3(S::WGT), S::LDS_FWD, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+template <int R, bool HALF>
+static int small_bwd_rh(const SmallBwdArgs& a, void* stream) {
+    typedef SmallCfg<R> S;
+    static thread_local int done = -1;
+    hy_allow_lds(small_bwd_kernel<R, HALF>, S::LDS_BWD, &done);
+    HY_LAUNCH((small_bwd_kernel<R, HALF>), dim3(a.D), dim3(S::WGT), S::LDS_BWD, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+int launch_small_fwd(int R, const void* x, void* out, const float* k, const float* bias, void* Hout, const void* tab, int B, int D, int L,
+                     int dtype, void* stream) {
+    SmallFwdArgs a;
+    a.x = x; a.out = out; a.k = k; a.bias = bias; a.Hout = reinterpret_cast<c32*>(Hout); a.tab = reinterpret_cast<const c32*>(tab);
+    a.B = B; a.D = D; a.L = L; a.dtype = dtype;
+    const bool half = dtype != DT_F32;
+    if (R == 1) return half ? small_fwd_rh<1, true>(a, stream) : small_fwd_rh<1, false>(a, stream);
+    if (R == 2) return half ? small_fwd_rh<2, true>(a, stream) : small_fwd_rh<2, false>(a, stream);
+    return HYENA_ERR_UNSUPPORTED_L;
+}
+int launch_small_bwd(int R, const void* dout, const void* u, void* du, float* dk, float* dbias, const void* H, const void* tab, int B, int D,
+                     int L, int dtype, void* stream) {
+    SmallBwdArgs a;
+    a.dout = dout; a.u = u; a.du = du; a.dk = dk; a.dbias = dbias; a.H = reinterpret_cast<const c32*>(H);
+    a.tab = reinterpret_cast<const c32*>(tab); a.B = B; a.D = D; a.L = L; a.dtype = dtype;
+    const bool half = dtype != DT_F32;
+    if (R == 1) return half ? small_bwd_rh<1, true>(a, stream) : small_bwd_rh<1, false>(a, stream);
+    if (R == 2) return half ? small_bwd_rh<2, true>(a, stream) : small_bwd_rh<2, false>(a, stream);
+    return HYENA_ERR_UNSUPPORTED_L;
 }
 
 #define HY_OC_SWITCH(R, call)                 \

@@ -26,5 +26,13 @@ int dk_slices(int R, int B, int D, int* nb_out);
 int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, void* partials, const void* tab, int B, int D, int L,
               int dtype, void* stream);
 
+// Short rows with a small batch (R <= 2, B <= 2 row groups' worth): one launch per direction.  small_ok says whether the pair of
+// fused kernels serves this call; launch_small_bwd needs the forward's filter spectrum H (the saved-spectrum buffer).
+bool small_ok(int R, int B, int D, int L, int dtype);
+int launch_small_fwd(int R, const void* x, void* out, const float* k, const float* bias, void* Hout, const void* tab, int B, int D, int L,
+                     int dtype, void* stream);
+int launch_small_bwd(int R, const void* dout, const void* u, void* du, float* dk, float* dbias, const void* H, const void* tab, int B, int D,
+                     int L, int dtype, void* stream);
+
 }  // namespace oc
 }  // namespace hyena

@@ -140,3 +140,37 @@ def test_dk_batch_slices_cover_the_batch_exactly():
                 assert 1 <= S <= steps and (S == 1 if D >= 256 else S * D < 2 * 256 + D)
                 if D < 256 and steps >= 2:
                     assert S >= 2                        # the case this exists for
+
+
+# ---- short rows, small batch: one launch per direction (small_fwd_kernel / small_bwd_kernel) ------------------------------
+SMALL_CASES = [(8, 5, 1024), (3, 3, 1000), (16, 2, 700), (1, 2, 37), (5, 3, 2048), (8, 2, 1500), (2, 9, 1), (7, 1, 1025)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,D,L", SMALL_CASES)
+def test_small_fused_pair_vs_oracle(emu_backend, monkeypatch, B, D, L, dtype):
+    """The fused forward keeps H for the fused backward (saved spectra); results vs the oracle, vs the general kernels of the
+    same library (HYENA_FFTCONV_SMALL=0: same transform, another summation order over the batch), options bitwise."""
+    u, k, bias, dout = _inputs(B, D, L, dtype, seed=3 * L + B)
+    out, saved = emu_backend.fftconv_fwd(u, k, bias, save=True)
+    du, dk, dbias = emu_backend.fftconv_bwd(dout, u, k, bias, saved=saved)
+    assert torch.equal(out, emu_backend.fftconv_fwd(u, k, bias))                 # with or without leaving H behind
+    monkeypatch.setenv("HYENA_FFTCONV_SMALL", "0")
+    g_out, g_saved = emu_backend.fftconv_fwd(u, k, bias, save=True)
+    g_du, g_dk, g_db = emu_backend.fftconv_bwd(dout, u, k, bias, saved=g_saved)
+    monkeypatch.delenv("HYENA_FFTCONV_SMALL")
+    assert torch.equal(out, g_out) and torch.equal(du, g_du)                       # row by row the same arithmetic
+    assert torch.equal(saved.view(torch.float32), g_saved.view(torch.float32))
+    assert _rel(dk, g_dk) < 1e-6 and (dbias - g_db).abs().max() < 1e-5 * (B * L) ** 0.5
+    r_out, r_du, r_dk, r_db = _oracle(u.float(), k, bias, dout.float())
+    tol = 2e-6 if dtype == torch.float32 else (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)
+    assert _rel(out.float(), r_out) < tol and _rel(du.float(), r_du) < tol and _rel(dk, r_dk) < 2e-6
+    db64 = (dout.double() * u.double()).sum(dim=(0, 2))
+    assert (dbias.double() - db64).abs().max() < 1e-6 * (B * L) ** 0.5 + 1e-6
+    # du only / dk only: the same bits as the combined launch; and run to run
+    du2, dk2, db2 = emu_backend.fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=False, saved=saved)
+    assert dk2 is None and db2 is None and torch.equal(du2, du)
+    du3, dk3, db3 = emu_backend.fftconv_bwd(dout, u, k, bias, need_du=False, need_dk=True, saved=saved)
+    assert du3 is None and torch.equal(dk3, dk) and torch.equal(db3, dbias)
+    du4, dk4, db4 = emu_backend.fftconv_bwd(dout, u, k, bias, saved=saved)
+    assert torch.equal(du4, du) and torch.equal(dk4, dk) and torch.equal(db4, dbias)
