@@ -148,6 +148,12 @@ def lib():
         L.hyena_cm_pre_bwd.restype = c_int
         L.hyena_cm_pre_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int, c_int, c_int, c_int, c_int, c_void_p]
+        # input projection on the matrix cores + front of the shell (include/hyena_proj.h)
+        L.hyena_proj_supported.restype = c_int
+        L.hyena_proj_supported.argtypes = [c_int, c_int, c_int, c_int]
+        L.hyena_inproj_pre_fwd.restype = c_int
+        L.hyena_inproj_pre_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_int, c_int, c_int, c_void_p]
         # fused implicit filter (include/hyena_filter.h)
         L.hyena_filter_supported.restype = c_int
         L.hyena_filter_supported.argtypes = [c_int, c_int, c_int, c_int]
@@ -435,6 +441,26 @@ def cm_pre_bwd(dvg, xT, bin_, w, b, dxT, part):
         check(lib().hyena_cm_pre_bwd(dvg.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
                                      dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D, dtype_code(xT.dtype),
                                      _backend.stream(xT.device)))
+
+
+# ---- input projection on the matrix cores with the front of the shell in its epilogue (include/hyena_proj.h) --------------------
+def proj_supported(B, Lx, D, dtype):
+    code = _DTYPES.get(dtype)
+    return code is not None and bool(lib().hyena_proj_supported(int(B), int(Lx), int(D), code))
+
+
+def inproj_pre_fwd(u, W, bin_, w, b, L):
+    """u (B, Lx, D) 16-bit, W (3D, D) same type, bin_ (3D,) fp32 or None, w (3D, 3) fp32, b (3D,) fp32
+    -> xT (3D, B, Lx) = W u^T (no bias), vg (B, D, L) = short_conv(xT + bin_)[v] * short_conv(xT + bin_)[x1]."""
+    _require_gpu(u, "u")
+    B, Lx, D = u.shape
+    assert W.shape == (3 * D, D) and W.dtype == u.dtype and u.is_contiguous() and W.is_contiguous()
+    xT = torch.empty((3 * D, B, Lx), dtype=u.dtype, device=u.device)
+    vg = torch.empty((B, D, L), dtype=u.dtype, device=u.device)
+    with _backend.guard(u.device):
+        check(lib().hyena_inproj_pre_fwd(u.data_ptr(), W.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                         xT.data_ptr(), vg.data_ptr(), B, Lx, int(L), D, dtype_code(u.dtype), _backend.stream(u.device)))
+    return xT, vg
 
 
 # ---- fused implicit filter (include/hyena_filter.h) ---------------------------------------------------------------------

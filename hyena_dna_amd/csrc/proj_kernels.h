@@ -1,0 +1,303 @@
+// proj_kernels.h -- the operator's input projection on the matrix cores, with the front of the element-wise shell in its epilogue.
+//
+// Reference: src/models/sequence/hyena.py:391-404,420 (order 2):
+//     u  = in_proj(u)                       (B, L, D) x (3D, D)^T                      hyena.py:391      nn.Linear(D, 3D)
+//     u  = rearrange(u, 'b l d -> b d l');  uc = short_filter(u)[..., :l_filter]       hyena.py:392-394  Conv1d(3D, 3D, 3, groups = 3D, padding = 2)
+//     *x, v = uc.split(D, dim = 1);  v = v * x[1]                                      hyena.py:404,420
+// Until round 3 this was a library GEMM writing xT (3D, B, L) followed by cm_pre_fwd (cm_kernels.h) reading two thirds of it
+// back.  Here ONE kernel produces both tensors the rest of the layer needs:
+//     xT [c, b, l] = sum_k W[c, k] u[b, l, k]                    (3D, B, Lx), 16-bit, WITHOUT the bias (as before: the shell
+//                                                                 kernels add it on load and return its gradient)
+//     vg [b, d, l] = xc[2D + d, b, l] xc[D + d, b, l],  l < Lc   (B, D, Lc),  xc = short conv of (xT + b_in) as in cm_kernels.h
+//
+// Shape of the GEMM: K = D in {128, 256}, 3D output rows, B L ~ 10^6 columns: 200 flop per byte moved -- HBM-bound on an MI355X
+// (2.5 PFLOP/s bf16 against 8 TB/s) even at a fraction of the MFMA peak.  So the design is WEIGHTS-STATIONARY: a wavefront owns 32
+// channels of each of the three groups (x0, x1, v) and keeps their 96 weight rows as MFMA A-fragments in registers for the
+// whole kernel (96 x K 16-bit values = 192 VGPRs at K = 256; a wavefront alone on its SIMD has 512); the four wavefronts of a
+// workgroup (128 channels) walk the SAME run of positions, 64 at a time: the u tile (64 x K, contiguous in memory) is staged
+// once through LDS, every wavefront reads its B-fragments from it (one 16-byte ds_read per 3 v_mfma_f32_32x32x16 = 96 MFMA
+// cycles), and the accumulators (position on lane, channel on register) are rounded to the storage type, parked in a
+// wavefront-private LDS tile [channel][position] and leave from there as 16-byte row pieces -- xT as is, vg after the 3-tap
+// window + gate, whose two-position halo is the tail of the previous tile (a workgroup's first tile is preceded by one
+// warm-up tile whose results are dropped).  The short-conv arithmetic is the one of cm_kernels.h::cm_sc on the ROUNDED xT
+// values, so vg is bit-identical to what cm_pre_fwd computes from the stored xT (and the backward, which recomputes the
+// window from xT, sees the same numbers).
+//
+// Compiled by hipcc for gfx950 (product) and, with -DHIPEMU, by g++ against tests/hipemu (tests only).
+#pragma once
+#define HY_HELPERS_ONLY
+#include "fftconv_kernels.h"
+
+namespace hyena {
+namespace pj {
+
+enum { PJ_THREADS = 256, PJ_WAVES = 4, PJ_CB = 32 /* channels per wavefront and group */, PJ_NT = 64 /* positions per tile */,
+       PJ_EW = PJ_NT + 8 /* row of the epilogue tile: 8 halo slots (the last two used) + the tile */ };
+
+#ifdef HIPEMU
+#define HY_WAVE_SYNC_PJ() hipemu::yield(2)
+#else
+// LDS operations of one wavefront execute in order: lanes of a wavefront exchange data through LDS without a workgroup barrier;
+// this only stops the compiler from moving LDS accesses across the exchange point.
+#define HY_WAVE_SYNC_PJ() __builtin_amdgcn_wave_barrier()
+#endif
+
+struct Frag { uint32_t w[4]; };                       // eight 16-bit values: one A or B operand of v_mfma_f32_32x32x16
+#ifdef HIPEMU
+typedef hipemu::floatx16 acc_t;
+template <int DT>
+__device__ __forceinline__ acc_t mfma(const Frag& a, const Frag& b, acc_t c) {
+    hipemu::u32x4 x, y;
+    __builtin_memcpy(x.w, a.w, 16);
+    __builtin_memcpy(y.w, b.w, 16);
+    return hipemu::mfma_f32_32x32x16_h<DT == DT_BF16>(x, y, c);
+}
+#else
+typedef float acc_t __attribute__((ext_vector_type(16)));
+template <int DT>
+__device__ __forceinline__ acc_t mfma(const Frag& a, const Frag& b, acc_t c) {
+    if constexpr (DT == DT_BF16) {
+        typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+    } else {
+        typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+    }
+}
+#endif
+
+// 16-byte moves.  Global rows start at any even byte offset (odd B L): the vector type carries 2-byte alignment, gfx950 global
+// memory takes unaligned dwordx4 accesses.
+#ifdef HIPEMU
+__device__ __forceinline__ Frag ld16(const void* p) { Frag f; __builtin_memcpy(f.w, p, 16); return f; }
+__device__ __forceinline__ void st16(void* p, const Frag& f) { __builtin_memcpy(p, f.w, 16); }
+__device__ __forceinline__ Frag lds_ld16(const HY_LDS char* p) { return ld16(p); }
+__device__ __forceinline__ void lds_st16(HY_LDS char* p, const Frag& f) { st16(p, f); }
+#else
+typedef unsigned pj_vec16 __attribute__((ext_vector_type(4), aligned(2)));
+typedef unsigned pj_lvec16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Frag ld16(const void* p) { return __builtin_bit_cast(Frag, *reinterpret_cast<const pj_vec16*>(p)); }
+__device__ __forceinline__ void st16(void* p, const Frag& f) {          // outputs are written once, read by a later launch: non-temporal
+    __builtin_nontemporal_store(__builtin_bit_cast(pj_vec16, f), reinterpret_cast<pj_vec16*>(p));
+}
+__device__ __forceinline__ Frag lds_ld16(const HY_LDS char* p) { return __builtin_bit_cast(Frag, *reinterpret_cast<const HY_LDS pj_lvec16*>(p)); }
+__device__ __forceinline__ void lds_st16(HY_LDS char* p, const Frag& f) { *reinterpret_cast<HY_LDS pj_lvec16*>(p) = __builtin_bit_cast(pj_lvec16, f); }
+#endif
+
+template <int K> struct PjCfg {
+    static_assert(K == 128 || K == 256, "d_model of the HyenaDNA models");
+    static constexpr int KS = K / 16;                         // MFMA steps over the contraction
+    static constexpr int UROW = (K + 8) * 2;                  // bytes per staged u row: +16 so that the 16-byte fragment reads of 8 neighbouring lanes hit 32 different banks
+    static constexpr int UBUF = PJ_NT * UROW;                 // one staging buffer
+    static constexpr int CH = PJ_NT * K * 2 / 16 / PJ_THREADS;   // 16-byte chunks of a u tile per thread (8 / 4)
+    static constexpr int EROW = PJ_EW * 2;                    // bytes per row of the epilogue tile (144: 16-byte aligned, 8 lanes x 36 dwords conflict-free)
+    static constexpr int EBUF = 3 * PJ_CB * EROW;             // per wavefront: [group][channel][PJ_EW]
+    static constexpr int TAPS = 2 * PJ_CB * 5 * 4;            // per wavefront: (w0, w1, w2, b_sc, b_in) of its x1 and v channels
+    static constexpr size_t LDS = 2 * (size_t)UBUF + PJ_WAVES * ((size_t)EBUF + TAPS);
+};
+
+struct InProjArgs {
+    const void* u;       // (B, Lx, K) 16-bit
+    const void* W;       // (3D, K) 16-bit, K = D
+    const float* bin;    // (3D,) in_proj bias or null
+    const float* w;      // (3D, 3) short-filter taps
+    const float* b;      // (3D,) short-filter bias
+    void* xT;            // (3D, B, Lx)
+    void* vg;            // (B, D, Lc)
+    int B, Lx, Lc, D;
+    int tiles;           // ceil(B Lx / 64)
+    int tiles_per_wg;
+};
+
+// rows of the C/D operand: register r of a lane in half-wave hb holds channel (r & 3) + 8 (r >> 2) + 4 hb of the 32
+__device__ __forceinline__ int pj_row(int r, int hb) { return (r & 3) + 8 * (r >> 2) + 4 * hb; }
+
+template <int K, int DT>
+__global__ void __launch_bounds__(PJ_THREADS) inproj_pre_fwd_kernel(InProjArgs a) {
+    typedef PjCfg<K> C;
+    typedef typename Elem<DT>::type elem_t;
+    static_assert(sizeof(elem_t) == 2, "16-bit element types only");
+    HY_SMEM(smem);
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hb = lane >> 5;
+    const int D = a.D;
+    const unsigned P = (unsigned)a.B * (unsigned)a.Lx;                       // flattened positions (< 2^31, checked by the host)
+    // workgroup -> (channel group of 128, run of tiles).  Workgroups are dealt to the 8 XCDs round-robin; the channel groups of
+    // one run of positions get slots of ONE XCD, so its L2 serves the second read of the u tiles.
+    const int ncg = (D + PJ_WAVES * PJ_CB - 1) / (PJ_WAVES * PJ_CB);
+    int cg, run;
+    {
+        const int wg = blockIdx.x, xcd = wg & 7, seq = wg >> 3;
+        cg = seq % ncg;
+        run = (seq / ncg) * 8 + xcd;
+    }
+    const int t_begin = run * a.tiles_per_wg;
+    if (t_begin >= a.tiles) return;
+    const int t_end = (t_begin + a.tiles_per_wg < a.tiles) ? t_begin + a.tiles_per_wg : a.tiles;
+    const int d0 = cg * PJ_WAVES * PJ_CB + wave * PJ_CB;                   // first channel of this wavefront
+    const bool wave_live = d0 < D;                                          // (D = 128 + 32 m: the last group's idle wavefronts only help staging)
+
+    HY_LDS char* const ubuf = HY_LDS_CAST(char, smem);
+    HY_LDS char* const ebuf = HY_LDS_CAST(char, smem) + 2 * C::UBUF + wave * C::EBUF;
+    HY_LDS float* const taps = HY_LDS_CAST(float, smem + 2 * C::UBUF + PJ_WAVES * C::EBUF + wave * C::TAPS);
+
+    // stationary operand: the 96 weight rows of this wavefront, as A fragments (row = channel j of group g, k = 16 ks + 8 hb ...)
+    Frag wf[3][C::KS];
+    if (wave_live) {
+        HY_UNROLL
+        for (int g = 0; g < 3; ++g) {
+            const char* row = reinterpret_cast<const char*>(a.W) + ((size_t)(g * D + d0 + j) * K + 8 * hb) * 2;
+            HY_UNROLL
+            for (int ks = 0; ks < C::KS; ++ks) wf[g][ks] = ld16(row + ks * 32);
+        }
+        // short-filter taps of the x1 and v channels, (w0, w1, w2, b_sc, b_in) per channel
+        if (lane < 2 * PJ_CB) {
+            const int c = (1 + (lane >> 5)) * D + d0 + (lane & 31);
+            HY_LDS float* t = taps + lane * 5;
+            t[0] = a.w[c * 3]; t[1] = a.w[c * 3 + 1]; t[2] = a.w[c * 3 + 2]; t[3] = a.b[c];
+            t[4] = a.bin != nullptr ? a.bin[c] : 0.f;
+        }
+    }
+
+    const char* const ubase = reinterpret_cast<const char*>(a.u);
+    Frag st[C::CH];
+    auto prefetch = [&](int t) {                     // the u tile of positions [64 t, 64 t + 64): one contiguous block of 64 K 2 bytes
+        HY_UNROLL
+        for (int c = 0; c < C::CH; ++c) {
+            const int q = tid + PJ_THREADS * c;      // 16-byte chunk within the tile
+            const unsigned p = (unsigned)t * PJ_NT + (unsigned)(q / (K / 8));
+            Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+            st[c] = p < P ? ld16(ubase + ((size_t)t * PJ_NT * K * 2 + (size_t)q * 16)) : z;
+        }
+    };
+    auto stage = [&](int buf) {
+        HY_UNROLL
+        for (int c = 0; c < C::CH; ++c) {
+            const int q = tid + PJ_THREADS * c;
+            lds_st16(ubuf + buf * C::UBUF + (q / (K / 8)) * C::UROW + (q % (K / 8)) * 16, st[c]);
+        }
+    };
+
+    const int t_first = t_begin > 0 ? t_begin - 1 : t_begin;                // warm-up tile: provides the halo of tile t_begin
+    prefetch(t_first);
+    int cur = 0;
+    for (int t = t_first; t < t_end; ++t) {
+        stage(cur);
+        __syncthreads();
+        if (t + 1 < t_end) prefetch(t + 1);
+        if (wave_live) {
+            acc_t acc[3][2];
+            HY_UNROLL
+            for (int g = 0; g < 3; ++g) {
+                HY_UNROLL
+                for (int nt = 0; nt < 2; ++nt) {
+                    HY_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
+                }
+            }
+            const HY_LDS char* const ub = ubuf + cur * C::UBUF + j * C::UROW + hb * 16;
+            HY_UNROLL
+            for (int ks = 0; ks < C::KS; ++ks) {
+                HY_UNROLL
+                for (int nt = 0; nt < 2; ++nt) {
+                    const Frag bf = lds_ld16(ub + nt * 32 * C::UROW + ks * 32);
+                    HY_UNROLL
+                    for (int g = 0; g < 3; ++g) acc[g][nt] = mfma<DT>(wf[g][ks], bf, acc[g][nt]);
+                }
+            }
+            // ---- epilogue, wavefront-private ---------------------------------------------------------------------------
+            // (1) the previous tile's last two positions become this tile's halo (slots 6, 7: one dword per row)
+            if (lane < 48) {
+                HY_UNROLL
+                for (int h = 0; h < 2; ++h) {
+                    HY_LDS uint32_t* row = reinterpret_cast<HY_LDS uint32_t*>(ebuf + (lane * 2 + h) * C::EROW);
+                    row[3] = row[3 + PJ_NT / 2];
+                }
+            }
+            HY_WAVE_SYNC_PJ();
+            // (2) accumulators -> storage type -> [group][channel][8 + position]
+            HY_UNROLL
+            for (int g = 0; g < 3; ++g) {
+                HY_UNROLL
+                for (int nt = 0; nt < 2; ++nt) {
+                    HY_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        HY_LDS elem_t* e = reinterpret_cast<HY_LDS elem_t*>(ebuf + (g * PJ_CB + pj_row(r, hb)) * C::EROW);
+                        e[8 + nt * 32 + j] = Elem<DT>::cvt(acc[g][nt][r]);
+                    }
+                }
+            }
+            HY_WAVE_SYNC_PJ();
+            if (t >= t_begin) {
+                const unsigned p0 = (unsigned)t * PJ_NT;
+                // (3) xT: 3 x 32 rows x 8 pieces of 8 positions
+                HY_UNROLL
+                for (int m = 0; m < 3 * PJ_CB * 8 / 64; ++m) {
+                    const int id = lane + 64 * m, g = id >> 8, ch = (id >> 3) & 31, pc = id & 7;
+                    const unsigned p = p0 + 8u * (unsigned)pc;
+                    const Frag v = lds_ld16(ebuf + (g * PJ_CB + ch) * C::EROW + 16 + pc * 16);
+                    elem_t* dst = reinterpret_cast<elem_t*>(a.xT) + (size_t)(g * D + d0 + ch) * P + p;
+                    if (p + 8 <= P) st16(dst, v);
+                    else {
+                        elem_t s[8];
+                        __builtin_memcpy(s, v.w, 16);
+                        for (int i = 0; i < 8; ++i)
+                            if (p + i < P) dst[i] = s[i];
+                    }
+                }
+                // (4) vg = shortconv(v) * shortconv(x1): 32 channels x 8 pieces
+                HY_UNROLL
+                for (int m = 0; m < PJ_CB * 8 / 64; ++m) {
+                    const int id = lane + 64 * m, ch = id >> 3, pc = id & 7;
+                    const unsigned p = p0 + 8u * (unsigned)pc;
+                    if (p >= P) continue;
+                    float prod[8];
+                    const unsigned b = p / (unsigned)a.Lx;
+                    const int l = (int)(p - b * (unsigned)a.Lx);
+                    HY_UNROLL
+                    for (int gi = 0; gi < 2; ++gi) {                    // gi = 0: x1 (group 1), gi = 1: v (group 2)
+                        const HY_LDS char* row = ebuf + ((1 + gi) * PJ_CB + ch) * C::EROW + pc * 16;
+                        const Frag lo = lds_ld16(row), hi = lds_ld16(row + 16);
+                        elem_t pl[8], ph[8];
+                        __builtin_memcpy(pl, lo.w, 16);
+                        __builtin_memcpy(ph, hi.w, 16);
+                        float xs[10];
+                        xs[0] = Elem<DT>::dec(pl[6]); xs[1] = Elem<DT>::dec(pl[7]);
+                        HY_UNROLL
+                        for (int i = 0; i < 8; ++i) xs[2 + i] = Elem<DT>::dec(ph[i]);
+                        const HY_LDS float* tp = taps + (gi * PJ_CB + ch) * 5;
+                        const float w0 = tp[0], w1 = tp[1], w2 = tp[2], bsc = tp[3], bin = tp[4];
+                        HY_UNROLL
+                        for (int i = 0; i < 8; ++i) {
+                            int li = l + i;                             // position within its sequence (the piece may cross into the next one)
+                            if (li >= a.Lx) li -= a.Lx;
+                            const float x0 = li >= 2 ? xs[i] + bin : 0.f, x1 = li >= 1 ? xs[i + 1] + bin : 0.f, x2 = xs[i + 2] + bin;
+                            const float c = bsc + w0 * x0 + w1 * x1 + w2 * x2;
+                            prod[i] = gi == 0 ? c : prod[i] * c;
+                        }
+                    }
+                    elem_t out[8];
+                    HY_UNROLL
+                    for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
+                    elem_t* vrow = reinterpret_cast<elem_t*>(a.vg) + ((size_t)b * D + d0 + ch) * a.Lc;
+                    if (l + 8 <= a.Lc) {
+                        Frag f;
+                        __builtin_memcpy(f.w, out, 16);
+                        st16(vrow + l, f);
+                    } else {
+                        for (int i = 0; i < 8; ++i) {
+                            int li = l + i;
+                            unsigned bi = b;
+                            if (li >= a.Lx) { li -= a.Lx; ++bi; }
+                            if (p + i < P && li < a.Lc) reinterpret_cast<elem_t*>(a.vg)[((size_t)bi * D + d0 + ch) * a.Lc + li] = out[i];
+                        }
+                    }
+                }
+            }
+            HY_WAVE_SYNC_PJ();                        // the tile is re-written in the next round
+        }
+        cur ^= 1;
+    }
+}
+
+}  // namespace pj
+}  // namespace hyena

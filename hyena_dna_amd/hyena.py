@@ -21,7 +21,7 @@ from .filter import fused_filter_ok, hyena_filter_dl
 import os
 
 from .mixer import hyena_mixer_core, hyena_mixer_core_cm
-from .projection import hyena_linear, in_proj_cm, out_proj_cm
+from .projection import hyena_linear, in_proj_cm, in_proj_pre_cm, out_proj_cm
 
 # Layout of the tensors between the operator's two projections: channel-major (x^T written by the in_proj GEMM, z^T read by
 # the out_proj GEMM, no transposes anywhere: csrc/cm_kernels.h) or the reference's position-major (B, L, 3D) with the
@@ -268,8 +268,12 @@ class HyenaOperator(nn.Module):
             fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
             if CHANNEL_MAJOR:
                 # x^T = W_in u^T straight out of the GEMM (3D, B, L): nothing between the projections is ever transposed
-                xT = in_proj_cm(u, self.in_proj.weight)
-                zT = hyena_mixer_core_cm(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter)
+                # (16-bit operands at d_model 128 / 256: this package's MFMA kernel, which also hands back the conv's input v * x1
+                # from its epilogue -- csrc/proj_kernels.h; otherwise the library GEMM and vg = None)
+                xT, vg = in_proj_pre_cm(u, self.in_proj.weight, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias,
+                                        l_filter)
+                zT = hyena_mixer_core_cm(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter,
+                                         vg=vg)
                 y = out_proj_cm(zT, self.out_proj.weight, self.out_proj.bias)   # activation is the identity (_fused_ok)
             else:
                 x = hyena_linear(u, self.in_proj.weight, self.in_proj.bias)     # (B, L, 3D), hipBLASLt GEMM

@@ -81,7 +81,9 @@ class HyenaMixerCMFunc(torch.autograd.Function):
     result ``zT`` (D, B, L) for ``projection.out_proj_cm``.  No tensor between the two projections is ever transposed."""
 
     @staticmethod
-    def forward(ctx, xT, b_in, sf_weight, sf_bias, k, bias, L):
+    def forward(ctx, xT, b_in, sf_weight, sf_bias, k, bias, L, vg=None):
+        # vg: the conv's input v * x1 if the projection kernel already produced it (projection.in_proj_pre_cm: bit-identical to
+        # cm_pre_fwd on this xT) -- a cached value, not a differentiable input
         D3, B, Lx = xT.shape
         D = D3 // 3
         xc = xT.contiguous()
@@ -90,7 +92,8 @@ class HyenaMixerCMFunc(torch.autograd.Function):
         b = sf_bias.detach().to(torch.float32).contiguous()
         kf = k.detach().to(torch.float32).contiguous()
         bf = bias.detach().to(torch.float32).reshape(D).contiguous()
-        vg = _lib.cm_pre_fwd(xc, bi, w, b, L)
+        if vg is None:
+            vg = _lib.cm_pre_fwd(xc, bi, w, b, L)
         want_grad = any(ctx.needs_input_grad[:6])
         spectra = None
         if want_grad and _lib.save_spectra_default(B, D, L, device=vg.device):
@@ -123,13 +126,13 @@ class HyenaMixerCMFunc(torch.autograd.Function):
         db = red[:, 3].to(b_dtype)
         dbin = red[:, 4].to(bin_dtype)
         return (dxT, dbin, dw, db, dk.to(k_dtype) if dk is not None else None,
-                dbias.reshape(bias_shape).to(bias_dtype) if dbias is not None else None, None)
+                dbias.reshape(bias_shape).to(bias_dtype) if dbias is not None else None, None, None)
 
 
-def hyena_mixer_core_cm(xT, b_in, sf_weight, sf_bias, k, bias, L):
+def hyena_mixer_core_cm(xT, b_in, sf_weight, sf_bias, k, bias, L, vg=None):
     """zT (D, B, L) = fftconv(v * x1, k, bias) * x0 with (x0, x1, v) = short_conv(xT + b_in)[..., :L].split(D) (channel-major)."""
     if xT.shape[1] == 0 or L == 0:
         D = xT.shape[0] // 3
         zero = 0 * (b_in.sum() + sf_weight.sum() + sf_bias.sum() + k.sum() + bias.sum())
         return xT[:D, :, :L] * 0 + zero.to(xT.dtype)
-    return HyenaMixerCMFunc.apply(xT, b_in, sf_weight, sf_bias, k, bias, L)
+    return HyenaMixerCMFunc.apply(xT, b_in, sf_weight, sf_bias, k, bias, L, vg)

@@ -11,10 +11,12 @@ sum.  Forward and input gradient are the ordinary library GEMMs.
 Used by ``hyena_dna_amd.hyena.HyenaOperator`` on the GPU when there are at least ``MIN_ROWS`` positions (16-bit autocast, or
 plain fp32 / 16-bit tensors); everything else goes through ``torch.nn.functional.linear`` unchanged.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
-__all__ = ["hyena_linear", "SplitKLinearFunc", "split_count", "split_k_weight_grad", "in_proj_cm", "out_proj_cm"]
+__all__ = ["hyena_linear", "SplitKLinearFunc", "split_count", "split_k_weight_grad", "in_proj_cm", "out_proj_cm", "in_proj_pre_cm"]
 
 MIN_ROWS = 32768          # below this the library's own schedule is fine
 MAX_SPLITS = 64
@@ -124,6 +126,48 @@ class InProjCMFunc(torch.autograd.Function):
                 dw = dw + torch.mm(d2[:, body:].float(), u2[body:].float())
             dw = dw.to(weight.dtype)
         return du, dw
+
+
+class InProjPreCMFunc(torch.autograd.Function):
+    """xT (N, B, L) = W u^T as InProjCMFunc, from this package's matrix-core kernel (csrc/proj_kernels.h), which also hands back
+    vg = short_conv(xT + b_in)[v] * short_conv(xT + b_in)[x1] -- the long convolution's input -- from its epilogue.  vg is a cached
+    value for HyenaMixerCMFunc (whose backward recomputes it from xT), not a differentiable output; the gradients of the projection
+    are the library GEMMs of InProjCMFunc."""
+
+    @staticmethod
+    def forward(ctx, u, weight, b_in, sf_weight, sf_bias, L):
+        from . import _lib
+        B, Lx, K = u.shape
+        ctx.save_for_backward(u.reshape(B * Lx, K), weight)
+        ctx.ushape = u.shape
+        bi = None if b_in is None else b_in.detach().to(torch.float32).contiguous()
+        w = sf_weight.detach().to(torch.float32).reshape(weight.shape[0], 3).contiguous()
+        b = sf_bias.detach().to(torch.float32).contiguous()
+        xT, vg = _lib.inproj_pre_fwd(u, weight, bi, w, b, L)
+        ctx.mark_non_differentiable(vg)
+        return xT, vg
+
+    @staticmethod
+    def backward(ctx, dxT, _dvg):
+        du, dw = InProjCMFunc.backward(ctx, dxT)
+        return du, dw, None, None, None, None
+
+
+INPROJ_MFMA = os.environ.get("HYENA_INPROJ_MFMA", "1") != "0"      # A/B knob: 0 = library GEMM + cm_pre_fwd
+
+
+def in_proj_pre_cm(u, weight, b_in, sf_weight, sf_bias, L):
+    """(B, Lx, K) -> (xT (N, B, Lx), vg (B, D, L) or None).  Where the matrix-core kernel serves the call (16-bit operands --
+    autocast or plain --, d_model 128 / 256, short_filter_order 3) both come from ONE launch; otherwise xT is the library GEMM of
+    in_proj_cm and vg is None (hyena_mixer_core_cm then runs cm_pre_fwd)."""
+    from . import _lib
+    dt = _autocast_dtype(u) or (u.dtype if u.dtype in (torch.bfloat16, torch.float16) and weight.dtype == u.dtype else None)
+    B, Lx, K = u.shape
+    if (INPROJ_MFMA and dt is not None and weight.shape == (3 * K, K) and sf_weight.shape[-1] == 3 and sf_weight.shape[0] == 3 * K
+            and (u.is_cuda or _lib._backend.name != "hip") and L >= 1 and _lib.proj_supported(B, Lx, K, dt)):
+        with torch.autocast("cuda" if u.is_cuda else "cpu", enabled=False):
+            return InProjPreCMFunc.apply(u.to(dt).contiguous(), weight.to(dt).contiguous(), b_in, sf_weight, sf_bias, L)
+    return in_proj_cm(u, weight), None
 
 
 class OutProjCMFunc(torch.autograd.Function):

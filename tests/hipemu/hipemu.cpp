@@ -45,6 +45,8 @@ static void run_block(dim3 grid, dim3 block, size_t smem_bytes, const std::funct
     }
     S.xchg.assign(nthreads, 0);
     S.xchg2.assign(nthreads, 0);
+    S.xq.assign(4 * (size_t)nthreads, 0);
+    S.xq2.assign(4 * (size_t)nthreads, 0);
     std::vector<char> smem(smem_bytes + 64);
     memset(smem.data(), 0xFF, smem.size());   // NaN pattern: uninitialised LDS reads show up
     S.smem = (char*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);

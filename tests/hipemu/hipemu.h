@@ -51,6 +51,7 @@ struct State {
     const std::function<void()>* body;
     std::vector<uint32_t> xchg;   // shuffle exchange slots, one per thread
     std::vector<uint32_t> xchg2;  // second operand slot (MFMA B operand)
+    std::vector<uint32_t> xq, xq2;  // four words per thread: the 16-byte A / B operands of the 16-bit MFMAs
 };
 
 extern thread_local State S;
@@ -91,6 +92,41 @@ inline floatx16 mfma_f32_32x32x2f32(float a, float b, floatx16 c) {
             memcpy(&av, &S.xchg[base + row + 32 * k], 4);
             memcpy(&bv, &S.xchg2[base + col + 32 * k], 4);
             acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    yield(2);
+    return c;
+}
+
+// v_mfma_f32_32x32x16_{bf16,f16} (gfx950): D = A(32x16) * B(16x32) + C, one wave.  Lane l supplies the eight 16-bit values
+// A[l & 31][8 (l >> 5) + j] and B[8 (l >> 5) + j][l & 31], j = 0..7 (16 bytes each), and owns the same C/D elements as above.
+// Products are exact in fp32; the sum is taken as a k-ordered fmaf chain here -- the hardware's internal order may differ, so
+// GPU results are compared with a tolerance, not bitwise.
+struct u32x4 { uint32_t w[4]; };
+template <bool BF16>
+inline floatx16 mfma_f32_32x32x16_h(u32x4 a, u32x4 b, floatx16 c) {
+    int t = S.cur, lane = t & (WAVE - 1), base = t - lane;
+    memcpy(&S.xq[4 * t], a.w, 16);
+    memcpy(&S.xq2[4 * t], b.w, 16);
+    yield(2);
+    auto dec = [](uint16_t h) -> float {
+        if (BF16) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+        uint32_t sign = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31, m = h & 1023, u;
+        if (e == 0) {
+            if (m == 0) u = sign;
+            else { int sh = 0; while (!(m & 1024)) { m <<= 1; ++sh; } u = sign | ((uint32_t)(113 - sh) << 23) | ((m & 1023) << 13); }
+        } else if (e == 31) u = sign | 0x7F800000u | (m << 13);
+        else u = sign | ((e + 112) << 23) | (m << 13);
+        float f; memcpy(&f, &u, 4); return f;
+    };
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            const uint16_t* ap = reinterpret_cast<const uint16_t*>(&S.xq[4 * (base + row + 32 * (k >> 3))]);
+            const uint16_t* bp = reinterpret_cast<const uint16_t*>(&S.xq2[4 * (base + col + 32 * (k >> 3))]);
+            acc = fmaf(dec(ap[k & 7]), dec(bp[k & 7]), acc);
         }
         c[r] = acc;
     }

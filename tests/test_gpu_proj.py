@@ -1,0 +1,63 @@
+"""The matrix-core input projection with the front of the shell in its epilogue (csrc/proj_kernels.h) on a real MI355X, through
+the C ABI: xT against the library GEMM on the same 16-bit operands (one rounding of an fp32 sum either way) and against the fp64
+product, vg BIT-IDENTICAL to cm_pre_fwd on the kernel's own xT, at the contract shapes incl. an odd length (rows start
+under-aligned) and a truncated one (Lc < Lx), determinism."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,Lx,Lc,D,dtype", [(8, 1024, 1024, 128, torch.bfloat16), (8, 32768, 32768, 256, torch.bfloat16),
+                                             (2, 160000, 160000, 256, torch.bfloat16), (1, 1048576, 1048576, 256, torch.bfloat16),
+                                             (1, 999999, 999999, 256, torch.bfloat16), (3, 4099, 4000, 128, torch.float16),
+                                             (2, 70001, 70001, 256, torch.float16), (5, 9, 9, 128, torch.bfloat16)])
+def test_inproj_pre_fwd_on_gpu(gpu_lib, B, Lx, Lc, D, dtype):
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(Lx + D)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
+    u = rn(B, Lx, D).to(dtype)
+    W = (rn(3 * D, D) / D ** 0.5).to(dtype)
+    bin_, w, b = rn(3 * D) * 0.3, rn(3 * D, 3) * 0.5, rn(3 * D) * 0.2
+    assert gpu_lib.proj_supported(B, Lx, D, dtype)
+    xT, vg = gpu_lib.inproj_pre_fwd(u, W, bin_, w, b, Lc)
+    lib = torch.mm(W, u.reshape(B * Lx, D).t()).view(3 * D, B, Lx)              # hipBLASLt, fp32 accumulation, one rounding
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    diff = (xT.float() - lib.float()).abs()
+    assert (diff <= 2 * eps * lib.float().abs() + 1e-6).all()                   # at most one ulp apart ...
+    assert (xT != lib).float().mean().item() < 0.02                              # ... and almost everywhere identical
+    # a slice against the fp64 product
+    rows = torch.arange(0, 3 * D, 37, device=dev)
+    ref = torch.mm(W[rows].double(), u.reshape(B * Lx, D)[: 4096].double().t())
+    got = xT.reshape(3 * D, B * Lx)[rows][:, : 4096].double()
+    assert ((got - ref).abs() <= eps * ref.abs() + 1e-6).all()
+    assert torch.equal(vg, gpu_lib.cm_pre_fwd(xT, bin_, w, b, Lc))
+    xT2, vg2 = gpu_lib.inproj_pre_fwd(u, W, bin_, w, b, Lc)
+    assert torch.equal(xT, xT2) and torch.equal(vg, vg2)
+
+
+def test_operator_uses_the_mfma_projection_and_matches_the_library_path(gpu_lib, monkeypatch):
+    import hyena_dna_amd.projection as P
+    from hyena_dna_amd.hyena import HyenaOperator
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    B, L, D = 2, 40000, 256
+    op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
+                       lr=6e-4, wd=0.0, lr_pos_emb=0.0).to(dev)
+    u0 = torch.randn(B, L, D, device=dev, dtype=torch.bfloat16)
+    dy = torch.randn(B, L, D, device=dev, dtype=torch.bfloat16)
+    calls, real = [], gpu_lib.inproj_pre_fwd
+    monkeypatch.setattr(gpu_lib, "inproj_pre_fwd", lambda *a: (calls.append(1), real(*a))[1])
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(P, "INPROJ_MFMA", on)
+        op.zero_grad(set_to_none=True)
+        u = u0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = op(u)
+        y.backward(dy)
+        res.append([y.float(), u.grad.float()] + [p.grad.float() for _, p in sorted(op.named_parameters())])
+    assert len(calls) == 1
+    for a, b in zip(*res):
+        err = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+        assert err < 1e-2, err
