@@ -154,6 +154,14 @@ def lib():
         L.hyena_inproj_pre_fwd.restype = c_int
         L.hyena_inproj_pre_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_mlp_supported.restype = c_int
+        L.hyena_mlp_supported.argtypes = [ctypes.c_long, c_int, c_int, c_int]
+        L.hyena_mlp_partial_floats.restype = c_size_t
+        L.hyena_mlp_partial_floats.argtypes = [ctypes.c_long, c_int]
+        L.hyena_mlp_fc1_gelu_fwd.restype = c_int
+        L.hyena_mlp_fc1_gelu_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_void_p]
+        L.hyena_mlp_dh_dgelu_bwd.restype = c_int
+        L.hyena_mlp_dh_dgelu_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_void_p]
         # fused implicit filter (include/hyena_filter.h)
         L.hyena_filter_supported.restype = c_int
         L.hyena_filter_supported.argtypes = [c_int, c_int, c_int, c_int]
@@ -461,6 +469,38 @@ def inproj_pre_fwd(u, W, bin_, w, b, L):
         check(lib().hyena_inproj_pre_fwd(u.data_ptr(), W.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
                                          xT.data_ptr(), vg.data_ptr(), B, Lx, int(L), D, dtype_code(u.dtype), _backend.stream(u.device)))
     return xT, vg
+
+
+def mlp_supported(P, K, N, dtype):
+    code = _DTYPES.get(dtype)
+    return code is not None and bool(lib().hyena_mlp_supported(int(P), int(K), int(N), code))
+
+
+def mlp_fc1_gelu_fwd(x2, W1, b1):
+    """x2 (P, K) 16-bit, W1 (N, K) same type, b1 (N,) fp32 (values already rounded to the element type) or None
+    -> a = x2 W1^T + b1, h = gelu_tanh(a), both (P, N)."""
+    _require_gpu(x2, "x")
+    P, K = x2.shape
+    N = W1.shape[0]
+    a = torch.empty((P, N), dtype=x2.dtype, device=x2.device)
+    h = torch.empty((P, N), dtype=x2.dtype, device=x2.device)
+    with _backend.guard(x2.device):
+        check(lib().hyena_mlp_fc1_gelu_fwd(x2.data_ptr(), W1.data_ptr(), None if b1 is None else b1.data_ptr(), a.data_ptr(), h.data_ptr(),
+                                           P, K, N, dtype_code(x2.dtype), _backend.stream(x2.device)))
+    return a, h
+
+
+def mlp_dh_dgelu_bwd(dy2, W2T, a):
+    """dy2 (P, K), W2T (N, K) = fc2.weight^T contiguous, a (P, N) -> da (P, N) = (dy2 W2) * gelu_tanh'(a), db1 (N,) fp32 = da.sum(0)."""
+    _require_gpu(dy2, "dy")
+    P, K = dy2.shape
+    N = W2T.shape[0]
+    da = torch.empty((P, N), dtype=dy2.dtype, device=dy2.device)
+    part = torch.empty(lib().hyena_mlp_partial_floats(P, N), dtype=torch.float32, device=dy2.device)
+    with _backend.guard(dy2.device):
+        check(lib().hyena_mlp_dh_dgelu_bwd(dy2.data_ptr(), W2T.data_ptr(), a.data_ptr(), da.data_ptr(), part.data_ptr(), P, K, N,
+                                           dtype_code(dy2.dtype), _backend.stream(dy2.device)))
+    return da, part.view(-1, N).sum(0)                          # fixed-order two-stage sum: deterministic
 
 
 # ---- fused implicit filter (include/hyena_filter.h) ---------------------------------------------------------------------

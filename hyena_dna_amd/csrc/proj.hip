@@ -15,9 +15,68 @@ int launch_inproj(const pj::InProjArgs& a, int grid, void* stream) {
     HY_LAUNCH((pj::inproj_pre_fwd_kernel<K, DT>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
+template <int K, int DT, int MODE>
+int launch_mlp(const pj::MlpArgs& a, int grid, void* stream) {
+    typedef pj::PmCfg<K> C;
+    static thread_local int done = -1;
+    hy_allow_lds(pj::mlp_kernel<K, DT, MODE>, C::LDS, &done);
+    HY_LAUNCH((pj::mlp_kernel<K, DT, MODE>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+// runs of tiles per channel group: a few per CU (tail balance), at least 8 tiles long (weight load amortised)
+void mlp_schedule(size_t P, int ncg, pj::MlpArgs* a, int* runs_out, int* grid_out) {
+    a->tiles = (int)((P + pj::PJ_NT - 1) / pj::PJ_NT);
+    int runs = 256 * 4 / ncg;
+    if (runs > a->tiles) runs = a->tiles;
+    a->tiles_per_wg = (a->tiles + runs - 1) / runs;
+    if (a->tiles_per_wg < 8 && a->tiles >= 8) a->tiles_per_wg = 8;
+    runs = (a->tiles + a->tiles_per_wg - 1) / a->tiles_per_wg;
+    *runs_out = runs;
+    *grid_out = ((runs + 7) / 8) * 8 * ncg;
+}
+template <int MODE>
+int dispatch_mlp(const pj::MlpArgs& a, int K, int dtype, int grid, void* stream) {
+    if (K == 256) return dtype == HYENA_BF16 ? launch_mlp<256, DT_BF16, MODE>(a, grid, stream) : launch_mlp<256, DT_F16, MODE>(a, grid, stream);
+    return dtype == HYENA_BF16 ? launch_mlp<128, DT_BF16, MODE>(a, grid, stream) : launch_mlp<128, DT_F16, MODE>(a, grid, stream);
+}
 }  // namespace
 
 extern "C" {
+
+int hyena_mlp_supported(long P, int K, int N, int dtype) {
+    if (!(K == 128 || K == 256) || !(dtype == HYENA_BF16 || dtype == HYENA_F16)) return 0;
+    if (N < 256 || N % 256 != 0 || P < 1) return 0;
+    return (size_t)P < ((size_t)1 << 31) ? 1 : 0;
+}
+
+size_t hyena_mlp_partial_floats(long P, int N) {
+    if (P < 1 || N < 256) return 0;
+    pj::MlpArgs a;
+    int runs, grid;
+    mlp_schedule((size_t)P, N / 256, &a, &runs, &grid);
+    return (size_t)runs * N;
+}
+
+int hyena_mlp_fc1_gelu_fwd(const void* x, const void* W1, const float* b1, void* a_out, void* h_out, long P, int K, int N, int dtype,
+                           void* stream) {
+    if (x == nullptr || W1 == nullptr || a_out == nullptr || h_out == nullptr || !hyena_mlp_supported(P, K, N, dtype)) return HYENA_ERR_BAD_ARG;
+    pj::MlpArgs a;
+    a.x = x; a.W = W1; a.bias = b1; a.a_in = nullptr; a.o0 = a_out; a.o1 = h_out; a.part = nullptr; a.P = (unsigned)P; a.N = N;
+    int runs, grid;
+    mlp_schedule((size_t)P, N / 256, &a, &runs, &grid);
+    return dispatch_mlp<0>(a, K, dtype, grid, stream);
+}
+
+int hyena_mlp_dh_dgelu_bwd(const void* dy, const void* W2T, const void* a_in, void* da, float* part, long P, int K, int N, int dtype,
+                           void* stream) {
+    if (dy == nullptr || W2T == nullptr || a_in == nullptr || da == nullptr || part == nullptr || !hyena_mlp_supported(P, K, N, dtype))
+        return HYENA_ERR_BAD_ARG;
+    pj::MlpArgs a;
+    a.x = dy; a.W = W2T; a.bias = nullptr; a.a_in = a_in; a.o0 = da; a.o1 = nullptr; a.part = part; a.P = (unsigned)P; a.N = N;
+    int runs, grid;
+    mlp_schedule((size_t)P, N / 256, &a, &runs, &grid);
+    return dispatch_mlp<1>(a, K, dtype, grid, stream);
+}
 
 int hyena_proj_supported(int B, int Lx, int D, int dtype) {
     if (!(D == 128 || D == 256) || !(dtype == HYENA_BF16 || dtype == HYENA_F16)) return 0;

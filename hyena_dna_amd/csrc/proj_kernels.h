@@ -299,5 +299,212 @@ __global__ void __launch_bounds__(PJ_THREADS) inproj_pre_fwd_kernel(InProjArgs a
     }
 }
 
+
+// =============================================================================================================================
+// The block's MLP (flash_attn.modules.mlp.Mlp; simple_lm.py:191-211, long_conv_lm.py:117-123: fc1 -> tanh-GELU -> fc2): the two
+// products whose contraction is d_model (K = 128 / 256) on the same weights-stationary scheme, POSITION-major, with the
+// element-wise passes of the reference in their epilogues:
+//     mlp_fc1_gelu_kernel :  a = x W1^T + b1   (P, N);   h = gelu_tanh(a)   (P, N)         forward   (replaces GEMM + bias + GELU pass)
+//     mlp_dh_dgelu_kernel :  da = (dy W2) * gelu_tanh'(a)   (P, N);   partial column sums of da (-> d b1)
+//                                                                                            backward  (replaces GEMM + GELU-backward
+//                                                                                                       pass + bias-gradient pass)
+// Roles are swapped with respect to the in_proj kernel: positions are the ROWS of the MFMA (A fragments from the staged
+// activation tile), the stationary weights are its COLUMNS (B fragments in registers: 64 hidden units x K per wavefront =
+// 128 VGPRs at K = 256), so that an accumulator register holds 32 neighbouring hidden units of ONE position across the lanes
+// and rows of the position-major outputs leave as 128-byte pieces (through a wavefront-private LDS tile, 16 bytes per lane).
+// A workgroup = 4 wavefronts = 256 hidden units over a run of positions; the N / 256 workgroups of a run share an XCD's L2.
+// Numerics follow the autocast graph they replace: a is the rounded GEMM result (bias added in fp32 before the one rounding, as
+// the library's epilogue does), h = round(gelu(a)) from the ROUNDED a, da = round(round(dh) * gelu'(a)).
+// =============================================================================================================================
+enum { PM_UW = 64 /* hidden units per wavefront */, PM_EW = PM_UW + 8 };
+
+template <int K> struct PmCfg {
+    static constexpr int KS = K / 16;
+    static constexpr int UROW = PjCfg<K>::UROW, UBUF = PjCfg<K>::UBUF, CH = PjCfg<K>::CH;
+    static constexpr int EROW = PM_EW * 2;                    // bytes per row of the epilogue tile [position][unit]
+    static constexpr int EBUF = PJ_NT * EROW;                 // one tile per wavefront
+    static constexpr size_t LDS = 2 * (size_t)UBUF + PJ_WAVES * 2 * (size_t)EBUF;
+};
+
+struct MlpArgs {
+    const void* x;        // fc1: x (P, K);  dh: dy (P, K)
+    const void* W;        // fc1: W1 (N, K);  dh: W2^T (N, K)        [K contiguous]
+    const float* bias;    // fc1: b1 (N,) fp32 (already rounded to the element type by the caller) or null
+    const void* a_in;     // dh: a (P, N)
+    void* o0;             // fc1: a (P, N);  dh: da (P, N)
+    void* o1;             // fc1: h (P, N)
+    float* part;          // dh: [runs][N] partial column sums of da
+    unsigned P;
+    int N;
+    int tiles, tiles_per_wg;
+};
+
+__device__ __forceinline__ float pm_tanh(float x) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1): exact limits at +-inf, ~2 ulp -- far inside the 16-bit rounding that follows
+#ifdef HIPEMU
+    const float e = expf(2.0f * x);
+#else
+    const float e = __expf(2.0f * x);
+#endif
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+// the tanh approximation PyTorch's F.gelu(approximate="tanh") evaluates (aten/src/ATen/native/cuda/ActivationGeluKernel.cu), fp32
+__device__ __forceinline__ float pm_gelu(float x) {
+    const float kBeta = 0.7978845608028654f /* sqrt(2 / pi) */, kKappa = 0.044715f;
+    const float inner = kBeta * (x + kKappa * x * x * x);
+    return 0.5f * x * (1.0f + pm_tanh(inner));
+}
+__device__ __forceinline__ float pm_dgelu(float x) {
+    const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
+    const float x2 = x * x;
+    const float inner = kBeta * (x + kKappa * x2 * x);
+    const float t = pm_tanh(inner);
+    const float left = 0.5f * x, right = 1.0f + t;
+    const float dleft = 0.5f, dtanh = 1.0f - t * t;
+    const float dinner = kBeta * (1.0f + 3.0f * kKappa * x2);
+    return dleft * right + left * dtanh * dinner;
+}
+
+// MODE 0: fc1 + bias + GELU (outputs a, h);  MODE 1: dh = dy W2, da = dh gelu'(a) (+ partial column sums)
+template <int K, int DT, int MODE>
+__global__ void __launch_bounds__(PJ_THREADS) mlp_kernel(MlpArgs a) {
+    typedef PmCfg<K> C;
+    typedef typename Elem<DT>::type elem_t;
+    HY_SMEM(smem);
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hb = lane >> 5;
+    const int N = a.N;
+    const unsigned P = a.P;
+    const int ncg = N / (PJ_WAVES * PM_UW);
+    int cg, run;
+    {
+        const int wg = blockIdx.x, xcd = wg & 7, seq = wg >> 3;
+        cg = seq % ncg;
+        run = (seq / ncg) * 8 + xcd;
+    }
+    const int t_begin = run * a.tiles_per_wg;
+    if (t_begin >= a.tiles) return;
+    const int t_end = (t_begin + a.tiles_per_wg < a.tiles) ? t_begin + a.tiles_per_wg : a.tiles;
+    const int n0 = cg * PJ_WAVES * PM_UW + wave * PM_UW;                   // first hidden unit of this wavefront
+
+    HY_LDS char* const ubuf = HY_LDS_CAST(char, smem);
+    HY_LDS char* const e0 = HY_LDS_CAST(char, smem) + 2 * C::UBUF + wave * 2 * C::EBUF;
+    HY_LDS char* const e1 = e0 + C::EBUF;
+
+    // stationary operand: 64 weight rows as B fragments (column = unit j of unit tile ut, k = 16 ks + 8 hb ...)
+    Frag wf[2][C::KS];
+    HY_UNROLL
+    for (int ut = 0; ut < 2; ++ut) {
+        const char* row = reinterpret_cast<const char*>(a.W) + ((size_t)(n0 + ut * 32 + j) * K + 8 * hb) * 2;
+        HY_UNROLL
+        for (int ks = 0; ks < C::KS; ++ks) wf[ut][ks] = ld16(row + ks * 32);
+    }
+    float bias[2] = {0.f, 0.f};
+    if (MODE == 0 && a.bias != nullptr) { bias[0] = a.bias[n0 + j]; bias[1] = a.bias[n0 + 32 + j]; }
+    float colsum[2] = {0.f, 0.f};
+
+    const char* const xbase = reinterpret_cast<const char*>(a.x);
+    Frag st[C::CH];
+    auto prefetch = [&](int t) {
+        HY_UNROLL
+        for (int c = 0; c < C::CH; ++c) {
+            const int q = tid + PJ_THREADS * c;
+            const unsigned p = (unsigned)t * PJ_NT + (unsigned)(q / (K / 8));
+            Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+            st[c] = p < P ? ld16(xbase + ((size_t)t * PJ_NT * K * 2 + (size_t)q * 16)) : z;
+        }
+    };
+    auto stage = [&](int buf) {
+        HY_UNROLL
+        for (int c = 0; c < C::CH; ++c) {
+            const int q = tid + PJ_THREADS * c;
+            lds_st16(ubuf + buf * C::UBUF + (q / (K / 8)) * C::UROW + (q % (K / 8)) * 16, st[c]);
+        }
+    };
+
+    prefetch(t_begin);
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        stage(cur);
+        __syncthreads();
+        if (t + 1 < t_end) prefetch(t + 1);
+        const unsigned p0 = (unsigned)t * PJ_NT;
+        if (MODE == 1) {
+            // the a tile of this wavefront's units, [position][unit], while the matrix cores work: 64 x 8 pieces of 16 bytes
+            HY_UNROLL
+            for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
+                const int id = lane + 64 * m, pos = id >> 3, pc = id & 7;
+                Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+                const Frag v = p0 + pos < P ? ld16(reinterpret_cast<const elem_t*>(a.a_in) + (size_t)(p0 + pos) * N + n0 + 8 * pc) : z;
+                lds_st16(e1 + pos * C::EROW + pc * 16, v);
+            }
+        }
+        acc_t acc[2][2];                           // [position tile][unit tile]
+        HY_UNROLL
+        for (int pt = 0; pt < 2; ++pt) {
+            HY_UNROLL
+            for (int ut = 0; ut < 2; ++ut) {
+                HY_UNROLL
+                for (int r = 0; r < 16; ++r) acc[pt][ut][r] = 0.f;
+            }
+        }
+        const HY_LDS char* const ub = ubuf + cur * C::UBUF + j * C::UROW + hb * 16;
+        HY_UNROLL
+        for (int ks = 0; ks < C::KS; ++ks) {
+            HY_UNROLL
+            for (int pt = 0; pt < 2; ++pt) {
+                const Frag af = lds_ld16(ub + pt * 32 * C::UROW + ks * 32);
+                HY_UNROLL
+                for (int ut = 0; ut < 2; ++ut) acc[pt][ut] = mfma<DT>(af, wf[ut][ks], acc[pt][ut]);
+            }
+        }
+        // ---- epilogue, wavefront-private: register r of lane (j, hb) = position pt 32 + pj_row(r, hb), unit ut 32 + j ----
+        HY_WAVE_SYNC_PJ();
+        HY_UNROLL
+        for (int pt = 0; pt < 2; ++pt) {
+            HY_UNROLL
+            for (int ut = 0; ut < 2; ++ut) {
+                HY_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int pos = pt * 32 + pj_row(r, hb), un = ut * 32 + j;
+                    HY_LDS elem_t* s0 = reinterpret_cast<HY_LDS elem_t*>(e0 + pos * C::EROW) + un;
+                    HY_LDS elem_t* s1 = reinterpret_cast<HY_LDS elem_t*>(e1 + pos * C::EROW) + un;
+                    if (MODE == 0) {
+                        const elem_t av = Elem<DT>::cvt(acc[pt][ut][r] + bias[ut]);
+                        *s0 = av;
+                        *s1 = Elem<DT>::cvt(pm_gelu(Elem<DT>::dec(av)));
+                    } else {
+                        const float dh = Elem<DT>::dec(Elem<DT>::cvt(acc[pt][ut][r]));          // the rounding of the unfused dh tensor
+                        const elem_t dv = Elem<DT>::cvt(dh * pm_dgelu(Elem<DT>::dec(*s1)));
+                        *s0 = dv;
+                        if (p0 + pos < P) colsum[ut] += Elem<DT>::dec(dv);
+                    }
+                }
+            }
+        }
+        HY_WAVE_SYNC_PJ();
+        HY_UNROLL
+        for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
+            const int id = lane + 64 * m, pos = id >> 3, pc = id & 7;
+            if (p0 + pos >= P) continue;
+            const size_t off = (size_t)(p0 + pos) * N + n0 + 8 * pc;
+            st16(reinterpret_cast<elem_t*>(a.o0) + off, lds_ld16(e0 + pos * C::EROW + pc * 16));
+            if (MODE == 0) st16(reinterpret_cast<elem_t*>(a.o1) + off, lds_ld16(e1 + pos * C::EROW + pc * 16));
+        }
+        HY_WAVE_SYNC_PJ();
+        cur ^= 1;
+    }
+    if (MODE == 1) {
+        // column sums of da over this run: the two half-waves hold different positions of the same unit
+        HY_LDS float* red = reinterpret_cast<HY_LDS float*>(e0);
+        HY_WAVE_SYNC_PJ();
+        if (hb == 1) { red[j] = colsum[0]; red[32 + j] = colsum[1]; }
+        HY_WAVE_SYNC_PJ();
+        if (hb == 0) {
+            a.part[(size_t)run * N + n0 + j] = colsum[0] + red[j];
+            a.part[(size_t)run * N + n0 + 32 + j] = colsum[1] + red[32 + j];
+        }
+    }
+}
+
 }  // namespace pj
 }  // namespace hyena

@@ -30,6 +30,24 @@ int hyena_proj_supported(int B, int Lx, int D, int dtype);
 int hyena_inproj_pre_fwd(const void* u, const void* W, const float* bin, const float* w, const float* b, void* xT, void* vg,
                          int B, int Lx, int Lc, int D, int dtype, void* stream);
 
+
+/* ---- the block's MLP (flash_attn.modules.mlp.Mlp = simple_lm.py:191-211; long_conv_lm.py:117-123: fc1 -> tanh-GELU -> fc2) ---------
+ * The two products contracting over d_model, position-major, with the reference's element-wise passes in their epilogues:
+ *   forward   a = x W1^T + b1,  h = gelu_tanh(a)          x (P, K), W1 (N, K), b1 (N,) fp32 or NULL [values already rounded to the
+ *                                                          element type, as autocast rounds the bias] -> a, h (P, N), both stored
+ *                                                          (a is what the backward needs, h is fc2's input)
+ *   backward  da = (dy W2) * gelu_tanh'(a)                 dy (P, K), W2T (N, K) = fc2.weight^T, a (P, N) -> da (P, N) and
+ *             part[runs][N] = per-run column sums of da    (summing axis 0 gives d b1; hyena_mlp_partial_floats(P, N) floats)
+ * K = d_model in {128, 256}, N = d_inner a multiple of 256, 16-bit element types, P < 2^31 positions (B L).  fc2 itself, the
+ * input gradient da W1 and the weight gradients contract over d_inner or over the positions and stay library GEMMs.
+ * Numerics: fp32 accumulation; a = one rounding of (sum + b1); h = round(gelu(a)) from the rounded a; da = round(round(dy W2) gelu'(a))
+ * -- the values the autocast graph of the reference produces, up to the summation order inside the products. */
+int hyena_mlp_supported(long P, int K, int N, int dtype);
+size_t hyena_mlp_partial_floats(long P, int N);
+int hyena_mlp_fc1_gelu_fwd(const void* x, const void* W1, const float* b1, void* a, void* h, long P, int K, int N, int dtype, void* stream);
+int hyena_mlp_dh_dgelu_bwd(const void* dy, const void* W2T, const void* a, void* da, float* part, long P, int K, int N, int dtype,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,8 +141,27 @@ def short_conv(u_bdl, weight, bias, L_out):
     return F.conv1d(u_bdl, weight, bias, padding=ksz - 1, groups=C)[..., :L_out]
 
 
+def short_conv_taps(u_bdl, weight, bias, L_out):
+    """The same depthwise causal convolution written out tap by tap (Conv1d(C, C, k, groups=C, padding=k-1)(u)[..., :L_out]:
+    y[c, t] = bias[c] + sum_j weight[c, 0, j] u[c, t - (k - 1) + j], zero left padding; hyena.py:363-369, 394).  Plain
+    element-wise ops, so it runs in any dtype on any device -- F.conv1d over millions of positions in 768 groups takes the host
+    minutes, and has no float64 device kernel.  tests/test_oracle_golden.py pins it to `short_conv`."""
+    ksz = weight.shape[-1]
+    L_in = u_bdl.shape[-1]
+    n = min(L_out, L_in + ksz - 1)
+    up = F.pad(u_bdl, (ksz - 1, 0))                                # (B, C, L_in + k - 1): up[..., t + j] = u[..., t - (k-1) + j]
+    y = None
+    for j in range(ksz):
+        hi = min(n, up.shape[-1] - j)
+        term = weight[None, :, 0, j, None] * up[..., j:j + hi]
+        if hi < n:
+            term = F.pad(term, (0, n - hi))
+        y = term if y is None else y + term
+    return y + bias[None, :, None]
+
+
 def hyena_operator(sd: Dict[str, torch.Tensor], u: torch.Tensor, l_max: int, order: int = 2,
-                   modulate: bool = True, shift: float = 0.0, conv_fn=None):
+                   modulate: bool = True, shift: float = 0.0, conv_fn=None, short_conv_fn=None):
     """HyenaOperator.forward for the default options (num_heads=1, num_blocks=1, inner_factor=1,
     no outer mixing / post-order FFN, activation 'id', dropout 0).  hyena.py:388-444.
 
@@ -150,12 +169,13 @@ def hyena_operator(sd: Dict[str, torch.Tensor], u: torch.Tensor, l_max: int, ord
     conv (default: :func:`fftconv_ref`).
     """
     conv_fn = conv_fn or fftconv_ref
+    short_conv_fn = short_conv_fn or short_conv
     l = u.size(-2)
     l_filter = min(l, l_max)                                       # hyena.py:389-390
     d_model = sd["out_proj.weight"].shape[0]
     x = F.linear(u, sd["in_proj.weight"], sd["in_proj.bias"])      # hyena.py:391
     x = x.transpose(1, 2)                                          # b l d -> b d l (392)
-    uc = short_conv(x, sd["short_filter.weight"], sd["short_filter.bias"], l_filter)   # 394
+    uc = short_conv_fn(x, sd["short_filter.weight"], sd["short_filter.bias"], l_filter)   # 394
     B = uc.shape[0]
     uc = uc.reshape(B, 1, d_model * (order + 1), 1, l_filter)      # hyena.py:396-402
     *xs, v = uc.split(d_model, dim=2)                              # hyena.py:404

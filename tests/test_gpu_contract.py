@@ -8,7 +8,13 @@
 * ``HyenaDNALM`` against the golden minted from the reference's ``SimpleLMHeadModel`` (oracle/make_golden_lm.py,
   simple_lm.py:26-305): logits, loss and every gradient.
 
-The oracle runs on the host cores in fp32 (tens of seconds at L = 2^20)."""
+Where the oracle is evaluated.  `oracle/hyena_oracle.py` is pinned on the CPU against the reference-minted goldens
+(tests/test_oracle_golden.py).  At the contract shapes the host cores of the GPU box need ~3 minutes per case for it (measured:
+seven cases did not fit a 25-minute budget; F.conv1d over 2^20 positions x 768 groups and the fp32 autograd graph dominate), so
+here the SAME oracle functions are evaluated in FLOAT64 by PyTorch's own device ops (hipFFT, rocBLAS, element-wise kernels --
+none of this package's kernels), with the depthwise convolution in its tap-by-tap form `O.short_conv_taps` (pinned to
+`O.short_conv`'s F.conv1d in tests/test_oracle_golden.py); `test_device_evaluated_oracle_equals_host_oracle` ties the two
+evaluations together at (2, 8192, 256) in this file, on the GPU box."""
 import os
 
 import pytest
@@ -22,34 +28,51 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SHAPES = [(8, 32768, 256), (2, 160000, 256), (1, 1048576, 256)]
 
 
+def _f64(t):
+    return t.detach().to(device=torch.device("cuda", 0), dtype=torch.float64)      # norms of 10^9-element tensors: on the device
+
+
 def _rel(a, b):
-    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    a, b = _f64(a), _f64(b)
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
 def _per_channel_rel(a, b, dim):
     """worst relative L2 error over the slices along `dim` (a per-channel bound: one bad channel cannot hide in the norm)"""
-    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    a, b = _f64(a), _f64(b)
     dims = [d for d in range(a.dim()) if d != dim]
     num = (a - b).pow(2).sum(dim=dims).sqrt()
     den = b.pow(2).sum(dim=dims).sqrt().clamp_min(1e-30)
     return (num / den).max().item()
 
 
-def _ref_core_cm(xT, b_in, w, b, k, bias, L):
+def _ref_core_cm(xT, b_in, w, b, k, bias, L, short_conv=O.short_conv_taps):
     D = xT.shape[0] // 3
     x = (xT + b_in[:, None, None]).permute(1, 0, 2)
-    xc = O.short_conv(x, w, b, L)
+    xc = short_conv(x, w, b, L)
     x0, x1, v = xc.split(D, dim=1)
     return (O.fftconv_ref(v * x1, k, bias) * x0).permute(1, 0, 2)
 
 
+def test_device_evaluated_oracle_equals_host_oracle(gpu_lib):
+    """the oracle functions evaluated by PyTorch's device ops in float64 (what the contract-shape cases below compare with) against
+    their evaluation on the host in fp32 with F.conv1d (what tests/test_oracle_golden.py pins to the reference) -- same function,
+    two executors, at a size the host does in seconds"""
+    dev = torch.device("cuda", 0)
+    B, L, D = 2, 8192, 256
+    op, u, dy, ref = _operator_and_oracle(B, L, D, seed=77, device=torch.device("cpu"), dtype=torch.float32, short_conv=O.short_conv)
+    _, _, _, ref64 = _operator_and_oracle(B, L, D, seed=77, device=dev, dtype=torch.float64, short_conv=O.short_conv_taps)
+    assert _rel(ref["y"], ref64["y"]) < 5e-6 and _rel(ref["du"], ref64["du"]) < 2e-5
+    for n, g in ref["grads"].items():
+        if g is not None:
+            assert _rel(g, ref64["grads"][n]) < 5e-5, n
+
+
 @pytest.mark.parametrize("B,L,D", SHAPES)
 def test_mixer_core_cm_at_contract_shapes_vs_oracle(gpu_lib, B, L, D):
-    """hyena.py:392-439 between the projections, bf16 tensors as under autocast; oracle in fp32 on the same bf16 inputs"""
+    """hyena.py:392-439 between the projections, bf16 tensors as under autocast; oracle in float64 on the same bf16 inputs"""
     from hyena_dna_amd.mixer import hyena_mixer_core_cm
     dev = torch.device("cuda", 0)
-    torch.set_num_threads(os.cpu_count() or 1)
     g = torch.Generator(device=dev).manual_seed(L + D)
     rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
     xT = rn(3 * D, B, L).to(torch.bfloat16)
@@ -62,11 +85,15 @@ def test_mixer_core_cm_at_contract_shapes_vs_oracle(gpu_lib, B, L, D):
     leaves = [t.clone().requires_grad_(True) for t in (xT, b_in, w, b, k, bias)]
     z = hyena_mixer_core_cm(*leaves, L)
     z.backward(dz)
-    ref_leaves = [t.detach().float().cpu().requires_grad_(True) for t in (xT, b_in, w, b, k, bias)]
+    ref_leaves = [t.detach().double().requires_grad_(True) for t in (xT, b_in, w, b, k, bias)]      # float64, PyTorch device ops
     zr = _ref_core_cm(*ref_leaves, L)
-    zr.backward(dz.float().cpu())
+    zr.backward(dz.double())
+    del zr
+    torch.cuda.empty_cache()
     # 16-bit storage of vg, y, z and of the gradients between the kernels: ~3 roundings of 2^-9 on each path
+    zr = _ref_core_cm(*[t.detach() for t in ref_leaves], L)
     assert _rel(z.float(), zr) < 8e-3 and _per_channel_rel(z.float(), zr, 0) < 1.2e-2
+    del zr
     assert _rel(leaves[0].grad.float(), ref_leaves[0].grad) < 1.2e-2
     assert _per_channel_rel(leaves[0].grad.float(), ref_leaves[0].grad, 0) < 2e-2
     for n, a, r in zip(["db_in", "dw_sc", "db_sc", "dk", "dbias"], leaves[1:], ref_leaves[1:]):
@@ -75,8 +102,11 @@ def test_mixer_core_cm_at_contract_shapes_vs_oracle(gpu_lib, B, L, D):
     assert _per_channel_rel(leaves[4].grad.float(), ref_leaves[4].grad, 0) < 2e-2
 
 
-def _operator_and_oracle(B, L, D, seed):
+def _operator_and_oracle(B, L, D, seed, device=None, dtype=torch.float64, short_conv=O.short_conv_taps):
+    """(operator, u, dy, oracle results): the oracle's HyenaOperator.forward (O.hyena_operator) + autograd, evaluated on `device`
+    (default cuda:0) in `dtype`"""
     from hyena_dna_amd.hyena import HyenaOperator
+    device = device or torch.device("cuda", 0)
     torch.manual_seed(seed)
     op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
                        lr=6e-4, wd=0.0, lr_pos_emb=0.0)
@@ -89,13 +119,18 @@ def _operator_and_oracle(B, L, D, seed):
     u = torch.randn(B, L, D, generator=g)
     dy = torch.randn(B, L, D, generator=g)
     # oracle: the reference's forward restated (hyena.py:388-444), fp32 on the host, autograd for the gradients
-    leaves = {k_: v.clone().requires_grad_(v.is_floating_point() and k_ in dict(op.named_parameters())) for k_, v in sd.items()}
+    params = dict(op.named_parameters())
+    leaves = {k_: v.to(device=device, dtype=dtype if v.is_floating_point() else v.dtype).requires_grad_(v.is_floating_point() and k_ in params)
+              for k_, v in sd.items()}
     for i in (3, 5):                            # hyena.py:199: ONE freq parameter shared by the three activations
         leaves[f"filter_fn.implicit_filter.{i}.freq"] = leaves["filter_fn.implicit_filter.1.freq"]
-    u_ref = u.clone().requires_grad_(True)
-    y_ref = O.hyena_operator(leaves, u_ref, l_max=L + 2)
-    y_ref.backward(dy)
-    ref = dict(y=y_ref.detach(), du=u_ref.grad, grads={n: leaves[n].grad for n, _ in op.named_parameters()})
+    u_ref = u.to(device=device, dtype=dtype).requires_grad_(True)
+    y_ref = O.hyena_operator(leaves, u_ref, l_max=L + 2, short_conv_fn=short_conv)
+    y_ref.backward(dy.to(device=device, dtype=dtype))
+    ref = dict(y=y_ref.detach().cpu(), du=u_ref.grad.cpu(), grads={n: None if leaves[n].grad is None else leaves[n].grad.cpu() for n in params})
+    del leaves, u_ref, y_ref
+    if device.type == "cuda":
+        torch.cuda.empty_cache()
     return op, u, dy, ref
 
 
@@ -103,7 +138,6 @@ def _operator_and_oracle(B, L, D, seed):
 def test_operator_at_contract_shapes_vs_oracle(gpu_lib, B, L, D):
     """The whole HyenaOperator.forward (hyena.py:388-444) on the fused path, fp32 and bf16 autocast, vs the oracle."""
     dev = torch.device("cuda", 0)
-    torch.set_num_threads(os.cpu_count() or 1)
     op, u, dy, ref = _operator_and_oracle(B, L, D, seed=L // 7 + B)
     op = op.to(dev)
     assert op._fused_ok()

@@ -79,3 +79,21 @@ def test_pos_emb_and_deltas_restatement(golden_operator):
     assert torch.equal(z, c["state_dict"]["filter_fn.pos_emb.z"])
     assert torch.equal(t, c["state_dict"]["filter_fn.pos_emb.t"])
     assert torch.equal(O.exp_modulation_deltas(c["d_model"]), c["state_dict"]["filter_fn.modulation.deltas"])
+
+
+def test_short_conv_taps_is_the_conv1d_restatement(golden_operator):
+    """oracle.short_conv_taps (element-wise, any dtype / device: what the contract-shape GPU tests evaluate in float64) against
+    oracle.short_conv (F.conv1d, the reference's own op) incl. truncation and outputs beyond the input, and inside the whole
+    operator against the reference-minted goldens."""
+    import torch
+    from oracle import hyena_oracle as O
+    g = torch.Generator().manual_seed(0)
+    for (B, C, Lin, Lout, k) in [(2, 6, 37, 37, 3), (1, 5, 10, 8, 3), (2, 4, 5, 7, 3), (1, 3, 9, 9, 4), (1, 3, 1, 1, 3), (3, 768, 300, 300, 3)]:
+        u, w, b = torch.randn(B, C, Lin, generator=g), torch.randn(C, 1, k, generator=g), torch.randn(C, generator=g)
+        a, c = O.short_conv(u, w, b, Lout), O.short_conv_taps(u, w, b, Lout)
+        assert a.shape == c.shape and (a - c).abs().max() <= 1e-6 * (1 + a.abs().max())
+        a64 = O.short_conv_taps(u.double(), w.double(), b.double(), Lout)
+        assert (a64 - a.double()).abs().max() <= 2e-6 * (1 + a.abs().max())
+    for name, c in golden_operator.items():
+        y = O.hyena_operator(c["state_dict"], c["u"], l_max=c["l_max"], short_conv_fn=O.short_conv_taps)
+        torch.testing.assert_close(y, c["y"], rtol=1e-5, atol=1e-6)
