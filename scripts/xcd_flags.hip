@@ -52,14 +52,18 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 // 16-byte loads with an explicit cache policy.  MODE 0: sc1 (agent scope; round 2: returned stale lines), 3: sc0 sc1 (system scope),
 // 4: nt, 5: sc0 sc1 nt -- round 3's one follow-up: can the consumer skip the L1 invalidate with a load that
 // cannot hit the L1?
+// (Both loads AND the s_waitcnt live in ONE asm statement: with the wait in a separate statement nothing stops the compiler from
+// scheduling the consumers of the loaded registers above it -- the first version of this experiment, and round 2's, read the
+// registers before the data had arrived and reported every policy as "stale".)
 template <int MODE>
-__device__ __forceinline__ float4 ld_pol(const float4* p) {
-    u4 r;
-    if (MODE == 0) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
-    else if (MODE == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(r) : "v"(p) : "memory");
-    else if (MODE == 4) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(r) : "v"(p) : "memory");
-    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+__device__ __forceinline__ void ld_pol2(const float4* pa, const float4* pb, float4& a, float4& b) {
+    u4 ra, rb;
+    if (MODE == 0) asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(ra), "=&v"(rb) : "v"(pa), "v"(pb) : "memory");
+    else if (MODE == 3) asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(ra), "=&v"(rb) : "v"(pa), "v"(pb) : "memory");
+    else if (MODE == 4) asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx4 %1, %3, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(ra), "=&v"(rb) : "v"(pa), "v"(pb) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1 nt\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1 nt\n\ts_waitcnt vmcnt(0)" : "=&v"(ra), "=&v"(rb) : "v"(pa), "v"(pb) : "memory");
+    a = make_float4(__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w));
+    b = make_float4(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z), __uint_as_float(rb.w));
 }
 // producer side of the same question: stores at agent scope (PST = 1: `sc1`) instead of plain write-through stores
 template <int PST>
@@ -88,7 +92,7 @@ __global__ void __launch_bounds__(THREADS) exchange(float4* slabs, size_t slab_f
         if (!flag_barrier<1, (INV == 1 ? 1 : 0)>(fl, r, ++phase, err)) return;
         for (int row = r; row < rows; row += WG_PER_XCD) {
             float4 a, b;
-            if (INV != 1) { a = ld_pol<INV>(slab + (size_t)row * 512 + t); b = ld_pol<INV>(slab + (size_t)row * 512 + 256 + t); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (INV != 1) ld_pol2<INV>(slab + (size_t)row * 512 + t, slab + (size_t)row * 512 + 256 + t, a, b);
             else { a = slab[(size_t)row * 512 + t]; b = slab[(size_t)row * 512 + 256 + t]; }
             acc += a.x + b.x - 2.f * (float)(it + row) - (float)(t >> 3) - (float)((256 + t) >> 3);
         }
