@@ -339,30 +339,29 @@ struct MlpArgs {
     int tiles, tiles_per_wg;
 };
 
-__device__ __forceinline__ float pm_tanh(float x) {
-    // tanh(x) = 1 - 2 / (exp(2x) + 1): exact limits at +-inf, ~2 ulp -- far inside the 16-bit rounding that follows
+// 0.5 (1 + tanh(z)) = sigmoid(2 z) = 1 / (1 + exp(-2 z)): no cancellation in the negative tail (where 1 + tanh loses its digits),
+// exact limits 0 and 1.
+__device__ __forceinline__ float pm_sigmoid2(float z) {
 #ifdef HIPEMU
-    const float e = expf(2.0f * x);
+    const float s = expf(-2.0f * z);
 #else
-    const float e = __expf(2.0f * x);
+    const float s = __expf(-2.0f * z);
 #endif
-    return 1.0f - 2.0f / (e + 1.0f);
+    return 1.0f / (1.0f + s);
 }
-// the tanh approximation PyTorch's F.gelu(approximate="tanh") evaluates (aten/src/ATen/native/cuda/ActivationGeluKernel.cu), fp32
+// the tanh approximation PyTorch's F.gelu(approximate="tanh") evaluates (aten/src/ATen/native/cuda/ActivationGeluKernel.cu):
+// 0.5 x (1 + tanh(z)), z = sqrt(2 / pi) (x + 0.044715 x^3); fp32
 __device__ __forceinline__ float pm_gelu(float x) {
     const float kBeta = 0.7978845608028654f /* sqrt(2 / pi) */, kKappa = 0.044715f;
-    const float inner = kBeta * (x + kKappa * x * x * x);
-    return 0.5f * x * (1.0f + pm_tanh(inner));
+    return x * pm_sigmoid2(kBeta * (x + kKappa * x * x * x));
 }
+// its derivative: 0.5 (1 + t) + 0.5 x (1 - t^2) z'  with  0.5 (1 + t) = sg,  1 - t^2 = 4 sg (1 - sg)
 __device__ __forceinline__ float pm_dgelu(float x) {
     const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
     const float x2 = x * x;
-    const float inner = kBeta * (x + kKappa * x2 * x);
-    const float t = pm_tanh(inner);
-    const float left = 0.5f * x, right = 1.0f + t;
-    const float dleft = 0.5f, dtanh = 1.0f - t * t;
-    const float dinner = kBeta * (1.0f + 3.0f * kKappa * x2);
-    return dleft * right + left * dtanh * dinner;
+    const float sg = pm_sigmoid2(kBeta * (x + kKappa * x2 * x));
+    const float dz = kBeta * (1.0f + 3.0f * kKappa * x2);
+    return sg + 2.0f * x * sg * (1.0f - sg) * dz;
 }
 
 // MODE 0: fc1 + bias + GELU (outputs a, h);  MODE 1: dh = dy W2, da = dh gelu'(a) (+ partial column sums)

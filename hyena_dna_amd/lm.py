@@ -10,9 +10,10 @@ this module) is on ``sys.path`` -- INTEGRATION.md section 4.  What is MI355X-spe
 
 * ``Block`` routes its two (dropout ->) add -> LayerNorm steps through the fused HIP kernels of
   ``hyena_dna_amd.block.dropout_add_layer_norm`` when ``fused_dropout_add_ln=True``;
-* ``Mlp`` keeps its two products on the library GEMMs (hipBLASLt MFMA kernels) with the split-K weight gradient of
-  ``hyena_dna_amd.projection`` (the same B*L-long contraction pathology as the operator's projections); the tanh-GELU
-  the backbone asks for (``long_conv_lm.py:117-123``) is PyTorch's fused elementwise kernel;
+* ``Mlp`` (tanh-GELU, ``long_conv_lm.py:117-123``) runs its two products that contract over d_model on this package's
+  weights-stationary MFMA kernels with the element-wise passes in their epilogues (``FusedMlpFunc``: fc1 + bias + GELU forward,
+  (dy W2) * GELU' + bias-gradient sums backward; ``csrc/proj_kernels.h``); fc2, the input gradient and the weight gradients
+  stay library GEMMs, the latter with the split-K schedule of ``hyena_dna_amd.projection``;
 * the mixer is whatever ``mixer_cls`` builds -- ``hyena_dna_amd.hyena.HyenaOperator`` through the registry swap.
 
 ``HyenaDNALM`` = embedding -> n_layer x Block -> (dropout, add,) LayerNorm -> tied LM head, the hyenadna-* model family
@@ -50,10 +51,83 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features, **factory_kwargs)
 
     def forward(self, x):
-        y = hyena_linear(x, self.fc1.weight, self.fc1.bias)
-        y = self.activation(y)
-        y = hyena_linear(y, self.fc2.weight, self.fc2.bias)
+        if self._fused_ok(x):
+            y = fused_mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        else:
+            y = hyena_linear(x, self.fc1.weight, self.fc1.bias)
+            y = self.activation(y)
+            y = hyena_linear(y, self.fc2.weight, self.fc2.bias)
         return y if not self.return_residual else (y, x)
+
+    def _fused_ok(self, x):
+        """The matrix-core MLP kernels (csrc/proj_kernels.h) cover the HyenaDNA block: tanh-GELU, 16-bit compute (autocast or
+        plain), d_model 128 / 256, d_inner a multiple of 256, biases present."""
+        act = self.activation
+        tanh_gelu = (isinstance(act, partial) and act.func is F.gelu and act.keywords.get("approximate") == "tanh" and not act.args)
+        if not (FUSED_MLP and tanh_gelu and self.fc1.bias is not None and self.fc2.bias is not None):
+            return False
+        from . import _lib
+        if not (x.is_cuda or _lib._backend.name != "hip"):
+            return False
+        dt = _mlp_dtype(x, self.fc1.weight)
+        rows = x.numel() // max(x.shape[-1], 1)
+        return dt is not None and rows >= 1 and _lib.mlp_supported(rows, self.fc1.in_features, self.fc1.out_features, dt)
+
+
+FUSED_MLP = os.environ.get("HYENA_FUSED_MLP", "1") != "0"          # A/B knob: 0 = two library GEMMs + PyTorch's GELU
+
+
+def _mlp_dtype(x, weight):
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda" if x.is_cuda else "cpu")
+        return dt if dt in (torch.bfloat16, torch.float16) else None
+    return x.dtype if x.dtype in (torch.bfloat16, torch.float16) and weight.dtype == x.dtype else None
+
+
+class FusedMlpFunc(torch.autograd.Function):
+    """y = fc2(gelu_tanh(fc1(x))) (simple_lm.py:207-211) with the element-wise passes inside this package's MFMA kernels:
+
+        forward   a, h = mlp_fc1_gelu_fwd(x, W1, b1)          one launch: a = x W1^T + b1 and h = gelu(a), both kept (a for the
+                  y = h W2^T + b2                              backward, h as fc2's operand -- what autograd keeps today as well)
+        backward  da, db1 = mlp_dh_dgelu_bwd(dy, W2^T, a)      one launch: (dy W2) * gelu'(a) and its column sums
+                  dx = da W1;  dW1 = da^T x;  dW2 = dy^T h;  db2 = sum dy        library GEMMs (contractions over d_inner / positions)
+
+    Gone: the GELU pass (read a, write h), the GELU-backward pass (read a, dh, write da), the dh tensor and fc1's bias-gradient
+    reduction -- 12 of the ~28 GB a layer's MLP moves at L = 2^20."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        from . import _lib
+        x2 = x.reshape(-1, x.shape[-1])
+        a, h = _lib.mlp_fc1_gelu_fwd(x2, w1, b1.float().contiguous())       # b1 arrives rounded to the compute type (autocast semantics)
+        y = torch.addmm(b2, h, w2.t())
+        ctx.save_for_backward(x2, w1, w2, a, h)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        from .projection import split_k_weight_grad
+        x2, w1, w2, a, h = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        da, db1 = _lib.mlp_dh_dgelu_bwd(dy2, w2.t().contiguous(), a)
+        dx = dw1 = dw2 = db2 = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(da, w1).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw1 = split_k_weight_grad(da, x2).to(w1.dtype)
+        if ctx.needs_input_grad[3]:
+            dw2 = split_k_weight_grad(dy2, h).to(w2.dtype)
+        if ctx.needs_input_grad[4]:
+            db2 = dy2.sum(0, dtype=torch.float32).to(dy.dtype)
+        return dx, dw1, db1.to(dy.dtype) if ctx.needs_input_grad[2] else None, dw2, db2
+
+
+def fused_mlp(x, w1, b1, w2, b2):
+    dt = _mlp_dtype(x, w1)
+    with torch.autocast("cuda" if x.is_cuda else "cpu", enabled=False):
+        return FusedMlpFunc.apply(x.to(dt).contiguous(), w1.to(dt).contiguous(), b1.to(dt), w2.to(dt).contiguous(), b2.to(dt))
 
 
 def _refuse(name):

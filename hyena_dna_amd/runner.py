@@ -285,6 +285,12 @@ def build_optimizer(model, opt_cfg, capturable=False):
         if "betas" in hp:
             hp["betas"] = tuple(hp["betas"])
         groups.append({"params": [params[n] for n in names], **hp})
+    if capturable:
+        # inside a hipGraph a Python-float learning rate is frozen at its value at capture time: keep it in a device tensor that the
+        # schedule updates in place between replays (lm.GraphedTrainStep)
+        dev = groups[0]["params"][0].device
+        for g in groups:
+            g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)
     first = {k: v for k, v in groups[0].items() if k != "params"}
     extra = {"capturable": True} if capturable else {}
     opt = torch.optim.AdamW(groups[0]["params"], **first, **extra)

@@ -61,3 +61,62 @@ def test_operator_uses_the_mfma_projection_and_matches_the_library_path(gpu_lib,
     for a, b in zip(*res):
         err = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
         assert err < 1e-2, err
+
+
+@pytest.mark.parametrize("P,K,N,dtype", [(8 * 1024, 128, 512, torch.bfloat16), (8 * 32768, 256, 1024, torch.bfloat16), (1048576, 256, 1024, torch.bfloat16),
+                                         (999999, 256, 1024, torch.float16), (77, 128, 256, torch.bfloat16)])
+def test_mlp_kernels_on_gpu(gpu_lib, P, K, N, dtype):
+    """fc1 + bias + GELU and (dy W2) * GELU'(a) + column sums (csrc/proj_kernels.h mlp_kernel) against the autocast graph they
+    replace: library GEMMs + PyTorch's tanh-GELU forward / backward on the same 16-bit tensors."""
+    F = torch.nn.functional
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(P % 1000 + N)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
+    x = rn(P, K).to(dtype)
+    W1, b1 = (rn(N, K) / K ** 0.5).to(dtype), (rn(N) * 0.2).to(dtype)
+    W2 = (rn(K, N) / N ** 0.5).to(dtype)
+    dy = rn(P, K).to(dtype)
+    assert gpu_lib.mlp_supported(P, K, N, dtype)
+    a, h = gpu_lib.mlp_fc1_gelu_fwd(x, W1, b1.float())
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    a_lib = F.linear(x, W1, b1)
+    assert ((a.float() - a_lib.float()).abs() <= 2 * eps * a_lib.float().abs() + 1e-5).all() and (a != a_lib).float().mean().item() < 0.02
+    h_ref = F.gelu(a, approximate="tanh")                       # PyTorch's kernel on the kernel's own a
+    assert ((h.float() - h_ref.float()).abs() <= 2 * eps * h_ref.float().abs() + 1e-6).all() and (h != h_ref).float().mean().item() < 0.01
+    da, db1 = gpu_lib.mlp_dh_dgelu_bwd(dy, W2.t().contiguous(), a)
+    dh = torch.mm(dy, W2)
+    a_ = a.clone().requires_grad_(True)
+    F.gelu(a_, approximate="tanh").backward(dh)
+    da_ref = a_.grad
+    err = ((da.float() - da_ref.float()).norm() / da_ref.float().norm()).item()
+    assert err < 3e-3, err                                       # 16-bit roundings of dh on either side
+    assert ((da.float() - da_ref.float()).abs() <= 4 * eps * da_ref.float().abs() + 4 * eps * 0.05).all()
+    ref_db1 = da.float().sum(0)
+    assert ((db1 - ref_db1).abs() <= 1e-4 * (1 + da.float().abs().sum(0))).all()
+    a2, h2 = gpu_lib.mlp_fc1_gelu_fwd(x, W1, b1.float())
+    da2, db2 = gpu_lib.mlp_dh_dgelu_bwd(dy, W2.t().contiguous(), a)
+    assert torch.equal(a, a2) and torch.equal(h, h2) and torch.equal(da, da2) and torch.equal(db1, db2)
+
+
+def test_lm_step_with_and_without_the_fused_mlp(gpu_lib, monkeypatch):
+    """HyenaDNALM loss and gradients, bf16 autocast, with the MFMA MLP kernels vs two library GEMMs + PyTorch's GELU"""
+    import hyena_dna_amd.lm as LM
+    dev = torch.device("cuda", 0)
+    L, B, D = 8192, 2, 128
+    layer = dict(l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10)
+    torch.manual_seed(3)
+    m = LM.HyenaDNALM(d_model=D, n_layer=2, d_inner=4 * D, vocab_size=12, layer=layer, resid_dropout=0.0, embed_dropout=0.0,
+                      pad_vocab_size_multiple=8).to(dev)
+    ids = torch.randint(7, 11, (B, L), device=dev)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(LM, "FUSED_MLP", on)
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = m.loss(ids, torch.roll(ids, -1, 1))
+        loss.backward()
+        res.append((loss.item(), {n: p.grad.float().clone() for n, p in m.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) < 2e-3 * abs(res[1][0])
+    for n, gref in res[1][1].items():
+        e = ((res[0][1][n] - gref).norm() / gref.norm().clamp_min(1e-20)).item()
+        assert e < 3e-2, (n, e)

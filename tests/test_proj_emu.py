@@ -71,3 +71,67 @@ def test_operator_with_and_without_the_mfma_projection(emu_backend, monkeypatch)
     for a, b in zip(*res):
         err = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
         assert err < 2e-2, err
+
+
+# ---- the MLP's kernels -------------------------------------------------------------------------------------------------
+def _gelu_ref(a):
+    return torch.nn.functional.gelu(a.float(), approximate="tanh")
+
+
+@pytest.mark.parametrize("P,K,N,dtype", [(64, 128, 256, torch.bfloat16), (200, 128, 512, torch.bfloat16), (77, 256, 1024, torch.float16),
+                                         (1000, 256, 256, torch.bfloat16), (9, 128, 256, torch.float16)])
+def test_mlp_kernels_vs_autocast_graph(emu_backend, P, K, N, dtype):
+    """fc1 + bias + GELU and (dy W2) * GELU'(a) + column sums against the graph they replace, evaluated in fp32 with the roundings
+    autocast applies: a = round(x W1^T + b1), h = round(gelu(a)), dh = round(dy W2), da = round(dh * gelu'(a))."""
+    _lib = emu_backend
+    g = torch.Generator().manual_seed(P + N)
+    x = torch.randn(P, K, generator=g).to(dtype)
+    W1 = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
+    b1 = (torch.randn(N, generator=g) * 0.2).to(dtype)
+    W2 = (torch.randn(K, N, generator=g) / N ** 0.5).to(dtype)
+    dy = torch.randn(P, K, generator=g).to(dtype)
+    assert _lib.mlp_supported(P, K, N, dtype)
+    a, h = _lib.mlp_fc1_gelu_fwd(x, W1, b1.float())
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    a_ref = x.float() @ W1.float().t() + b1.float()
+    assert ((a.float() - a_ref).abs() <= eps * a_ref.abs() + 1e-6).all()
+    h_ref = _gelu_ref(a).to(dtype)                                   # from the kernel's own rounded a: the same value or its neighbour
+    assert ((h.float() - h_ref.float()).abs() <= 2 * eps * h_ref.float().abs() + 1e-6).all() and (h != h_ref).float().mean() < 0.01
+    h64 = torch.nn.functional.gelu(a.double(), approximate="tanh")    # and not further from the exact value than PyTorch's fp32 evaluation
+    assert (h.double() - h64).abs().max() <= (h_ref.double() - h64).abs().max() * 1.01 + 1e-9
+    da, db1 = _lib.mlp_dh_dgelu_bwd(dy, W2.t().contiguous(), a)
+    dh = (dy.float() @ W2.float()).to(dtype)
+    af = a.float().requires_grad_(True)
+    _gelu_ref(af).backward(dh.float())
+    da_ref = af.grad.to(dtype)
+    d = (da.float() - da_ref.float()).abs()
+    assert (d <= 2 * eps * da_ref.float().abs() + 2 * eps * 1e-2).all()           # (dh itself may differ by an ulp: another summation order)
+    assert (da != da_ref).float().mean() < 0.03
+    assert ((db1 - da.float().sum(0)).abs() <= 1e-5 * (1 + da.float().abs().sum(0))).all()
+
+
+def test_fused_mlp_module_matches_the_unfused_graph(emu_backend, monkeypatch):
+    """lm.Mlp with and without the kernels (HYENA_FUSED_MLP knob), bf16 tensors: output and every gradient"""
+    from functools import partial
+
+    import torch.nn.functional as F
+
+    import hyena_dna_amd.lm as LM
+    torch.manual_seed(1)
+    mlp = LM.Mlp(128, hidden_features=512, activation=partial(F.gelu, approximate="tanh")).to(torch.bfloat16)
+    x0 = torch.randn(3, 50, 128).to(torch.bfloat16)
+    dy = torch.randn(3, 50, 128).to(torch.bfloat16)
+    calls, real = [], emu_backend.mlp_fc1_gelu_fwd
+    monkeypatch.setattr(emu_backend, "mlp_fc1_gelu_fwd", lambda *a: (calls.append(1), real(*a))[1])
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(LM, "FUSED_MLP", on)
+        mlp.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = mlp(x)
+        y.backward(dy)
+        res.append([y.float(), x.grad.float()] + [p.grad.float() for _, p in sorted(mlp.named_parameters())])
+    assert len(calls) == 1
+    for a, b in zip(*res):
+        err = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+        assert err < 1e-2, err
