@@ -97,6 +97,7 @@ def parse():
     ap.add_argument("--no-save-spectra", action="store_true",
                     help="backward recomputes the column spectra of u and k instead of reusing the forward's")
     ap.add_argument("--fwd-only", action="store_true", help="diagnostic; the reported metric needs fwd+bwd")
+    ap.add_argument("--no-graph", action="store_true", help="launch-bound sizes: time eager calls instead of hipGraph replays of the step")
     ap.add_argument("--share-gpu0", action="store_true",
                     help="TEST ONLY: every rank on cuda:0 with the gloo backend (exercises the N > 1 GPU leg on a 1-GPU box)")
     ap.add_argument("--emu", action="store_true",
@@ -237,6 +238,7 @@ def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=3, warmup=
             for _ in range(2):
                 gstep()
             torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n = max(steps, 10)
             e0.record()
             for _ in range(n):
@@ -319,12 +321,32 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # Launch-bound sizes (a hyenadna-tiny-1k layer call is ~15 us of GPU work behind ~35 us of Python + ctypes per call): the step
+    # is captured into ONE hipGraph and replayed -- the same launches on the same buffers, issued by the runtime instead of the
+    # interpreter (what lm.GraphedTrainStep does for the whole training step).  --no-graph times the eager calls.
+    graphed = False
+    run_step = step
+    if not args.emu and not args.no_graph and algorithmic_bytes(B, D, L, 2 if dtype != torch.float32 else 4) <= 64 * 2 ** 20:
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):                       # this stream's workspace and the allocator's blocks exist before the capture
+                step()
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        run_step, graphed = graph.replay, True
+        for _ in range(args.warmup):
+            run_step()
+        sync()
     if not args.emu:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run_step()
     if not args.emu:
         e1.record()
     sync()
@@ -364,7 +386,7 @@ def main():
                                    f"{args.dtype} activations, fp32 filter and FFT math" +
                                    (" [FWD ONLY -- diagnostic]" if args.fwd_only else ""),
                        "seq_len": L, "channels": D, "batch_per_gpu": B, "io_dtype": args.dtype,
-                       "save_spectra": bool(save),
+                       "save_spectra": bool(save), "hipgraph_replay": bool(graphed),
                        "chunk": int(_lib.lib().hyena_fftconv_default_chunk(B, D, L, 1)) if chunk is None else chunk,
                        "parallelism": f"dp{world} (batch-sharded replicas: the convolution has no exchange step, so no collective in the "
                                       f"timed region; the DDP gradient all-reduce is measured in `model_step`)"

@@ -112,7 +112,9 @@ __device__ __forceinline__ void cm_sc(const float (&xs)[N + 2], int l0, const Cm
     for (int i = 0; i < N; ++i) {
         const int l = l0 + i;
         const float x0 = l >= 2 ? xs[i] + t.bin : 0.f, x1 = l >= 1 ? xs[i + 1] + t.bin : 0.f, x2 = xs[i + 2] + t.bin;
-        out[i] = t.bsc + t.w0 * x0 + t.w1 * x1 + t.w2 * x2;
+        // explicit fused multiply-adds in a fixed order: the projection kernel's epilogue (proj_kernels.h) evaluates the same
+        // expression and must give the same bits -- left to the compiler, the contraction into FMAs differs between kernels
+        out[i] = __builtin_fmaf(t.w2, x2, __builtin_fmaf(t.w1, x1, __builtin_fmaf(t.w0, x0, t.bsc)));
     }
 }
 __device__ __forceinline__ const char* cm_row(const void* base, size_t row, int len, size_t es) {

@@ -177,10 +177,22 @@ __global__ void __launch_bounds__(PJ_THREADS) inproj_pre_fwd_kernel(InProjArgs a
         }
     };
 
+    // per-lane constants of the straight-line epilogue: element offsets of the 12 xT pieces and the 4 vg pieces a lane moves per
+    // tile, and the taps of the 4 (channel, piece) pairs whose short convolution it evaluates
+    // Piece m of a lane: id = lane + 64 m -> group m >> 2, channel (lane >> 3) + 8 (m & 3), piece lane & 7: the m-dependent part
+    // of every address is wave-uniform (scalar registers), only piece 0's offset is held per lane.
+    const size_t xoff0 = (size_t)(d0 + (lane >> 3)) * P + 8u * (unsigned)(lane & 7);
+    const unsigned voff0 = (unsigned)(d0 + (lane >> 3)) * (unsigned)a.Lc + 8u * (unsigned)(lane & 7);
+    HY_WAVE_SYNC_PJ();
+
     const int t_first = t_begin > 0 ? t_begin - 1 : t_begin;                // warm-up tile: provides the halo of tile t_begin
+    // (sequence, position within it) of the first position of the current tile, carried along instead of divided out per tile
+    unsigned sb = ((unsigned)t_first * PJ_NT) / (unsigned)a.Lx;
+    int sl0 = (int)((unsigned)t_first * PJ_NT - sb * (unsigned)a.Lx);
     prefetch(t_first);
     int cur = 0;
-    for (int t = t_first; t < t_end; ++t) {
+    for (int t = t_first; t < t_end; ++t, sl0 += PJ_NT) {
+        while (sl0 >= a.Lx) { sl0 -= a.Lx; ++sb; }
         stage(cur);
         __syncthreads();
         if (t + 1 < t_end) prefetch(t + 1);
@@ -229,66 +241,111 @@ __global__ void __launch_bounds__(PJ_THREADS) inproj_pre_fwd_kernel(InProjArgs a
             HY_WAVE_SYNC_PJ();
             if (t >= t_begin) {
                 const unsigned p0 = (unsigned)t * PJ_NT;
-                // (3) xT: 3 x 32 rows x 8 pieces of 8 positions
-                HY_UNROLL
-                for (int m = 0; m < 3 * PJ_CB * 8 / 64; ++m) {
-                    const int id = lane + 64 * m, g = id >> 8, ch = (id >> 3) & 31, pc = id & 7;
-                    const unsigned p = p0 + 8u * (unsigned)pc;
-                    const Frag v = lds_ld16(ebuf + (g * PJ_CB + ch) * C::EROW + 16 + pc * 16);
-                    elem_t* dst = reinterpret_cast<elem_t*>(a.xT) + (size_t)(g * D + d0 + ch) * P + p;
-                    if (p + 8 <= P) st16(dst, v);
-                    else {
-                        elem_t s[8];
-                        __builtin_memcpy(s, v.w, 16);
-                        for (int i = 0; i < 8; ++i)
-                            if (p + i < P) dst[i] = s[i];
-                    }
-                }
-                // (4) vg = shortconv(v) * shortconv(x1): 32 channels x 8 pieces
-                HY_UNROLL
-                for (int m = 0; m < PJ_CB * 8 / 64; ++m) {
-                    const int id = lane + 64 * m, ch = id >> 3, pc = id & 7;
-                    const unsigned p = p0 + 8u * (unsigned)pc;
-                    if (p >= P) continue;
-                    float prod[8];
-                    const unsigned b = p / (unsigned)a.Lx;
-                    const int l = (int)(p - b * (unsigned)a.Lx);
+                // Interior tiles -- whole, inside one sequence, at least two positions into it, inside the convolved length -- take a
+                // straight-line path: no per-element predicates, no divisions, addresses from offsets hoisted out of the loop.  (The
+                // generic path below costs ~2.5x the instructions; with one wavefront per SIMD the kernel is bound by instruction
+                // issue, not by the matrix cores or by memory.)
+                const bool fast = p0 + PJ_NT <= P && sl0 >= 2 && sl0 + PJ_NT <= a.Lc;
+                if (fast) {
                     HY_UNROLL
-                    for (int gi = 0; gi < 2; ++gi) {                    // gi = 0: x1 (group 1), gi = 1: v (group 2)
-                        const HY_LDS char* row = ebuf + ((1 + gi) * PJ_CB + ch) * C::EROW + pc * 16;
-                        const Frag lo = lds_ld16(row), hi = lds_ld16(row + 16);
-                        elem_t pl[8], ph[8];
-                        __builtin_memcpy(pl, lo.w, 16);
-                        __builtin_memcpy(ph, hi.w, 16);
-                        float xs[10];
-                        xs[0] = Elem<DT>::dec(pl[6]); xs[1] = Elem<DT>::dec(pl[7]);
+                    for (int m = 0; m < 3 * PJ_CB * 8 / 64; ++m) {
+                        const int id = lane + 64 * m, g = id >> 8, ch = (id >> 3) & 31, pc = id & 7;
+                        const size_t rowm = (size_t)((m >> 2) * D + 8 * (m & 3)) * P + p0;               // wave-uniform
+                        st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), lds_ld16(ebuf + (g * PJ_CB + ch) * C::EROW + 16 + pc * 16));
+                    }
+                    const size_t vbase = (size_t)sb * D * a.Lc + (size_t)sl0;
+                    HY_UNROLL
+                    for (int m = 0; m < PJ_CB * 8 / 64; ++m) {
+                        const int id = lane + 64 * m, ch = id >> 3, pc = id & 7;
+                        float prod[8];
                         HY_UNROLL
-                        for (int i = 0; i < 8; ++i) xs[2 + i] = Elem<DT>::dec(ph[i]);
-                        const HY_LDS float* tp = taps + (gi * PJ_CB + ch) * 5;
-                        const float w0 = tp[0], w1 = tp[1], w2 = tp[2], bsc = tp[3], bin = tp[4];
-                        HY_UNROLL
-                        for (int i = 0; i < 8; ++i) {
-                            int li = l + i;                             // position within its sequence (the piece may cross into the next one)
-                            if (li >= a.Lx) li -= a.Lx;
-                            const float x0 = li >= 2 ? xs[i] + bin : 0.f, x1 = li >= 1 ? xs[i + 1] + bin : 0.f, x2 = xs[i + 2] + bin;
-                            const float c = bsc + w0 * x0 + w1 * x1 + w2 * x2;
-                            prod[i] = gi == 0 ? c : prod[i] * c;
+                        for (int gi = 0; gi < 2; ++gi) {
+                            const HY_LDS char* row = ebuf + ((1 + gi) * PJ_CB + ch) * C::EROW + pc * 16;
+                            const Frag lo = lds_ld16(row), hi = lds_ld16(row + 16);
+                            elem_t pl[8], ph[8];
+                            __builtin_memcpy(pl, lo.w, 16);
+                            __builtin_memcpy(ph, hi.w, 16);
+                            float xs[10];
+                            const HY_LDS float* tp = taps + (gi * PJ_CB + ch) * 5;
+                            const float w0 = tp[0], w1 = tp[1], w2 = tp[2], bsc = tp[3], bin = tp[4];
+                            xs[0] = Elem<DT>::dec(pl[6]) + bin; xs[1] = Elem<DT>::dec(pl[7]) + bin;
+                            HY_UNROLL
+                            for (int i = 0; i < 8; ++i) xs[2 + i] = Elem<DT>::dec(ph[i]) + bin;
+                            HY_UNROLL
+                            for (int i = 0; i < 8; ++i) {
+                                const float c = __builtin_fmaf(w2, xs[i + 2], __builtin_fmaf(w1, xs[i + 1], __builtin_fmaf(w0, xs[i], bsc)));   // = cm_sc
+                                prod[i] = gi == 0 ? c : prod[i] * c;
+                            }
                         }
-                    }
-                    elem_t out[8];
-                    HY_UNROLL
-                    for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
-                    elem_t* vrow = reinterpret_cast<elem_t*>(a.vg) + ((size_t)b * D + d0 + ch) * a.Lc;
-                    if (l + 8 <= a.Lc) {
+                        elem_t out[8];
+                        HY_UNROLL
+                        for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
                         Frag f;
                         __builtin_memcpy(f.w, out, 16);
-                        st16(vrow + l, f);
-                    } else {
-                        for (int i = 0; i < 8; ++i) {
-                            int li = l + i;
-                            unsigned bi = b;
-                            if (li >= a.Lx) { li -= a.Lx; ++bi; }
-                            if (p + i < P && li < a.Lc) reinterpret_cast<elem_t*>(a.vg)[((size_t)bi * D + d0 + ch) * a.Lc + li] = out[i];
+                        st16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * m) * (unsigned)a.Lc), f);
+                    }
+                } else {
+                    // (3) xT: 3 x 32 rows x 8 pieces of 8 positions
+                    HY_UNROLL
+                    for (int m = 0; m < 3 * PJ_CB * 8 / 64; ++m) {
+                        const int id = lane + 64 * m, g = id >> 8, ch = (id >> 3) & 31, pc = id & 7;
+                        const unsigned p = p0 + 8u * (unsigned)pc;
+                        const Frag v = lds_ld16(ebuf + (g * PJ_CB + ch) * C::EROW + 16 + pc * 16);
+                        elem_t* dst = reinterpret_cast<elem_t*>(a.xT) + (size_t)(g * D + d0 + ch) * P + p;
+                        if (p + 8 <= P) st16(dst, v);
+                        else {
+                            elem_t s[8];
+                            __builtin_memcpy(s, v.w, 16);
+                            for (int i = 0; i < 8; ++i)
+                                if (p + i < P) dst[i] = s[i];
+                        }
+                    }
+                    // (4) vg = shortconv(v) * shortconv(x1): 32 channels x 8 pieces
+                    HY_UNROLL
+                    for (int m = 0; m < PJ_CB * 8 / 64; ++m) {
+                        const int id = lane + 64 * m, ch = id >> 3, pc = id & 7;
+                        const unsigned p = p0 + 8u * (unsigned)pc;
+                        if (p >= P) continue;
+                        float prod[8];
+                        const unsigned b = p / (unsigned)a.Lx;
+                        const int l = (int)(p - b * (unsigned)a.Lx);
+                        HY_UNROLL
+                        for (int gi = 0; gi < 2; ++gi) {                    // gi = 0: x1 (group 1), gi = 1: v (group 2)
+                            const HY_LDS char* row = ebuf + ((1 + gi) * PJ_CB + ch) * C::EROW + pc * 16;
+                            const Frag lo = lds_ld16(row), hi = lds_ld16(row + 16);
+                            elem_t pl[8], ph[8];
+                            __builtin_memcpy(pl, lo.w, 16);
+                            __builtin_memcpy(ph, hi.w, 16);
+                            float xs[10];
+                            xs[0] = Elem<DT>::dec(pl[6]); xs[1] = Elem<DT>::dec(pl[7]);
+                            HY_UNROLL
+                            for (int i = 0; i < 8; ++i) xs[2 + i] = Elem<DT>::dec(ph[i]);
+                            const HY_LDS float* tp = taps + (gi * PJ_CB + ch) * 5;
+                            const float w0 = tp[0], w1 = tp[1], w2 = tp[2], bsc = tp[3], bin = tp[4];
+                            HY_UNROLL
+                            for (int i = 0; i < 8; ++i) {
+                                int li = l + i;                             // position within its sequence (the piece may cross into the next one)
+                                if (li >= a.Lx) li -= a.Lx;
+                                const float x0 = li >= 2 ? xs[i] + bin : 0.f, x1 = li >= 1 ? xs[i + 1] + bin : 0.f, x2 = xs[i + 2] + bin;
+                                const float c = __builtin_fmaf(w2, x2, __builtin_fmaf(w1, x1, __builtin_fmaf(w0, x0, bsc)));   // = cm_sc
+                                prod[i] = gi == 0 ? c : prod[i] * c;
+                            }
+                        }
+                        elem_t out[8];
+                        HY_UNROLL
+                        for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
+                        elem_t* vrow = reinterpret_cast<elem_t*>(a.vg) + ((size_t)b * D + d0 + ch) * a.Lc;
+                        if (l + 8 <= a.Lc) {
+                            Frag f;
+                            __builtin_memcpy(f.w, out, 16);
+                            st16(vrow + l, f);
+                        } else {
+                            for (int i = 0; i < 8; ++i) {
+                                int li = l + i;
+                                unsigned bi = b;
+                                if (li >= a.Lx) { li -= a.Lx; ++bi; }
+                                if (p + i < P && li < a.Lc) reinterpret_cast<elem_t*>(a.vg)[((size_t)bi * D + d0 + ch) * a.Lc + li] = out[i];
+                            }
                         }
                     }
                 }
@@ -347,7 +404,11 @@ __device__ __forceinline__ float pm_sigmoid2(float z) {
 #else
     const float s = __expf(-2.0f * z);
 #endif
+#ifdef HIPEMU
     return 1.0f / (1.0f + s);
+#else
+    return __builtin_amdgcn_rcpf(1.0f + s);          // v_rcp_f32 (1 ulp): a correctly rounded division costs ten instructions
+#endif
 }
 // the tanh approximation PyTorch's F.gelu(approximate="tanh") evaluates (aten/src/ATen/native/cuda/ActivationGeluKernel.cu):
 // 0.5 x (1 + tanh(z)), z = sqrt(2 / pi) (x + 0.044715 x^3); fp32
@@ -420,23 +481,35 @@ __global__ void __launch_bounds__(PJ_THREADS) mlp_kernel(MlpArgs a) {
         }
     };
 
+    // MODE 1: the a tile of this wavefront's units ([position][unit]: 64 x 8 pieces of 16 bytes, 8 per lane) is fetched one tile
+    // ahead, like the staged operand, and parked in the wavefront's second LDS tile while the matrix cores work.
+    // Piece m of a lane: position (lane >> 3) + 8 m, piece lane & 7 -- the m-dependent part of its address is wave-uniform.
+    const size_t eoff0 = (size_t)(lane >> 3) * N + n0 + 8 * (lane & 7);
+    Frag at[MODE == 1 ? PJ_NT * 8 / 64 : 1];
+    auto prefetch_a = [&](int t) {
+        if (MODE != 1) return;
+        const unsigned q0 = (unsigned)t * PJ_NT;
+        HY_UNROLL
+        for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
+            Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+            at[m] = q0 + (unsigned)(lane >> 3) + 8u * m < P
+                        ? ld16(reinterpret_cast<const elem_t*>(a.a_in) + (eoff0 + ((size_t)q0 + 8u * m) * N)) : z;
+        }
+    };
+
     prefetch(t_begin);
+    prefetch_a(t_begin);
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
         stage(cur);
-        __syncthreads();
-        if (t + 1 < t_end) prefetch(t + 1);
-        const unsigned p0 = (unsigned)t * PJ_NT;
         if (MODE == 1) {
-            // the a tile of this wavefront's units, [position][unit], while the matrix cores work: 64 x 8 pieces of 16 bytes
             HY_UNROLL
-            for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
-                const int id = lane + 64 * m, pos = id >> 3, pc = id & 7;
-                Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
-                const Frag v = p0 + pos < P ? ld16(reinterpret_cast<const elem_t*>(a.a_in) + (size_t)(p0 + pos) * N + n0 + 8 * pc) : z;
-                lds_st16(e1 + pos * C::EROW + pc * 16, v);
-            }
+            for (int m = 0; m < PJ_NT * 8 / 64; ++m) lds_st16(e1 + ((lane >> 3) + 8 * m) * C::EROW + (lane & 7) * 16, at[m]);
         }
+        __syncthreads();
+        if (t + 1 < t_end) { prefetch(t + 1); prefetch_a(t + 1); }
+        const unsigned p0 = (unsigned)t * PJ_NT;
+        const bool full = p0 + PJ_NT <= P;                       // wave-uniform: whole tiles skip every per-position predicate
         acc_t acc[2][2];                           // [position tile][unit tile]
         HY_UNROLL
         for (int pt = 0; pt < 2; ++pt) {
@@ -475,7 +548,7 @@ __global__ void __launch_bounds__(PJ_THREADS) mlp_kernel(MlpArgs a) {
                         const float dh = Elem<DT>::dec(Elem<DT>::cvt(acc[pt][ut][r]));          // the rounding of the unfused dh tensor
                         const elem_t dv = Elem<DT>::cvt(dh * pm_dgelu(Elem<DT>::dec(*s1)));
                         *s0 = dv;
-                        if (p0 + pos < P) colsum[ut] += Elem<DT>::dec(dv);
+                        if (full || p0 + pos < P) colsum[ut] += Elem<DT>::dec(dv);
                     }
                 }
             }
@@ -483,9 +556,9 @@ __global__ void __launch_bounds__(PJ_THREADS) mlp_kernel(MlpArgs a) {
         HY_WAVE_SYNC_PJ();
         HY_UNROLL
         for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
-            const int id = lane + 64 * m, pos = id >> 3, pc = id & 7;
-            if (p0 + pos >= P) continue;
-            const size_t off = (size_t)(p0 + pos) * N + n0 + 8 * pc;
+            const int pos = (lane >> 3) + 8 * m, pc = lane & 7;
+            if (!full && p0 + pos >= P) continue;
+            const size_t off = eoff0 + ((size_t)p0 + 8u * m) * N;                       // (second term wave-uniform)
             st16(reinterpret_cast<elem_t*>(a.o0) + off, lds_ld16(e0 + pos * C::EROW + pc * 16));
             if (MODE == 0) st16(reinterpret_cast<elem_t*>(a.o1) + off, lds_ld16(e1 + pos * C::EROW + pc * 16));
         }
