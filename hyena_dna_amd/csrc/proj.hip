@@ -9,7 +9,7 @@ using namespace hyena;
 namespace {
 template <int K, int DT>
 int launch_inproj(const pj::InProjArgs& a, int grid, void* stream) {
-    typedef pj::PjCfg<K> C;
+    typedef pj::IpCfg<K> C;
     static thread_local int done = -1;
     hy_allow_lds(pj::inproj_pre_fwd_kernel<K, DT>, C::LDS, &done);
     HY_LAUNCH((pj::inproj_pre_fwd_kernel<K, DT>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS, stream, a);
@@ -23,10 +23,10 @@ int launch_mlp(const pj::MlpArgs& a, int grid, void* stream) {
     HY_LAUNCH((pj::mlp_kernel<K, DT, MODE>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
-// runs of tiles per channel group: a few per CU (tail balance), at least 8 tiles long (weight load amortised)
+// runs of tiles per unit group: a few per workgroup slot (2 per CU; tail balance), at least 8 tiles long (weight load amortised)
 void mlp_schedule(size_t P, int ncg, pj::MlpArgs* a, int* runs_out, int* grid_out) {
     a->tiles = (int)((P + pj::PJ_NT - 1) / pj::PJ_NT);
-    int runs = 256 * 4 / ncg;
+    int runs = 256 * 8 / ncg;
     if (runs > a->tiles) runs = a->tiles;
     a->tiles_per_wg = (a->tiles + runs - 1) / runs;
     if (a->tiles_per_wg < 8 && a->tiles >= 8) a->tiles_per_wg = 8;
@@ -95,8 +95,10 @@ int hyena_inproj_pre_fwd(const void* u, const void* W, const float* bin, const f
     a.tiles = (int)((P + pj::PJ_NT - 1) / pj::PJ_NT);
     // One workgroup per CU is resident (its wavefronts hold the weights in ~350 registers): a few runs per CU balance the tail,
     // long runs amortise the weight load and the warm-up tile.
-    const int ncg = (D + pj::PJ_WAVES * pj::PJ_CB - 1) / (pj::PJ_WAVES * pj::PJ_CB);
-    int runs = 256 * 4 / ncg;
+    // Two workgroups per CU are resident (each wavefront holds its 48 weight rows in 96 registers): a few runs per slot balance
+    // the tail, long runs amortise the weight load and the warm-up tile.
+    const int ncg = D / (pj::PJ_WAVES * pj::IP_CB);
+    int runs = 256 * 8 / ncg;
     if (runs > a.tiles) runs = a.tiles;
     a.tiles_per_wg = (a.tiles + runs - 1) / runs;
     if (a.tiles_per_wg < 8 && a.tiles >= 8) a.tiles_per_wg = 8;

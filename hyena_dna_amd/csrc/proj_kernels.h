@@ -112,18 +112,57 @@ struct InProjArgs {
 // rows of the C/D operand: register r of a lane in half-wave hb holds channel (r & 3) + 8 (r >> 2) + 4 hb of the 32
 __device__ __forceinline__ int pj_row(int r, int hb) { return (r & 3) + 8 * (r >> 2) + 4 * hb; }
 
+// v_mfma_f32_16x16x32: lane l = (j = l & 15, kq = l >> 4) supplies A[j][8 kq ...] and B[8 kq ...][j], owns D[4 kq + r][j], r < 4
+#ifdef HIPEMU
+typedef hipemu::floatx4 acc4_t;
+template <int DT>
+__device__ __forceinline__ acc4_t mfma16(const Frag& a, const Frag& b, acc4_t c) {
+    hipemu::u32x4 x, y;
+    __builtin_memcpy(x.w, a.w, 16);
+    __builtin_memcpy(y.w, b.w, 16);
+    return hipemu::mfma_f32_16x16x32_h<DT == DT_BF16>(x, y, c);
+}
+#else
+typedef float acc4_t __attribute__((ext_vector_type(4)));
+template <int DT>
+__device__ __forceinline__ acc4_t mfma16(const Frag& a, const Frag& b, acc4_t c) {
+    if constexpr (DT == DT_BF16) {
+        typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+    } else {
+        typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+    }
+}
+#endif
+
+// The in_proj kernel proper.  A wavefront owns IP_CB = 16 channels of each of the three groups (48 weight rows x K = 96 VGPRs at
+// K = 256) on v_mfma_f32_16x16x32 and stays under 256 registers; a workgroup (4 wavefronts, 64 channels) needs 63 KB of LDS -- ONE
+// staging buffer, the wavefronts' epilogue tiles and taps -- so TWO workgroups share a CU: 2 wavefronts per SIMD.  (The first
+// version -- 32 channels per wavefront on 32x32x16, ~350 registers, one wavefront per SIMD -- was bound by the lone wavefront's
+// instruction issue: 0.77 ms at L = 2^20 against 0.55 ms of memory time.)
+enum { IP_CB = 16, IP_NT4 = PJ_NT / 16 };
+template <int K> struct IpCfg {
+    static constexpr int KS = K / 32;                         // v_mfma_f32_16x16x32 steps over the contraction
+    static constexpr int UROW = PjCfg<K>::UROW, UBUF = PjCfg<K>::UBUF, CH = PjCfg<K>::CH;
+    static constexpr int EROW = PJ_EW * 2;
+    static constexpr int EBUF = 3 * IP_CB * EROW;             // per wavefront: [group][channel][PJ_EW]
+    static constexpr int TAPS = 2 * IP_CB * 5 * 4;
+    static constexpr size_t LDS = (size_t)UBUF + PJ_WAVES * ((size_t)EBUF + TAPS);
+};
+
 template <int K, int DT>
-__global__ void __launch_bounds__(PJ_THREADS) inproj_pre_fwd_kernel(InProjArgs a) {
-    typedef PjCfg<K> C;
+__global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArgs a) {
+    typedef IpCfg<K> C;
     typedef typename Elem<DT>::type elem_t;
     static_assert(sizeof(elem_t) == 2, "16-bit element types only");
     HY_SMEM(smem);
-    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hb = lane >> 5;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, kq = lane >> 4;
     const int D = a.D;
     const unsigned P = (unsigned)a.B * (unsigned)a.Lx;                       // flattened positions (< 2^31, checked by the host)
-    // workgroup -> (channel group of 128, run of tiles).  Workgroups are dealt to the 8 XCDs round-robin; the channel groups of
-    // one run of positions get slots of ONE XCD, so its L2 serves the second read of the u tiles.
-    const int ncg = (D + PJ_WAVES * PJ_CB - 1) / (PJ_WAVES * PJ_CB);
+    // workgroup -> (channel group of 64, run of tiles).  Workgroups are dealt to the 8 XCDs round-robin; the channel groups of
+    // one run of positions get slots of ONE XCD, so its L2 serves all but the first read of the u tiles.
+    const int ncg = D / (PJ_WAVES * IP_CB);
     int cg, run;
     {
         const int wg = blockIdx.x, xcd = wg & 7, seq = wg >> 3;
@@ -133,229 +172,211 @@ __global__ void __launch_bounds__(PJ_THREADS) inproj_pre_fwd_kernel(InProjArgs a
     const int t_begin = run * a.tiles_per_wg;
     if (t_begin >= a.tiles) return;
     const int t_end = (t_begin + a.tiles_per_wg < a.tiles) ? t_begin + a.tiles_per_wg : a.tiles;
-    const int d0 = cg * PJ_WAVES * PJ_CB + wave * PJ_CB;                   // first channel of this wavefront
-    const bool wave_live = d0 < D;                                          // (D = 128 + 32 m: the last group's idle wavefronts only help staging)
+    const int d0 = cg * PJ_WAVES * IP_CB + wave * IP_CB;                   // first channel of this wavefront
 
     HY_LDS char* const ubuf = HY_LDS_CAST(char, smem);
-    HY_LDS char* const ebuf = HY_LDS_CAST(char, smem) + 2 * C::UBUF + wave * C::EBUF;
-    HY_LDS float* const taps = HY_LDS_CAST(float, smem + 2 * C::UBUF + PJ_WAVES * C::EBUF + wave * C::TAPS);
+    HY_LDS char* const ebuf = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::EBUF;
+    HY_LDS float* const taps = HY_LDS_CAST(float, smem + C::UBUF + PJ_WAVES * C::EBUF + wave * C::TAPS);
 
-    // stationary operand: the 96 weight rows of this wavefront, as A fragments (row = channel j of group g, k = 16 ks + 8 hb ...)
+    // stationary operand: the 48 weight rows of this wavefront, as A fragments (row = channel j of group g, k = 32 ks + 8 kq ...)
     Frag wf[3][C::KS];
-    if (wave_live) {
+    HY_UNROLL
+    for (int g = 0; g < 3; ++g) {
+        const char* row = reinterpret_cast<const char*>(a.W) + ((size_t)(g * D + d0 + j) * K + 8 * kq) * 2;
         HY_UNROLL
-        for (int g = 0; g < 3; ++g) {
-            const char* row = reinterpret_cast<const char*>(a.W) + ((size_t)(g * D + d0 + j) * K + 8 * hb) * 2;
-            HY_UNROLL
-            for (int ks = 0; ks < C::KS; ++ks) wf[g][ks] = ld16(row + ks * 32);
-        }
-        // short-filter taps of the x1 and v channels, (w0, w1, w2, b_sc, b_in) per channel
-        if (lane < 2 * PJ_CB) {
-            const int c = (1 + (lane >> 5)) * D + d0 + (lane & 31);
-            HY_LDS float* t = taps + lane * 5;
-            t[0] = a.w[c * 3]; t[1] = a.w[c * 3 + 1]; t[2] = a.w[c * 3 + 2]; t[3] = a.b[c];
-            t[4] = a.bin != nullptr ? a.bin[c] : 0.f;
-        }
+        for (int ks = 0; ks < C::KS; ++ks) wf[g][ks] = ld16(row + ks * 64);
     }
-
-    const char* const ubase = reinterpret_cast<const char*>(a.u);
-    Frag st[C::CH];
-    auto prefetch = [&](int t) {                     // the u tile of positions [64 t, 64 t + 64): one contiguous block of 64 K 2 bytes
-        HY_UNROLL
-        for (int c = 0; c < C::CH; ++c) {
-            const int q = tid + PJ_THREADS * c;      // 16-byte chunk within the tile
-            const unsigned p = (unsigned)t * PJ_NT + (unsigned)(q / (K / 8));
-            Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
-            st[c] = p < P ? ld16(ubase + ((size_t)t * PJ_NT * K * 2 + (size_t)q * 16)) : z;
-        }
-    };
-    auto stage = [&](int buf) {
-        HY_UNROLL
-        for (int c = 0; c < C::CH; ++c) {
-            const int q = tid + PJ_THREADS * c;
-            lds_st16(ubuf + buf * C::UBUF + (q / (K / 8)) * C::UROW + (q % (K / 8)) * 16, st[c]);
-        }
-    };
-
-    // per-lane constants of the straight-line epilogue: element offsets of the 12 xT pieces and the 4 vg pieces a lane moves per
-    // tile, and the taps of the 4 (channel, piece) pairs whose short convolution it evaluates
-    // Piece m of a lane: id = lane + 64 m -> group m >> 2, channel (lane >> 3) + 8 (m & 3), piece lane & 7: the m-dependent part
+    // short-filter taps of the x1 and v channels, (w0, w1, w2, b_sc, b_in) per channel
+    if (lane < 2 * IP_CB) {
+        const int c = (1 + (lane >> 4)) * D + d0 + (lane & 15);
+        HY_LDS float* t = taps + lane * 5;
+        t[0] = a.w[c * 3]; t[1] = a.w[c * 3 + 1]; t[2] = a.w[c * 3 + 2]; t[3] = a.b[c];
+        t[4] = a.bin != nullptr ? a.bin[c] : 0.f;
+    }
+    // Piece m of a lane: id = lane + 64 m -> group m >> 1, channel (lane >> 3) + 8 (m & 1), piece lane & 7: the m-dependent part
     // of every address is wave-uniform (scalar registers), only piece 0's offset is held per lane.
     const size_t xoff0 = (size_t)(d0 + (lane >> 3)) * P + 8u * (unsigned)(lane & 7);
     const unsigned voff0 = (unsigned)(d0 + (lane >> 3)) * (unsigned)a.Lc + 8u * (unsigned)(lane & 7);
-    HY_WAVE_SYNC_PJ();
+    const char* const ubase = reinterpret_cast<const char*>(a.u);
 
     const int t_first = t_begin > 0 ? t_begin - 1 : t_begin;                // warm-up tile: provides the halo of tile t_begin
     // (sequence, position within it) of the first position of the current tile, carried along instead of divided out per tile
     unsigned sb = ((unsigned)t_first * PJ_NT) / (unsigned)a.Lx;
     int sl0 = (int)((unsigned)t_first * PJ_NT - sb * (unsigned)a.Lx);
-    prefetch(t_first);
-    int cur = 0;
     for (int t = t_first; t < t_end; ++t, sl0 += PJ_NT) {
         while (sl0 >= a.Lx) { sl0 -= a.Lx; ++sb; }
-        stage(cur);
+        const unsigned p0 = (unsigned)t * PJ_NT;
+        {
+            // the u tile of positions [64 t, 64 t + 64): one contiguous block of 64 K 2 bytes, global -> registers -> LDS
+            // (no register double-buffering across the matrix-core phase: the CU's other workgroup covers these waits)
+            Frag st[C::CH];
+            HY_UNROLL
+            for (int c = 0; c < C::CH; ++c) {
+                const int q = tid + PJ_THREADS * c;
+                const unsigned p = p0 + (unsigned)(q / (K / 8));
+                Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+                st[c] = p < P ? ld16(ubase + ((size_t)p0 * K * 2 + (size_t)q * 16)) : z;
+            }
+            __syncthreads();                                     // every wavefront is done with the previous u tile
+            HY_UNROLL
+            for (int c = 0; c < C::CH; ++c) {
+                const int q = tid + PJ_THREADS * c;
+                lds_st16(ubuf + (q / (K / 8)) * C::UROW + (q % (K / 8)) * 16, st[c]);
+            }
+        }
         __syncthreads();
-        if (t + 1 < t_end) prefetch(t + 1);
-        if (wave_live) {
-            acc_t acc[3][2];
+        acc4_t acc[3][IP_NT4];
+        HY_UNROLL
+        for (int g = 0; g < 3; ++g) {
             HY_UNROLL
-            for (int g = 0; g < 3; ++g) {
+            for (int nt = 0; nt < IP_NT4; ++nt) {
                 HY_UNROLL
-                for (int nt = 0; nt < 2; ++nt) {
-                    HY_UNROLL
-                    for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
-                }
+                for (int r = 0; r < 4; ++r) acc[g][nt][r] = 0.f;
             }
-            const HY_LDS char* const ub = ubuf + cur * C::UBUF + j * C::UROW + hb * 16;
+        }
+        const HY_LDS char* const ub = ubuf + j * C::UROW + kq * 16;
+        HY_UNROLL
+        for (int ks = 0; ks < C::KS; ++ks) {
             HY_UNROLL
-            for (int ks = 0; ks < C::KS; ++ks) {
+            for (int nt = 0; nt < IP_NT4; ++nt) {
+                const Frag bf = lds_ld16(ub + nt * 16 * C::UROW + ks * 64);
                 HY_UNROLL
-                for (int nt = 0; nt < 2; ++nt) {
-                    const Frag bf = lds_ld16(ub + nt * 32 * C::UROW + ks * 32);
-                    HY_UNROLL
-                    for (int g = 0; g < 3; ++g) acc[g][nt] = mfma<DT>(wf[g][ks], bf, acc[g][nt]);
-                }
+                for (int g = 0; g < 3; ++g) acc[g][nt] = mfma16<DT>(wf[g][ks], bf, acc[g][nt]);
             }
-            // ---- epilogue, wavefront-private ---------------------------------------------------------------------------
-            // (1) the previous tile's last two positions become this tile's halo (slots 6, 7: one dword per row)
-            if (lane < 48) {
-                HY_UNROLL
-                for (int h = 0; h < 2; ++h) {
-                    HY_LDS uint32_t* row = reinterpret_cast<HY_LDS uint32_t*>(ebuf + (lane * 2 + h) * C::EROW);
-                    row[3] = row[3 + PJ_NT / 2];
-                }
-            }
-            HY_WAVE_SYNC_PJ();
-            // (2) accumulators -> storage type -> [group][channel][8 + position]
+        }
+        // ---- epilogue, wavefront-private ---------------------------------------------------------------------------
+        // (1) the previous tile's last two positions become this tile's halo (slots 6, 7: one dword per row)
+        if (lane < 3 * IP_CB) {
+            HY_LDS uint32_t* row = reinterpret_cast<HY_LDS uint32_t*>(ebuf + lane * C::EROW);
+            row[3] = row[3 + PJ_NT / 2];
+        }
+        HY_WAVE_SYNC_PJ();
+        // (2) accumulators -> storage type -> [group][channel 4 kq + r][8 + position 16 nt + j]
+        HY_UNROLL
+        for (int g = 0; g < 3; ++g) {
             HY_UNROLL
-            for (int g = 0; g < 3; ++g) {
+            for (int nt = 0; nt < IP_NT4; ++nt) {
                 HY_UNROLL
-                for (int nt = 0; nt < 2; ++nt) {
-                    HY_UNROLL
-                    for (int r = 0; r < 16; ++r) {
-                        HY_LDS elem_t* e = reinterpret_cast<HY_LDS elem_t*>(ebuf + (g * PJ_CB + pj_row(r, hb)) * C::EROW);
-                        e[8 + nt * 32 + j] = Elem<DT>::cvt(acc[g][nt][r]);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    HY_LDS elem_t* e = reinterpret_cast<HY_LDS elem_t*>(ebuf + (g * IP_CB + 4 * kq + r) * C::EROW);
+                    e[8 + nt * 16 + j] = Elem<DT>::cvt(acc[g][nt][r]);
                 }
             }
-            HY_WAVE_SYNC_PJ();
-            if (t >= t_begin) {
-                const unsigned p0 = (unsigned)t * PJ_NT;
-                // Interior tiles -- whole, inside one sequence, at least two positions into it, inside the convolved length -- take a
-                // straight-line path: no per-element predicates, no divisions, addresses from offsets hoisted out of the loop.  (The
-                // generic path below costs ~2.5x the instructions; with one wavefront per SIMD the kernel is bound by instruction
-                // issue, not by the matrix cores or by memory.)
-                const bool fast = p0 + PJ_NT <= P && sl0 >= 2 && sl0 + PJ_NT <= a.Lc;
-                if (fast) {
+        }
+        HY_WAVE_SYNC_PJ();
+        if (t >= t_begin) {
+            // Interior tiles -- whole, inside one sequence, at least two positions into it, inside the convolved length -- take a
+            // straight-line path: no per-element predicates, no divisions, addresses from offsets hoisted out of the loop.
+            const bool fast = p0 + PJ_NT <= P && sl0 >= 2 && sl0 + PJ_NT <= a.Lc;
+            if (fast) {
+                // (3) xT: 3 x 16 rows x 8 pieces of 8 positions
+                HY_UNROLL
+                for (int m = 0; m < 3 * IP_CB * 8 / 64; ++m) {
+                    const int g = m >> 1, ch = (lane >> 3) + 8 * (m & 1), pc = lane & 7;
+                    const size_t rowm = (size_t)(g * D + 8 * (m & 1)) * P + p0;                     // wave-uniform
+                    st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), lds_ld16(ebuf + (g * IP_CB + ch) * C::EROW + 16 + pc * 16));
+                }
+                // (4) vg = shortconv(v) * shortconv(x1): 16 channels x 8 pieces
+                const size_t vbase = (size_t)sb * D * a.Lc + (size_t)sl0;
+                HY_UNROLL
+                for (int m = 0; m < IP_CB * 8 / 64; ++m) {
+                    const int ch = (lane >> 3) + 8 * m, pc = lane & 7;
+                    float prod[8];
                     HY_UNROLL
-                    for (int m = 0; m < 3 * PJ_CB * 8 / 64; ++m) {
-                        const int id = lane + 64 * m, g = id >> 8, ch = (id >> 3) & 31, pc = id & 7;
-                        const size_t rowm = (size_t)((m >> 2) * D + 8 * (m & 3)) * P + p0;               // wave-uniform
-                        st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), lds_ld16(ebuf + (g * PJ_CB + ch) * C::EROW + 16 + pc * 16));
-                    }
-                    const size_t vbase = (size_t)sb * D * a.Lc + (size_t)sl0;
-                    HY_UNROLL
-                    for (int m = 0; m < PJ_CB * 8 / 64; ++m) {
-                        const int id = lane + 64 * m, ch = id >> 3, pc = id & 7;
-                        float prod[8];
+                    for (int gi = 0; gi < 2; ++gi) {                    // gi = 0: x1 (group 1), gi = 1: v (group 2)
+                        const HY_LDS char* row = ebuf + ((1 + gi) * IP_CB + ch) * C::EROW + pc * 16;
+                        const Frag lo = lds_ld16(row), hi = lds_ld16(row + 16);
+                        elem_t pl[8], ph[8];
+                        __builtin_memcpy(pl, lo.w, 16);
+                        __builtin_memcpy(ph, hi.w, 16);
+                        float xs[10];
+                        const HY_LDS float* tp = taps + (gi * IP_CB + ch) * 5;
+                        const float w0 = tp[0], w1 = tp[1], w2 = tp[2], bsc = tp[3], bin = tp[4];
+                        xs[0] = Elem<DT>::dec(pl[6]) + bin; xs[1] = Elem<DT>::dec(pl[7]) + bin;
                         HY_UNROLL
-                        for (int gi = 0; gi < 2; ++gi) {
-                            const HY_LDS char* row = ebuf + ((1 + gi) * PJ_CB + ch) * C::EROW + pc * 16;
-                            const Frag lo = lds_ld16(row), hi = lds_ld16(row + 16);
-                            elem_t pl[8], ph[8];
-                            __builtin_memcpy(pl, lo.w, 16);
-                            __builtin_memcpy(ph, hi.w, 16);
-                            float xs[10];
-                            const HY_LDS float* tp = taps + (gi * PJ_CB + ch) * 5;
-                            const float w0 = tp[0], w1 = tp[1], w2 = tp[2], bsc = tp[3], bin = tp[4];
-                            xs[0] = Elem<DT>::dec(pl[6]) + bin; xs[1] = Elem<DT>::dec(pl[7]) + bin;
-                            HY_UNROLL
-                            for (int i = 0; i < 8; ++i) xs[2 + i] = Elem<DT>::dec(ph[i]) + bin;
-                            HY_UNROLL
-                            for (int i = 0; i < 8; ++i) {
-                                const float c = __builtin_fmaf(w2, xs[i + 2], __builtin_fmaf(w1, xs[i + 1], __builtin_fmaf(w0, xs[i], bsc)));   // = cm_sc
-                                prod[i] = gi == 0 ? c : prod[i] * c;
-                            }
+                        for (int i = 0; i < 8; ++i) xs[2 + i] = Elem<DT>::dec(ph[i]) + bin;
+                        HY_UNROLL
+                        for (int i = 0; i < 8; ++i) {
+                            const float c = __builtin_fmaf(w2, xs[i + 2], __builtin_fmaf(w1, xs[i + 1], __builtin_fmaf(w0, xs[i], bsc)));   // = cm_sc
+                            prod[i] = gi == 0 ? c : prod[i] * c;
                         }
-                        elem_t out[8];
+                    }
+                    elem_t out[8];
+                    HY_UNROLL
+                    for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
+                    Frag f;
+                    __builtin_memcpy(f.w, out, 16);
+                    st16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * m) * (unsigned)a.Lc), f);
+                }
+            } else {
+                // generic path: ragged tiles, sequence boundaries inside the tile, the first two positions of a sequence,
+                // positions beyond the convolved length
+                HY_UNROLL
+                for (int m = 0; m < 3 * IP_CB * 8 / 64; ++m) {
+                    const int g = m >> 1, ch = (lane >> 3) + 8 * (m & 1), pc = lane & 7;
+                    const unsigned p = p0 + 8u * (unsigned)pc;
+                    const Frag v = lds_ld16(ebuf + (g * IP_CB + ch) * C::EROW + 16 + pc * 16);
+                    elem_t* dst = reinterpret_cast<elem_t*>(a.xT) + (size_t)(g * D + d0 + ch) * P + p;
+                    if (p + 8 <= P) st16(dst, v);
+                    else {
+                        elem_t sv[8];
+                        __builtin_memcpy(sv, v.w, 16);
+                        for (int i = 0; i < 8; ++i)
+                            if (p + i < P) dst[i] = sv[i];
+                    }
+                }
+                HY_UNROLL
+                for (int m = 0; m < IP_CB * 8 / 64; ++m) {
+                    const int ch = (lane >> 3) + 8 * m, pc = lane & 7;
+                    const unsigned p = p0 + 8u * (unsigned)pc;
+                    if (p >= P) continue;
+                    float prod[8];
+                    const unsigned b = p / (unsigned)a.Lx;
+                    const int l = (int)(p - b * (unsigned)a.Lx);
+                    HY_UNROLL
+                    for (int gi = 0; gi < 2; ++gi) {
+                        const HY_LDS char* row = ebuf + ((1 + gi) * IP_CB + ch) * C::EROW + pc * 16;
+                        const Frag lo = lds_ld16(row), hi = lds_ld16(row + 16);
+                        elem_t pl[8], ph[8];
+                        __builtin_memcpy(pl, lo.w, 16);
+                        __builtin_memcpy(ph, hi.w, 16);
+                        float xs[10];
+                        xs[0] = Elem<DT>::dec(pl[6]); xs[1] = Elem<DT>::dec(pl[7]);
                         HY_UNROLL
-                        for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
+                        for (int i = 0; i < 8; ++i) xs[2 + i] = Elem<DT>::dec(ph[i]);
+                        const HY_LDS float* tp = taps + (gi * IP_CB + ch) * 5;
+                        const float w0 = tp[0], w1 = tp[1], w2 = tp[2], bsc = tp[3], bin = tp[4];
+                        HY_UNROLL
+                        for (int i = 0; i < 8; ++i) {
+                            int li = l + i;                             // position within its sequence (the piece may cross into the next one)
+                            if (li >= a.Lx) li -= a.Lx;
+                            const float x0 = li >= 2 ? xs[i] + bin : 0.f, x1 = li >= 1 ? xs[i + 1] + bin : 0.f, x2 = xs[i + 2] + bin;
+                            const float c = __builtin_fmaf(w2, x2, __builtin_fmaf(w1, x1, __builtin_fmaf(w0, x0, bsc)));   // = cm_sc
+                            prod[i] = gi == 0 ? c : prod[i] * c;
+                        }
+                    }
+                    elem_t out[8];
+                    HY_UNROLL
+                    for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
+                    elem_t* vrow = reinterpret_cast<elem_t*>(a.vg) + ((size_t)b * D + d0 + ch) * a.Lc;
+                    if (l + 8 <= a.Lc) {
                         Frag f;
                         __builtin_memcpy(f.w, out, 16);
-                        st16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * m) * (unsigned)a.Lc), f);
-                    }
-                } else {
-                    // (3) xT: 3 x 32 rows x 8 pieces of 8 positions
-                    HY_UNROLL
-                    for (int m = 0; m < 3 * PJ_CB * 8 / 64; ++m) {
-                        const int id = lane + 64 * m, g = id >> 8, ch = (id >> 3) & 31, pc = id & 7;
-                        const unsigned p = p0 + 8u * (unsigned)pc;
-                        const Frag v = lds_ld16(ebuf + (g * PJ_CB + ch) * C::EROW + 16 + pc * 16);
-                        elem_t* dst = reinterpret_cast<elem_t*>(a.xT) + (size_t)(g * D + d0 + ch) * P + p;
-                        if (p + 8 <= P) st16(dst, v);
-                        else {
-                            elem_t s[8];
-                            __builtin_memcpy(s, v.w, 16);
-                            for (int i = 0; i < 8; ++i)
-                                if (p + i < P) dst[i] = s[i];
-                        }
-                    }
-                    // (4) vg = shortconv(v) * shortconv(x1): 32 channels x 8 pieces
-                    HY_UNROLL
-                    for (int m = 0; m < PJ_CB * 8 / 64; ++m) {
-                        const int id = lane + 64 * m, ch = id >> 3, pc = id & 7;
-                        const unsigned p = p0 + 8u * (unsigned)pc;
-                        if (p >= P) continue;
-                        float prod[8];
-                        const unsigned b = p / (unsigned)a.Lx;
-                        const int l = (int)(p - b * (unsigned)a.Lx);
-                        HY_UNROLL
-                        for (int gi = 0; gi < 2; ++gi) {                    // gi = 0: x1 (group 1), gi = 1: v (group 2)
-                            const HY_LDS char* row = ebuf + ((1 + gi) * PJ_CB + ch) * C::EROW + pc * 16;
-                            const Frag lo = lds_ld16(row), hi = lds_ld16(row + 16);
-                            elem_t pl[8], ph[8];
-                            __builtin_memcpy(pl, lo.w, 16);
-                            __builtin_memcpy(ph, hi.w, 16);
-                            float xs[10];
-                            xs[0] = Elem<DT>::dec(pl[6]); xs[1] = Elem<DT>::dec(pl[7]);
-                            HY_UNROLL
-                            for (int i = 0; i < 8; ++i) xs[2 + i] = Elem<DT>::dec(ph[i]);
-                            const HY_LDS float* tp = taps + (gi * PJ_CB + ch) * 5;
-                            const float w0 = tp[0], w1 = tp[1], w2 = tp[2], bsc = tp[3], bin = tp[4];
-                            HY_UNROLL
-                            for (int i = 0; i < 8; ++i) {
-                                int li = l + i;                             // position within its sequence (the piece may cross into the next one)
-                                if (li >= a.Lx) li -= a.Lx;
-                                const float x0 = li >= 2 ? xs[i] + bin : 0.f, x1 = li >= 1 ? xs[i + 1] + bin : 0.f, x2 = xs[i + 2] + bin;
-                                const float c = __builtin_fmaf(w2, x2, __builtin_fmaf(w1, x1, __builtin_fmaf(w0, x0, bsc)));   // = cm_sc
-                                prod[i] = gi == 0 ? c : prod[i] * c;
-                            }
-                        }
-                        elem_t out[8];
-                        HY_UNROLL
-                        for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
-                        elem_t* vrow = reinterpret_cast<elem_t*>(a.vg) + ((size_t)b * D + d0 + ch) * a.Lc;
-                        if (l + 8 <= a.Lc) {
-                            Frag f;
-                            __builtin_memcpy(f.w, out, 16);
-                            st16(vrow + l, f);
-                        } else {
-                            for (int i = 0; i < 8; ++i) {
-                                int li = l + i;
-                                unsigned bi = b;
-                                if (li >= a.Lx) { li -= a.Lx; ++bi; }
-                                if (p + i < P && li < a.Lc) reinterpret_cast<elem_t*>(a.vg)[((size_t)bi * D + d0 + ch) * a.Lc + li] = out[i];
-                            }
+                        st16(vrow + l, f);
+                    } else {
+                        for (int i = 0; i < 8; ++i) {
+                            int li = l + i;
+                            unsigned bi = b;
+                            if (li >= a.Lx) { li -= a.Lx; ++bi; }
+                            if (p + i < P && li < a.Lc) reinterpret_cast<elem_t*>(a.vg)[((size_t)bi * D + d0 + ch) * a.Lc + li] = out[i];
                         }
                     }
                 }
             }
-            HY_WAVE_SYNC_PJ();                        // the tile is re-written in the next round
         }
-        cur ^= 1;
+        HY_WAVE_SYNC_PJ();                        // the tile is re-written in the next round
     }
 }
-
 
 // =============================================================================================================================
 // The block's MLP (flash_attn.modules.mlp.Mlp; simple_lm.py:191-211, long_conv_lm.py:117-123: fc1 -> tanh-GELU -> fc2): the two
@@ -380,7 +401,10 @@ template <int K> struct PmCfg {
     static constexpr int UROW = PjCfg<K>::UROW, UBUF = PjCfg<K>::UBUF, CH = PjCfg<K>::CH;
     static constexpr int EROW = PM_EW * 2;                    // bytes per row of the epilogue tile [position][unit]
     static constexpr int EBUF = PJ_NT * EROW;                 // one tile per wavefront
-    static constexpr size_t LDS = 2 * (size_t)UBUF + PJ_WAVES * 2 * (size_t)EBUF;
+    // ONE staging buffer and ONE epilogue tile per wavefront: 70 KB, so that TWO workgroups share a CU (2 wavefronts per SIMD,
+    // <= 256 registers each).  A lone wavefront issues an instruction every ~7 cycles here (LDS and transcendental latencies in
+    // a dependent chain); the second one fills the gaps -- and covers the first one's barriers and global-load waits.
+    static constexpr size_t LDS = (size_t)UBUF + PJ_WAVES * (size_t)EBUF;
 };
 
 struct MlpArgs {
@@ -427,7 +451,7 @@ __device__ __forceinline__ float pm_dgelu(float x) {
 
 // MODE 0: fc1 + bias + GELU (outputs a, h);  MODE 1: dh = dy W2, da = dh gelu'(a) (+ partial column sums)
 template <int K, int DT, int MODE>
-__global__ void __launch_bounds__(PJ_THREADS) mlp_kernel(MlpArgs a) {
+__global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     typedef PmCfg<K> C;
     typedef typename Elem<DT>::type elem_t;
     HY_SMEM(smem);
@@ -447,8 +471,7 @@ __global__ void __launch_bounds__(PJ_THREADS) mlp_kernel(MlpArgs a) {
     const int n0 = cg * PJ_WAVES * PM_UW + wave * PM_UW;                   // first hidden unit of this wavefront
 
     HY_LDS char* const ubuf = HY_LDS_CAST(char, smem);
-    HY_LDS char* const e0 = HY_LDS_CAST(char, smem) + 2 * C::UBUF + wave * 2 * C::EBUF;
-    HY_LDS char* const e1 = e0 + C::EBUF;
+    HY_LDS char* const et = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::EBUF;      // this wavefront's tile [position][unit]
 
     // stationary operand: 64 weight rows as B fragments (column = unit j of unit tile ut, k = 16 ks + 8 hb ...)
     Frag wf[2][C::KS];
@@ -463,53 +486,45 @@ __global__ void __launch_bounds__(PJ_THREADS) mlp_kernel(MlpArgs a) {
     float colsum[2] = {0.f, 0.f};
 
     const char* const xbase = reinterpret_cast<const char*>(a.x);
-    Frag st[C::CH];
-    auto prefetch = [&](int t) {
-        HY_UNROLL
-        for (int c = 0; c < C::CH; ++c) {
-            const int q = tid + PJ_THREADS * c;
-            const unsigned p = (unsigned)t * PJ_NT + (unsigned)(q / (K / 8));
-            Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
-            st[c] = p < P ? ld16(xbase + ((size_t)t * PJ_NT * K * 2 + (size_t)q * 16)) : z;
-        }
-    };
-    auto stage = [&](int buf) {
-        HY_UNROLL
-        for (int c = 0; c < C::CH; ++c) {
-            const int q = tid + PJ_THREADS * c;
-            lds_st16(ubuf + buf * C::UBUF + (q / (K / 8)) * C::UROW + (q % (K / 8)) * 16, st[c]);
-        }
-    };
-
-    // MODE 1: the a tile of this wavefront's units ([position][unit]: 64 x 8 pieces of 16 bytes, 8 per lane) is fetched one tile
-    // ahead, like the staged operand, and parked in the wavefront's second LDS tile while the matrix cores work.
-    // Piece m of a lane: position (lane >> 3) + 8 m, piece lane & 7 -- the m-dependent part of its address is wave-uniform.
+    // Piece m of a lane in the [position][unit] tile: position (lane >> 3) + 8 m, piece lane & 7 -- the m-dependent part of its
+    // global address is wave-uniform.
     const size_t eoff0 = (size_t)(lane >> 3) * N + n0 + 8 * (lane & 7);
-    Frag at[MODE == 1 ? PJ_NT * 8 / 64 : 1];
-    auto prefetch_a = [&](int t) {
-        if (MODE != 1) return;
-        const unsigned q0 = (unsigned)t * PJ_NT;
-        HY_UNROLL
-        for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
-            Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
-            at[m] = q0 + (unsigned)(lane >> 3) + 8u * m < P
-                        ? ld16(reinterpret_cast<const elem_t*>(a.a_in) + (eoff0 + ((size_t)q0 + 8u * m) * N)) : z;
-        }
-    };
 
-    prefetch(t_begin);
-    prefetch_a(t_begin);
-    int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
-        stage(cur);
-        if (MODE == 1) {
-            HY_UNROLL
-            for (int m = 0; m < PJ_NT * 8 / 64; ++m) lds_st16(e1 + ((lane >> 3) + 8 * m) * C::EROW + (lane & 7) * 16, at[m]);
-        }
-        __syncthreads();
-        if (t + 1 < t_end) { prefetch(t + 1); prefetch_a(t + 1); }
         const unsigned p0 = (unsigned)t * PJ_NT;
         const bool full = p0 + PJ_NT <= P;                       // wave-uniform: whole tiles skip every per-position predicate
+        {
+            // the operand tile (64 x K, one contiguous block) and, MODE 1, this wavefront's a tile: global -> registers -> LDS.
+            // (No register double-buffering across the matrix-core phase: the CU's other workgroup covers these waits.)
+            Frag st[C::CH];
+            HY_UNROLL
+            for (int c = 0; c < C::CH; ++c) {
+                const int q = tid + PJ_THREADS * c;
+                const unsigned p = p0 + (unsigned)(q / (K / 8));
+                Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+                st[c] = (full || p < P) ? ld16(xbase + ((size_t)p0 * K * 2 + (size_t)q * 16)) : z;
+            }
+            Frag at[MODE == 1 ? PJ_NT * 8 / 64 : 1];
+            if (MODE == 1) {
+                HY_UNROLL
+                for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
+                    Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+                    at[m] = (full || p0 + (unsigned)(lane >> 3) + 8u * m < P)
+                                ? ld16(reinterpret_cast<const elem_t*>(a.a_in) + (eoff0 + ((size_t)p0 + 8u * m) * N)) : z;
+                }
+            }
+            __syncthreads();                                     // every wavefront is done with the previous operand tile
+            HY_UNROLL
+            for (int c = 0; c < C::CH; ++c) {
+                const int q = tid + PJ_THREADS * c;
+                lds_st16(ubuf + (q / (K / 8)) * C::UROW + (q % (K / 8)) * 16, st[c]);
+            }
+            if (MODE == 1) {
+                HY_UNROLL
+                for (int m = 0; m < PJ_NT * 8 / 64; ++m) lds_st16(et + ((lane >> 3) + 8 * m) * C::EROW + (lane & 7) * 16, at[m]);
+            }
+        }
+        __syncthreads();
         acc_t acc[2][2];                           // [position tile][unit tile]
         HY_UNROLL
         for (int pt = 0; pt < 2; ++pt) {
@@ -519,7 +534,7 @@ __global__ void __launch_bounds__(PJ_THREADS) mlp_kernel(MlpArgs a) {
                 for (int r = 0; r < 16; ++r) acc[pt][ut][r] = 0.f;
             }
         }
-        const HY_LDS char* const ub = ubuf + cur * C::UBUF + j * C::UROW + hb * 16;
+        const HY_LDS char* const ub = ubuf + j * C::UROW + hb * 16;
         HY_UNROLL
         for (int ks = 0; ks < C::KS; ++ks) {
             HY_UNROLL
@@ -530,44 +545,45 @@ __global__ void __launch_bounds__(PJ_THREADS) mlp_kernel(MlpArgs a) {
             }
         }
         // ---- epilogue, wavefront-private: register r of lane (j, hb) = position pt 32 + pj_row(r, hb), unit ut 32 + j ----
-        HY_WAVE_SYNC_PJ();
+        // The tile is used twice in MODE 0 (a, then h -- recomputed from the accumulators rather than held in 32 more registers)
+        // and in place in MODE 1 (every lane overwrites the a values it read with its da values).
         HY_UNROLL
-        for (int pt = 0; pt < 2; ++pt) {
+        for (int pass = 0; pass < (MODE == 0 ? 2 : 1); ++pass) {
+            HY_WAVE_SYNC_PJ();
             HY_UNROLL
-            for (int ut = 0; ut < 2; ++ut) {
+            for (int pt = 0; pt < 2; ++pt) {
                 HY_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int pos = pt * 32 + pj_row(r, hb), un = ut * 32 + j;
-                    HY_LDS elem_t* s0 = reinterpret_cast<HY_LDS elem_t*>(e0 + pos * C::EROW) + un;
-                    HY_LDS elem_t* s1 = reinterpret_cast<HY_LDS elem_t*>(e1 + pos * C::EROW) + un;
-                    if (MODE == 0) {
-                        const elem_t av = Elem<DT>::cvt(acc[pt][ut][r] + bias[ut]);
-                        *s0 = av;
-                        *s1 = Elem<DT>::cvt(pm_gelu(Elem<DT>::dec(av)));
-                    } else {
-                        const float dh = Elem<DT>::dec(Elem<DT>::cvt(acc[pt][ut][r]));          // the rounding of the unfused dh tensor
-                        const elem_t dv = Elem<DT>::cvt(dh * pm_dgelu(Elem<DT>::dec(*s1)));
-                        *s0 = dv;
-                        if (full || p0 + pos < P) colsum[ut] += Elem<DT>::dec(dv);
+                for (int ut = 0; ut < 2; ++ut) {
+                    HY_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        const int pos = pt * 32 + pj_row(r, hb), un = ut * 32 + j;
+                        HY_LDS elem_t* slot = reinterpret_cast<HY_LDS elem_t*>(et + pos * C::EROW) + un;
+                        if (MODE == 0) {
+                            const elem_t av = Elem<DT>::cvt(acc[pt][ut][r] + bias[ut]);
+                            *slot = pass == 0 ? av : Elem<DT>::cvt(pm_gelu(Elem<DT>::dec(av)));
+                        } else {
+                            const float dh = Elem<DT>::dec(Elem<DT>::cvt(acc[pt][ut][r]));          // the rounding of the unfused dh tensor
+                            const elem_t dv = Elem<DT>::cvt(dh * pm_dgelu(Elem<DT>::dec(*slot)));
+                            *slot = dv;
+                            if (full || p0 + pos < P) colsum[ut] += Elem<DT>::dec(dv);
+                        }
                     }
                 }
             }
+            HY_WAVE_SYNC_PJ();
+            elem_t* const dst = reinterpret_cast<elem_t*>(pass == 0 ? a.o0 : a.o1);
+            HY_UNROLL
+            for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
+                const int pos = (lane >> 3) + 8 * m, pc = lane & 7;
+                if (!full && p0 + pos >= P) continue;
+                st16(dst + (eoff0 + ((size_t)p0 + 8u * m) * N), lds_ld16(et + pos * C::EROW + pc * 16));      // (second term wave-uniform)
+            }
         }
         HY_WAVE_SYNC_PJ();
-        HY_UNROLL
-        for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
-            const int pos = (lane >> 3) + 8 * m, pc = lane & 7;
-            if (!full && p0 + pos >= P) continue;
-            const size_t off = eoff0 + ((size_t)p0 + 8u * m) * N;                       // (second term wave-uniform)
-            st16(reinterpret_cast<elem_t*>(a.o0) + off, lds_ld16(e0 + pos * C::EROW + pc * 16));
-            if (MODE == 0) st16(reinterpret_cast<elem_t*>(a.o1) + off, lds_ld16(e1 + pos * C::EROW + pc * 16));
-        }
-        HY_WAVE_SYNC_PJ();
-        cur ^= 1;
     }
     if (MODE == 1) {
         // column sums of da over this run: the two half-waves hold different positions of the same unit
-        HY_LDS float* red = reinterpret_cast<HY_LDS float*>(e0);
+        HY_LDS float* red = reinterpret_cast<HY_LDS float*>(et);
         HY_WAVE_SYNC_PJ();
         if (hb == 1) { red[j] = colsum[0]; red[32 + j] = colsum[1]; }
         HY_WAVE_SYNC_PJ();

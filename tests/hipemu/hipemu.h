@@ -134,6 +134,39 @@ inline floatx16 mfma_f32_32x32x16_h(u32x4 a, u32x4 b, floatx16 c) {
     return c;
 }
 
+// v_mfma_f32_16x16x32_{bf16,f16} (gfx950): D = A(16x32) * B(32x16) + C.  Lane l supplies A[l & 15][8 (l >> 4) + j] and
+// B[8 (l >> 4) + j][l & 15], j = 0..7, and owns C/D[4 (l >> 4) + r][l & 15] for r in [0, 4).
+typedef float floatx4 __attribute__((vector_size(16)));
+template <bool BF16>
+inline floatx4 mfma_f32_16x16x32_h(u32x4 a, u32x4 b, floatx4 c) {
+    int t = S.cur, lane = t & (WAVE - 1), base = t - lane;
+    memcpy(&S.xq[4 * t], a.w, 16);
+    memcpy(&S.xq2[4 * t], b.w, 16);
+    yield(2);
+    auto dec = [](uint16_t h) -> float {
+        if (BF16) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+        uint32_t sign = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31, m = h & 1023, u;
+        if (e == 0) {
+            if (m == 0) u = sign;
+            else { int sh = 0; while (!(m & 1024)) { m <<= 1; ++sh; } u = sign | ((uint32_t)(113 - sh) << 23) | ((m & 1023) << 13); }
+        } else if (e == 31) u = sign | 0x7F800000u | (m << 13);
+        else u = sign | ((e + 112) << 23) | (m << 13);
+        float f; memcpy(&f, &u, 4); return f;
+    };
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (lane >> 4) + r, col = lane & 15;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            const uint16_t* ap = reinterpret_cast<const uint16_t*>(&S.xq[4 * (base + row + 16 * (k >> 3))]);
+            const uint16_t* bp = reinterpret_cast<const uint16_t*>(&S.xq2[4 * (base + col + 16 * (k >> 3))]);
+            acc = fmaf(dec(ap[k & 7]), dec(bp[k & 7]), acc);
+        }
+        c[r] = acc;
+    }
+    yield(2);
+    return c;
+}
+
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
 
 }  // namespace hipemu

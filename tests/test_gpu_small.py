@@ -34,8 +34,10 @@ def test_small_fused_pair_on_gpu(gpu_lib, monkeypatch, B, D, L, dtype):
     monkeypatch.delenv("HYENA_FFTCONV_SMALL")
     # two kernels, the same transform: on the GPU the compiler contracts their products into FMAs differently, so the comparison
     # is to rounding noise, not bitwise (under tests/hipemu, where nothing is contracted, the two are bit-identical)
-    assert _rel(out.float(), g_out.float()) < 1e-6 and _rel(du.float(), g_du.float()) < 1e-6 and _rel(dk, g_dk) < 1e-6
-    assert (out != g_out).float().mean().item() < (0.02 if dtype != torch.float32 else 1.0)
+    tol_x = 1e-6 if dtype == torch.float32 else 1e-4        # 16-bit outputs: a handful of neighbouring-value roundings
+    assert _rel(out.float(), g_out.float()) < tol_x and _rel(du.float(), g_du.float()) < tol_x and _rel(dk, g_dk) < 1e-6
+    if dtype != torch.float32:
+        assert (out != g_out).float().mean().item() < 0.02 and (du != g_du).float().mean().item() < 0.02
     # oracle on the same (16-bit) inputs in fp32
     u_, k_, b_ = u.float().requires_grad_(True), k.clone().requires_grad_(True), bias.clone().requires_grad_(True)
     r_out = O.fftconv_ref(u_, k_, b_)
