@@ -76,9 +76,25 @@ __device__ __forceinline__ void lds_st16(HY_LDS char* p, const Frag& f) { st16(p
 #else
 typedef unsigned pj_vec16 __attribute__((ext_vector_type(4), aligned(2)));
 typedef unsigned pj_lvec16 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ Frag ld16(const void* p) { return __builtin_bit_cast(Frag, *reinterpret_cast<const pj_vec16*>(p)); }
-__device__ __forceinline__ void st16(void* p, const Frag& f) {          // outputs are written once, read by a later launch: non-temporal
-    __builtin_nontemporal_store(__builtin_bit_cast(pj_vec16, f), reinterpret_cast<pj_vec16*>(p));
+// PJ_DBG_* (profiling builds only, scripts/build_variant.sh; results are wrong by construction): leave out the global stores or
+// the global loads to see what each side of the memory traffic costs
+__device__ __forceinline__ Frag ld16(const void* p) {
+#ifdef PJ_DBG_NO_LD
+    Frag f; f.w[0] = f.w[1] = f.w[2] = f.w[3] = (uint32_t)(size_t)p; return f;
+#else
+    return __builtin_bit_cast(Frag, *reinterpret_cast<const pj_vec16*>(p));
+#endif
+}
+#ifndef PJ_POL_ST
+#define PJ_POL_ST 1                                                      // 1 = non-temporal stores (outputs are written once, read by a later launch)
+#endif
+__device__ __forceinline__ void st16(void* p, const Frag& f) {
+#ifdef PJ_DBG_NO_ST
+    if (f.w[0] == 0x12345678u && f.w[3] == 0x9abcdef0u) *reinterpret_cast<pj_vec16*>(p) = __builtin_bit_cast(pj_vec16, f);
+#else
+    if (PJ_POL_ST) __builtin_nontemporal_store(__builtin_bit_cast(pj_vec16, f), reinterpret_cast<pj_vec16*>(p));
+    else *reinterpret_cast<pj_vec16*>(p) = __builtin_bit_cast(pj_vec16, f);
+#endif
 }
 __device__ __forceinline__ Frag lds_ld16(const HY_LDS char* p) { return __builtin_bit_cast(Frag, *reinterpret_cast<const HY_LDS pj_lvec16*>(p)); }
 __device__ __forceinline__ void lds_st16(HY_LDS char* p, const Frag& f) { *reinterpret_cast<HY_LDS pj_lvec16*>(p) = __builtin_bit_cast(pj_lvec16, f); }
