@@ -154,6 +154,12 @@ def lib():
         L.hyena_inproj_pre_fwd.restype = c_int
         L.hyena_inproj_pre_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_colsum_supported.restype = c_int
+        L.hyena_colsum_supported.argtypes = [ctypes.c_long, c_int, c_int]
+        L.hyena_colsum_partial_floats.restype = c_size_t
+        L.hyena_colsum_partial_floats.argtypes = [ctypes.c_long, c_int]
+        L.hyena_colsum.restype = c_int
+        L.hyena_colsum.argtypes = [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]
         L.hyena_mlp_supported.restype = c_int
         L.hyena_mlp_supported.argtypes = [ctypes.c_long, c_int, c_int, c_int]
         L.hyena_mlp_partial_floats.restype = c_size_t
@@ -469,6 +475,20 @@ def inproj_pre_fwd(u, W, bin_, w, b, L):
         check(lib().hyena_inproj_pre_fwd(u.data_ptr(), W.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
                                          xT.data_ptr(), vg.data_ptr(), B, Lx, int(L), D, dtype_code(u.dtype), _backend.stream(u.device)))
     return xT, vg
+
+
+def colsum(x2):
+    """x2 (P, N) 16-bit contiguous -> (N,) fp32 = x2.sum(0) (the bias gradient of a linear layer) in one pass at the memory rate;
+    falls back to torch's reduction for shapes the kernel does not serve (and for host tensors outside the test double)."""
+    P, N = x2.shape
+    code = _DTYPES.get(x2.dtype)
+    if code is None or not (x2.is_cuda or _backend.name != "hip") or not x2.is_contiguous() or not lib().hyena_colsum_supported(P, N, code):
+        return x2.sum(0, dtype=torch.float32)
+    out = torch.empty(N, dtype=torch.float32, device=x2.device)
+    part = torch.empty(lib().hyena_colsum_partial_floats(P, N), dtype=torch.float32, device=x2.device)
+    with _backend.guard(x2.device):
+        check(lib().hyena_colsum(x2.data_ptr(), part.data_ptr(), out.data_ptr(), P, N, code, _backend.stream(x2.device)))
+    return out
 
 
 def mlp_supported(P, K, N, dtype):

@@ -381,8 +381,16 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
         if (saved != nullptr && saved_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
         void* partials = reinterpret_cast<char*>(workspace) + oc::spectrum_bytes(D, p.R);
         int st;
-        if (saved != nullptr && (du != nullptr || dk != nullptr) && oc::small_ok(p.R, B, D, L, dtype))
-            return oc::launch_small_bwd(p.R, dout, u, du, dk, dbias, saved, d_tables, B, D, L, dtype, stream);   // du and dk from one launch
+        if ((du != nullptr || dk != nullptr) && oc::small_ok(p.R, B, D, L, dtype)) {
+            // du and dk from one launch.  Without the forward's spectrum the filter is transformed first by the forward kernel run
+            // over an empty batch: the same code, hence the same bits, as the H the saved path reads.
+            const void* H = saved;
+            if (H == nullptr) {
+                if ((st = oc::launch_small_fwd(p.R, nullptr, nullptr, k, bias, workspace, d_tables, 0, D, L, dtype, stream))) return st;
+                H = workspace;
+            }
+            return oc::launch_small_bwd(p.R, dout, u, du, dk, dbias, H, d_tables, B, D, L, dtype, stream);
+        }
         if (du != nullptr) {
             const void* H = saved;
             if (H == nullptr) {

@@ -43,6 +43,31 @@ int dispatch_mlp(const pj::MlpArgs& a, int K, int dtype, int grid, void* stream)
 
 extern "C" {
 
+static int colsum_groups(long P) {
+    long g = (P + 511) / 512;                        // >= 512 rows per workgroup
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+int hyena_colsum_supported(long P, int N, int dtype) {
+    if (!(dtype == HYENA_BF16 || dtype == HYENA_F16) || N < 8 || N % 8 != 0 || pj::PJ_THREADS % (N / 8) != 0) return 0;
+    return P >= 1 && (size_t)P < ((size_t)1 << 31) ? 1 : 0;
+}
+
+size_t hyena_colsum_partial_floats(long P, int N) { return P < 1 || N < 1 ? 0 : (size_t)colsum_groups(P) * N; }
+
+int hyena_colsum(const void* x, float* part, float* out, long P, int N, int dtype, void* stream) {
+    if (x == nullptr || part == nullptr || out == nullptr || !hyena_colsum_supported(P, N, dtype)) return HYENA_ERR_BAD_ARG;
+    pj::ColsumArgs a;
+    a.x = x; a.part = part; a.out = out; a.P = (unsigned)P; a.N = N; a.G = colsum_groups(P);
+    a.rows_per_wg = (int)((P + a.G - 1) / a.G);
+    a.G = (int)((P + a.rows_per_wg - 1) / a.rows_per_wg);
+    const size_t lds = (size_t)pj::PJ_THREADS * 8 * sizeof(float);
+    if (dtype == HYENA_BF16) HY_LAUNCH((pj::colsum_kernel<DT_BF16>), dim3(a.G), dim3(pj::PJ_THREADS), lds, stream, a);
+    else HY_LAUNCH((pj::colsum_kernel<DT_F16>), dim3(a.G), dim3(pj::PJ_THREADS), lds, stream, a);
+    HY_LAUNCH(pj::colsum_final_kernel, dim3((N + pj::PJ_THREADS - 1) / pj::PJ_THREADS), dim3(pj::PJ_THREADS), 0, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
 int hyena_mlp_supported(long P, int K, int N, int dtype) {
     if (!(K == 128 || K == 256) || !(dtype == HYENA_BF16 || dtype == HYENA_F16)) return 0;
     if (N < 256 || N % 256 != 0 || P < 1) return 0;

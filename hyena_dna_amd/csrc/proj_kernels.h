@@ -610,5 +610,62 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     }
 }
 
+// =============================================================================================================================
+// Column sums of a position-major 16-bit matrix (P, N) in fp32: the bias gradient of a linear layer, d b = sum over the positions
+// of d y (out_proj, fc2: projection.py, lm.py).  One streaming pass with 16-byte loads at the memory rate (the generic reduction
+// kernel PyTorch picks for this shape reaches a third of it); per-workgroup partial sums, added in workgroup order by a second
+// small kernel: bitwise reproducible, no atomics.
+// =============================================================================================================================
+struct ColsumArgs {
+    const void* x;       // (P, N) 16-bit
+    float* part;         // [G][N]
+    float* out;          // (N,)
+    unsigned P;
+    int N, G, rows_per_wg;
+};
+
+template <int DT>
+__global__ void __launch_bounds__(PJ_THREADS) colsum_kernel(ColsumArgs a) {
+    typedef typename Elem<DT>::type elem_t;
+    HY_SMEM(smem);
+    const int tid = (int)threadIdx.x;
+    const int cpr = a.N / 8;                              // 16-byte pieces per row; divides 256 (checked by the host)
+    const int pc = tid % cpr, ro = tid / cpr, rstep = PJ_THREADS / cpr;
+    const unsigned r0 = (unsigned)blockIdx.x * (unsigned)a.rows_per_wg;
+    const unsigned r1 = r0 + (unsigned)a.rows_per_wg < a.P ? r0 + (unsigned)a.rows_per_wg : a.P;
+    float acc[8];
+    HY_UNROLL
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    const elem_t* base = reinterpret_cast<const elem_t*>(a.x) + 8 * pc;
+    for (unsigned r = r0 + (unsigned)ro; r < r1; r += (unsigned)rstep) {
+        const Frag f = ld16(base + (size_t)r * a.N);
+        elem_t e[8];
+        __builtin_memcpy(e, f.w, 16);
+        HY_UNROLL
+        for (int i = 0; i < 8; ++i) acc[i] += Elem<DT>::dec(e[i]);
+    }
+    // the rstep threads of a column piece add up through LDS in a fixed order
+    HY_LDS float* red = HY_LDS_CAST(float, smem);
+    HY_UNROLL
+    for (int i = 0; i < 8; ++i) red[(ro * cpr + pc) * 8 + i] = acc[i];
+    __syncthreads();
+    if (ro == 0) {
+        for (int o = 1; o < rstep; ++o) {
+            HY_UNROLL
+            for (int i = 0; i < 8; ++i) acc[i] += red[(o * cpr + pc) * 8 + i];
+        }
+        HY_UNROLL
+        for (int i = 0; i < 8; ++i) a.part[(size_t)blockIdx.x * a.N + 8 * pc + i] = acc[i];
+    }
+}
+
+__global__ void __launch_bounds__(PJ_THREADS) colsum_final_kernel(ColsumArgs a) {
+    const int n = (int)(blockIdx.x * PJ_THREADS + threadIdx.x);
+    if (n >= a.N) return;
+    float acc = 0.f;
+    for (int g = 0; g < a.G; ++g) acc += a.part[(size_t)g * a.N + n];
+    a.out[n] = acc;
+}
+
 }  // namespace pj
 }  // namespace hyena

@@ -120,7 +120,7 @@ class FusedMlpFunc(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             dw2 = split_k_weight_grad(dy2, h).to(w2.dtype)
         if ctx.needs_input_grad[4]:
-            db2 = dy2.sum(0, dtype=torch.float32).to(dy.dtype)
+            db2 = _lib.colsum(dy2).to(dy.dtype)
         return dx, dw1, db1.to(dy.dtype) if ctx.needs_input_grad[2] else None, dw2, db2
 
 

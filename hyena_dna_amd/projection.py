@@ -70,7 +70,8 @@ class SplitKLinearFunc(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = split_k_weight_grad(dy2, x2).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0, dtype=torch.float32).to(dy.dtype)
+            from . import _lib
+            db = _lib.colsum(dy2.contiguous()).to(dy.dtype) if dy2.is_cuda else dy2.sum(0, dtype=torch.float32).to(dy.dtype)
         return dx, dw, db
 
 
@@ -200,7 +201,8 @@ class OutProjCMFunc(torch.autograd.Function):
                 dw = dw + torch.mm(dy2[body:].t().float(), z2[:, body:].t().float())
             dw = dw.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0, dtype=torch.float32).to(dy.dtype)
+            from . import _lib
+            db = _lib.colsum(dy2.contiguous()).to(dy.dtype)
         return dz, dw, db
 
 

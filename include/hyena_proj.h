@@ -48,6 +48,14 @@ int hyena_mlp_fc1_gelu_fwd(const void* x, const void* W1, const float* b1, void*
 int hyena_mlp_dh_dgelu_bwd(const void* dy, const void* W2T, const void* a, void* da, float* part, long P, int K, int N, int dtype,
                            void* stream);
 
+/* ---- bias gradient of a linear layer: out[n] = sum over p of x[p, n], fp32 ------------------------------------------------------
+ * x (P, N) 16-bit position-major (the gradient arriving at out_proj / fc2: hyena.py:440, simple_lm.py:210); N a multiple of 8 with
+ * N / 8 dividing 256 (128, 256, 512, 1024 ...); part = hyena_colsum_partial_floats(P, N) floats of scratch.  One pass at the memory
+ * rate, two-stage fixed-order sums (bitwise reproducible). */
+int hyena_colsum_supported(long P, int N, int dtype);
+size_t hyena_colsum_partial_floats(long P, int N);
+int hyena_colsum(const void* x, float* part, float* out, long P, int N, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

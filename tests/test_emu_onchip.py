@@ -174,3 +174,6 @@ def test_small_fused_pair_vs_oracle(emu_backend, monkeypatch, B, D, L, dtype):
     assert du3 is None and torch.equal(dk3, dk) and torch.equal(db3, dbias)
     du4, dk4, db4 = emu_backend.fftconv_bwd(dout, u, k, bias, saved=saved)
     assert torch.equal(du4, du) and torch.equal(dk4, dk) and torch.equal(db4, dbias)
+    # without the forward's spectrum: the filter is transformed by the same code first -- the same bits
+    du5, dk5, db5 = emu_backend.fftconv_bwd(dout, u, k, bias)
+    assert torch.equal(du5, du) and torch.equal(dk5, dk) and torch.equal(db5, dbias)

@@ -53,3 +53,5 @@ def test_small_fused_pair_on_gpu(gpu_lib, monkeypatch, B, D, L, dtype):
     for _ in range(3):
         du4, dk4, db4 = gpu_lib.fftconv_bwd(dd, ud, kd, bd, saved=saved)
         assert torch.equal(du4, du) and torch.equal(dk4, dk) and torch.equal(db4, dbias)
+    du5, dk5, db5 = gpu_lib.fftconv_bwd(dd, ud, kd, bd)             # no saved spectrum: the same kernels transform the filter first
+    assert torch.equal(du5, du) and torch.equal(dk5, dk) and torch.equal(db5, dbias)

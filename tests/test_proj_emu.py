@@ -135,3 +135,15 @@ def test_fused_mlp_module_matches_the_unfused_graph(emu_backend, monkeypatch):
     for a, b in zip(*res):
         err = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
         assert err < 1e-2, err
+
+
+@pytest.mark.parametrize("P,N,dtype", [(1, 128, torch.bfloat16), (700, 256, torch.bfloat16), (5000, 1024, torch.float16), (33, 64, torch.bfloat16)])
+def test_colsum_kernel(emu_backend, P, N, dtype):
+    x = torch.randn(P, N, generator=torch.Generator().manual_seed(P)).to(dtype)
+    out = emu_backend.colsum(x)
+    ref = x.double().sum(0)
+    assert out.dtype == torch.float32 and ((out.double() - ref).abs() <= 1e-5 * x.double().abs().sum(0) + 1e-6).all()
+    assert torch.equal(out, emu_backend.colsum(x))
+    # shapes the kernel does not serve fall back to torch's reduction
+    y = torch.randn(10, 96).to(dtype)
+    assert torch.allclose(emu_backend.colsum(y), y.float().sum(0))
