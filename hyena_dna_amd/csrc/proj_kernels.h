@@ -100,23 +100,6 @@ __device__ __forceinline__ Frag lds_ld16(const HY_LDS char* p) { return __builti
 __device__ __forceinline__ void lds_st16(HY_LDS char* p, const Frag& f) { *reinterpret_cast<HY_LDS pj_lvec16*>(p) = __builtin_bit_cast(pj_lvec16, f); }
 #endif
 
-// Asynchronous 16-byte copies global -> LDS (global_load_lds_dwordx4): lane i of the wavefront writes base + 16 i (base wave-uniform,
-// through M0) from its OWN global address, no VGPR in between; they count in vmcnt like any load.  The staged operand tiles use
-// them so that the next tile streams in while the current one's epilogue runs.  The LDS image is therefore linear per instruction:
-// rows are NOT padded; bank conflicts are avoided by a swizzle instead -- the 16-byte chunk c of row r lives in slot c ^ (r & 7)
-// (the per-lane GLOBAL address picks the chunk, the LDS side stays linear), so the fragment reads of 8 neighbouring rows at one k
-// offset hit 8 different 16-byte slots = all 32 banks.
-#ifdef HIPEMU
-__device__ __forceinline__ void g2lds16(const void* g, HY_LDS char* base) { __builtin_memcpy(base + (hipemu::S.cur & 63) * 16, g, 16); }
-#define PJ_WAIT_VM(n) do {} while (0)
-#else
-__device__ __forceinline__ void g2lds16(const void* g, HY_LDS char* base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (HY_LDS void*)base, 16, 0, 0);
-}
-#define PJ_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#endif
-__device__ __forceinline__ int pj_swz(int row, int chunk) { return chunk ^ (row & 7); }
-
 template <int K> struct PjCfg {
     static_assert(K == 128 || K == 256, "d_model of the HyenaDNA models");
     static constexpr int KS = K / 16;                         // MFMA steps over the contraction
@@ -177,9 +160,7 @@ __device__ __forceinline__ acc4_t mfma16(const Frag& a, const Frag& b, acc4_t c)
 enum { IP_CB = 16, IP_NT4 = PJ_NT / 16 };
 template <int K> struct IpCfg {
     static constexpr int KS = K / 32;                         // v_mfma_f32_16x16x32 steps over the contraction
-    static constexpr int UROW = K * 2;                        // staged u rows: unpadded, chunks swizzled (pj_swz; asynchronous copies)
-    static constexpr int UBUF = PJ_NT * UROW;
-    static constexpr int CH = PjCfg<K>::CH;
+    static constexpr int UROW = PjCfg<K>::UROW, UBUF = PjCfg<K>::UBUF, CH = PjCfg<K>::CH;
     static constexpr int EROW = PJ_EW * 2;
     static constexpr int EBUF = 3 * IP_CB * EROW;             // per wavefront: [group][channel][PJ_EW]
     static constexpr int TAPS = 2 * IP_CB * 5 * 4;
@@ -238,34 +219,27 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
     // (sequence, position within it) of the first position of the current tile, carried along instead of divided out per tile
     unsigned sb = ((unsigned)t_first * PJ_NT) / (unsigned)a.Lx;
     int sl0 = (int)((unsigned)t_first * PJ_NT - sb * (unsigned)a.Lx);
-    // the u tile of positions [64 t, 64 t + 64) -- one contiguous block of 64 K 2 bytes -- by asynchronous copies into the staging
-    // buffer (rows beyond P clamped: their results are never stored)
-    const int wave64 = HY_SGPR(wave * 64);
-    constexpr int RS = PJ_THREADS / (K / 8);                      // a multiple of 8: one swizzled chunk per lane for all its pieces
-    const int urow0 = tid / (K / 8);
-    const char* const ulane = ubase + ((size_t)urow0 * K + 8 * pj_swz(urow0, tid % (K / 8))) * 2;
-    auto issue_u = [&](int t) {
-        const unsigned q0 = (unsigned)t * PJ_NT;
-        if (q0 + PJ_NT <= P) {
-            HY_UNROLL
-            for (int c = 0; c < C::CH; ++c) g2lds16(ulane + ((size_t)q0 + RS * c) * K * 2, ubuf + (PJ_THREADS * c + wave64) * 16);
-        } else {
-            HY_UNROLL
-            for (int c = 0; c < C::CH; ++c) {
-                unsigned p = q0 + (unsigned)(urow0 + RS * c);
-                p = p < P ? p : P - 1;
-                g2lds16(ulane + ((size_t)p - urow0) * K * 2, ubuf + (PJ_THREADS * c + wave64) * 16);
-            }
-        }
-    };
-    issue_u(t_first);
-    bool prev_fast = false;                                   // the previous tile left exactly 8 stores per lane behind
     for (int t = t_first; t < t_end; ++t, sl0 += PJ_NT) {
         while (sl0 >= a.Lx) { sl0 -= a.Lx; ++sb; }
         const unsigned p0 = (unsigned)t * PJ_NT;
-        // in flight, oldest first: this tile's u (issued during the previous epilogue), then the previous epilogue's stores
-        // (they count in vmcnt too): wait for all but those -- if their number is known
-        if (prev_fast) PJ_WAIT_VM(8); else PJ_WAIT_VM(0);
+        {
+            // the u tile of positions [64 t, 64 t + 64): one contiguous block of 64 K 2 bytes, global -> registers -> LDS
+            // (no register double-buffering across the matrix-core phase: the CU's other workgroup covers these waits)
+            Frag st[C::CH];
+            HY_UNROLL
+            for (int c = 0; c < C::CH; ++c) {
+                const int q = tid + PJ_THREADS * c;
+                const unsigned p = p0 + (unsigned)(q / (K / 8));
+                Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+                st[c] = p < P ? ld16(ubase + ((size_t)p0 * K * 2 + (size_t)q * 16)) : z;
+            }
+            __syncthreads();                                     // every wavefront is done with the previous u tile
+            HY_UNROLL
+            for (int c = 0; c < C::CH; ++c) {
+                const int q = tid + PJ_THREADS * c;
+                lds_st16(ubuf + (q / (K / 8)) * C::UROW + (q % (K / 8)) * 16, st[c]);
+            }
+        }
         __syncthreads();
         acc4_t acc[3][IP_NT4];
         HY_UNROLL
@@ -276,19 +250,16 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                 for (int r = 0; r < 4; ++r) acc[g][nt][r] = 0.f;
             }
         }
-        const HY_LDS char* const ub = ubuf + j * C::UROW;
+        const HY_LDS char* const ub = ubuf + j * C::UROW + kq * 16;
         HY_UNROLL
         for (int ks = 0; ks < C::KS; ++ks) {
             HY_UNROLL
             for (int nt = 0; nt < IP_NT4; ++nt) {
-                const Frag bf = lds_ld16(ub + nt * 16 * C::UROW + pj_swz(j, 4 * ks + kq) * 16);
+                const Frag bf = lds_ld16(ub + nt * 16 * C::UROW + ks * 64);
                 HY_UNROLL
                 for (int g = 0; g < 3; ++g) acc[g][nt] = mfma16<DT>(wf[g][ks], bf, acc[g][nt]);
             }
         }
-        __syncthreads();                                         // every wavefront is done with the u tile ...
-        if (t + 1 < t_end) issue_u(t + 1);                       // ... the next one streams in under the epilogue
-        prev_fast = false;
         // ---- epilogue, wavefront-private ---------------------------------------------------------------------------
         // (1) the previous tile's last two positions become this tile's halo (slots 6, 7: one dword per row)
         if (lane < 3 * IP_CB) {
@@ -313,7 +284,6 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
             // Interior tiles -- whole, inside one sequence, at least two positions into it, inside the convolved length -- take a
             // straight-line path: no per-element predicates, no divisions, addresses from offsets hoisted out of the loop.
             const bool fast = p0 + PJ_NT <= P && sl0 >= 2 && sl0 + PJ_NT <= a.Lc;
-            prev_fast = fast;
             if (fast) {
                 // (3) xT: 3 x 16 rows x 8 pieces of 8 positions
                 HY_UNROLL
@@ -444,15 +414,12 @@ enum { PM_UW = 64 /* hidden units per wavefront */, PM_EW = PM_UW + 8 };
 
 template <int K> struct PmCfg {
     static constexpr int KS = K / 16;
-    static constexpr int UROW = K * 2;                        // bytes per staged operand row: unpadded, chunks swizzled (pj_swz)
-    static constexpr int UBUF = PJ_NT * UROW;
-    static constexpr int CH = PjCfg<K>::CH;
-    static constexpr int EROW0 = PM_EW * 2;                   // MODE 0: padded rows of the epilogue tile [position][unit]
-    static constexpr int EROW1 = PM_UW * 2;                   // MODE 1: linear rows (the a tile arrives by asynchronous copies)
-    static constexpr int EBUF = PJ_NT * EROW0;                // one tile per wavefront
-    // ONE staging buffer and ONE epilogue tile per wavefront: 69 KB, so that TWO workgroups share a CU (2 wavefronts per SIMD,
+    static constexpr int UROW = PjCfg<K>::UROW, UBUF = PjCfg<K>::UBUF, CH = PjCfg<K>::CH;
+    static constexpr int EROW = PM_EW * 2;                    // bytes per row of the epilogue tile [position][unit]
+    static constexpr int EBUF = PJ_NT * EROW;                 // one tile per wavefront
+    // ONE staging buffer and ONE epilogue tile per wavefront: 70 KB, so that TWO workgroups share a CU (2 wavefronts per SIMD,
     // <= 256 registers each).  A lone wavefront issues an instruction every ~7 cycles here (LDS and transcendental latencies in
-    // a dependent chain); the second one fills the gaps -- and covers the first one's barriers.
+    // a dependent chain); the second one fills the gaps -- and covers the first one's barriers and global-load waits.
     static constexpr size_t LDS = (size_t)UBUF + PJ_WAVES * (size_t)EBUF;
 };
 
@@ -535,58 +502,44 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     float colsum[2] = {0.f, 0.f};
 
     const char* const xbase = reinterpret_cast<const char*>(a.x);
-    constexpr int EROW = MODE == 1 ? C::EROW1 : C::EROW0;
     // Piece m of a lane in the [position][unit] tile: position (lane >> 3) + 8 m, piece lane & 7 -- the m-dependent part of its
     // global address is wave-uniform.
     const size_t eoff0 = (size_t)(lane >> 3) * N + n0 + 8 * (lane & 7);
-    const int wave64 = HY_SGPR(wave * 64);
-    // asynchronous copies: the operand tile (64 x K, one contiguous block; rows beyond P clamped -- their results are never
-    // stored) into the staging buffer, and -- MODE 1 -- this wavefront's a tile into its epilogue tile
-    // (chunk q = tid + 256 c of a tile sits in row tid / (K / 8) + RS c with RS = 2048 / K a multiple of 8: the same swizzled
-    // chunk for every c, so a lane's eight source addresses are one base + uniform strides)
-    constexpr int RS = PJ_THREADS / (K / 8);
-    const int xrow0 = tid / (K / 8);
-    const char* const xlane = xbase + ((size_t)xrow0 * K + 8 * pj_swz(xrow0, tid % (K / 8))) * 2;
-    auto issue_x = [&](int t) {
-        const unsigned q0 = (unsigned)t * PJ_NT;
-        if (q0 + PJ_NT <= P) {
-            HY_UNROLL
-            for (int c = 0; c < C::CH; ++c) g2lds16(xlane + ((size_t)q0 + RS * c) * K * 2, ubuf + (PJ_THREADS * c + wave64) * 16);
-        } else {
-            HY_UNROLL
-            for (int c = 0; c < C::CH; ++c) {
-                unsigned p = q0 + (unsigned)(xrow0 + RS * c);
-                p = p < P ? p : P - 1;
-                g2lds16(xlane + ((size_t)p - xrow0) * K * 2, ubuf + (PJ_THREADS * c + wave64) * 16);
-            }
-        }
-    };
-    auto issue_a = [&](int t) {
-        const unsigned q0 = (unsigned)t * PJ_NT;
-        const elem_t* const ab = reinterpret_cast<const elem_t*>(a.a_in) + eoff0;
-        if (q0 + PJ_NT <= P) {
-            HY_UNROLL
-            for (int m = 0; m < PJ_NT * 8 / 64; ++m) g2lds16(ab + ((size_t)q0 + 8u * m) * N, et + m * 1024);
-        } else {
-            HY_UNROLL
-            for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
-                unsigned p = q0 + (unsigned)(lane >> 3) + 8u * m;
-                p = p < P ? p : P - 1;
-                g2lds16(ab + ((size_t)p - (lane >> 3)) * N, et + m * 1024);
-            }
-        }
-    };
 
-    issue_x(t_begin);
-    bool prev_full = false;
     for (int t = t_begin; t < t_end; ++t) {
         const unsigned p0 = (unsigned)t * PJ_NT;
         const bool full = p0 + PJ_NT <= P;                       // wave-uniform: whole tiles skip every per-position predicate
-        // In flight, oldest first: the operand tile t (issued during the previous epilogue), the previous epilogue's stores
-        // (16 / 8 per lane for a whole tile; stores count in vmcnt too), and now the a tile.  Waiting for the operand tile = all but
-        // the stores and the a tile -- whose number is known only after a whole tile; otherwise wait for everything older than a.
-        if (MODE == 1) issue_a(t);
-        if (prev_full) PJ_WAIT_VM(16); else if (MODE == 1) PJ_WAIT_VM(8); else PJ_WAIT_VM(0);
+        {
+            // the operand tile (64 x K, one contiguous block) and, MODE 1, this wavefront's a tile: global -> registers -> LDS.
+            // (No register double-buffering across the matrix-core phase: the CU's other workgroup covers these waits.)
+            Frag st[C::CH];
+            HY_UNROLL
+            for (int c = 0; c < C::CH; ++c) {
+                const int q = tid + PJ_THREADS * c;
+                const unsigned p = p0 + (unsigned)(q / (K / 8));
+                Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+                st[c] = (full || p < P) ? ld16(xbase + ((size_t)p0 * K * 2 + (size_t)q * 16)) : z;
+            }
+            Frag at[MODE == 1 ? PJ_NT * 8 / 64 : 1];
+            if (MODE == 1) {
+                HY_UNROLL
+                for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
+                    Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
+                    at[m] = (full || p0 + (unsigned)(lane >> 3) + 8u * m < P)
+                                ? ld16(reinterpret_cast<const elem_t*>(a.a_in) + (eoff0 + ((size_t)p0 + 8u * m) * N)) : z;
+                }
+            }
+            __syncthreads();                                     // every wavefront is done with the previous operand tile
+            HY_UNROLL
+            for (int c = 0; c < C::CH; ++c) {
+                const int q = tid + PJ_THREADS * c;
+                lds_st16(ubuf + (q / (K / 8)) * C::UROW + (q % (K / 8)) * 16, st[c]);
+            }
+            if (MODE == 1) {
+                HY_UNROLL
+                for (int m = 0; m < PJ_NT * 8 / 64; ++m) lds_st16(et + ((lane >> 3) + 8 * m) * C::EROW + (lane & 7) * 16, at[m]);
+            }
+        }
         __syncthreads();
         acc_t acc[2][2];                           // [position tile][unit tile]
         HY_UNROLL
@@ -597,20 +550,16 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
                 for (int r = 0; r < 16; ++r) acc[pt][ut][r] = 0.f;
             }
         }
-        const HY_LDS char* const ub = ubuf + j * C::UROW;
+        const HY_LDS char* const ub = ubuf + j * C::UROW + hb * 16;
         HY_UNROLL
         for (int ks = 0; ks < C::KS; ++ks) {
             HY_UNROLL
             for (int pt = 0; pt < 2; ++pt) {
-                const Frag af = lds_ld16(ub + pt * 32 * C::UROW + pj_swz(j, 2 * ks + hb) * 16);
+                const Frag af = lds_ld16(ub + pt * 32 * C::UROW + ks * 32);
                 HY_UNROLL
                 for (int ut = 0; ut < 2; ++ut) acc[pt][ut] = mfma<DT>(af, wf[ut][ks], acc[pt][ut]);
             }
         }
-        __syncthreads();                                         // every wavefront is done with the operand tile ...
-        if (t + 1 < t_end) issue_x(t + 1);                       // ... the next one streams in under the epilogue
-        if (MODE == 1) { if (t + 1 < t_end) PJ_WAIT_VM(8); else PJ_WAIT_VM(0); }      // the a tile has landed
-        prev_full = full;
         // ---- epilogue, wavefront-private: register r of lane (j, hb) = position pt 32 + pj_row(r, hb), unit ut 32 + j ----
         // The tile is used twice in MODE 0 (a, then h -- recomputed from the accumulators rather than held in 32 more registers)
         // and in place in MODE 1 (every lane overwrites the a values it read with its da values).
@@ -624,7 +573,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
                     HY_UNROLL
                     for (int r = 0; r < 16; ++r) {
                         const int pos = pt * 32 + pj_row(r, hb), un = ut * 32 + j;
-                        HY_LDS elem_t* slot = reinterpret_cast<HY_LDS elem_t*>(et + pos * EROW) + un;
+                        HY_LDS elem_t* slot = reinterpret_cast<HY_LDS elem_t*>(et + pos * C::EROW) + un;
                         if (MODE == 0) {
                             const elem_t av = Elem<DT>::cvt(acc[pt][ut][r] + bias[ut]);
                             *slot = pass == 0 ? av : Elem<DT>::cvt(pm_gelu(Elem<DT>::dec(av)));
@@ -643,7 +592,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
             for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
                 const int pos = (lane >> 3) + 8 * m, pc = lane & 7;
                 if (!full && p0 + pos >= P) continue;
-                st16(dst + (eoff0 + ((size_t)p0 + 8u * m) * N), lds_ld16(et + pos * EROW + pc * 16));      // (second term wave-uniform)
+                st16(dst + (eoff0 + ((size_t)p0 + 8u * m) * N), lds_ld16(et + pos * C::EROW + pc * 16));      // (second term wave-uniform)
             }
         }
         HY_WAVE_SYNC_PJ();
