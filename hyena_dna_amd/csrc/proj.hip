@@ -44,8 +44,8 @@ int dispatch_mlp(const pj::MlpArgs& a, int K, int dtype, int grid, void* stream)
 extern "C" {
 
 static int colsum_groups(long P) {
-    long g = (P + 511) / 512;                        // >= 512 rows per workgroup
-    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+    long g = (P + 511) / 512;                        // >= 512 rows per workgroup, at most two workgroups per CU
+    return (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
 }
 
 int hyena_colsum_supported(long P, int N, int dtype) {
@@ -64,7 +64,7 @@ int hyena_colsum(const void* x, float* part, float* out, long P, int N, int dtyp
     const size_t lds = (size_t)pj::PJ_THREADS * 8 * sizeof(float);
     if (dtype == HYENA_BF16) HY_LAUNCH((pj::colsum_kernel<DT_BF16>), dim3(a.G), dim3(pj::PJ_THREADS), lds, stream, a);
     else HY_LAUNCH((pj::colsum_kernel<DT_F16>), dim3(a.G), dim3(pj::PJ_THREADS), lds, stream, a);
-    HY_LAUNCH(pj::colsum_final_kernel, dim3((N + pj::PJ_THREADS - 1) / pj::PJ_THREADS), dim3(pj::PJ_THREADS), 0, stream, a);
+    HY_LAUNCH(pj::colsum_final_kernel, dim3((N + 63) / 64), dim3(pj::PJ_THREADS), pj::PJ_THREADS * sizeof(float), stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 

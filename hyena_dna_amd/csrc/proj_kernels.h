@@ -659,12 +659,21 @@ __global__ void __launch_bounds__(PJ_THREADS) colsum_kernel(ColsumArgs a) {
     }
 }
 
+// 64 columns per workgroup; the G partial rows are split over the workgroup's 4 thread rows (each adds its rows in order), the four
+// sums are added in thread-row order: a fixed order, G / 4 loads per thread
 __global__ void __launch_bounds__(PJ_THREADS) colsum_final_kernel(ColsumArgs a) {
-    const int n = (int)(blockIdx.x * PJ_THREADS + threadIdx.x);
-    if (n >= a.N) return;
+    HY_SMEM(smem);
+    const int col = (int)blockIdx.x * 64 + ((int)threadIdx.x & 63), q = (int)threadIdx.x >> 6;
+    const int per = (a.G + 3) / 4;
     float acc = 0.f;
-    for (int g = 0; g < a.G; ++g) acc += a.part[(size_t)g * a.N + n];
-    a.out[n] = acc;
+    if (col < a.N) {
+        const int g1 = (q + 1) * per < a.G ? (q + 1) * per : a.G;
+        for (int g = q * per; g < g1; ++g) acc += a.part[(size_t)g * a.N + col];
+    }
+    HY_LDS float* red = HY_LDS_CAST(float, smem);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (q == 0 && col < a.N) a.out[col] = ((red[threadIdx.x] + red[threadIdx.x + 64]) + red[threadIdx.x + 128]) + red[threadIdx.x + 192];
 }
 
 }  // namespace pj

@@ -66,3 +66,6 @@ for cfg in sys.argv[1:]:
           f"({(P * D * 2 + 2 * P * N * 2) / t_f / 1e6:.2f} TB/s, {2 * P * D * N / t_f / 1e6:.0f} TFLOP/s)", flush=True)
     print(f"   MLP bwd: library dh {t_dh:.1f} + GELU' {t_dg:.1f} + bias sum {t_db:.1f} = {t_dh + t_dg + t_db:.1f} us;  fused {t_b:.1f} us "
           f"({(P * D * 2 + 2 * P * N * 2) / t_b / 1e6:.2f} TB/s)", flush=True)
+    t_cs = timeit(lambda: _lib.colsum(dy))
+    t_ts = timeit(lambda: dy.sum(0, dtype=torch.float32))
+    print(f"   bias gradient (P x {D} column sums): torch {t_ts:.1f} us;  colsum kernel {t_cs:.1f} us ({P * D * 2 / t_cs / 1e6:.2f} TB/s)", flush=True)

@@ -126,3 +126,14 @@ def test_lm_step_with_and_without_the_fused_mlp(gpu_lib, monkeypatch):
     for n, gref in res[1][1].items():
         e = ((res[0][1][n] - gref).norm() / gref.norm().clamp_min(1e-20)).item()
         assert e < 3e-2, (n, e)
+
+
+@pytest.mark.parametrize("P,N,dtype", [(1048576, 256, torch.bfloat16), (262144, 1024, torch.float16), (999999, 128, torch.bfloat16), (7, 256, torch.bfloat16)])
+def test_colsum_on_gpu(gpu_lib, P, N, dtype):
+    """the bias-gradient column sums (csrc/proj_kernels.h colsum_kernel) against the fp64 sums; deterministic"""
+    dev = torch.device("cuda", 0)
+    x = torch.randn(P, N, device=dev, generator=torch.Generator(device=dev).manual_seed(P % 997)).to(dtype)
+    out = gpu_lib.colsum(x)
+    ref = x.double().sum(0)
+    assert out.dtype == torch.float32 and ((out.double() - ref).abs() <= 2e-6 * x.double().abs().sum(0) + 1e-5).all()
+    assert torch.equal(out, gpu_lib.colsum(x))
