@@ -314,88 +314,6 @@ __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two independent forward transforms, phase by phase (the one-launch kernels for short rows: a lone wavefront issues one
-// instruction every ~4.4 cycles and every LDS / table round trip is exposed; two interleaved dependency chains hide each other's
-// latencies, and the twiddle tables are loaded once for both).  `xb2`: a second exchange buffer of Cfg<R>::XBYTES for `w`.
-// Only for rows that live in one wavefront (T <= 64: the exchanges contain no workgroup barrier).
-// ---------------------------------------------------------------------------------------------
-template <int R, bool INV>
-__device__ __forceinline__ void x1p2(c32 (&v)[32], c32 (&w)[32], HY_LDS float* xa, HY_LDS float* xb, int tid, int ka, int tp) {
-    constexpr int T = Cfg<R>::T, ROW1 = Cfg<R>::ROW1;
-    static_assert(T <= 64 && !INV, "paired exchange: forward transforms of single-wavefront rows");
-    HY_LDS float* const pa0 = xa + tid;
-    HY_LDS float* const pb0 = xa + ka * ROW1 + tp;
-    HY_LDS float* const pa1 = xb + tid;
-    HY_LDS float* const pb1 = xb + ka * ROW1 + tp;
-    HY_UNROLL
-    for (int part = 0; part < 2; ++part) {
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) { pa0[q * ROW1] = part ? v[q].y : v[q].x; pa1[q * ROW1] = part ? w[q].y : w[q].x; }
-        row_sync<T>();
-        HY_UNROLL
-        for (int s = 0; s < 32; ++s) {
-            if (part) { v[s].y = pb0[R * s]; w[s].y = pb1[R * s]; } else { v[s].x = pb0[R * s]; w[s].x = pb1[R * s]; }
-        }
-        row_sync<T>();
-    }
-}
-template <int R>
-__device__ __forceinline__ void x2p2(c32 (&v)[32], c32 (&w)[32], HY_LDS float* xa, HY_LDS float* xb, int ka, int tp) {
-    constexpr int NB = Cfg<R>::NB, GRP2 = Cfg<R>::GRP2;
-    HY_LDS float* const pa0 = xa + ka * GRP2 + tp * 33;
-    HY_LDS float* const pb0 = xa + ka * GRP2 + tp;
-    HY_LDS float* const pa1 = xb + ka * GRP2 + tp * 33;
-    HY_LDS float* const pb1 = xb + ka * GRP2 + tp;
-    HY_UNROLL
-    for (int part = 0; part < 2; ++part) {
-        HY_UNROLL
-        for (int q = 0; q < 32; ++q) { pa0[q] = part ? v[q].y : v[q].x; pa1[q] = part ? w[q].y : w[q].x; }
-        HY_WAVE_SYNC();
-        HY_UNROLL
-        for (int i = 0; i < NB; ++i) {
-            HY_UNROLL
-            for (int t2 = 0; t2 < R; ++t2) {
-                const float f0 = pb0[33 * t2 + R * i], f1 = pb1[33 * t2 + R * i];
-                if (part) { v[i * R + t2].y = f0; w[i * R + t2].y = f1; } else { v[i * R + t2].x = f0; w[i * R + t2].x = f1; }
-            }
-        }
-        HY_WAVE_SYNC();
-    }
-}
-template <int R>
-__device__ __forceinline__ void fft_fwd2(c32 (&v)[32], c32 (&w)[32], const Ctx& c, HY_LDS char* xb2) {
-    dft_reg<32, false>(v);
-    dft_reg<32, false>(w);
-    OC_FENCE();
-    {
-        Tw tw;
-        load_tw1<R>(tw, c.tab, c.tid);
-        apply_tw<false, true>(v, tw);
-        apply_tw<false, true>(w, tw);
-    }
-    OC_FENCE();
-    x1p2<R, false>(v, w, HY_LDS_CAST(float, c.xb), HY_LDS_CAST(float, xb2), c.tid, c.ka, c.tp);
-    OC_FENCE();
-    dft_reg<32, false>(v);
-    dft_reg<32, false>(w);
-    OC_FENCE();
-    if constexpr (R > 1) {
-        {
-            Tw tw;
-            load_tw2<R>(tw, c.tab, c.tp);
-            apply_tw<false, false>(v, tw);
-            apply_tw<false, false>(w, tw);
-        }
-        OC_FENCE();
-        x2p2<R>(v, w, HY_LDS_CAST(float, c.xb), HY_LDS_CAST(float, xb2), c.ka, c.tp);
-        OC_FENCE();
-        pass3<R, false>(v);
-        pass3<R, false>(w);
-        OC_FENCE();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // row I/O.  A workgroup's rows are RPW consecutive rows of the (B, D, L) tensor; the buffer descriptor covers them
 // (RPW = 1: hardware bounds checking clips n >= L for free; RPW = 2 -- two rows per wavefront at T = 32 -- adds an
 // explicit predicate).  Element n of the thread's register s is n = tid + T s.
@@ -844,7 +762,7 @@ template <int R> struct SmallCfg {
     static constexpr int T = Cfg<R>::T;
     static constexpr int WGT = 256;
     static constexpr int G = WGT / T;                                   // row groups per workgroup
-    static constexpr size_t LDS_X = Cfg<R>::XBYTES * G * 2;             // two exchange buffers per row group (paired transforms)
+    static constexpr size_t LDS_X = Cfg<R>::XBYTES * G;
     static constexpr size_t LDS_RED = (size_t)G * Cfg<R>::M * 8;        // the groups' partial dk spectra
     static constexpr size_t LDS_FWD = LDS_X;
     static constexpr size_t LDS_BWD = LDS_X + LDS_RED;
@@ -860,37 +778,32 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(SmallFwdArgs a) {
     const int rg = (int)threadIdx.x / T, tid = (int)threadIdx.x % T;
     const int d = blockIdx.x;
     const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
-    HY_LDS char* const xb2 = HY_LDS_CAST(char, smem) + (size_t)(G + rg) * C::XBYTES;      // second exchange buffer of this row group
+    // the filter spectrum of this channel, in registers: H = (FFT(c_k) + bias) / M
+    c32 h[32];
+    {
+        const GBuf kb = make_gbuf(a.k, (unsigned)a.D * (unsigned)a.L * 4u);
+        load_row<R, 2, false, true>(h, kb, false, tid, (unsigned)d * (unsigned)a.L * 4u, a.L);
+        fft_fwd<R>(h, c);
+        const float bias = (a.bias != nullptr) ? a.bias[d] : 0.f;
+        const float sc = 1.0f / (float)C::M;
+        HY_UNROLL
+        for (int q = 0; q < 32; ++q) h[q] = mk((h[q].x + bias) * sc, h[q].y * sc);
+        if (a.Hout != nullptr && rg == 0 && blockIdx.y == 0) {
+            c32* Hd = a.Hout + (size_t)d * C::M + tid;
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) Hd[q * T] = h[q];
+        }
+    }
     const unsigned total = (unsigned)a.B * (unsigned)a.D * (unsigned)a.L * ES;
     const GBuf xb = make_gbuf(a.x, total);
     const GBuf ob = make_gbuf(a.out, total);
-    const GBuf kb = make_gbuf(a.k, (unsigned)a.D * (unsigned)a.L * 4u);
-    const float bias = (a.bias != nullptr) ? a.bias[d] : 0.f;
-    const float sc = 1.0f / (float)C::M;
-    // the filter spectrum of this channel, in registers: H = (FFT(c_k) + bias) / M -- transformed TOGETHER with the group's first row
-    c32 h[32];
-    load_row<R, 2, false, true>(h, kb, false, tid, (unsigned)d * (unsigned)a.L * 4u, a.L);
-    bool first = true;
-    for (int b0 = blockIdx.y * G; first || b0 < a.B; b0 += G * gridDim.y) {
+    for (int b0 = blockIdx.y * G; b0 < a.B; b0 += G * gridDim.y) {
         const bool live = b0 + rg < a.B;
-        const int b = live ? b0 + rg : (a.B > 0 ? a.B - 1 : 0);
+        const int b = live ? b0 + rg : a.B - 1;
         const unsigned row_off = ((unsigned)b * (unsigned)a.D + (unsigned)d) * (unsigned)a.L * ES;
         c32 v[32];
-        load_row<R, 2, HALF, true>(v, xb, bf, tid, row_off, a.B > 0 ? a.L : 0);
-        if (first) {
-            fft_fwd2<R>(h, v, c, xb2);
-            HY_UNROLL
-            for (int q = 0; q < 32; ++q) h[q] = mk((h[q].x + bias) * sc, h[q].y * sc);
-            if (a.Hout != nullptr && rg == 0 && blockIdx.y == 0) {
-                c32* Hd = a.Hout + (size_t)d * C::M + tid;
-                HY_UNROLL
-                for (int q = 0; q < 32; ++q) Hd[q * T] = h[q];
-            }
-            first = false;
-            if (b0 >= a.B) break;                           // empty batch (the backward asks for H only): nothing to convolve
-        } else {
-            fft_fwd<R>(v, c);
-        }
+        load_row<R, 2, HALF, true>(v, xb, bf, tid, row_off, a.L);
+        fft_fwd<R>(v, c);
         HY_UNROLL
         for (int q = 0; q < 32; ++q) v[q] = cmul(v[q], h[q]);
         fft_inv<R>(v, c);
@@ -927,7 +840,6 @@ __global__ void __launch_bounds__(256) small_bwd_kernel(SmallBwdArgs a) {
     // next to G and U.
     HY_LDS lc32* const red = HY_LDS_CAST(lc32, smem + SmallCfg<R>::LDS_X);
     HY_LDS lc32* const mine = red + rg * C::M + tid;
-    HY_LDS char* const xb2 = HY_LDS_CAST(char, smem) + (size_t)(G + rg) * C::XBYTES;      // second exchange buffer of this row group
     bool first = true;
     for (int b0 = 0; b0 < a.B; b0 += G) {
         const bool live = b0 + rg < a.B;
@@ -935,12 +847,12 @@ __global__ void __launch_bounds__(256) small_bwd_kernel(SmallBwdArgs a) {
         const unsigned row_off = ((unsigned)b * (unsigned)a.D + (unsigned)d) * (unsigned)a.L * ES;
         c32 g[32];
         load_row<R, 2, HALF, true>(g, gb, bf, tid, row_off, a.L);
-        if (!want_dk) fft_fwd<R>(g, c);
+        fft_fwd<R>(g, c);
         HY_SCHED_FENCE();
         if (want_dk) {
             c32 u[32];
             load_row<R, 2, HALF, true>(u, ub, bf, tid, row_off, a.L);
-            fft_fwd2<R>(g, u, c, xb2);                                    // both transforms of the row, interleaved
+            fft_fwd<R>(u, c);
             const float lv = live ? 1.f : 0.f;
             HY_UNROLL
             for (int q = 0; q < 32; ++q) {
