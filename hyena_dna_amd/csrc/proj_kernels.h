@@ -11,17 +11,18 @@
 //     vg [b, d, l] = xc[2D + d, b, l] xc[D + d, b, l],  l < Lc   (B, D, Lc),  xc = short conv of (xT + b_in) as in cm_kernels.h
 //
 // Shape of the GEMM: K = D in {128, 256}, 3D output rows, B L ~ 10^6 columns: 200 flop per byte moved -- HBM-bound on an MI355X
-// (2.5 PFLOP/s bf16 against 8 TB/s) even at a fraction of the MFMA peak.  So the design is WEIGHTS-STATIONARY: a wavefront owns 32
-// channels of each of the three groups (x0, x1, v) and keeps their 96 weight rows as MFMA A-fragments in registers for the
-// whole kernel (96 x K 16-bit values = 192 VGPRs at K = 256; a wavefront alone on its SIMD has 512); the four wavefronts of a
-// workgroup (128 channels) walk the SAME run of positions, 64 at a time: the u tile (64 x K, contiguous in memory) is staged
-// once through LDS, every wavefront reads its B-fragments from it (one 16-byte ds_read per 3 v_mfma_f32_32x32x16 = 96 MFMA
-// cycles), and the accumulators (position on lane, channel on register) are rounded to the storage type, parked in a
-// wavefront-private LDS tile [channel][position] and leave from there as 16-byte row pieces -- xT as is, vg after the 3-tap
-// window + gate, whose two-position halo is the tail of the previous tile (a workgroup's first tile is preceded by one
-// warm-up tile whose results are dropped).  The short-conv arithmetic is the one of cm_kernels.h::cm_sc on the ROUNDED xT
-// values, so vg is bit-identical to what cm_pre_fwd computes from the stored xT (and the backward, which recomputes the
-// window from xT, sees the same numbers).
+// (2.5 PFLOP/s bf16 against 8 TB/s) even at a fraction of the MFMA peak.  So the design is WEIGHTS-STATIONARY: a wavefront owns 16
+// channels of each of the three groups (x0, x1, v) and keeps their 48 weight rows as MFMA A-fragments in registers for the whole
+// kernel (48 x K 16-bit values = 96 VGPRs at K = 256, v_mfma_f32_16x16x32); the four wavefronts of a workgroup (64 channels) walk
+// the SAME run of positions, 64 at a time: the u tile (64 x K, contiguous in memory) is staged once through LDS, every wavefront
+// reads its B-fragments from it (one 16-byte ds_read per 3 MFMAs), and the accumulators (position on lane, channel on register)
+// are rounded to the storage type, parked in a wavefront-private LDS tile [channel][position] and leave from there as 16-byte row
+// pieces -- xT as is, vg after the 3-tap window + gate, whose two-position halo is the tail of the previous tile (a workgroup's
+// first tile is preceded by one warm-up tile whose results are dropped).  A workgroup needs 63 KB of LDS and < 256 registers per
+// wavefront: TWO workgroups share a CU (2 wavefronts per SIMD) -- a lone wavefront per SIMD (the first version: 32 channels per
+// wavefront on 32x32x16) was bound by its own instruction issue.  The short-conv arithmetic is the one of cm_kernels.h::cm_sc, FMA by
+// FMA, on the ROUNDED xT values: vg is what cm_pre_fwd computes from the stored xT (and what the backward, which recomputes the window
+// from xT, sees).
 //
 // Compiled by hipcc for gfx950 (product) and, with -DHIPEMU, by g++ against tests/hipemu (tests only).
 #pragma once
@@ -31,8 +32,8 @@
 namespace hyena {
 namespace pj {
 
-enum { PJ_THREADS = 256, PJ_WAVES = 4, PJ_CB = 32 /* channels per wavefront and group */, PJ_NT = 64 /* positions per tile */,
-       PJ_EW = PJ_NT + 8 /* row of the epilogue tile: 8 halo slots (the last two used) + the tile */ };
+enum { PJ_THREADS = 256, PJ_WAVES = 4, PJ_NT = 64 /* positions per tile */,
+       PJ_EW = PJ_NT + 8 /* row of the epilogue tile: 8 halo slots (the last two used) + the tile; 144 B: 16-byte aligned, conflict-free */ };
 
 #ifdef HIPEMU
 #define HY_WAVE_SYNC_PJ() hipemu::yield(2)
@@ -106,10 +107,6 @@ template <int K> struct PjCfg {
     static constexpr int UROW = (K + 8) * 2;                  // bytes per staged u row: +16 so that the 16-byte fragment reads of 8 neighbouring lanes hit 32 different banks
     static constexpr int UBUF = PJ_NT * UROW;                 // one staging buffer
     static constexpr int CH = PJ_NT * K * 2 / 16 / PJ_THREADS;   // 16-byte chunks of a u tile per thread (8 / 4)
-    static constexpr int EROW = PJ_EW * 2;                    // bytes per row of the epilogue tile (144: 16-byte aligned, 8 lanes x 36 dwords conflict-free)
-    static constexpr int EBUF = 3 * PJ_CB * EROW;             // per wavefront: [group][channel][PJ_EW]
-    static constexpr int TAPS = 2 * PJ_CB * 5 * 4;            // per wavefront: (w0, w1, w2, b_sc, b_in) of its x1 and v channels
-    static constexpr size_t LDS = 2 * (size_t)UBUF + PJ_WAVES * ((size_t)EBUF + TAPS);
 };
 
 struct InProjArgs {
