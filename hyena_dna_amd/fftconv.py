@@ -13,7 +13,10 @@ Differences from the reference's fused op (all lifts of restrictions, SURVEY.md 
   (``hyena.py:396-423``) with ``k`` ``(v, l)`` and ``D`` ``(1, v, 1)`` / ``(v,)``; any ``L`` in ``[1, 2**20]``.
 * saves only ``(u, k, D)`` for backward and recomputes spectra (the reference's autograd keeps ``u_f``,
   8(L+1) bytes per row).
-* options no HyenaDNA config enables (``gelu``, ``dropout_mask``, ``v``/``q``/``head_dim``, ``k_rev``,
+* ``k_rev`` (src/ops/fftconv.py:64-66: ``k_f + conj(rfft(k_rev))`` = an anti-causal convolution added to the causal one) and
+  ``bidirectional`` (hyena.py:67-73: the input centred in the 2L window = the causal result delayed by L // 2) are served by the same
+  kernels through flips / shifts (``fftconv_func`` / ``fftconv_ref`` below);
+* options no HyenaDNA config enables (``gelu``, ``dropout_mask``, ``v``/``q``/``head_dim``,
   ``output_hbl_layout``, ``fftfp16``) raise ``NotImplementedError`` instead of silently running something else.
 There is no CPU / torch.fft fallback in this module.
 """
@@ -66,7 +69,7 @@ class FFTConvFunc(torch.autograd.Function):
                 v=None, head_dim=1, q=None, fftfp16=False, k_rev=None):
         _unsupported(dropout_mask=dropout_mask is not None, gelu=bool(gelu), output_hbl_layout=bool(output_hbl_layout),
                      v=v is not None, q=q is not None, head_dim=head_dim != 1, fftfp16=bool(fftfp16),
-                     k_rev=k_rev is not None)
+                     k_rev=k_rev is not None)          # (k_rev: composed from two calls by fftconv_func)
         if k.dim() != 2:
             raise ValueError(f"k must be (H, L), got {tuple(k.shape)}")
         H, L = k.shape
@@ -119,18 +122,57 @@ class FFTConvFunc(torch.autograd.Function):
         return du, dk_out, dD, None, None, None, None, None, None, None, None, None
 
 
+def _conv(u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, head_dim, q, fftfp16):
+    return FFTConvFunc.apply(u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, head_dim, q, fftfp16, None)
+
+
 def fftconv_func(u, k, D, dropout_mask=None, gelu=True, force_fp16_output=False, output_hbl_layout=False, v=None,
                  head_dim=1, q=None, fftfp16=False, k_rev=None):
-    """Same signature as the reference's ``fftconv_func`` (src/ops/fftconv.py:105-108)."""
-    return FFTConvFunc.apply(u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, head_dim, q,
-                             fftfp16, k_rev)
+    """Same signature as the reference's ``fftconv_func`` (src/ops/fftconv.py:105-108).
+
+    ``k_rev`` (src/ops/fftconv.py:64-66; hyena.py:63-65): the reference adds ``conj(rfft(k_rev, 2L))`` to the filter spectrum, i.e. the
+    circularly time-reversed ``k_rev``: ``out[t] += sum_{s >= t} k_rev[s - t] u[s]`` -- an anti-causal convolution, which is the causal
+    one of the flipped input, flipped back.  Both run on the HIP kernels; 16-bit inputs are convolved in fp32 so that the sum is
+    rounded once, as in the reference."""
+    if k_rev is None:
+        return _conv(u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, head_dim, q, fftfp16)
+    _unsupported(dropout_mask=dropout_mask is not None, gelu=bool(gelu), force_fp16_output=bool(force_fp16_output))
+    uf = u.float()
+    out = _conv(uf, k, D, None, False, False, output_hbl_layout, v, head_dim, q, fftfp16)
+    out = out + _conv(uf.flip(-1), k_rev, None, None, False, False, output_hbl_layout, v, head_dim, q, fftfp16).flip(-1)
+    return out.to(u.dtype)
 
 
 def fftconv_ref(u, k, D, dropout_mask=None, gelu=True, k_rev=None, bidirectional=False):
     """Name-compatible with the reference's ``fftconv_ref`` (src/ops/fftconv.py:15-34; hyena.py:59-88), but
-    routed through the same HIP kernels: this package ships no torch.fft implementation."""
-    _unsupported(bidirectional=bool(bidirectional))
-    return fftconv_func(u, k, D, dropout_mask=dropout_mask, gelu=gelu, k_rev=k_rev)
+    routed through the same HIP kernels: this package ships no torch.fft implementation.
+
+    ``bidirectional`` (hyena.py:67-73): the reference centres the input in the 2L-point window (pb = L // 2 zeros in front) before the
+    CIRCULAR product with the L-tap filter and keeps the first L outputs.  Written out, with c = L - pb + 1:
+        out[t] = sum_{j <= t - pb} k[t - pb - j] u[j]            the causal convolution, delayed by pb positions
+               + sum_{m >= 0} k[L - 1 - m] u[t + c + m]          the wrap-around: later inputs through the filter's tail
+               + D u[t]
+    i.e. one causal convolution, and one anti-causal convolution (= the causal one of the flipped input, flipped back) of the
+    input advanced by c positions with the flipped filter -- two calls of the same HIP kernels.  Together with ``k_rev`` (a
+    combination hyena.py never builds: hyena.py:261 passes ``bidirectional`` alone) it is not implemented."""
+    if not bidirectional:
+        return fftconv_func(u, k, D, dropout_mask=dropout_mask, gelu=gelu, k_rev=k_rev)
+    _unsupported(dropout_mask=dropout_mask is not None, gelu=bool(gelu), k_rev_with_bidirectional=k_rev is not None)
+    pad = torch.nn.functional.pad
+    L = u.shape[-1]
+    pb = L // 2
+    c = L - pb + 1
+    uf = u.float()
+    y = pad(fftconv_func(uf, k, None, gelu=False)[..., : L - pb], (pb, 0))
+    if c < L:
+        adv = pad(uf[..., c:], (0, c))                                      # u advanced by c positions, zeros behind
+        y = y + fftconv_func(adv.flip(-1), k.flip(-1), None, gelu=False).flip(-1)
+    if D is not None:
+        Dv = D if D.dim() > 1 else D.unsqueeze(-1)                     # (1, H, 1) as HyenaOperator passes it, or (H,)
+        if u.dim() == 5 and D.dim() == 3:
+            Dv = D.reshape(1, 1, -1, 1, 1)
+        y = y + uf * Dv
+    return y.to(u.dtype)
 
 
 def fftconv_heads_ref(*args, **kwargs):

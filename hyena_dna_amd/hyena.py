@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fftconv import fftconv_func
+from .fftconv import fftconv_func, fftconv_ref
 from .filter import fused_filter_ok, hyena_filter_dl
 import os
 
@@ -110,9 +110,6 @@ class HyenaFilter(_OptimModule):
                  dropout=0.0, w=1, wd=0, bias=True, num_inner_mlps=2, linear_mixer=False, modulate: bool = True,
                  normalized=False, bidirectional=False, **kwargs):
         super().__init__()
-        if bidirectional:
-            raise NotImplementedError("bidirectional=True needs the circular wrap of an exactly-2L FFT "
-                                      "(hyena.py:67-73); not implemented by the MI355X kernel")
         self.d_model = d_model
         self.emb_dim = emb_dim
         self.seq_len = seq_len
@@ -199,8 +196,12 @@ class HyenaFilter(_OptimModule):
         if bias is None:
             bias = self.bias
         bias = bias if self.use_bias else 0 * bias
-        y = fftconv_func(x, k, bias.to(dtype=torch.float32), dropout_mask=None, gelu=False,
-                         force_fp16_output=torch.is_autocast_enabled())
+        if self.bidirectional:
+            # hyena.py:67-73 (README "Experimental"): the input centred in the 2L window = the causal result delayed by L // 2
+            y = fftconv_ref(x, k, bias.to(dtype=torch.float32), dropout_mask=None, gelu=False, bidirectional=True)
+        else:
+            y = fftconv_func(x, k, bias.to(dtype=torch.float32), dropout_mask=None, gelu=False,
+                             force_fp16_output=torch.is_autocast_enabled())
         return y.to(dtype=x.dtype)
 
 
@@ -258,7 +259,7 @@ class HyenaOperator(nn.Module):
         """The fused HIP mixer core covers exactly the HyenaDNA operator configuration."""
         return (self.order == 2 and self.num_heads == 1 and self.num_blocks == 1 and self.inner_factor == 1
                 and not self.outer_mixing and not self.post_order_ffn and self.short_filter_order == 3
-                and (self.dropout.p == 0.0 or not self.training))
+                and (self.dropout.p == 0.0 or not self.training) and not getattr(self.filter_fn, "bidirectional", False))
 
     def forward(self, u, *args, **kwargs):
         l = u.size(-2)

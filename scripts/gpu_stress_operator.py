@@ -40,7 +40,7 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-t0, n, worst = time.time(), 0, 0.0
+t0, n, worst, worst16 = time.time(), 0, 0.0, 0.0
 names = None
 while time.time() - t0 < budget:
     D = [64, 128, 256][ri(0, 2)]
@@ -69,6 +69,14 @@ while time.time() - t0 < budget:
             worst = max(worst, e)
     else:
         assert all(x is None or bool(torch.isfinite(x).all()) for x in a), tag
+        # 16-bit path (matrix-core in_proj + shell epilogue at d_model 128 / 256): against the generic path under the same autocast
+        r = run(op, u, dy, False, True)
+        for i, (x, y) in enumerate(zip(a, r)):
+            if x is None:
+                continue
+            e = rel(x.float(), y.float())
+            assert e < 3e-2, ((["y", "du"] + names)[i], e, tag)
+            worst16 = max(worst16, e)
     n += 1
 print(f"{n} operator cases in {time.time() - t0:.0f} s ({'channel' if hyena.CHANNEL_MAJOR else 'position'}-major shell): bitwise deterministic; "
-      f"fp32 cases within {worst:.2e} rel-L2 of the generic PyTorch-op path")
+      f"fp32 cases within {worst:.2e}, bf16-autocast cases within {worst16:.2e} rel-L2 of the generic PyTorch-op path")
