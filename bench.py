@@ -255,7 +255,7 @@ def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=3, warmup=
             "peak_mem_GB": None if emu else torch.cuda.max_memory_allocated(dev) / 2 ** 30,
             "parallelism": "single GPU" if world == 1 else
                            f"dp{world}: torch DDP (find_unused_parameters=False, gradient_as_bucket_view=True), one sequence batch per "
-                           f"rank, gradients all-reduced in DDP's buckets over {'gloo (test)' if emu else 'RCCL'}",
+                           f"rank, gradients all-reduced in DDP's buckets over {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (test)'}",
             "workload": f"full model step (fwd + bwd + AdamW): hyenadna d_model={D}, n_layer={n_layer}, d_inner={4 * D}, L={L}, B={B}/GPU, "
                         f"{str(dtype).split('.')[-1]} autocast, synthetic tokens; whole-job nt/s, barrier-bracketed, max over ranks; "
                         f"secondary figure, not `value`"}
