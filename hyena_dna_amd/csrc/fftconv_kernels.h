@@ -123,7 +123,34 @@ __device__ __forceinline__ c32 cmulc(c32 a, c32 b) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
     return toc(r);
 }
+// -i (a - b) (forward) / +i (a - b) (inverse): the quarter-turn twiddle of a butterfly rides on the subtraction's source modifiers
+template <bool INV>
+__device__ __forceinline__ c32 csub_rot(c32 a, c32 b) {
+    hy_f2 r;
+    if (!INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(tov(a)), "v"(tov(b)));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(tov(a)), "v"(tov(b)));
+    return toc(r);
+}
+// a * (c + i s) (CONJ: a * (c - i s)) with a compile-time constant held in a scalar register pair
+template <bool CONJ>
+__device__ __forceinline__ c32 cmul_k(c32 a, float c, float s) {
+    hy_f2 t, r, kv;
+    kv.x = c; kv.y = s;
+    const hy_f2 av = tov(a);
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "s"(kv));
+    if (!CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "s"(kv), "v"(t));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(av), "s"(kv), "v"(t));
+    return toc(r);
+}
 #endif
+#if defined(HIPEMU) || !defined(HY_PACKED_F32)
+template <bool INV>
+__device__ __forceinline__ c32 csub_rot(c32 a, c32 b) {
+    const c32 d = csub(a, b);
+    return INV ? mk(-d.y, d.x) : mk(d.y, -d.x);
+}
+#endif
+__device__ __forceinline__ c32 rmul(float x, c32 w) { return mk(x * w.x, x * w.y); }          // real x complex (two multiplies by literals)
 __device__ __forceinline__ c32 cconj(c32 a) { return mk(a.x, -a.y); }
 __device__ __forceinline__ c32 cscale(c32 a, float s) { return mk(a.x * s, a.y * s); }
 
@@ -434,6 +461,9 @@ template <bool INV>
 __device__ __forceinline__ c32 mul_tw32(c32 d, int t) {
     const float r = 0.70710678118654752440f;
     if (t == 0) return d;
+#if !defined(HIPEMU) && defined(HY_PACKED_F32)
+    if (t != 8) return cmul_k<!INV>(d, tw32_cos(t), tw32_sin(t));       // two packed instructions (t = 8 never gets here: csub_rot)
+#endif
     if (t == 8) return INV ? mk(-d.y, d.x) : mk(d.y, -d.x);
     if (t == 4) return INV ? mk((d.x - d.y) * r, (d.x + d.y) * r) : mk((d.x + d.y) * r, (d.y - d.x) * r);
     if (t == 12) return INV ? mk(-(d.x + d.y) * r, (d.x - d.y) * r) : mk((d.y - d.x) * r, -(d.x + d.y) * r);
@@ -453,7 +483,7 @@ __device__ __forceinline__ void dft_reg(c32 (&v)[N]) {
             for (int j = 0; j < half; ++j) {
                 const c32 a = v[base + j], b = v[base + j + half];
                 v[base + j] = cadd(a, b);
-                v[base + j + half] = mul_tw32<INV>(csub(a, b), j * tstep);
+                v[base + j + half] = (j * tstep == 8) ? csub_rot<INV>(a, b) : mul_tw32<INV>(csub(a, b), j * tstep);
             }
         }
     }

@@ -18,7 +18,6 @@ int plan_r(int L) {
     return r;
 }
 
-namespace {
 // one table set [tw1[11][T] | tw2[10][R]] of transform size 1024 R with input twist phi
 void fill_set(int R, double phi, float* out) {
     const int T = 32 * R, M = 1024 * R;
@@ -50,7 +49,6 @@ void fill_set(int R, double phi, float* out) {
     }
 }
 size_t set_entries(int R) { return (size_t)11 * 32 * R + (size_t)10 * R; }
-}  // namespace
 
 // layout: the set of size R with phi = 1/4; for R = 32 additionally the two parity sets of size 16 (phi = 1/8, 5/8)
 // that dk_kernel<16, 2> uses
@@ -107,25 +105,6 @@ template <int R>
 static int conv_r(const ConvArgs& a, void* stream) {
     return a.dtype == DT_F32 ? conv_rh<R, false>(a, stream) : conv_rh<R, true>(a, stream);
 }
-template <int R, int NP, bool HALF>
-static int dk_rh(const DkArgs& a, void* stream) {
-    typedef DkCfg<R, NP> K;
-    static thread_local int done = -1;
-    hy_allow_lds(dk_kernel<R, NP, HALF, 0>, K::LDS, &done);
-    HY_LAUNCH((dk_kernel<R, NP, HALF, 0>), dim3(a.D, a.S), dim3(K::WGT), K::LDS, stream, a);
-    if constexpr (NP == 2) {       // the odd bins, a second launch (it adds to what the first one left in dk)
-        static thread_local int done1 = -1;
-        hy_allow_lds(dk_kernel<R, NP, HALF, 1>, K::LDS, &done1);
-        HY_LAUNCH((dk_kernel<R, NP, HALF, 1>), dim3(a.D, a.S), dim3(K::WGT), K::LDS, stream, a);
-    }
-    if (a.S > 1) HY_LAUNCH(dk_sum_kernel, dim3((a.L + 255) / 256, a.D), dim3(256), 0, stream, a);
-    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
-}
-template <int R, int NP>
-static int dk_r(const DkArgs& a, void* stream) {
-    return a.dtype == DT_F32 ? dk_rh<R, NP, false>(a, stream) : dk_rh<R, NP, true>(a, stream);
-}
-
 // ---- short rows, small batch: one launch per direction (small_fwd_kernel / small_bwd_kernel) --------------------------------
 // HYENA_FFTCONV_SMALL=0 keeps the general kernels reachable at these sizes (A/B, tests).
 static bool small_enabled() {
@@ -141,43 +120,6 @@ bool small_ok(int R, int B, int D, int L, int dtype) {
     const size_t es = dtype == DT_F32 ? 4 : 2;
     return (size_t)B * D * L * es < ((size_t)1 << 32) && (size_t)D * L * 4 < ((size_t)1 << 32);       // 32-bit buffer offsets
 }
-template <int R, bool HALF>
-static int small_fwd_rh(const SmallFwdArgs& a, void* stream) {
-    typedef SmallCfg<R> S;
-    static thread_local int done = -1;
-    hy_allow_lds(small_fwd_kernel<R, HALF>, S::LDS_FWD, &done);
-    HY_LAUNCH((small_fwd_kernel<R, HALF>), dim3(a.D, 1), dim3(S::WGT), S::LDS_FWD, stream, a);
-    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
-}
-template <int R, bool HALF>
-static int small_bwd_rh(const SmallBwdArgs& a, void* stream) {
-    typedef SmallCfg<R> S;
-    static thread_local int done = -1;
-    hy_allow_lds(small_bwd_kernel<R, HALF>, S::LDS_BWD, &done);
-    HY_LAUNCH((small_bwd_kernel<R, HALF>), dim3(a.D), dim3(S::WGT), S::LDS_BWD, stream, a);
-    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
-}
-int launch_small_fwd(int R, const void* x, void* out, const float* k, const float* bias, void* Hout, const void* tab, int B, int D, int L,
-                     int dtype, void* stream) {
-    SmallFwdArgs a;
-    a.x = x; a.out = out; a.k = k; a.bias = bias; a.Hout = reinterpret_cast<c32*>(Hout); a.tab = reinterpret_cast<const c32*>(tab);
-    a.B = B; a.D = D; a.L = L; a.dtype = dtype;
-    const bool half = dtype != DT_F32;
-    if (R == 1) return half ? small_fwd_rh<1, true>(a, stream) : small_fwd_rh<1, false>(a, stream);
-    if (R == 2) return half ? small_fwd_rh<2, true>(a, stream) : small_fwd_rh<2, false>(a, stream);
-    return HYENA_ERR_UNSUPPORTED_L;
-}
-int launch_small_bwd(int R, const void* dout, const void* u, void* du, float* dk, float* dbias, const void* H, const void* tab, int B, int D,
-                     int L, int dtype, void* stream) {
-    SmallBwdArgs a;
-    a.dout = dout; a.u = u; a.du = du; a.dk = dk; a.dbias = dbias; a.H = reinterpret_cast<const c32*>(H);
-    a.tab = reinterpret_cast<const c32*>(tab); a.B = B; a.D = D; a.L = L; a.dtype = dtype;
-    const bool half = dtype != DT_F32;
-    if (R == 1) return half ? small_bwd_rh<1, true>(a, stream) : small_bwd_rh<1, false>(a, stream);
-    if (R == 2) return half ? small_bwd_rh<2, true>(a, stream) : small_bwd_rh<2, false>(a, stream);
-    return HYENA_ERR_UNSUPPORTED_L;
-}
-
 #define HY_OC_SWITCH(R, call)                 \
     switch (R) {                              \
         case 1: return call(1);               \
@@ -204,30 +146,6 @@ int launch_conv(int R, const void* x, void* out, const void* H, const void* tab,
     a.B = B; a.D = D; a.L = L; a.dtype = dtype; a.conj_sign = conj ? -1.0f : 1.0f;
 #define HY_CALL(r) conv_r<r>(a, stream)
     HY_OC_SWITCH(R, HY_CALL)
-#undef HY_CALL
-}
-
-int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, void* partials, const void* tab, int B, int D, int L,
-              int dtype, void* stream) {
-    DkArgs a;
-    a.dout = dout; a.u = u; a.dk = dk; a.dbias = dbias; a.tab = reinterpret_cast<const c32*>(tab);
-    a.B = B; a.D = D; a.L = L; a.dtype = dtype;
-    a.S = dk_slices(R, B, D, &a.nb);
-    a.part = reinterpret_cast<float*>(partials);
-    if (a.S > 1 && partials == nullptr) return HYENA_ERR_WORKSPACE;
-    if (R == 32) {       // two 16384-point parity problems; their tables follow the size-32 set
-        a.tab = reinterpret_cast<const c32*>(tab) + set_entries(32);
-        return dk_r<16, 2>(a, stream);
-    }
-#define HY_CALL(r) dk_r<r, 1>(a, stream)
-    switch (R) {
-        case 1: return HY_CALL(1);
-        case 2: return HY_CALL(2);
-        case 4: return HY_CALL(4);
-        case 8: return HY_CALL(8);
-        case 16: return HY_CALL(16);
-        default: return HYENA_ERR_UNSUPPORTED_L;
-    }
 #undef HY_CALL
 }
 

@@ -11,6 +11,7 @@ enum { MAX_L = 32768 };
 int plan_r(int L);
 // twiddle tables: number of complex64 entries, and their construction on the host (double precision)
 size_t table_entries(int R);
+size_t set_entries(int R);            // one table set [tw1 | tw2] of transform size 1024 R
 void build_tables(int R, float* host_c32);
 // device memory for the filter spectrum H [D][M] (the only intermediate of this path)
 size_t spectrum_bytes(int D, int R);

@@ -385,8 +385,7 @@ __device__ __forceinline__ void load_row(c32 (&v)[32], GBuf xb, bool bf, int tid
     load_raw<Cfg<R>::T, HALF, PRED>(x, xb, bf, tid, row_off, L, 0);
     HY_UNROLL
     for (int s = 0; s < 32; ++s) {
-        const c32 w = twist_const<PHI8>(s);
-        v[s] = mk(x[s] * w.x, x[s] * w.y);
+        v[s] = rmul(x[s], twist_const<PHI8>(s));
     }
 }
 // y[s] -> sample tid + T s of the row.  One running address register (32 precomputed voffsets cost 32 VGPRs); with one
@@ -576,7 +575,11 @@ template <int R, int NP> struct DkCfg {
     static_assert(WGT == 512 && (NP == 1 || BP == 1), "dk workgroups are 512 threads");
     static constexpr size_t LDS_X = Cfg<R>::XBYTES * BP;
     static constexpr size_t LDS_RED = BP > 1 ? (size_t)BP * Cfg<R>::M * 8 : 0;
-    static constexpr size_t LDS = LDS_X > LDS_RED ? LDS_X : LDS_RED;
+    // NP = 2 (two spectra + the accumulator = 192 of the 256 registers): the upper half of the accumulator lives in LDS (64 KB next to
+    // the 68 KB exchange buffer; 16 b64 reads + writes per batch item against the 512 LDS accesses of its two transforms)
+    static constexpr int PARKQ = NP == 2 ? 16 : 0;
+    static constexpr size_t PARK = (size_t)PARKQ * WGT * 8;
+    static constexpr size_t LDS = (LDS_X > LDS_RED ? LDS_X : LDS_RED) + PARK;
 };
 
 // spectrum input of sub-problem e (NP = 2: PHI8 = 1 + 4 e, sigma = +-1) or of the whole row (NP = 1)
@@ -629,6 +632,10 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
         c32 acc[32];
         HY_UNROLL
         for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
+        constexpr int NREG = 32 - K::PARKQ;                  // accumulator entries kept in registers; the rest at park[(q - NREG) WGT]
+        HY_LDS lc32* const park = HY_LDS_CAST(lc32, HY_LDS_CAST(char, smem) + (K::LDS - K::PARK)) + threadIdx.x;
+        HY_UNROLL
+        for (int q = NREG; q < 32; ++q) lds_st(park + (q - NREG) * K::WGT, mk(0.f, 0.f));
         for (int b0 = b_lo; b0 < b_hi; b0 += BP) {    // uniform trip count: the transforms contain workgroup barriers
             const bool live = b0 + rg < b_hi;
             const int b = live ? b0 + rg : b_hi - 1;
@@ -652,9 +659,15 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
             HY_UNROLL
             for (int q = 0; q < 32; ++q) {
                 const c32 p = cmulc(v[q], u[q]);                                             // G conj(U)
-                acc[q] = mk(acc[q].x + lv * p.x, acc[q].y + lv * p.y);
+                if (q < NREG) acc[q] = mk(acc[q].x + lv * p.x, acc[q].y + lv * p.y);
+                else {                                                                       // (own slots: no synchronisation)
+                    const c32 o = lds_ld(park + (q - NREG) * K::WGT);
+                    lds_st(park + (q - NREG) * K::WGT, mk(o.x + lv * p.x, o.y + lv * p.y));
+                }
             }
         }
+        HY_UNROLL
+        for (int q = NREG; q < 32; ++q) acc[q] = lds_ld(park + (q - NREG) * K::WGT);
         if constexpr (BP > 1) {
             // sum of the groups' partial spectra, in group order, through LDS (the exchange buffers are idle now)
             __syncthreads();
@@ -711,6 +724,7 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
 }
 
 // dk[d][n] = sum over the S batch slices of part[s][d][n], in slice order (deterministic); dbias[d] = dk[d][0]
+template <int UNUSED = 0>     // (a template only so that the two translation units including this header do not both define it)
 __global__ void __launch_bounds__(256) dk_sum_kernel(DkArgs a) {
     const int d = blockIdx.y;
     const int n = (int)(blockIdx.x * 256 + threadIdx.x);

@@ -6,6 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "_emu_fftconv_test_only.so")
 SRC = [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv.hip"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "onchip.hip"),
+       os.path.join(ROOT, "hyena_dna_amd", "csrc", "onchip_dk.hip"),
        os.path.join(ROOT, "hyena_dna_amd", "csrc", "cm.hip"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "proj.hip"), os.path.join(HERE, "hipemu.cpp")]
 DEPS = SRC + [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv_kernels.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "onchip_kernels.h"),
               os.path.join(ROOT, "hyena_dna_amd", "csrc", "onchip_host.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "launch.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "cm_kernels.h"),
