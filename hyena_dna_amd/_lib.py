@@ -180,6 +180,13 @@ def lib():
         L.hyena_filter_bwd.restype = c_int
         L.hyena_filter_bwd.argtypes = [ctypes.POINTER(FilterParams), c_void_p, c_void_p, ctypes.POINTER(FilterGrads),
                                        c_void_p, c_size_t, c_void_p]
+        L.hyena_filter16_saved_bytes.restype = c_size_t
+        L.hyena_filter16_saved_bytes.argtypes = [c_int]
+        L.hyena_filter16_fwd.restype = c_int
+        L.hyena_filter16_fwd.argtypes = [ctypes.POINTER(FilterParams), c_int, c_void_p, c_void_p, c_void_p]
+        L.hyena_filter16_bwd.restype = c_int
+        L.hyena_filter16_bwd.argtypes = [ctypes.POINTER(FilterParams), c_int, c_void_p, c_void_p, ctypes.POINTER(FilterGrads),
+                                         c_void_p, c_size_t, c_void_p]
         # fused residual add + LayerNorm (include/hyena_block.h)
         c_long, c_float = ctypes.c_long, ctypes.c_float
         L.hyena_add_norm_supported.restype = c_int
@@ -541,19 +548,28 @@ def _filter_params(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modula
     return p
 
 
-def filter_fwd(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate, save):
-    """z (L, E), t (L,), weights as in include/hyena_filter.h -> k (D, L) [, saved pre-activations (3, 64, L)]."""
+def filter_fwd(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate, save, compute_dtype=None):
+    """z (L, E), t (L,), weights as in include/hyena_filter.h -> k (D, L) [, saved pre-activations].  ``compute_dtype`` bfloat16 /
+    float16: the graph the reference computes under torch.autocast of that type (hyena_filter16_fwd; the pre-activations are kept as
+    (3, 32, L) 32-bit words holding 16-bit pairs); None: the fp32 graph ((3, 64, L) fp32)."""
     p = _filter_params(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate)
     k = torch.empty((p.D, p.L), dtype=torch.float32, device=z.device)
-    saved = torch.empty((3, 64, p.L), dtype=torch.float32, device=z.device) if save else None
+    if compute_dtype is None:
+        saved = torch.empty((3, 64, p.L), dtype=torch.float32, device=z.device) if save else None
+    else:
+        saved = torch.empty((3, 32, p.L), dtype=torch.int32, device=z.device) if save else None
     with _backend.guard(z.device):
-        check(lib().hyena_filter_fwd(ctypes.byref(p), k.data_ptr(), None if saved is None else saved.data_ptr(),
-                                     _backend.stream(z.device)))
+        sp = None if saved is None else saved.data_ptr()
+        if compute_dtype is None:
+            check(lib().hyena_filter_fwd(ctypes.byref(p), k.data_ptr(), sp, _backend.stream(z.device)))
+        else:
+            check(lib().hyena_filter16_fwd(ctypes.byref(p), dtype_code(compute_dtype), k.data_ptr(), sp, _backend.stream(z.device)))
     return (k, saved) if save else k
 
 
-def filter_bwd(dk, saved, z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate, need_dz):
-    """-> (dw0, db0, dw1, db1, dw2, db2, dw3, dfreq, dz or None); dz is (L, E)."""
+def filter_bwd(dk, saved, z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate, need_dz, compute_dtype=None):
+    """-> (dw0, db0, dw1, db1, dw2, db2, dw3, dfreq, dz or None); dz is (L, E).  ``compute_dtype`` as in filter_fwd (``saved`` must come
+    from the forward of the same type)."""
     p = _filter_params(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate)
     _require_gpu(dk, "dk")
     assert dk.dtype == torch.float32 and dk.is_contiguous() and dk.shape == (p.D, p.L)
@@ -566,8 +582,14 @@ def filter_bwd(dk, saved, z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift,
     nbytes = lib().hyena_filter_workspace_bytes(p.L, p.D)
     with _backend.guard(z.device):
         ws, stream = workspace_for(z.device, nbytes)
-        check(lib().hyena_filter_bwd(ctypes.byref(p), dk.data_ptr(), saved.data_ptr(), ctypes.byref(g), ws.data_ptr(),
-                                     ws.numel(), stream))
+        if compute_dtype is None:
+            assert saved.dtype == torch.float32
+            check(lib().hyena_filter_bwd(ctypes.byref(p), dk.data_ptr(), saved.data_ptr(), ctypes.byref(g), ws.data_ptr(),
+                                         ws.numel(), stream))
+        else:
+            assert saved.dtype == torch.int32
+            check(lib().hyena_filter16_bwd(ctypes.byref(p), dtype_code(compute_dtype), dk.data_ptr(), saved.data_ptr(), ctypes.byref(g),
+                                           ws.data_ptr(), ws.numel(), stream))
     return tuple(outs) + (None if dzt is None else dzt.t().contiguous(),)
 
 

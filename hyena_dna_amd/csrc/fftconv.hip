@@ -699,7 +699,7 @@ int hyena_filter_bwd(const hyena_filter_params* p, const float* dk, const float*
     const float* a2 = saved + (size_t)2 * FLT_O * L;
 
     FilterBwdArgs a;
-    a.freq = p->freq; a.t = p->t; a.deltas = p->deltas; a.shift = p->shift; a.modulate = p->modulate; a.L = L; a.zs = p->z_stride;
+    a.freq = p->freq; a.t = p->t; a.deltas = p->deltas; a.shift = p->shift; a.modulate = p->modulate; a.L = L; a.zs = p->z_stride; a.rdt = 0;
     // last layer: delta_out = dk * modulation;  dW3, and delta_2 -> dA
     a.dout = dk; a.w = p->w3; a.aprev = a2; a.dprev = dA; a.ni = FLT_O;
     switch (p->D) {

@@ -293,7 +293,16 @@ struct FilterBwdArgs {
     float shift;
     int modulate;
     int L, ni, zs;
+    int rdt;               // DT_BF16 / DT_F16: the 16-bit path's first layer (filter16_kernels.h) -- the weight and the embedding rows are
+                           // rounded to that type on load, dz on store (what the reference's autocast Linear sees); 0 = plain fp32
 };
+
+// value of v after a round trip through the 16-bit type rdt (0: unchanged)
+__device__ __forceinline__ float flt_rnd(float v, int rdt) {
+    if (rdt == DT_BF16) return bf16_to_f32(f32_to_bf16(v));
+    if (rdt == DT_F16) return f16_to_f32(f32_to_f16(v));
+    return v;
+}
 
 template <int NO, int NI>
 struct FltBwdCfg {
@@ -344,7 +353,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
 
     for (int i = tid; i < NO * NI; i += FLT_THREADS) {
         const int o = i / NI, c = i % NI;
-        Ws[o * Cfg::WS + c] = c < a.ni ? a.w[o * a.ni + c] : 0.f;
+        Ws[o * Cfg::WS + c] = flt_rnd(c < a.ni ? a.w[o * a.ni + c] : 0.f, a.rdt);
     }
     for (int i = tid; i < FLT_O; i += FLT_THREADS) freq[i] = ACT ? a.freq[i] : 0.f;
     for (int i = tid; i < NO; i += FLT_THREADS) cdec[i] = modulate ? fabsf(a.deltas[i]) * FLT_LOG2E : 0.f;
@@ -444,8 +453,8 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
                 for (int r = 0; r < 4; ++r) {
                     const int e = crow(r, half);        // 0 .. 7
                     const bool ev = e < a.ni;
-                    fb_st(Pb, ev ? vpos + (unsigned)e * L4 : FLT_OOB, dh[0][r]);
-                    Hs[e * FLT_HS + FLT_TP * wave + n] = fb_ld(Ab, valid && ev ? (unsigned)(pos * a.zs + e) * 4u : FLT_OOB, 0);
+                    fb_st(Pb, ev ? vpos + (unsigned)e * L4 : FLT_OOB, flt_rnd(dh[0][r], a.rdt));
+                    Hs[e * FLT_HS + FLT_TP * wave + n] = flt_rnd(fb_ld(Ab, valid && ev ? (unsigned)(pos * a.zs + e) * 4u : FLT_OOB, 0), a.rdt);
                 }
             }
         }
@@ -507,9 +516,15 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
     }
 }
 
+// (filter.hip defines FLT_DECLARE_ONLY: the non-template kernels below are defined once, in fftconv.hip's translation unit)
+enum { FLT_RED_J = 16, FLT_RED_S = 16 };
+#ifdef FLT_DECLARE_ONLY
+__global__ void filter_reduce_kernel(const float* part, float* out, int count, int n, int accumulate);
+__global__ void filter_reduce_strided_kernel(const float* part, float* out, int count, int n, int stride);
+__global__ void filter_compact_kernel(const float* src, float* dst, int rows, int cols, int used);
+#else
 // out[j] (+)= sum_c part[c][j] in a fixed order: a workgroup owns 16 outputs, its 16 thread rows sum interleaved
 // slices of c (independent loads in flight), thread row 0 adds the slices in order.
-enum { FLT_RED_J = 16, FLT_RED_S = 16 };
 __global__ void __launch_bounds__(256) filter_reduce_kernel(const float* part, float* out, int count, int n, int accumulate) {
     HY_SMEM(smem);
     HY_LDS float* sm = HY_LDS_CAST(float, smem);            // [FLT_RED_S][FLT_RED_J]
@@ -558,5 +573,7 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const float* src, f
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < rows * used) dst[j] = src[(j / used) * cols + j % used];
 }
+
+#endif  // FLT_DECLARE_ONLY
 
 }  // namespace hyena

@@ -10,6 +10,10 @@
  *     a0 = W0 z_l + b0,  a1 = W1 sin(f a0) + b1,  a2 = W2 sin(f a1) + b2,  y = W3 sin(f a2)
  *     k[d, l] = y[d] * (exp(-t_l |delta_d|) + shift)            (modulate = 0:  k = y)
  *
+ * Under torch.autocast the reference's four nn.Linear run in the 16-bit autocast type with fp32 accumulation (inputs, weights, biases
+ * and outputs rounded to that type; the sine and the modulation stay fp32 by type promotion).  hyena_filter16_fwd / _bwd reproduce that
+ * graph rounding by rounding on the 16-bit matrix cores (csrc/filter16_kernels.h); hyena_filter_fwd / _bwd are the fp32 graph.
+ *
  * Supported shapes (hyena_filter_supported): filter order 64 with two inner layers, emb_dim <= 8, D in {64, 128, 256}.
  * Anything else is left to the caller's generic path.  All tensors fp32, row-major, device memory of the device that
  * is current for `stream`; nothing is allocated or synchronised inside the entry points.
@@ -69,6 +73,21 @@ int hyena_filter_fwd(const hyena_filter_params* p, float* k, float* saved, void*
  * parameters.  Reductions over L are deterministic (fixed-order partial sums, no atomics). */
 int hyena_filter_bwd(const hyena_filter_params* p, const float* dk, const float* saved, const hyena_filter_grads* g,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the same filter as the reference computes it under torch.autocast(dtype), dtype = HYENA_BF16 or HYENA_F16 (hyena_fftconv.h) ----
+ * Parameters are passed in fp32 exactly as above (autocast casts them per call: hyena.py:199-215 run under the trainer's autocast
+ * context); k is fp32 (the modulation promotes to fp32, hyena.py:152-155).  `saved` holds the three pre-activations as 16-bit pairs. */
+
+/* Bytes of the pre-activation buffer hyena_filter16_fwd fills for the backward (3 x 64 x L 16-bit values). */
+size_t hyena_filter16_saved_bytes(int L);
+
+/* k (D, L) fp32 <- filter.  `saved` may be NULL (inference). */
+int hyena_filter16_fwd(const hyena_filter_params* p, int dtype, float* k, void* saved, void* stream);
+
+/* Gradients (fp32: the sums over L are kept in fp32, the reference rounds them to `dtype` once more).  Workspace as for hyena_filter_bwd
+ * (hyena_filter_workspace_bytes). */
+int hyena_filter16_bwd(const hyena_filter_params* p, int dtype, const float* dk, const void* saved, const hyena_filter_grads* g,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

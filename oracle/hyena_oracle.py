@@ -160,15 +160,31 @@ def short_conv_taps(u_bdl, weight, bias, L_out):
     return y + bias[None, :, None]
 
 
+def hyena_filter_autocast(sd: Dict[str, torch.Tensor], L: int, dtype=torch.bfloat16, **kw):
+    """:func:`hyena_filter` as the reference evaluates it in training: the whole model runs under ``torch.autocast`` (Lightning's
+    ``trainer.precision`` 16 / bf16, configs/trainer/default.yaml + experiment yaml), so the filter MLP's four ``nn.Linear`` run in
+    the 16-bit autocast type (inputs, weights, biases, outputs rounded; fp32 accumulation) while ``Sin`` (fp32 ``freq`` times a 16-bit
+    tensor) and the modulation are promoted to fp32.  PyTorch's own autocast does the casting here -- on whatever device ``sd`` lives
+    on -- with the parameters first brought to fp32 (they are fp32 in the reference model); the result is cast to ``sd``'s dtype so
+    that a higher-precision evaluation of the rest of the operator can consume it."""
+    some = sd[kw.get("prefix", "filter_fn.") + "pos_emb.z"]
+    sd32 = {k: (v.to(torch.float32) if v.is_floating_point() else v) for k, v in sd.items()}
+    with torch.autocast(some.device.type, dtype=dtype):
+        k = hyena_filter(sd32, L, **kw)
+    return k.to(some.dtype)
+
+
 def hyena_operator(sd: Dict[str, torch.Tensor], u: torch.Tensor, l_max: int, order: int = 2,
-                   modulate: bool = True, shift: float = 0.0, conv_fn=None, short_conv_fn=None):
+                   modulate: bool = True, shift: float = 0.0, conv_fn=None, short_conv_fn=None, filter_fn=None):
     """HyenaOperator.forward for the default options (num_heads=1, num_blocks=1, inner_factor=1,
     no outer mixing / post-order FFN, activation 'id', dropout 0).  hyena.py:388-444.
 
     u: (B, L, D) -> (B, L', D) with L' = min(L, l_max).  ``conv_fn`` lets a test swap the long
-    conv (default: :func:`fftconv_ref`).
+    conv (default: :func:`fftconv_ref`), ``filter_fn`` the filter evaluation (default: :func:`hyena_filter`;
+    :func:`hyena_filter_autocast` for the training-time graph).
     """
     conv_fn = conv_fn or fftconv_ref
+    filter_fn = filter_fn or hyena_filter
     short_conv_fn = short_conv_fn or short_conv
     l = u.size(-2)
     l_filter = min(l, l_max)                                       # hyena.py:389-390
@@ -179,7 +195,7 @@ def hyena_operator(sd: Dict[str, torch.Tensor], u: torch.Tensor, l_max: int, ord
     B = uc.shape[0]
     uc = uc.reshape(B, 1, d_model * (order + 1), 1, l_filter)      # hyena.py:396-402
     *xs, v = uc.split(d_model, dim=2)                              # hyena.py:404
-    k = hyena_filter(sd, l_filter, modulate=modulate, shift=shift) # (1, L, D*(order-1))
+    k = filter_fn(sd, l_filter, modulate=modulate, shift=shift)    # (1, L, D*(order-1))
     # 'c l (v o) -> c o v l'                                        hyena.py:408
     k = k.reshape(1, l_filter, d_model, order - 1).permute(0, 3, 2, 1)[0]
     bias = sd["filter_fn.bias"].reshape(d_model, order - 1).transpose(0, 1)   # '(v o) -> o v' (410-412)

@@ -1,35 +1,38 @@
-"""Print VGPR / spill / scratch / occupancy per kernel of one HIP translation unit (hipcc -Rpass-analysis=kernel-resource-usage).
+"""Per-kernel register / LDS / occupancy table from hipcc's -Rpass-analysis=kernel-resource-usage remarks.
 
-    python scripts/kernel_resources.py hyena_dna_amd/csrc/onchip.hip [filter-substring] [-D...]
+    python scripts/kernel_resources.py hyena_dna_amd/csrc/filter16.hip [extra hipcc flags]
 """
 import re
 import subprocess
 import sys
 
-src = sys.argv[1]
-flt = [a for a in sys.argv[2:] if not a.startswith("-")]
-extra = [a for a in sys.argv[2:] if a.startswith("-")]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
-       "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/tmp/_kr.o"] + extra
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
-rows, cur = [], None
-for line in out.splitlines():
-    m = re.search(r"remark:\s+(.*?) \[-Rpass", line)
-    if not m:
-        if "error" in line:
-            print(line)
-        continue
-    t = m.group(1).strip()
-    if t.startswith("Function Name:"):
-        name = subprocess.run(["c++filt", t.split(":", 1)[1].strip()], capture_output=True, text=True).stdout.strip()
-        cur = {"name": re.sub(r"\(.*\)$", "", name).replace("void hyena::", "")}
-        rows.append(cur)
-    elif cur is not None and ":" in t:
-        k, v = t.split(":", 1)
-        cur[k.strip()] = v.strip()
-print(f"{'kernel':58s} {'VGPR':>5s} {'spill':>5s} {'scratch':>7s} {'SGPR':>5s} {'sspill':>6s} {'occ':>3s}")
-for r in rows:
-    if flt and not any(f in r["name"] for f in flt):
-        continue
-    print(f"{r['name'][:58]:58s} {r.get('VGPRs','?'):>5s} {r.get('VGPRs Spill','?'):>5s} {r.get('ScratchSize [bytes/lane]','?'):>7s} "
-          f"{r.get('SGPRs','?'):>5s} {r.get('SGPRs Spill','?'):>6s} {r.get('Occupancy [waves/SIMD]','?'):>3s}")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"]
+
+
+def main():
+    src, extra = sys.argv[1], sys.argv[2:]
+    out = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + ["-c", src, "-o", "/dev/null"], capture_output=True, text=True)
+    txt = out.stderr
+    rows, cur = [], None
+    for line in txt.splitlines():
+        m = re.search(r"remark: [^:]*:\d+:\d+:\s+(.*?) \[-Rpass", line) or re.search(r"remark:\s+(.*?) \[-Rpass", line)
+        if not m:
+            if "error" in line:
+                print(line)
+            continue
+        body = m.group(1).strip()
+        if body.startswith("Function Name:") or body.startswith("Name:"):
+            cur = {"name": body.split(":", 1)[1].strip()}
+            rows.append(cur)
+        elif cur is not None and ":" in body:
+            k, v = body.split(":", 1)
+            cur[k.strip()] = v.strip()
+    demangled = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
+    print(f"{'kernel':90s} {'VGPR':>5s} {'AGPR':>5s} {'spill':>6s} {'occ':>4s} {'LDS':>7s}")
+    for r, n in zip(rows, demangled):
+        n = re.sub(r"\(.*\)$", "", n)[:90]
+        print(f"{n:90s} {r.get('VGPRs', '?'):>5s} {r.get('AGPRs', '?'):>5s} {r.get('VGPRs Spill', '?'):>6s} {r.get('Occupancy [waves/SIMD]', '?'):>4s} {r.get('LDS Size [bytes/block]', '?'):>7s}")
+
+
+if __name__ == "__main__":
+    main()

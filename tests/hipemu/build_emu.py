@@ -7,11 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "_emu_fftconv_test_only.so")
 SRC = [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv.hip"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "onchip.hip"),
        os.path.join(ROOT, "hyena_dna_amd", "csrc", "onchip_dk.hip"),
-       os.path.join(ROOT, "hyena_dna_amd", "csrc", "cm.hip"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "proj.hip"), os.path.join(HERE, "hipemu.cpp")]
+       os.path.join(ROOT, "hyena_dna_amd", "csrc", "cm.hip"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "proj.hip"),
+       os.path.join(ROOT, "hyena_dna_amd", "csrc", "filter16.hip"), os.path.join(HERE, "hipemu.cpp")]
 DEPS = SRC + [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv_kernels.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "onchip_kernels.h"),
               os.path.join(ROOT, "hyena_dna_amd", "csrc", "onchip_host.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "launch.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "cm_kernels.h"),
               os.path.join(ROOT, "hyena_dna_amd", "csrc", "mixer_kernels.h"),
-              os.path.join(ROOT, "hyena_dna_amd", "csrc", "filter_kernels.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "block_kernels.h"),
+              os.path.join(ROOT, "hyena_dna_amd", "csrc", "filter_kernels.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "filter16_kernels.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "block_kernels.h"),
               os.path.join(ROOT, "include", "hyena_block.h"), os.path.join(ROOT, "include", "hyena_filter.h"), os.path.join(HERE, "hipemu.h"),
               os.path.join(ROOT, "include", "hyena_fftconv.h"), os.path.join(ROOT, "include", "hyena_mixer.h"),
               os.path.join(ROOT, "hyena_dna_amd", "csrc", "proj_kernels.h"), os.path.join(ROOT, "include", "hyena_proj.h")]

@@ -102,7 +102,7 @@ def test_mixer_core_cm_at_contract_shapes_vs_oracle(gpu_lib, B, L, D):
     assert _per_channel_rel(leaves[4].grad.float(), ref_leaves[4].grad, 0) < 2e-2
 
 
-def _operator_and_oracle(B, L, D, seed, device=None, dtype=torch.float64, short_conv=O.short_conv_taps):
+def _operator_and_oracle(B, L, D, seed, device=None, dtype=torch.float64, short_conv=O.short_conv_taps, filter_fn=None):
     """(operator, u, dy, oracle results): the oracle's HyenaOperator.forward (O.hyena_operator) + autograd, evaluated on `device`
     (default cuda:0) in `dtype`"""
     from hyena_dna_amd.hyena import HyenaOperator
@@ -125,7 +125,7 @@ def _operator_and_oracle(B, L, D, seed, device=None, dtype=torch.float64, short_
     for i in (3, 5):                            # hyena.py:199: ONE freq parameter shared by the three activations
         leaves[f"filter_fn.implicit_filter.{i}.freq"] = leaves["filter_fn.implicit_filter.1.freq"]
     u_ref = u.to(device=device, dtype=dtype).requires_grad_(True)
-    y_ref = O.hyena_operator(leaves, u_ref, l_max=L + 2, short_conv_fn=short_conv)
+    y_ref = O.hyena_operator(leaves, u_ref, l_max=L + 2, short_conv_fn=short_conv, filter_fn=filter_fn)
     y_ref.backward(dy.to(device=device, dtype=dtype))
     ref = dict(y=y_ref.detach().cpu(), du=u_ref.grad.cpu(), grads={n: None if leaves[n].grad is None else leaves[n].grad.cpu() for n in params})
     del leaves, u_ref, y_ref
@@ -135,25 +135,38 @@ def _operator_and_oracle(B, L, D, seed, device=None, dtype=torch.float64, short_
 
 
 @pytest.mark.parametrize("B,L,D", SHAPES)
-def test_operator_at_contract_shapes_vs_oracle(gpu_lib, B, L, D):
-    """The whole HyenaOperator.forward (hyena.py:388-444) on the fused path, fp32 and bf16 autocast, vs the oracle."""
+def test_operator_at_contract_shapes_vs_oracle(gpu_lib, B, L, D, monkeypatch):
+    """The whole HyenaOperator.forward (hyena.py:388-444) on the fused path vs the oracle: fp32; bf16 autocast with the fp32 filter
+    kernels (HYENA_FILTER_AUTOCAST=fp32: everything but the filter at 16-bit tolerance of the fp64 oracle); bf16 autocast as it runs
+    by default -- the filter from the 16-bit kernels -- against the oracle with the filter evaluated as the reference evaluates it
+    under autocast (O.hyena_filter_autocast, PyTorch's device GEMMs): that graph's 16-bit roundings sit in front of sin(10 a), so
+    rounding flips between two fp32 summation orders move ~5 % of the positions by a few % (tests/test_gpu_filter.py) -- looser bounds."""
     dev = torch.device("cuda", 0)
     op, u, dy, ref = _operator_and_oracle(B, L, D, seed=L // 7 + B)
+    ref16 = _operator_and_oracle(B, L, D, seed=L // 7 + B, filter_fn=O.hyena_filter_autocast)[3]
     op = op.to(dev)
     assert op._fused_ok()
-    for mode in ("fp32", "bf16"):
+    for mode in ("fp32", "bf16", "bf16-filter16"):
         op.zero_grad(set_to_none=True)
         ud = u.to(dev).requires_grad_(True)
-        if mode == "fp32":
+        if mode == "bf16-filter16":
+            ref = ref16
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = op(ud.to(torch.bfloat16))
+            y.float().backward(dy.to(dev))
+            ty, tg = 3e-2, 6e-2
+        elif mode == "fp32":
             y = op(ud)
             y.backward(dy.to(dev))
             # fp32 everywhere (library GEMMs in fp32, fused filter, exact-fp32 transforms): rounding noise only.  The
             # filter's sin(10 x) chain amplifies one fp32 rounding to ~1e-6 (DESIGN 3c), the GEMMs sum 256-768 terms.
             ty, tg = 2e-5, 2e-4
         else:
+            monkeypatch.setenv("HYENA_FILTER_AUTOCAST", "fp32")
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y = op(ud.to(torch.bfloat16))
             y.float().backward(dy.to(dev))
+            monkeypatch.delenv("HYENA_FILTER_AUTOCAST")
             ty, tg = 1.5e-2, 3e-2
         assert y.shape == ref["y"].shape
         e = _rel(y.float(), ref["y"])
@@ -199,7 +212,9 @@ def test_lm_vs_reference_simple_lm_golden(gpu_lib):
         logits = model(ids)[0].logits
     loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), tgt.reshape(-1))
     loss.backward()
-    assert _rel(logits.float(), c["logits"]) < 3e-2 and abs(loss.item() - c["loss"]) < 2e-2 * abs(c["loss"])
+    # (the filter now follows the reference's autocast graph -- 16-bit Linear layers -- where the golden is the fp32 model: at the LM's
+    # initialisation, N(0, 0.02) weights, that graph is ~5e-3 from the fp32 filter)
+    assert _rel(logits.float(), c["logits"]) < 5e-2 and abs(loss.item() - c["loss"]) < 2e-2 * abs(c["loss"])
     for n, p in model.named_parameters():
         e = _rel(p.grad.float(), c["grads"][n])
         assert e < 0.1, (n, e)

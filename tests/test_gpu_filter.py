@@ -1,6 +1,7 @@
 """MI355X parity of the fused implicit-filter kernels (include/hyena_filter.h) through the C ABI: values and every
 parameter gradient against the oracle's restatement of HyenaFilter.filter (hyena.py:229-238) evaluated in fp64 on the
-CPU, and -- at the full HyenaDNA lengths -- against the module's own PyTorch-op path on the same GPU."""
+CPU, and -- at the full HyenaDNA lengths -- against the module's own PyTorch-op path on the same GPU; the 16-bit kernels
+(torch.autocast) against the reference's graph under the same autocast."""
 import pytest
 import torch
 
@@ -87,9 +88,87 @@ def test_fused_filter_at_hyenadna_lengths(gpu_lib, D, L):
             assert _rel(got[n], p.grad) < 2e-4, (n, _rel(got[n], p.grad))      # both sum ~1e6 fp32 terms per entry
 
 
+def _autocast_graph(f, L, dtype, dk):
+    """the reference's own graph for the filter under autocast, evaluated by PyTorch's device ops (library GEMMs in `dtype`, fp32 sine
+    and modulation by type promotion): HyenaFilter.filter (hyena.py:229-238) as the trainer runs it"""
+    f.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=dtype):
+        k = f.filter(L)[0].transpose(0, 1)
+    assert k.dtype == torch.float32
+    k.backward(dk)
+    grads = {n: p.grad.clone() for n, p in f.named_parameters() if p.grad is not None}
+    f.zero_grad(set_to_none=True)
+    return k.detach(), grads
+
+
+@pytest.mark.parametrize("D,L,emb_dim,dtype", [(64, 300, 5, torch.bfloat16), (128, 1024, 5, torch.bfloat16), (256, 4099, 5, torch.bfloat16),
+                                               (256, 32768, 5, torch.bfloat16), (128, 7, 3, torch.bfloat16), (256, 1, 7, torch.bfloat16),
+                                               (128, 1024, 5, torch.float16), (256, 4100, 5, torch.float16)])
+def test_filter16_vs_autocast_graph(gpu_lib, D, L, emb_dim, dtype):
+    """the 16-bit filter kernels (hyena_filter16_fwd / _bwd, csrc/filter16_kernels.h) under torch.autocast vs the reference's graph
+    under the same autocast on the same device.  The kernels round where that graph rounds (bit-identical to the oracle under CPU
+    autocast on the emulator, tests/test_filter16_emu.py), so here the two differ only where the library GEMM's and the kernel's
+    different fp32 summation orders (1e-7 relative) flip a 16-bit rounding: ~1e-4 per rounded value, ~450 rounded values per position,
+    and a flip moves that position's downstream by a few % (sin(10 a)).  A wrong layout or a missed rounding moves everything (the
+    fp32 kernels are ~2e-1 away at these weights, asserted below)."""
+    f = _make_filter(D, L, emb_dim=emb_dim, seed=D + L).cuda()
+    dk = torch.randn(D, L, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    want, gref = _autocast_graph(f, L, dtype, dk)
+    calls = []
+    real = gpu_lib.filter_fwd
+    gpu_lib.filter_fwd = lambda *a, **k_: (calls.append(k_.get("compute_dtype")), real(*a, **k_))[1]
+    try:
+        with torch.autocast("cuda", dtype=dtype):
+            k = f.filter_dl(L)
+    finally:
+        gpu_lib.filter_fwd = real
+    assert calls == [dtype] and k.dtype == torch.float32 and k.shape == (D, L)
+    k.backward(dk)
+    cols_off = ((k.detach() - want).abs() > 1e-5 * want.abs().max()).any(dim=0).float().mean().item()
+    assert cols_off < 0.2, cols_off                             # positions touched by a rounding flip
+    assert _rel(k, want) < 3e-2, _rel(k, want)
+    if L >= 256:
+        with torch.no_grad():
+            k32 = f.filter_dl(L)                                    # no autocast: the fp32 kernels -- a different graph
+        assert _rel(k32, want) > 3 * _rel(k, want) + 2e-3, (_rel(k32, want), _rel(k, want))
+    for n, p in f.named_parameters():
+        if p.grad is None:
+            assert n not in gref, n
+            continue
+        # the reference rounds every weight / bias gradient sum to `dtype` once more (2^-9 per element in bf16); the kernels keep fp32
+        e = _rel(p.grad, gref[n])
+        assert e < 4e-2, (n, e)
+
+
+@pytest.mark.parametrize("D,L", [(256, 160000), (256, 1048576), (256, 1048575)])
+def test_filter16_at_hyenadna_lengths(gpu_lib, D, L):
+    """full-size, bf16 autocast: vs the reference graph on the same device, run-to-run bitwise determinism"""
+    f = _make_filter(D, L, seed=3, lr_pos_emb=0.0).cuda()
+    dk = torch.randn(D, L, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    outs = []
+    for _ in range(2):
+        f.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            k = f.filter_dl(L)
+        k.backward(dk)
+        outs.append((k.detach(), {n: p.grad.clone() for n, p in f.named_parameters() if p.grad is not None}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for n in outs[0][1]:
+        assert torch.equal(outs[0][1][n], outs[1][1][n]), n          # fixed-order reductions: bitwise reproducible
+    k, got = outs[0]
+    del outs
+    want, gref = _autocast_graph(f, L, torch.bfloat16, dk)
+    assert ((k - want).abs() > 1e-5 * want.abs().max()).any(dim=0).float().mean().item() < 0.2
+    assert _rel(k, want) < 3e-2, _rel(k, want)
+    for n, g in got.items():
+        # sums of ~1e6 random-sign terms: the positions whose roundings flipped and the reference's own final rounding of the sums
+        assert _rel(g, gref[n]) < 6e-2, (n, _rel(g, gref[n]))
+
+
 @pytest.mark.parametrize("amp_dtype", [torch.bfloat16, torch.float16])
-def test_operator_uses_the_fused_filter(gpu_lib, amp_dtype):
-    """HyenaOperator in the HyenaDNA configuration under 16-bit autocast: filter comes from the fused kernels (fp32)"""
+def test_operator_uses_the_fused_filter(gpu_lib, amp_dtype, monkeypatch):
+    """HyenaOperator in the HyenaDNA configuration under 16-bit autocast: the filter comes from the 16-bit kernels (the reference's
+    autocast graph); with HYENA_FILTER_AUTOCAST=fp32 from the fp32 ones"""
     from hyena_dna_amd.hyena import HyenaOperator
     torch.manual_seed(0)
     op = HyenaOperator(d_model=128, l_max=1026, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True,
@@ -102,10 +181,24 @@ def test_operator_uses_the_fused_filter(gpu_lib, amp_dtype):
         y = op(u)
     y.float().square().mean().backward()
     assert y.dtype == amp_dtype
-    y32 = op(u)                                                  # the same layer without autocast (fp32 end to end)
-    assert _rel(y, y32) < (2e-2 if amp_dtype == torch.bfloat16 else 4e-3)
+    grads = {n: p.grad.clone() for n, p in op.named_parameters()}
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    # the same layer with the filter from PyTorch's ops under the same autocast (the reference graph), everything else unchanged
+    op.zero_grad(set_to_none=True)
+    monkeypatch.setattr(op.filter_fn, "_fused_filter_ok", lambda *a: False)
+    with torch.autocast("cuda", dtype=amp_dtype):
+        yg = op(u)
+    yg.float().square().mean().backward()
+    monkeypatch.undo()
+    assert _rel(y, yg) < 3e-2, _rel(y, yg)
     for n, p in op.named_parameters():
-        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        assert _rel(grads[n], p.grad) < 6e-2, (n, _rel(grads[n], p.grad))
+    # the fp32 filter kernels under autocast (the knob): the 16-bit layer against fp32 end to end at 16-bit tolerance, as before round 3
+    monkeypatch.setenv("HYENA_FILTER_AUTOCAST", "fp32")
+    with torch.autocast("cuda", dtype=amp_dtype):
+        ya = op(u)
+    y32 = op(u)                                                  # the same layer without autocast (fp32 end to end)
+    assert _rel(ya, y32) < (2e-2 if amp_dtype == torch.bfloat16 else 4e-3)
 
 
 def test_split_k_projection_on_gpu(gpu_lib):
