@@ -37,6 +37,16 @@ def main():
         with torch.no_grad():
             f.filter_dl(L)
 
+    def fused16():
+        f.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            k = f.filter_dl(L)
+        k.backward(dk)
+
+    def fused16_fwd():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            f.filter_dl(L)
+
     def generic(autocast):
         def run():
             f.zero_grad(set_to_none=True)
@@ -45,7 +55,8 @@ def main():
             k.backward(dk)
         return run
 
-    print(f"filter L={L} D={D}: fused fwd {timeit(fused_fwd):.3f} ms, fused fwd+bwd {timeit(fused):.3f} ms, "
+    print(f"filter L={L} D={D}: fused fp32 fwd {timeit(fused_fwd):.3f} ms, fwd+bwd {timeit(fused):.3f} ms; fused bf16-autocast graph fwd "
+          f"{timeit(fused16_fwd):.3f} ms, fwd+bwd {timeit(fused16):.3f} ms; "
           f"PyTorch ops fp32 {timeit(generic(False), 3):.3f} ms, PyTorch ops bf16 autocast {timeit(generic(True), 3):.3f} ms")
 
 
