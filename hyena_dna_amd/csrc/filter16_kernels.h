@@ -60,6 +60,7 @@ __device__ __forceinline__ uint32_t fb_ldu(FBuf b, unsigned voff, unsigned soff)
 __device__ __forceinline__ void fb_stu(FBuf b, unsigned voff, uint32_t v) {
     if ((size_t)voff + 4 <= b.n) __builtin_memcpy(b.p + voff, &v, 4);
 }
+__device__ __forceinline__ void fb_stf(FBuf b, unsigned voff, float v) { fb_st(b, voff, v); }
 __device__ __forceinline__ void fb_ld4u(FBuf b, unsigned voff, uint32_t* v) {      // fully in range by contract
     if ((size_t)voff + 16 > b.n) abort();
     __builtin_memcpy(v, b.p + voff, 16);
@@ -77,8 +78,14 @@ __device__ __forceinline__ f32x16 mfma16(const Frag& a, const Frag& b, f32x16 c)
 }
 typedef unsigned f16_lvec __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ Frag lds_ld16(const HY_LDS char* p) { return __builtin_bit_cast(Frag, *reinterpret_cast<const HY_LDS f16_lvec*>(p)); }
+// F16_POL_ST: cache policy of this path's stores (k, the saved pre-activations, the layer gradients: written once, read by a LATER launch);
+// 2 = non-temporal: forward 0.41 -> 0.35 ms, forward + backward 1.48 -> 1.40 ms at L = 2^20 (profiles/r3x_filter16_ab.txt)
+#ifndef F16_POL_ST
+#define F16_POL_ST 2
+#endif
 __device__ __forceinline__ uint32_t fb_ldu(FBuf b, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0); }
-__device__ __forceinline__ void fb_stu(FBuf b, unsigned voff, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b.r, voff, 0, 0); }
+__device__ __forceinline__ void fb_stu(FBuf b, unsigned voff, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b.r, voff, 0, F16_POL_ST); }
+__device__ __forceinline__ void fb_stf(FBuf b, unsigned voff, float v) { __builtin_amdgcn_raw_buffer_store_b32(f2u(v), b.r, voff, 0, F16_POL_ST); }
 __device__ __forceinline__ void fb_ld4u(FBuf b, unsigned voff, uint32_t* v) {
     const hy_u4 w = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, 0, 0);
     v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
@@ -228,7 +235,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) flt16_fwd_kernel(FilterArgs a)
             HY_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int d = 32 * db + crow(r, half);
-                fb_st(Kb, vpos + (unsigned)d * L4, rnd16<DT>(y[r]) * (hy_exp2(-tl * cdec[d]) + shift));
+                fb_stf(Kb, vpos + (unsigned)d * L4, rnd16<DT>(y[r]) * (hy_exp2(-tl * cdec[d]) + shift));
             }
         }
     }
@@ -253,9 +260,19 @@ struct F16BwdArgs {
     int L;
 };
 
-// wavefronts per SIMD the backward kernels are compiled for (4 = two workgroups per CU, at most 128 registers)
+// wavefronts per SIMD the backward kernels are compiled for (4 = two workgroups per CU, at most 128 registers: measured slower,
+// 1.52 -> 1.91 ms forward + backward at L = 2^20 with 20 - 75 spilled registers, profiles/r3v_filter16_ab.txt)
 #ifndef F16_BWD_MINW
 #define F16_BWD_MINW 2
+#endif
+// memory-level parallelism of the backward kernels (at 2 wavefronts per SIMD nothing else hides a round trip): MFMA steps of the
+// feature contraction whose operand loads are in flight together, and MFMA steps of the position contraction per round of loads
+// (2 / 1: 1.57 ms forward + backward at L = 2^20; 4 / 4: 1.48; 8 / 4 and 4 / 8: 1.51 -- profiles/r3x_filter16_ab.txt)
+#ifndef F16_S1
+#define F16_S1 4
+#endif
+#ifndef F16_S2
+#define F16_S2 4
 #endif
 
 template <int NO>
@@ -340,28 +357,29 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
                 for (int r = 0; r < 16; ++r) dh[q][r] = 0.f;
             }
             HY_SCHED_FENCE();
-            // two MFMA steps (32 output features) per round: 16 / 8 loads in flight per lane
-            for (int s0 = 0; s0 < KS16; s0 += 2) {
-                Frag db[2];
+            // S1 MFMA steps (16 output features each) per round: 8 S1 / 4 S1 loads in flight per lane
+            constexpr int S1 = KS16 < F16_S1 ? KS16 : F16_S1;
+            for (int s0 = 0; s0 < KS16; s0 += S1) {
+                Frag db[S1];
                 if (MOD) {
-                    float dv[16];
+                    float dv[8 * S1];
                     HY_UNROLL
-                    for (int j = 0; j < 16; ++j)
+                    for (int j = 0; j < 8 * S1; ++j)
                         dv[j] = fb_ld(Db, vpos + (unsigned)(8 * half) * L4, (unsigned)(16 * (s0 + (j >> 3)) + (j & 7)) * L4);
                     HY_UNROLL
-                    for (int j = 0; j < 16; ++j) {
+                    for (int j = 0; j < 8 * S1; ++j) {
                         const int o = 16 * (s0 + (j >> 3)) + 8 * half + (j & 7);
                         dv[j] *= hy_exp2(-tl * cdec[o]) + shift;
                     }
                     HY_UNROLL
-                    for (int j = 0; j < 8; ++j) db[j >> 2].w[j & 3] = pack16<DT>(dv[2 * j], dv[2 * j + 1]);
+                    for (int j = 0; j < 4 * S1; ++j) db[j >> 2].w[j & 3] = pack16<DT>(dv[2 * j], dv[2 * j + 1]);
                 } else {
                     HY_UNROLL
-                    for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < 4 * S1; ++j)
                         db[j >> 2].w[j & 3] = fb_ldu(Db, vpos + (unsigned)(4 * half) * L4, (unsigned)(8 * (s0 + (j >> 2)) + (j & 3)) * L4);
                 }
                 HY_UNROLL
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < S1; ++u) {
                     HY_UNROLL
                     for (int q = 0; q < 2; ++q)
                         dh[q] = mfma16<DT>(lds_ld16(wtrow + 32 * q * Lds::WROW + 32 * (s0 + u)), db[u], dh[q]);
@@ -381,8 +399,8 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
                     accf[q][r] += g0 * ap0;
                     accf[q][r + 1] += g1 * ap1;
                     if (OUTF32) {
-                        fb_st(Pb, vpos + (unsigned)f * L4, rnd16<DT>(g0 * fr0));
-                        fb_st(Pb, vpos + (unsigned)(f + 1) * L4, rnd16<DT>(g1 * fr1));
+                        fb_stf(Pb, vpos + (unsigned)f * L4, rnd16<DT>(g0 * fr0));
+                        fb_stf(Pb, vpos + (unsigned)(f + 1) * L4, rnd16<DT>(g1 * fr1));
                     } else {
                         fb_stu(Pb, vpos + (unsigned)(f >> 1) * L4, pack16<DT>(g0 * fr0, g1 * fr1));
                     }
@@ -396,49 +414,55 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
         // ---- contraction over positions: dW[rb, cb] += delta[rows of rb][positions] h[rows of cb][positions]^T, 16 positions per MFMA
         {
             const int o = 32 * rb + n;
-            for (int kk = ks * NKS; kk < (ks + 1) * NKS; ++kk) {
-                const int q0 = 16 * kk + 8 * half;                   // first of this lane's 8 positions within the tile
-                const int gp = p0 + q0;
-                const bool whole = (L & 3) == 0 && p0 + 16 * kk + 16 <= L;
-                Frag da;
-                if (MOD) {
-                    float av[8];
-                    const unsigned base = ((unsigned)o * (unsigned)L + (unsigned)gp) * 4u;
-                    if (whole) {
-                        fb_ld4(Db, base, &av[0]);
-                        fb_ld4(Db, base + 16u, &av[4]);
-                    } else {
-                        HY_UNROLL
-                        for (int j = 0; j < 8; ++j) av[j] = fb_ld(Db, gp + j < L ? base + 4u * j : FLT_OOB, 0);
+            constexpr int S2 = NKS < F16_S2 ? NKS : F16_S2;
+            const unsigned rowbase = (MOD ? (unsigned)o : (unsigned)(o >> 1)) * (unsigned)L;
+            const bool odd = (o & 1) != 0;                           // inner layers: this row's half of the pair words
+            const float cd = MOD ? cdec[o] : 0.f;
+            for (int kk0 = ks * NKS; kk0 < (ks + 1) * NKS; kk0 += S2) {
+                // the raw operand words of S2 steps first (8 per step: fp32 values or pair words), then the arithmetic
+                uint32_t raw[S2][8];
+                const bool whole = (L & 3) == 0 && p0 + 16 * (kk0 + S2) <= L;
+                if (whole) {
+                    HY_UNROLL
+                    for (int u = 0; u < S2; ++u) {
+                        const unsigned base = (rowbase + (unsigned)(p0 + 16 * (kk0 + u) + 8 * half)) * 4u;
+                        fb_ld4u(Db, base, &raw[u][0]);
+                        fb_ld4u(Db, base + 16u, &raw[u][4]);
                     }
-                    const float cd = cdec[o];
-                    HY_UNROLL
-                    for (int j = 0; j < 8; ++j) av[j] *= hy_exp2(-Tt[q0 + j] * cd) + shift;
-                    HY_UNROLL
-                    for (int j = 0; j < 4; ++j) da.w[j] = pack16<DT>(av[2 * j], av[2 * j + 1]);
                 } else {
-                    uint32_t wv[8];
-                    const unsigned base = ((unsigned)(o >> 1) * (unsigned)L + (unsigned)gp) * 4u;
-                    if (whole) {
-                        fb_ld4u(Db, base, &wv[0]);
-                        fb_ld4u(Db, base + 16u, &wv[4]);
-                    } else {
+                    HY_UNROLL
+                    for (int u = 0; u < S2; ++u) {
+                        const int gp = p0 + 16 * (kk0 + u) + 8 * half;
+                        const unsigned base = (rowbase + (unsigned)gp) * 4u;
                         HY_UNROLL
-                        for (int j = 0; j < 8; ++j) wv[j] = fb_ldu(Db, gp + j < L ? base + 4u * j : FLT_OOB, 0);
+                        for (int j = 0; j < 8; ++j) raw[u][j] = fb_ldu(Db, gp + j < L ? base + 4u * j : FLT_OOB, 0);
                     }
-                    const bool odd = (o & 1) != 0;                   // this row's half of the pair words
-                    HY_UNROLL
-                    for (int j = 0; j < 4; ++j)
-                        da.w[j] = odd ? (wv[2 * j] >> 16) | (wv[2 * j + 1] & 0xffff0000u) : (wv[2 * j] & 0xffffu) | (wv[2 * j + 1] << 16);
-                }
-                if (cb0 == 0) {
-                    HY_UNROLL
-                    for (int j = 0; j < 4; ++j) accb += lo16<DT>(da.w[j]) + hi16<DT>(da.w[j]);
                 }
                 HY_UNROLL
-                for (int q = 0; q < Cfg::BPW; ++q) {
-                    const Frag hbv = lds_ld16(sm + Lds::HS + (32 * (cb0 + q) + n) * F16_HROW + q0 * 2);
-                    accw[q] = mfma16<DT>(da, hbv, accw[q]);
+                for (int u = 0; u < S2; ++u) {
+                    const int q0 = 16 * (kk0 + u) + 8 * half;        // first of this lane's 8 positions within the tile
+                    Frag da;
+                    if (MOD) {
+                        float av[8];
+                        HY_UNROLL
+                        for (int j = 0; j < 8; ++j) av[j] = u2f(raw[u][j]) * (hy_exp2(-Tt[q0 + j] * cd) + shift);
+                        HY_UNROLL
+                        for (int j = 0; j < 4; ++j) da.w[j] = pack16<DT>(av[2 * j], av[2 * j + 1]);
+                    } else {
+                        HY_UNROLL
+                        for (int j = 0; j < 4; ++j)
+                            da.w[j] = odd ? (raw[u][2 * j] >> 16) | (raw[u][2 * j + 1] & 0xffff0000u)
+                                          : (raw[u][2 * j] & 0xffffu) | (raw[u][2 * j + 1] << 16);
+                    }
+                    if (cb0 == 0) {
+                        HY_UNROLL
+                        for (int j = 0; j < 4; ++j) accb += lo16<DT>(da.w[j]) + hi16<DT>(da.w[j]);
+                    }
+                    HY_UNROLL
+                    for (int q = 0; q < Cfg::BPW; ++q) {
+                        const Frag hbv = lds_ld16(sm + Lds::HS + (32 * (cb0 + q) + n) * F16_HROW + q0 * 2);
+                        accw[q] = mfma16<DT>(da, hbv, accw[q]);
+                    }
                 }
             }
         }

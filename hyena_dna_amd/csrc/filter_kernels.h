@@ -558,7 +558,15 @@ __global__ void __launch_bounds__(256) filter_reduce_strided_kernel(const float*
     const int j = blockIdx.x * FLT_RED_J + jj;
     const int jc = j < n ? j : n - 1;
     float s = 0.f;
-    for (int c = cs; c < count; c += FLT_RED_S) s += part[(size_t)c * stride + jc];
+    int c = cs;
+    for (; c + 7 * FLT_RED_S < count; c += 8 * FLT_RED_S) {          // eight independent loads in flight, added in the same order
+        float v[8];
+        HY_UNROLL
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u * FLT_RED_S) * stride + jc];
+        HY_UNROLL
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < count; c += FLT_RED_S) s += part[(size_t)c * stride + jc];
     sm[cs * FLT_RED_J + jj] = s;
     __syncthreads();
     if (cs == 0 && j < n) {

@@ -665,7 +665,15 @@ __global__ void __launch_bounds__(PJ_THREADS) colsum_final_kernel(ColsumArgs a) 
     float acc = 0.f;
     if (col < a.N) {
         const int g1 = (q + 1) * per < a.G ? (q + 1) * per : a.G;
-        for (int g = q * per; g < g1; ++g) acc += a.part[(size_t)g * a.N + col];
+        int g = q * per;
+        for (; g + 8 <= g1; g += 8) {                                // eight independent loads in flight, added in the same order
+            float v[8];
+            HY_UNROLL
+            for (int u = 0; u < 8; ++u) v[u] = a.part[(size_t)(g + u) * a.N + col];
+            HY_UNROLL
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; g < g1; ++g) acc += a.part[(size_t)g * a.N + col];
     }
     HY_LDS float* red = HY_LDS_CAST(float, smem);
     red[threadIdx.x] = acc;

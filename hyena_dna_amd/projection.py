@@ -146,10 +146,14 @@ class InProjPreCMFunc(torch.autograd.Function):
         b = sf_bias.detach().to(torch.float32).contiguous()
         xT, vg = _lib.inproj_pre_fwd(u, weight, bi, w, b, L)
         ctx.mark_non_differentiable(vg)
+        # (otherwise autograd hands backward a zero tensor for vg's "gradient": a 512 MB fill per layer at L = 2^20)
+        ctx.set_materialize_grads(False)
         return xT, vg
 
     @staticmethod
     def backward(ctx, dxT, _dvg):
+        if dxT is None:
+            return None, None, None, None, None, None
         du, dw = InProjCMFunc.backward(ctx, dxT)
         return du, dw, None, None, None, None
 

@@ -24,7 +24,7 @@ def timeit(fn, n=10):
 
 def main():
     L = int(sys.argv[1])
-    D = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    D = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else 256
     torch.manual_seed(0)
     f = HyenaFilter(D, emb_dim=5, order=64, seq_len=L + 2, w=10, lr_pos_emb=0.0).cuda()
     dk = torch.randn(D, L, device="cuda")
@@ -55,6 +55,9 @@ def main():
             k.backward(dk)
         return run
 
+    if "--fused16-only" in sys.argv:
+        print(f"filter L={L} D={D}: fused bf16-autocast graph fwd {timeit(fused16_fwd):.3f} ms, fwd+bwd {timeit(fused16):.3f} ms")
+        return
     print(f"filter L={L} D={D}: fused fp32 fwd {timeit(fused_fwd):.3f} ms, fwd+bwd {timeit(fused):.3f} ms; fused bf16-autocast graph fwd "
           f"{timeit(fused16_fwd):.3f} ms, fwd+bwd {timeit(fused16):.3f} ms; "
           f"PyTorch ops fp32 {timeit(generic(False), 3):.3f} ms, PyTorch ops bf16 autocast {timeit(generic(True), 3):.3f} ms")
