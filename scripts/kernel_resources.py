@@ -31,7 +31,7 @@ def main():
     print(f"{'kernel':90s} {'VGPR':>5s} {'AGPR':>5s} {'spill':>6s} {'occ':>4s} {'LDS':>7s}")
     for r, n in zip(rows, demangled):
         n = re.sub(r"\(.*\)$", "", n)[:90]
-        print(f"{n:90s} {r.get('VGPRs', '?'):>5s} {r.get('AGPRs', '?'):>5s} {r.get('VGPRs Spill', '?'):>6s} {r.get('Occupancy [waves/SIMD]', '?'):>4s} {r.get('LDS Size [bytes/block]', '?'):>7s}")
+        print(f"{n:90s} {r.get('VGPRs', '?'):>5s} {r.get('AGPRs', '?'):>5s} {r.get('VGPRs Spill', '?'):>6s} {r.get('Occupancy [waves/SIMD]', '?'):>4s} {r.get('LDS Size [bytes/block]', '?'):>7s} sgpr {r.get('SGPRs', '?')} sspill {r.get('SGPRs Spill', '?')}")
 
 
 if __name__ == "__main__":
