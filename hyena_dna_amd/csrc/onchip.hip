@@ -98,13 +98,7 @@ static int conv_rh(const ConvArgs& a, void* stream) {
     static thread_local int done = -1;
     hy_allow_lds(conv_kernel<R, HALF>, W::LDS, &done);
     const int rows = a.B * a.D;
-    int grid = (rows + W::RPW - 1) / W::RPW;
-#if OC_PERSIST
-    // one wave of resident workgroups (256 CUs x the workgroups a CU holds), a multiple of 8 so that a workgroup's rows stay on its XCD
-    const int resident = 256 * (32 / R < 1 ? 1 : 32 / R);
-    if (W::RPW == 1 && grid > resident) grid = resident;
-#endif
-    HY_LAUNCH((conv_kernel<R, HALF>), dim3(grid), dim3(W::WGT), W::LDS, stream, a);
+    HY_LAUNCH((conv_kernel<R, HALF>), dim3((rows + W::RPW - 1) / W::RPW), dim3(W::WGT), W::LDS, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 template <int R>

@@ -285,12 +285,8 @@ __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
 }
 // inverse (unnormalised); on exit v[s] = result[tid + T s] e^(-2 pi i (tid + T s) phi / M) e^(+2 pi i s phi / 32),
 // i.e. the caller still multiplies by conj(twist_const(s)).
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// `issue` runs once after the pass-2 twiddles, `settle` right before the pass-1 twiddle loads: between them lies the longest stretch of
-// a row without a wait on global memory (one radix-32 pass and the workgroup-wide exchange) -- where conv_kernel keeps its prefetch of
-// the next row in flight
-template <int R, class Issue = NoHook, class Settle = NoHook>
-__device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c, Issue issue = Issue(), Settle settle = Settle()) {
+template <int R>
+__device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
     if constexpr (R > 1) {
         OC_DFT((pass3<R, true>(v)));
         OC_FENCE();
@@ -300,7 +296,6 @@ __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c, Issue issue 
         load_tw2<R>(w, c.tab, c.tp);
         apply_tw<true, false>(v, w);
     }
-    issue();
     OC_FENCE();
     OC_DFT((dft_reg<32, true>(v)));
     OC_FENCE();
@@ -308,7 +303,6 @@ __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c, Issue issue 
     if constexpr (R > 1) row_sync<Cfg<R>::T>();
     OC_X1(x1p<R, true>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp));
     OC_FENCE();
-    settle();
     {
         Tw w;
         load_tw1<R>(w, c.tab, c.tid);
@@ -501,96 +495,66 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) spec_kernel(SpecArgs a
     }
 }
 
-// OC_PERSIST (one row per workgroup, T >= 64): the grid is one wave of resident workgroups, each walking its rows w = blockIdx.x,
-// blockIdx.x + gridDim.x, ... -- no dispatch / drain between the rows of a CU.  OC_PREFETCH: while a row's inverse transform runs, one
-// 4-byte load per 128-byte line of the workgroup's NEXT row pulls it into the XCD's L2 (the value is never used), so that the next
-// row's 32 loads per thread -- which nothing can be overlapped with: the row IS the register file -- hit L2 instead of HBM.
-#ifndef OC_PERSIST
-#define OC_PERSIST 0
-#endif
-#ifndef OC_PREFETCH
-#define OC_PREFETCH 0
-#endif
 template <int R, bool HALF>
 __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a) {
     typedef Cfg<R> C;
     constexpr int T = C::T, RPW = WgCfg<R>::RPW;
     constexpr unsigned ES = HALF ? 2u : 4u;
-    constexpr bool LOOP = OC_PERSIST && RPW == 1;
     HY_SMEM(smem);
     const bool bf = a.dtype == DT_BF16;
     const int rg = RPW == 1 ? 0 : (int)threadIdx.x / T, tid = RPW == 1 ? (int)threadIdx.x : (int)threadIdx.x % T;
     const int rows = a.B * a.D;
-    const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
-    const GBuf hb = make_gbuf(a.H, (unsigned)a.D * (unsigned)C::M * 8u);
-    const int nwork = (rows + RPW - 1) / RPW;
-    // Row of work item w.  One row per workgroup: workgroups are dealt to the 8 XCDs round-robin, so the B rows of a
+    // Row of this workgroup.  One row per workgroup: workgroups are dealt to the 8 XCDs round-robin, so the B rows of a
     // channel (which read the same 8 M bytes of H) are given consecutive slots of ONE XCD's sequence -- its L2 then
-    // serves B - 1 of the B reads of H.  (A persistent grid is a multiple of 8 workgroups: w and w + gridDim.x share the XCD.)
-    auto row_of = [&](int w) -> int {
-        if (RPW == 1 && (a.D & 7) == 0) {
-            const int xcd = w & 7, seq = w >> 3;
-            const int cs = seq / a.B, b = seq - cs * a.B;
-            return b * a.D + cs * 8 + xcd;
-        }
-        return w * RPW;
-    };
-    for (int w = blockIdx.x; w < (LOOP ? nwork : (int)blockIdx.x + 1); w += LOOP ? (int)gridDim.x : 1) {
-        const int r0 = RPW == 1 ? HY_SGPR(row_of(w)) : row_of(w);
-        const int r_raw = r0 + rg;
-        const bool valid = r_raw < rows;
-        const int r = valid ? r_raw : rows - 1;
-        const int d = RPW == 1 ? HY_SGPR(r % a.D) : r % a.D;
-        const int nrows = (rows - r0) < RPW ? (rows - r0) : RPW;
-        const GBuf xb = make_gbuf(reinterpret_cast<const char*>(a.x) + (size_t)r0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
-        const GBuf ob = make_gbuf(reinterpret_cast<char*>(a.out) + (size_t)r0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
-        const unsigned row_off = (unsigned)(r - r0) * (unsigned)a.L * ES;
-        c32 v[32];
-#if OC_PREFETCH && !defined(HIPEMU)
-        // descriptor of the workgroup's next row (its last row: itself -- L2 hits -- rather than a branch); built here, where registers
-        // are free: the index arithmetic between the product and the inverse transform costs 20 - 45 spilled registers
-        const int wn = HY_SGPR(w + (int)gridDim.x < nwork && LOOP ? w + (int)gridDim.x : w);
-        const GBuf nb = make_gbuf(reinterpret_cast<const char*>(a.x) + (size_t)HY_SGPR(row_of(wn)) * a.L * ES, (unsigned)a.L * ES);
-#endif
-        load_row<R, 2, HALF, (RPW > 1)>(v, xb, bf, tid, row_off, a.L);
-        fft_fwd<R>(v, c);
-        {
-            const unsigned ho = ((unsigned)d * (unsigned)C::M + (unsigned)tid) * 8u;
-            HY_UNROLL
-            for (int q0 = 0; q0 < 32; q0 += 8) {          // 8 at a time: 32 filter values at once do not fit 128 VGPRs at T = 1024
-                c32 h[8];
-#ifdef OC_DBG_NO_H
-                HY_UNROLL
-                for (int q = 0; q < 8; ++q) { h[q] = mk((float)(tid + q), 0.5f); HY_OPAQUE(h[q].x); }
-#else
-                HY_UNROLL
-                for (int q = 0; q < 8; ++q) h[q] = gb_ld(hb, ho, (unsigned)((q0 + q) * T) * 8u);
-#endif
-                HY_UNROLL
-                for (int q = 0; q < 8; ++q) v[q0 + q] = cmul(v[q0 + q], mk(h[q].x, a.conj_sign * h[q].y));
-                HY_SCHED_FENCE();
-            }
-        }
-#if OC_PREFETCH && !defined(HIPEMU)
-        unsigned pf;
-        fft_inv<R>(v, c,
-                   [&]() {      // lines past the end of the row fall outside the descriptor: the hardware drops those loads
-                       pf = __builtin_amdgcn_raw_buffer_load_b32(nb.r, (unsigned)tid * 128u, 0u, 0);
-                   },
-                   [&]() { asm volatile("" :: "v"(pf)); });      // (the prefetched word is dead: this only ends its register's life)
-#else
-        fft_inv<R>(v, c);
-#endif
-        float y[32];
-        HY_UNROLL
-        for (int s = 0; s < 32; ++s) {
-            const c32 tw = twist_const<2>(s);
-            y[s] = v[s].x * tw.x + v[s].y * tw.y;             // Re(v conj(twist))
-        }
-        // (one row per workgroup: the grid is exactly B D blocks, every block is valid; a conditional epilogue costs hipcc 36
-        // spilled registers at T = 1024)
-        if (RPW == 1 || valid) store_row<T, HALF, (RPW > 1)>(ob, bf, tid, row_off, a.L, y);
+    // serves B - 1 of the B reads of H.
+    int r0;
+    if (RPW == 1 && (a.D & 7) == 0) {
+        const int w = blockIdx.x, xcd = w & 7, seq = w >> 3;
+        const int cs = seq / a.B, b = seq - cs * a.B;
+        r0 = HY_SGPR(b * a.D + cs * 8 + xcd);
+    } else {
+        r0 = blockIdx.x * RPW;
     }
+    const int r_raw = r0 + rg;
+    const bool valid = r_raw < rows;
+    const int r = valid ? r_raw : rows - 1;
+    const int d = RPW == 1 ? HY_SGPR(r % a.D) : r % a.D;
+    const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
+    const int nrows = (rows - r0) < RPW ? (rows - r0) : RPW;
+    const GBuf xb = make_gbuf(reinterpret_cast<const char*>(a.x) + (size_t)r0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
+    const GBuf ob = make_gbuf(reinterpret_cast<char*>(a.out) + (size_t)r0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
+    const unsigned row_off = (unsigned)(r - r0) * (unsigned)a.L * ES;
+    const GBuf hb = make_gbuf(a.H, (unsigned)a.D * (unsigned)C::M * 8u);
+    c32 v[32];
+    load_row<R, 2, HALF, (RPW > 1)>(v, xb, bf, tid, row_off, a.L);
+    fft_fwd<R>(v, c);
+    {
+        const unsigned ho = ((unsigned)d * (unsigned)C::M + (unsigned)tid) * 8u;
+        HY_UNROLL
+        for (int q0 = 0; q0 < 32; q0 += 8) {          // 8 at a time: 32 filter values at once do not fit 128 VGPRs at T = 1024
+            c32 h[8];
+#ifdef OC_DBG_NO_H
+            HY_UNROLL
+            for (int q = 0; q < 8; ++q) { h[q] = mk((float)(tid + q), 0.5f); HY_OPAQUE(h[q].x); }
+#else
+            HY_UNROLL
+            for (int q = 0; q < 8; ++q) h[q] = gb_ld(hb, ho, (unsigned)((q0 + q) * T) * 8u);
+#endif
+            HY_UNROLL
+            for (int q = 0; q < 8; ++q) v[q0 + q] = cmul(v[q0 + q], mk(h[q].x, a.conj_sign * h[q].y));
+            HY_SCHED_FENCE();
+        }
+    }
+    fft_inv<R>(v, c);
+    float y[32];
+    HY_UNROLL
+    for (int s = 0; s < 32; ++s) {
+        const c32 w = twist_const<2>(s);
+        y[s] = v[s].x * w.x + v[s].y * w.y;             // Re(v conj(twist))
+    }
+    // (one row per workgroup: the grid is exactly B D blocks, every block is valid; a conditional epilogue costs hipcc 36
+    // spilled registers at T = 1024)
+    if (RPW == 1 || valid) store_row<T, HALF, (RPW > 1)>(ob, bf, tid, row_off, a.L, y);
 }
 
 // dk.  A workgroup owns a channel; its BP row groups (T threads each) take the batch items b = g, g + BP, ... and keep
