@@ -285,7 +285,7 @@ size_t hyena_fftconv_workspace_bytes(int B, int D, int L, int backward, int chun
     Plan p;
     if (!make_plan(L, &p) || B < 1 || D < 1) return 0;
     if (p.R)      // the filter spectrum is this path's only intermediate (+ dk's per-slice partial rows when D < number of CUs)
-        return oc::spectrum_bytes(D, p.R) + (backward ? oc::dk_partial_bytes(p.R, B, D, L) : 0);
+        return oc::spectrum_bytes(D, p.R) + (backward ? oc::dk_partial_bytes(p.R, B, D, L) + (oc::dk1_ok(p.R, B) ? oc::spectrum_bytes(D, p.R) : 0) : 0);
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, backward);
     if (chunk > D) chunk = D;
     if ((size_t)chunk * p.M > ((size_t)1 << 28)) chunk = (int)(((size_t)1 << 28) / p.M);
@@ -398,6 +398,10 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
                 H = workspace;
             }
             if ((st = oc::launch_conv(p.R, dout, du, H, d_tables, B, D, L, dtype, 1, stream))) return st;
+        }
+        if (dk != nullptr && oc::dk1_ok(p.R, B)) {          // B = 1: the spectrum of u behind the partial rows, then conv with the conjugate
+            void* uspec = reinterpret_cast<char*>(partials) + oc::dk_partial_bytes(p.R, B, D, L);
+            return oc::launch_dk1(p.R, dout, u, dk, dbias, uspec, d_tables, D, L, dtype, stream);
         }
         if (dk != nullptr && (st = oc::launch_dk(p.R, dout, u, dk, dbias, partials, d_tables, B, D, L, dtype, stream))) return st;
         return HYENA_OK;

@@ -84,13 +84,32 @@ size_t dk_partial_bytes(int R, int B, int D, int L) {
     return S > 1 ? (size_t)S * D * L * sizeof(float) : 0;
 }
 
-template <int R>
-static int spec_r(const SpecArgs& a, void* stream) {
+template <int R, bool HALF>
+static int spec_rh(const SpecArgs& a, void* stream) {
     typedef WgCfg<R> W;
     static thread_local int done = -1;
-    hy_allow_lds(spec_kernel<R>, W::LDS, &done);
-    HY_LAUNCH((spec_kernel<R>), dim3((a.D + W::RPW - 1) / W::RPW), dim3(W::WGT), W::LDS, stream, a);
+    hy_allow_lds(spec_kernel<R, HALF>, W::LDS, &done);
+    HY_LAUNCH((spec_kernel<R, HALF>), dim3((a.D + W::RPW - 1) / W::RPW), dim3(W::WGT), W::LDS, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+template <int R>
+static int spec_r(const SpecArgs& a, void* stream) {
+    return a.dtype == DT_F32 ? spec_rh<R, false>(a, stream) : spec_rh<R, true>(a, stream);
+}
+// dk at B = 1 (nothing to accumulate): dk = corr(dout, u) = the forward's two kernels -- spectrum of the u rows, then the convolution
+// kernel with the conjugate and fp32 output rows.  Four wavefronts per SIMD instead of dk_kernel's two.
+template <int R, bool HALF>
+static int conv_f32out_rh(const ConvArgs& a, void* stream) {
+    typedef WgCfg<R> W;
+    static thread_local int done = -1;
+    hy_allow_lds(conv_kernel<R, HALF, true>, W::LDS, &done);
+    const int rows = a.B * a.D;
+    HY_LAUNCH((conv_kernel<R, HALF, true>), dim3((rows + W::RPW - 1) / W::RPW), dim3(W::WGT), W::LDS, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+template <int R>
+static int conv_f32out_r(const ConvArgs& a, void* stream) {
+    return a.dtype == DT_F32 ? conv_f32out_rh<R, false>(a, stream) : conv_f32out_rh<R, true>(a, stream);
 }
 template <int R, bool HALF>
 static int conv_rh(const ConvArgs& a, void* stream) {
@@ -133,10 +152,42 @@ bool small_ok(int R, int B, int D, int L, int dtype) {
 
 int launch_spec(int R, const float* k, const float* bias, void* H, const void* tab, int D, int L, void* stream) {
     SpecArgs a;
-    a.k = k; a.bias = bias; a.H = reinterpret_cast<c32*>(H); a.tab = reinterpret_cast<const c32*>(tab); a.D = D; a.L = L;
+    a.k = k; a.bias = bias; a.H = reinterpret_cast<c32*>(H); a.tab = reinterpret_cast<const c32*>(tab); a.D = D; a.L = L; a.dtype = DT_F32;
 #define HY_CALL(r) spec_r<r>(a, stream)
     HY_OC_SWITCH(R, HY_CALL)
 #undef HY_CALL
+}
+
+// Used at M = 32768 only, where dk_kernel needs its two parity launches: 80.0 -> 65.6 us (L = 32768, D = 256, bf16, MI355X); at
+// M = 16384 / 8192 the single dk_kernel launch is the faster one (24.0 vs 38.7 us, 22.7 vs 25.6 us) -- profiles/r3ac_dk_batch1.txt.
+// HYENA_FFTCONV_DK1=0 keeps dk_kernel reachable there (A/B, tests).
+bool dk1_ok(int R, int B) {
+    const char* e = std::getenv("HYENA_FFTCONV_DK1");
+    return B == 1 && R == 32 && !(e != nullptr && e[0] == '0');
+}
+static int dk1_spec(int R, const SpecArgs& a, void* stream) {
+#define HY_CALL(r) spec_r<r>(a, stream)
+    HY_OC_SWITCH(R, HY_CALL)
+#undef HY_CALL
+}
+static int dk1_conv(int R, const ConvArgs& a, void* stream) {
+#define HY_CALL(r) conv_f32out_r<r>(a, stream)
+    HY_OC_SWITCH(R, HY_CALL)
+#undef HY_CALL
+}
+int launch_dk1(int R, const void* dout, const void* u, float* dk, float* dbias, void* Uspec, const void* tab, int D, int L, int dtype,
+               void* stream) {
+    SpecArgs sa;
+    sa.k = u; sa.bias = nullptr; sa.H = reinterpret_cast<c32*>(Uspec); sa.tab = reinterpret_cast<const c32*>(tab); sa.D = D; sa.L = L;
+    sa.dtype = dtype;
+    int st = dk1_spec(R, sa, stream);
+    if (st) return st;
+    ConvArgs a;
+    a.x = dout; a.out = dk; a.H = reinterpret_cast<const c32*>(Uspec); a.tab = reinterpret_cast<const c32*>(tab);
+    a.B = 1; a.D = D; a.L = L; a.dtype = dtype; a.conj_sign = -1.0f;
+    if ((st = dk1_conv(R, a, stream))) return st;
+    if (dbias != nullptr) HY_LAUNCH((dk_bias_kernel<0>), dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)dk, dbias, D, L);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
 int launch_conv(int R, const void* x, void* out, const void* H, const void* tab, int B, int D, int L, int dtype, int conj,

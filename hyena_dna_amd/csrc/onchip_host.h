@@ -27,6 +27,12 @@ int dk_slices(int R, int B, int D, int* nb_out);
 int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, void* partials, const void* tab, int B, int D, int L,
               int dtype, void* stream);
 
+// dk at B = 1, M = 32768: spectrum of the u rows into `Uspec` (spectrum_bytes(D, R) bytes of scratch), then the convolution kernel with
+// the conjugate and fp32 output rows -- nothing to accumulate over, so dk_kernel's shape (two spectra + an accumulator in registers) buys nothing
+bool dk1_ok(int R, int B);
+int launch_dk1(int R, const void* dout, const void* u, float* dk, float* dbias, void* Uspec, const void* tab, int D, int L, int dtype,
+               void* stream);
+
 // Short rows with a small batch (R <= 2, B <= 2 row groups' worth): one launch per direction.  small_ok says whether the pair of
 // fused kernels serves this call; launch_small_bwd needs the forward's filter spectrum H (the saved-spectrum buffer).
 bool small_ok(int R, int B, int D, int L, int dtype);

@@ -420,16 +420,16 @@ __device__ __forceinline__ void store_row(GBuf ob, bool bf, int tid, unsigned ro
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-struct SpecArgs {          // filter spectrum: H[d] = (FFT(c_k) + bias) / M
-    const float* k;        // (D, L) fp32
+struct SpecArgs {          // row spectrum: H[d] = (FFT(c_k) + bias) / M -- of the filter rows (fp32), or, for dk at B = 1, of the u rows
+    const void* k;         // (D, L) fp32 / 16-bit
     const float* bias;     // (D,) or null
     c32* H;                // [D][M], register order
     const c32* tab;
-    int D, L;
+    int D, L, dtype;
 };
 struct ConvArgs {          // out = IFFT(FFT(x) .* H) (conj_sign = +1) or .* conj(H) (conj_sign = -1)
     const void* x;         // (B, D, L)
-    void* out;             // (B, D, L)
+    void* out;             // (B, D, L), the type of x -- or fp32 (conv_kernel<R, HALF, true>: dk at B = 1)
     const c32* H;          // [D][M]
     const c32* tab;
     int B, D, L, dtype;
@@ -470,11 +470,13 @@ __device__ __forceinline__ Ctx make_ctx(HY_LDS char* smem, int rg, int tid, cons
     return c;
 }
 
-template <int R>
+template <int R, bool HALF = false>
 __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) spec_kernel(SpecArgs a) {
     typedef Cfg<R> C;
     constexpr int T = C::T, RPW = WgCfg<R>::RPW;
+    constexpr unsigned ES = HALF ? 2u : 4u;
     HY_SMEM(smem);
+    const bool bf = a.dtype == DT_BF16;
     const int rg = RPW == 1 ? 0 : (int)threadIdx.x / T, tid = RPW == 1 ? (int)threadIdx.x : (int)threadIdx.x % T;
     const int d0 = blockIdx.x * RPW;
     const int d_raw = d0 + rg;
@@ -482,9 +484,9 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) spec_kernel(SpecArgs a
     const int d = valid ? d_raw : a.D - 1;
     const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
     const int nrows = (a.D - d0) < RPW ? (a.D - d0) : RPW;
-    const GBuf kb = make_gbuf(a.k + (size_t)d0 * a.L, (unsigned)nrows * (unsigned)a.L * 4u);
+    const GBuf kb = make_gbuf(reinterpret_cast<const char*>(a.k) + (size_t)d0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
     c32 v[32];
-    load_row<R, 2, false, (RPW > 1)>(v, kb, false, tid, (unsigned)(d - d0) * (unsigned)a.L * 4u, a.L);
+    load_row<R, 2, HALF, (RPW > 1)>(v, kb, bf, tid, (unsigned)(d - d0) * (unsigned)a.L * ES, a.L);
     fft_fwd<R>(v, c);
     const float bias = (a.bias != nullptr) ? a.bias[d] : 0.f;
     const float sc = 1.0f / (float)C::M;
@@ -495,11 +497,13 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) spec_kernel(SpecArgs a
     }
 }
 
-template <int R, bool HALF>
+template <int R, bool HALF, bool OUTF32 = false>
 __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a) {
     typedef Cfg<R> C;
     constexpr int T = C::T, RPW = WgCfg<R>::RPW;
     constexpr unsigned ES = HALF ? 2u : 4u;
+    constexpr bool OHALF = HALF && !OUTF32;                  // element size of the output rows
+    constexpr unsigned EO = OHALF ? 2u : 4u;
     HY_SMEM(smem);
     const bool bf = a.dtype == DT_BF16;
     const int rg = RPW == 1 ? 0 : (int)threadIdx.x / T, tid = RPW == 1 ? (int)threadIdx.x : (int)threadIdx.x % T;
@@ -522,8 +526,8 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a
     const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
     const int nrows = (rows - r0) < RPW ? (rows - r0) : RPW;
     const GBuf xb = make_gbuf(reinterpret_cast<const char*>(a.x) + (size_t)r0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
-    const GBuf ob = make_gbuf(reinterpret_cast<char*>(a.out) + (size_t)r0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
-    const unsigned row_off = (unsigned)(r - r0) * (unsigned)a.L * ES;
+    const GBuf ob = make_gbuf(reinterpret_cast<char*>(a.out) + (size_t)r0 * a.L * EO, (unsigned)nrows * (unsigned)a.L * EO);
+    const unsigned row_off = (unsigned)(r - r0) * (unsigned)a.L * ES, orow_off = (unsigned)(r - r0) * (unsigned)a.L * EO;
     const GBuf hb = make_gbuf(a.H, (unsigned)a.D * (unsigned)C::M * 8u);
     c32 v[32];
     load_row<R, 2, HALF, (RPW > 1)>(v, xb, bf, tid, row_off, a.L);
@@ -554,7 +558,14 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a
     }
     // (one row per workgroup: the grid is exactly B D blocks, every block is valid; a conditional epilogue costs hipcc 36
     // spilled registers at T = 1024)
-    if (RPW == 1 || valid) store_row<T, HALF, (RPW > 1)>(ob, bf, tid, row_off, a.L, y);
+    if (RPW == 1 || valid) store_row<T, OHALF, (RPW > 1)>(ob, bf, tid, orow_off, a.L, y);
+}
+
+// dbias[d] = dk[d][0] (after a dk that came out of conv_kernel)
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) dk_bias_kernel(const float* dk, float* dbias, int D, int L) {
+    const int d = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (d < D) dbias[d] = dk[(size_t)d * L];
 }
 
 // dk.  A workgroup owns a channel; its BP row groups (T threads each) take the batch items b = g, g + BP, ... and keep

@@ -124,8 +124,9 @@ def test_properties(emu_backend):
 
 def test_dk_batch_slices_cover_the_batch_exactly():
     """host logic of the sliced dk (csrc/onchip.hip dk_slices), read back through the C ABI: the backward's workspace is the filter
-    spectrum + S D L floats of partial rows (S = 1: none).  A channel count >= the CU count is never sliced, the slice count never
-    exceeds the sequential steps an unsliced workgroup would take, and D S stays within ~2x the CUs."""
+    spectrum + S D L floats of partial rows (S = 1: none) (+ at B = 1, M = 32768 the spectrum of u that dk's spectrum-plus-conjugate-
+    convolution form uses).  A channel count >= the CU count is never sliced, the slice count never exceeds the sequential steps an
+    unsliced workgroup would take, and D S stays within ~2x the CUs."""
     from hyena_dna_amd import _lib
     L_ = _lib.lib()
     for L, R in ((700, 1), (2000, 2), (4000, 4), (8000, 8), (16000, 16), (32000, 32)):
@@ -133,6 +134,8 @@ def test_dk_batch_slices_cover_the_batch_exactly():
         for B in (1, 2, 7, 8, 16, 17, 64, 250):
             for D in (1, 3, 64, 128, 200, 256, 768):
                 extra = L_.hyena_fftconv_workspace_bytes(B, D, L, 1, 0) - L_.hyena_fftconv_workspace_bytes(B, D, L, 0, 0)
+                if B == 1 and R == 32:
+                    extra -= D * 1024 * R * 8                # the u spectrum [D][M] complex64
                 assert extra % (D * L * 4) == 0
                 S = extra // (D * L * 4) or 1
                 assert extra == (S * D * L * 4 if S > 1 else 0)
@@ -177,3 +180,22 @@ def test_small_fused_pair_vs_oracle(emu_backend, monkeypatch, B, D, L, dtype):
     # without the forward's spectrum: the filter is transformed by the same code first -- the same bits
     du5, dk5, db5 = emu_backend.fftconv_bwd(dout, u, k, bias)
     assert torch.equal(du5, du) and torch.equal(dk5, dk) and torch.equal(db5, dbias)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D,L", [(3, 3000), (2, 8000), (9, 12000), (2, 32768), (1, 20001)])
+def test_dk_at_batch_one_is_spectrum_plus_conjugate_conv(emu_backend, monkeypatch, D, L, dtype):
+    """B = 1, M = 32768: dk = corr(dout, u) runs as the forward's two kernels (spectrum of u, convolution with the conjugate, fp32
+    rows) instead of dk_kernel's two parity launches; HYENA_FFTCONV_DK1=0 keeps dk_kernel -- both against the oracle, du untouched by
+    the choice (the shorter rows: one code path either way)"""
+    u, k, bias, dout = _inputs(1, D, L, dtype, seed=L + D)
+    du, dk, dbias = emu_backend.fftconv_bwd(dout, u, k, bias)
+    monkeypatch.setenv("HYENA_FFTCONV_DK1", "0")
+    du0, dk0, dbias0 = emu_backend.fftconv_bwd(dout, u, k, bias)
+    monkeypatch.delenv("HYENA_FFTCONV_DK1")
+    _, _, r_dk, r_db = _oracle(u.float(), k, bias, dout.float())
+    assert torch.equal(du, du0)
+    assert dk.dtype == torch.float32 and _rel(dk, r_dk) < 2e-6 and _rel(dk0, r_dk) < 2e-6
+    assert torch.equal(dbias, dk[:, 0]) and (dbias - r_db).abs().max() < 1e-5 * L ** 0.5 + 1e-5
+    du1, dk1, db1 = emu_backend.fftconv_bwd(dout, u, k, bias, need_du=False, need_dk=True)
+    assert du1 is None and torch.equal(dk1, dk) and torch.equal(db1, dbias)
