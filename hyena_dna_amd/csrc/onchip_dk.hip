@@ -38,7 +38,7 @@ static int small_fwd_rh(const SmallFwdArgs& a, void* stream) {
     typedef SmallCfg<R> S;
     static thread_local int done = -1;
     hy_allow_lds(small_fwd_kernel<R, HALF>, S::LDS_FWD, &done);
-    HY_LAUNCH((small_fwd_kernel<R, HALF>), dim3(a.D, 1), dim3(S::WGT), S::LDS_FWD, stream, a);
+    HY_LAUNCH((small_fwd_kernel<R, HALF>), dim3(a.D, 1), dim3(S::WGT_FWD), S::LDS_FWD, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 template <int R, bool HALF>
@@ -46,7 +46,7 @@ static int small_bwd_rh(const SmallBwdArgs& a, void* stream) {
     typedef SmallCfg<R> S;
     static thread_local int done = -1;
     hy_allow_lds(small_bwd_kernel<R, HALF>, S::LDS_BWD, &done);
-    HY_LAUNCH((small_bwd_kernel<R, HALF>), dim3(a.D), dim3(S::WGT), S::LDS_BWD, stream, a);
+    HY_LAUNCH((small_bwd_kernel<R, HALF>), dim3(a.D), dim3(S::WGT_BWD), S::LDS_BWD, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 int launch_small_fwd(int R, const void* x, void* out, const float* k, const float* bias, void* Hout, const void* tab, int B, int D, int L,

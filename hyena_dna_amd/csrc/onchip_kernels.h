@@ -750,17 +750,21 @@ __global__ void __launch_bounds__(256) dk_sum_kernel(DkArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Short rows (M <= 2048) with a small batch: ONE launch per direction.  A hyenadna-tiny-1k step (L = 1024, B = 8, D = 128)
 // is 1.5 us of memory traffic; as spec + conv (forward) and conv + dk (+ dk_sum) (backward) it is four to five launches
-// of ~5-10 us each.  Here a workgroup owns a channel, its G = 256 / T row groups own the batch items b = g, g + G, ...:
-//   small_fwd_kernel : every row group transforms the filter row itself (H stays in 64 registers: the redundant transform is
-//                      cheaper than a launch and a trip through memory), then convolves its rows; group 0 leaves H in the
-//                      saved-spectrum buffer for the backward if asked to.
-//   small_bwd_kernel : per row G = FFT(dout), U = FFT(u): acc += G conj(U); G conj(H) -> inverse -> du; after the loop the
-//                      groups' partial dk spectra are added through LDS in group order (bitwise reproducible) and ONE inverse
-//                      gives dk, dbias = dk[0].  One transform of dout serves both gradients -- the shape of the
-//                      reference's fused backward (csrc/fftconv/fftconv_cuda.cu:945-1266).
-// For T <= 64 a row lives in one wavefront, so the transforms contain no workgroup barrier and the row groups run
-// independently (two row groups share a wavefront at T = 32: one whole-tensor descriptor + per-lane row offsets + an
-// explicit n < L predicate, as in dk_kernel).
+// of ~5-10 us each.  Here a workgroup owns a channel and its G = 256 / T row groups the batch items b = g, g + G, ...; what bounds a
+// launch is then the DEPENDENT CHAIN of 1024-point transforms one wavefront walks (a row lives in one wavefront: no workgroup barrier
+// inside a transform, but also nothing to overlap it with), so the independent transforms of a row are given to different wavefronts:
+//   small_fwd_kernel : 4 row wavefronts + 1 filter wavefront.  The filter wavefront transforms the filter row (H = (FFT(c_k) + bias) / M)
+//                      while the row wavefronts transform their rows; H crosses through LDS at ONE workgroup barrier (and goes to the
+//                      saved-spectrum buffer for the backward if asked to).  Chain: 2 transforms (was 3: every row group transformed
+//                      the filter itself).
+//   small_bwd_kernel : 4 "g" wavefronts (G = FFT(dout)) + 4 "u" wavefronts (U = FFT(u)), side by side; U crosses through LDS, the g
+//                      wavefront of a row forms G conj(U) (summed over its batch items in registers), leaves the sum in LDS, and runs
+//                      G conj(H) -> inverse -> du WHILE the first u wavefront adds the groups' sums in group order (bitwise
+//                      reproducible) and runs the ONE inverse per channel that gives dk, dbias = dk[0].  Chain: 2 transforms + the
+//                      sum (was 4 + the sum).  One transform of dout serves both gradients -- the shape of the reference's fused
+//                      backward (csrc/fftconv/fftconv_cuda.cu:945-1266).
+// At T = 32 two row groups share a wavefront (one whole-tensor descriptor + per-lane row offsets + an explicit n < L predicate, as in
+// dk_kernel).  Every thread of a workgroup passes the same number of workgroup barriers (1 forward, 2 per batch step backward).
 // ---------------------------------------------------------------------------------------------
 struct SmallFwdArgs {
     const void* x;         // (B, D, L)
@@ -785,27 +789,31 @@ struct SmallBwdArgs {
 template <int R> struct SmallCfg {
     static_assert(R <= 2, "row groups must not contain workgroup barriers");
     static constexpr int T = Cfg<R>::T;
-    static constexpr int WGT = 256;
-    static constexpr int G = WGT / T;                                   // row groups per workgroup
-    static constexpr size_t LDS_X = Cfg<R>::XBYTES * G;
-    static constexpr size_t LDS_RED = (size_t)G * Cfg<R>::M * 8;        // the groups' partial dk spectra
-    static constexpr size_t LDS_FWD = LDS_X;
-    static constexpr size_t LDS_BWD = LDS_X + LDS_RED;
+    static constexpr int G = 256 / T;                                   // row groups per workgroup (4 wavefronts)
+    static constexpr int FG = 64 / T;                                   // groups of the filter wavefront (T = 32: two, the second one redundant)
+    static constexpr int WGT_FWD = 256 + 64;
+    static constexpr int WGT_BWD = 512;                                 // G "g" groups, then G "u" groups
+    static constexpr size_t LDS_XF = Cfg<R>::XBYTES * (G + FG);
+    static constexpr size_t LDS_FWD = LDS_XF + (size_t)Cfg<R>::M * 8;   // + H
+    static constexpr size_t LDS_XB = Cfg<R>::XBYTES * 2 * G;
+    static constexpr size_t LDS_BWD = LDS_XB + (size_t)G * Cfg<R>::M * 8;   // + per group: U, later the group's sum of G conj(U)
 };
 
 template <int R, bool HALF>
-__global__ void __launch_bounds__(256) small_fwd_kernel(SmallFwdArgs a) {
+__global__ void __launch_bounds__(SmallCfg<R>::WGT_FWD) small_fwd_kernel(SmallFwdArgs a) {
     typedef Cfg<R> C;
-    constexpr int T = C::T, G = SmallCfg<R>::G;
+    typedef SmallCfg<R> S;
+    constexpr int T = C::T, G = S::G;
     constexpr unsigned ES = HALF ? 2u : 4u;
     HY_SMEM(smem);
     const bool bf = a.dtype == DT_BF16;
-    const int rg = (int)threadIdx.x / T, tid = (int)threadIdx.x % T;
+    const int grp = (int)threadIdx.x / T, tid = (int)threadIdx.x % T;
     const int d = blockIdx.x;
-    const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
-    // the filter spectrum of this channel, in registers: H = (FFT(c_k) + bias) / M
-    c32 h[32];
-    {
+    const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), grp, tid, a.tab);
+    HY_LDS lc32* const Hs = HY_LDS_CAST(lc32, HY_LDS_CAST(char, smem) + S::LDS_XF) + tid;
+    if (grp >= G) {
+        // the filter wavefront: H = (FFT(c_k) + bias) / M -> LDS (and the saved-spectrum buffer)
+        c32 h[32];
         const GBuf kb = make_gbuf(a.k, (unsigned)a.D * (unsigned)a.L * 4u);
         load_row<R, 2, false, true>(h, kb, false, tid, (unsigned)d * (unsigned)a.L * 4u, a.L);
         fft_fwd<R>(h, c);
@@ -813,22 +821,36 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(SmallFwdArgs a) {
         const float sc = 1.0f / (float)C::M;
         HY_UNROLL
         for (int q = 0; q < 32; ++q) h[q] = mk((h[q].x + bias) * sc, h[q].y * sc);
-        if (a.Hout != nullptr && rg == 0 && blockIdx.y == 0) {
-            c32* Hd = a.Hout + (size_t)d * C::M + tid;
+        if (grp == G) {
             HY_UNROLL
-            for (int q = 0; q < 32; ++q) Hd[q * T] = h[q];
+            for (int q = 0; q < 32; ++q) lds_st(Hs + q * T, h[q]);
+            if (a.Hout != nullptr) {
+                c32* Hd = a.Hout + (size_t)d * C::M + tid;
+                HY_UNROLL
+                for (int q = 0; q < 32; ++q) Hd[q * T] = h[q];
+            }
         }
+        __syncthreads();
+        return;
     }
     const unsigned total = (unsigned)a.B * (unsigned)a.D * (unsigned)a.L * ES;
     const GBuf xb = make_gbuf(a.x, total);
     const GBuf ob = make_gbuf(a.out, total);
-    for (int b0 = blockIdx.y * G; b0 < a.B; b0 += G * gridDim.y) {
-        const bool live = b0 + rg < a.B;
-        const int b = live ? b0 + rg : a.B - 1;
+    c32 h[32];
+    bool have_h = false;
+    for (int b0 = 0; b0 < a.B; b0 += G) {
+        const bool live = b0 + grp < a.B;
+        const int b = live ? b0 + grp : a.B - 1;
         const unsigned row_off = ((unsigned)b * (unsigned)a.D + (unsigned)d) * (unsigned)a.L * ES;
         c32 v[32];
         load_row<R, 2, HALF, true>(v, xb, bf, tid, row_off, a.L);
         fft_fwd<R>(v, c);
+        if (!have_h) {
+            __syncthreads();                              // H is in LDS
+            HY_UNROLL
+            for (int q = 0; q < 32; ++q) h[q] = lds_ld(Hs + q * T);
+            have_h = true;
+        }
         HY_UNROLL
         for (int q = 0; q < 32; ++q) v[q] = cmul(v[q], h[q]);
         fft_inv<R>(v, c);
@@ -841,18 +863,22 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(SmallFwdArgs a) {
         // (a dead row group of the last step stores nothing: L = 0 fails every n < L predicate)
         store_row<T, HALF, true>(ob, bf, tid, row_off, live ? a.L : 0, y);
     }
+    if (!have_h) __syncthreads();                         // empty batch (the backward's "transform the filter only" call): still one barrier
 }
 
 template <int R, bool HALF>
-__global__ void __launch_bounds__(256) small_bwd_kernel(SmallBwdArgs a) {
+__global__ void __launch_bounds__(SmallCfg<R>::WGT_BWD) small_bwd_kernel(SmallBwdArgs a) {
     typedef Cfg<R> C;
-    constexpr int T = C::T, G = SmallCfg<R>::G;
+    typedef SmallCfg<R> S;
+    constexpr int T = C::T, G = S::G;
     constexpr unsigned ES = HALF ? 2u : 4u;
     HY_SMEM(smem);
     const bool bf = a.dtype == DT_BF16;
-    const int rg = (int)threadIdx.x / T, tid = (int)threadIdx.x % T;
+    const int grp = (int)threadIdx.x / T, tid = (int)threadIdx.x % T;
+    const bool is_u = grp >= G;
+    const int rg = is_u ? grp - G : grp;
     const int d = blockIdx.x;
-    const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
+    const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), grp, tid, a.tab);
     const unsigned total = (unsigned)a.B * (unsigned)a.D * (unsigned)a.L * ES;
     const GBuf gb = make_gbuf(a.dout, total);
     const GBuf ub = make_gbuf(a.u != nullptr ? a.u : a.dout, total);
@@ -860,78 +886,87 @@ __global__ void __launch_bounds__(256) small_bwd_kernel(SmallBwdArgs a) {
     const GBuf hb = make_gbuf(a.H, (unsigned)a.D * (unsigned)C::M * 8u);
     const unsigned ho = ((unsigned)d * (unsigned)C::M + (unsigned)tid) * 8u;
     const bool want_dk = a.dk != nullptr, want_du = a.du != nullptr;
-    // The groups' partial dk spectra live in LDS, behind the exchange buffers (slot rg, element q T + tid: each thread touches only
-    // its own 32 entries, so no synchronisation until the final sum) -- in registers they would be the third 64-register array
-    // next to G and U.
-    HY_LDS lc32* const red = HY_LDS_CAST(lc32, smem + SmallCfg<R>::LDS_X);
-    HY_LDS lc32* const mine = red + rg * C::M + tid;
-    bool first = true;
-    for (int b0 = 0; b0 < a.B; b0 += G) {
+    // slot of row group rg in LDS, element q T + tid: first U of the group's batch item, after the last step the group's sum of
+    // G conj(U) (each thread touches only its own 32 entries of its group's slot)
+    HY_LDS lc32* const slots = HY_LDS_CAST(lc32, HY_LDS_CAST(char, smem) + S::LDS_XB);
+    HY_LDS lc32* const mine = slots + rg * C::M + tid;
+    c32 acc[32];
+    HY_UNROLL
+    for (int q = 0; q < 32; ++q) acc[q] = mk(0.f, 0.f);
+    for (int b0 = 0; b0 < a.B; b0 += G) {                 // uniform trip count: two workgroup barriers per step for every thread
+        const bool last = b0 + G >= a.B;
         const bool live = b0 + rg < a.B;
         const int b = live ? b0 + rg : a.B - 1;
         const unsigned row_off = ((unsigned)b * (unsigned)a.D + (unsigned)d) * (unsigned)a.L * ES;
-        c32 g[32];
-        load_row<R, 2, HALF, true>(g, gb, bf, tid, row_off, a.L);
-        fft_fwd<R>(g, c);
-        HY_SCHED_FENCE();
-        if (want_dk) {
-            c32 u[32];
-            load_row<R, 2, HALF, true>(u, ub, bf, tid, row_off, a.L);
-            fft_fwd<R>(u, c);
-            const float lv = live ? 1.f : 0.f;
-            HY_UNROLL
-            for (int q = 0; q < 32; ++q) {
-                const c32 p = cmulc(g[q], u[q]);                                             // G conj(U)
-                const c32 o = first ? mk(0.f, 0.f) : lds_ld(mine + q * T);
-                lds_st(mine + q * T, mk(o.x + lv * p.x, o.y + lv * p.y));
-            }
-            first = false;
-            HY_SCHED_FENCE();
-        }
-        if (want_du) {
-            HY_UNROLL
-            for (int q0 = 0; q0 < 32; q0 += 8) {
-                c32 h[8];
+        if (is_u) {
+            if (want_dk) {
+                c32 u[32];
+                load_row<R, 2, HALF, true>(u, ub, bf, tid, row_off, a.L);
+                fft_fwd<R>(u, c);
                 HY_UNROLL
-                for (int q = 0; q < 8; ++q) h[q] = gb_ld(hb, ho, (unsigned)((q0 + q) * T) * 8u);
+                for (int q = 0; q < 32; ++q) lds_st(mine + q * T, u[q]);
+            }
+            __syncthreads();                              // (A) U is in LDS
+            __syncthreads();                              // (B) the g groups have read it (last step: their sums are in its place)
+            // at T = 32 group 1 shares group 0's wavefront and runs the inverse along with it (on its own exchange buffer, storing nothing)
+            if (last && want_dk && rg < (T < 64 ? 2 : 1)) {
+                // sum of the groups' spectra in group order (bitwise reproducible), then ONE inverse per channel
+                c32 sum[32];
                 HY_UNROLL
-                for (int q = 0; q < 8; ++q) g[q0 + q] = cmulc(g[q0 + q], h[q]);              // G conj(H)
+                for (int q = 0; q < 32; ++q) sum[q] = lds_ld(slots + q * T + tid);
+                for (int o = 1; o < G; ++o) {
+                    HY_UNROLL
+                    for (int q = 0; q < 32; ++q) sum[q] = cadd(sum[q], lds_ld(slots + o * C::M + q * T + tid));
+                }
+                fft_inv<R>(sum, c);
+                if (rg == 0) {
+                    const float sc = 1.0f / (float)C::M;
+                    float* dkrow = a.dk + (size_t)d * a.L;
+                    HY_UNROLL
+                    for (int s = 0; s < 32; ++s) {
+                        const c32 w = twist_const<2>(s);
+                        const int n = tid + T * s;
+                        const float val = (sum[s].x * w.x + sum[s].y * w.y) * sc;
+                        if (n < a.L) dkrow[n] = val;
+                        if (n == 0 && a.dbias != nullptr) a.dbias[d] = val;
+                    }
+                }
             }
-            fft_inv<R>(g, c);
-            float y[32];
-            HY_UNROLL
-            for (int s = 0; s < 32; ++s) {
-                const c32 w = twist_const<2>(s);
-                y[s] = g[s].x * w.x + g[s].y * w.y;
-            }
-            store_row<T, HALF, true>(ob, bf, tid, row_off, live ? a.L : 0, y);
-        }
-    }
-    if (want_dk) {
-        // sum of the groups' partial spectra in group order (bitwise reproducible), then ONE inverse per channel
-        __syncthreads();
-        // at T = 32 group 1 shares group 0's wavefront and runs the inverse along with it (on its own exchange buffer, storing nothing)
-        if (rg < (T < 64 ? 2 : 1)) {
-            const int ng = a.B < G ? a.B : G;
-            c32 acc[32];
-            HY_UNROLL
-            for (int q = 0; q < 32; ++q) acc[q] = lds_ld(red + q * T + tid);
-            for (int o = 1; o < ng; ++o) {
+        } else {
+            c32 g[32];
+            load_row<R, 2, HALF, true>(g, gb, bf, tid, row_off, a.L);
+            fft_fwd<R>(g, c);
+            __syncthreads();                              // (A)
+            if (want_dk) {
+                const float lv = live ? 1.f : 0.f;
                 HY_UNROLL
-                for (int q = 0; q < 32; ++q) acc[q] = cadd(acc[q], lds_ld(red + o * C::M + q * T + tid));
+                for (int q = 0; q < 32; ++q) {
+                    const c32 p = cmulc(g[q], lds_ld(mine + q * T));                         // G conj(U)
+                    acc[q] = mk(acc[q].x + lv * p.x, acc[q].y + lv * p.y);
+                }
+                if (last) {
+                    HY_UNROLL
+                    for (int q = 0; q < 32; ++q) lds_st(mine + q * T, acc[q]);
+                }
             }
-            fft_inv<R>(acc, c);
-            if (rg == 0) {
-                const float sc = 1.0f / (float)C::M;
-                float* dkrow = a.dk + (size_t)d * a.L;
+            __syncthreads();                              // (B)
+            if (want_du) {
+                HY_UNROLL
+                for (int q0 = 0; q0 < 32; q0 += 8) {
+                    c32 h[8];
+                    HY_UNROLL
+                    for (int q = 0; q < 8; ++q) h[q] = gb_ld(hb, ho, (unsigned)((q0 + q) * T) * 8u);
+                    HY_UNROLL
+                    for (int q = 0; q < 8; ++q) g[q0 + q] = cmulc(g[q0 + q], h[q]);              // G conj(H)
+                }
+                fft_inv<R>(g, c);
+                float y[32];
                 HY_UNROLL
                 for (int s = 0; s < 32; ++s) {
                     const c32 w = twist_const<2>(s);
-                    const int n = tid + T * s;
-                    const float val = (acc[s].x * w.x + acc[s].y * w.y) * sc;
-                    if (n < a.L) dkrow[n] = val;
-                    if (n == 0 && a.dbias != nullptr) a.dbias[d] = val;
+                    y[s] = g[s].x * w.x + g[s].y * w.y;
                 }
+                store_row<T, HALF, true>(ob, bf, tid, row_off, live ? a.L : 0, y);
             }
         }
     }
