@@ -29,9 +29,10 @@
 // The forward saves the three pre-activations a0, a1, a2 (3 x 64 x L fp32) when gradients are needed -- less than the
 // reference's autograd keeps (z W^T, f*a, sin(...) per layer, some twice under autocast).
 //
-// Precision: fp32 throughout (v_mfma_f32_32x32x2_f32 is exact fp32 FMA arithmetic), also under autocast, where the
-// reference runs the four GEMMs in bf16 -- the result differs from the autocast reference by that path's own
-// rounding noise and agrees with the fp32 reference to ~1e-6 (tests/test_filter_*.py state the tolerances).
+// Precision: fp32 throughout (v_mfma_f32_32x32x2_f32 is exact fp32 FMA arithmetic) -- the graph the reference computes without
+// autocast; it agrees with the fp32 reference to ~1e-6 (tests/test_filter_*.py state the tolerances).  Under torch.autocast the
+// reference runs the four GEMMs in the 16-bit type: that graph is filter16_kernels.h's (this header's first-layer backward kernel
+// serves it too, with its operands rounded on load: FilterBwdArgs::rdt).
 #pragma once
 #include "fftconv_kernels.h"
 
