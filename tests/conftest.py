@@ -34,6 +34,13 @@ def golden_operator():
     return torch.load(os.path.join(GOLDEN, "hyena_operator_cases.pt"), weights_only=False)
 
 
+@pytest.fixture(scope="session")
+def golden_filter_autocast():
+    """the reference's HyenaFilter.filter under torch.autocast('cpu', bf16 / fp16), values and gradients (oracle/make_golden_filter_autocast.py)"""
+    import torch
+    return torch.load(os.path.join(GOLDEN, "hyena_filter_autocast.pt"), weights_only=False)
+
+
 @pytest.fixture()
 def emu_backend(monkeypatch):
     """Route hyena_dna_amd._lib to the CPU emulation of the kernels (test double; never used by the product)."""

@@ -107,3 +107,28 @@ def test_filter16_is_deterministic(emu_backend):
         k.backward(dk)
         outs.append([k.detach().clone()] + [p.grad.clone() for p in f.parameters() if p.grad is not None])
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+@pytest.mark.parametrize("name", ["d64l300_bf16", "d128l513_fp16", "d256l200_bf16_shift", "d64l130_bf16_nomod"])
+def test_filter16_vs_reference_minted_autocast_vectors(emu_backend, golden_filter_autocast, name):
+    """the kernels against vectors minted from the reference's own HyenaFilter under CPU autocast (oracle/make_golden_filter_autocast.py)"""
+    from hyena_dna_amd.hyena import HyenaFilter
+    c = golden_filter_autocast[name]
+    f = HyenaFilter(c["D"], emb_dim=c["emb_dim"], order=64, seq_len=c["L"] + 2, w=10, lr_pos_emb=1e-5, **c["kwargs"])
+    missing, unexpected = f.load_state_dict(c["state_dict"], strict=True)
+    assert not missing and not unexpected
+    with torch.autocast("cpu", dtype=c["dtype"]):
+        k = f.filter_dl(c["L"])
+    k.backward(c["dk"])
+    bf = c["dtype"] == torch.bfloat16
+    # bf16: every rounding of the reference graph reproduced (a handful of flips at most); fp16: the CPU's fp16 GEMMs accumulate
+    # differently from the matrix cores, 16-bit tolerance of a graph that amplifies roundings by sin(10 a)
+    assert _rel(k.detach(), c["k"]) < (2e-3 if bf else 3e-3), _rel(k.detach(), c["k"])
+    if bf:
+        assert ((k.detach() - c["k"]).abs() > 1e-6 * c["k"].abs().max()).float().mean().item() < 2e-3
+    params = dict(f.named_parameters())
+    for n, g in c["grads"].items():
+        got = params[n].grad
+        assert got is not None and got.shape == g.shape, n
+        tol = 1e-3 if (n.endswith("freq") and bf) else 6e-3
+        assert _rel(got, g) < tol, (n, _rel(got, g))
