@@ -14,6 +14,10 @@ into ``/root/reference``:
 * ``filter_mlp`` / ``Sin``  <- src/models/sequence/hyena.py:96-106, 199-215
 * ``exp_modulation``        <- src/models/sequence/hyena.py:134-155
 * ``hyena_filter``          <- src/models/sequence/hyena.py:229-238
+* ``hyena_filter_autocast`` <- the same under ``torch.autocast`` (the trainer's ``precision: 16`` -- "bf16 only a100" --,
+                               configs/experiment/hg38/hg38_hyena.yaml:41): PyTorch's own autocast
+                               does the casting; pinned to the reference's HyenaFilter under CPU autocast by
+                               ``oracle/make_golden_filter_autocast.py`` / ``tests/golden/hyena_filter_autocast.pt``
 * ``short_conv``            <- src/models/sequence/hyena.py:363-369, 394 (nn.Conv1d, groups=C, padding=k-1, cut to L)
 * ``hyena_operator``        <- src/models/sequence/hyena.py:388-444 (order-N recurrence, defaults only)
 * ``causal_conv_direct_f64``   an independent O(L^2) float64 truth for small L (no FFT at all)
@@ -162,7 +166,7 @@ def short_conv_taps(u_bdl, weight, bias, L_out):
 
 def hyena_filter_autocast(sd: Dict[str, torch.Tensor], L: int, dtype=torch.bfloat16, **kw):
     """:func:`hyena_filter` as the reference evaluates it in training: the whole model runs under ``torch.autocast`` (Lightning's
-    ``trainer.precision`` 16 / bf16, configs/trainer/default.yaml + experiment yaml), so the filter MLP's four ``nn.Linear`` run in
+    ``trainer.precision: 16``, configs/experiment/hg38/hg38_hyena.yaml:41), so the filter MLP's four ``nn.Linear`` run in
     the 16-bit autocast type (inputs, weights, biases, outputs rounded; fp32 accumulation) while ``Sin`` (fp32 ``freq`` times a 16-bit
     tensor) and the modulation are promoted to fp32.  PyTorch's own autocast does the casting here -- on whatever device ``sd`` lives
     on -- with the parameters first brought to fp32 (they are fp32 in the reference model); the result is cast to ``sd``'s dtype so
