@@ -65,19 +65,36 @@ def lds_exchange_bytes(B, D, M):
     return (5 * B + 2) * D * 2 * 2 * 8 * M
 
 
-def measured_traffic(L, D, B, io_dtype, save):
-    """HBM bytes per step from the committed PMC run (profiles/pmc_traffic.json, made by scripts/gpu_pmc.sh) if it was
-    taken on this exact configuration; None otherwise (rocprofv3 cannot run inside this process)."""
+# Which generation of the long-convolution kernels the tree holds; bumped BY HAND whenever a kernel of that plan changes in a way that can
+# change its HBM traffic.  A PMC record (profiles/pmc_traffic.json, `kernel_set`) taken on another generation is reported as stale (traffic
+# null) instead of being passed off as a measurement of the current kernels.
+KERNEL_SET = {"onchip": "r2", "twolevel": "r2"}
+
+
+def measured_traffic(L, D, B, io_dtype, save, plan):
+    """HBM bytes per step from the committed PMC run (profiles/pmc_traffic.json, made by scripts/gpu_pmc_cfg.sh + pmc_traffic_json.py) if
+    one was taken on this exact configuration AND on the current generation of this plan's kernels; (None, why) otherwise (rocprofv3
+    cannot run inside this process).  Returns (bytes or None, provenance string)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             doc = json.load(f)
         for t in doc["configs"]:
             c = t["config"]
             if (c["seq_len"], c["channels"], c["batch_per_gpu"], c["io_dtype"], c["save_spectra"]) == (L, D, B, io_dtype, bool(save)):
-                return t["traffic_bytes_per_step"]
+                ks = t.get("kernel_set", "?")
+                if ks != f"{plan}-{KERNEL_SET[plan]}":
+                    return None, f"stale: PMC run {t.get('source', '?')} was taken on kernel set {ks}, the tree holds {plan}-{KERNEL_SET[plan]}"
+                return t["traffic_bytes_per_step"], f"{t.get('source', '?')}; kernel set {ks}"
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, "no PMC run committed for this configuration"
+
+
+# The other four BASELINE.json configurations (L, B per GPU, d): timed by the same loop as the headline in the default N = 1 run
+SWEEP = [(1024, 8, 128), (32768, 8, 256), (160000, 2, 256), (450560, 1, 256)]
+# What the part sustains for the mixed read + write streams of the two-level plan (profiles/cpol_bw_r2.txt: 5.0-5.3 TB/s typical, 5.8 TB/s
+# the single best case): the floor of ANY exact-fp32 two-pass transform is its real traffic / this rate (DESIGN.md section 5)
+MIXED_STREAM_TBS = 5.8
 
 
 def parse():
@@ -94,6 +111,7 @@ def parse():
     ap.add_argument("--no-model", action="store_true", help="skip the secondary full-model step (for N > 1: the DDP-wrapped model)")
     ap.add_argument("--model-layers", type=int, default=8, help="n_layer of the secondary full-model step (hyenadna-large-1m: 8)")
     ap.add_argument("--no-operator", action="store_true", help="skip the secondary whole-layer measurement")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the `sweep` field (the other four BASELINE.json configurations, N = 1)")
     ap.add_argument("--no-save-spectra", action="store_true",
                     help="backward recomputes the column spectra of u and k instead of reusing the forward's")
     ap.add_argument("--fwd-only", action="store_true", help="diagnostic; the reported metric needs fwd+bwd")
@@ -107,12 +125,12 @@ def parse():
 
 def cpu_baseline(L, D, dtype, budget_s=25.0):
     """The oracle (reference torch.fft path) fwd+bwd on the host cores, on a bounded sample of the same workload:
-    the same L, a subset of the D channels (channels are independent), B = 1."""
+    the same L, a subset of the D channels (channels are independent), B = 1; best of 3 timed repetitions."""
     from oracle import hyena_oracle as O
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    # ~50 ns per (channel, position) per core-ish for fwd+bwd; size the sample for roughly 3-6 s per repetition
-    Ds = max(1, min(D, int(4.0e8 * max(cores, 8) / 8 / max(L, 1024) / 12)))
+    # ~50 ns per (channel, position) per core-ish for fwd+bwd; at most 64 channels, so that 1 warm-up + 3 timed repetitions fit the budget
+    Ds = max(1, min(D, 64, int(4.0e8 * max(cores, 8) / 8 / max(L, 1024) / 12)))
     g = torch.Generator().manual_seed(0)
     u = torch.randn(1, Ds, L, generator=g).to(dtype)
     k = torch.randn(Ds, L, generator=g) * torch.exp(-5.0 * torch.linspace(0, 1, L))[None] * 0.1
@@ -120,7 +138,7 @@ def cpu_baseline(L, D, dtype, budget_s=25.0):
     dout = torch.randn(1, Ds, L, generator=g).to(dtype)
     best, timed = None, 0
     t_start = time.perf_counter()
-    for rep in range(4):                      # 1 warm-up + up to 3 timed repetitions inside the time budget
+    for rep in range(4):                      # 1 warm-up + 3 timed repetitions (fewer only if one repetition alone overruns the budget)
         u_ = u.clone().requires_grad_(True)
         k_ = k.clone().requires_grad_(True)
         b_ = bias.clone().requires_grad_(True)
@@ -131,12 +149,12 @@ def cpu_baseline(L, D, dtype, budget_s=25.0):
         if rep > 0:
             best = dt if best is None else min(best, dt)
             timed += 1
-        if time.perf_counter() - t_start > budget_s and best is not None:
+        if best is not None and time.perf_counter() - t_start + dt > 1.5 * budget_s:
             break
     nt_per_s = L * (Ds / D) / best           # a nucleotide = one position through all D channels
-    return {"value": nt_per_s, "unit": "nt/s", "cores": cores, "kind": "port",
+    return {"value": nt_per_s, "unit": "nt/s", "cores": cores, "kind": "port", "repetitions": timed,
             "sample": f"oracle fftconv_ref fwd+bwd (torch.fft, fp32 math), B=1, L={L}, {Ds} of {D} channels, "
-                      f"best of {timed} timed repetition{'s' if timed != 1 else ''} after 1 warm-up ({budget_s:.0f} s budget), "
+                      f"best of {timed} timed repetition{'s' if timed != 1 else ''} after 1 warm-up, "
                       f"{best * 1e3:.0f} ms; scaled by {Ds}/{D} channels"}
 
 
@@ -261,6 +279,128 @@ def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=3, warmup=
                         f"secondary figure, not `value`"}
 
 
+def make_conv_step(L, B, D, dtype, dev, seed, chunk=None, save=True, fwd_only=False):
+    """Synthetic operands resident in HBM + the step closure: what hyena_dna_amd.fftconv.FFTConvFunc does per layer call -- forward
+    (keeping its spectra for the backward unless save is off), then the backward for a given upstream gradient."""
+    from hyena_dna_amd import _lib
+    g = torch.Generator(device=dev).manual_seed(seed)
+    u = torch.randn(B, D, L, generator=g, device=dev).to(dtype)
+    k = torch.randn(D, L, generator=g, device=dev) * torch.exp(-5.0 * torch.linspace(0, 1, L, device=dev))[None] * 0.1
+    bias = torch.randn(D, generator=g, device=dev)
+    dout = torch.randn(B, D, L, generator=g, device=dev).to(dtype)
+
+    def step():
+        if save:
+            out, saved = _lib.fftconv_fwd(u, k, bias, chunk=chunk, save=True)
+        else:
+            out, saved = _lib.fftconv_fwd(u, k, bias, chunk=chunk), None
+        if fwd_only:
+            return out
+        return _lib.fftconv_bwd(dout, u, k, bias, chunk=chunk, saved=saved)
+
+    return step
+
+
+def maybe_graph(step, L, B, D, dtype, dev, warmup, enabled):
+    """Launch-bound sizes (a hyenadna-tiny-1k layer call is ~15 us of GPU work behind ~35 us of Python + ctypes per call): the step is
+    captured into ONE hipGraph and replayed -- the same launches on the same buffers, issued by the runtime instead of the interpreter
+    (what lm.GraphedTrainStep does for the whole training step)."""
+    if not enabled or algorithmic_bytes(B, D, L, 2 if dtype != torch.float32 else 4) > 64 * 2 ** 20:
+        return step, False
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):                       # this stream's workspace and the allocator's blocks exist before the capture
+            step()
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for _ in range(warmup):
+        graph.replay()
+    return graph.replay, True
+
+
+def conv_rooflines(L, B, D, dtype_name, save, ev_ms_step):
+    """Both rooflines of SURVEY.md 8d for one fftconv fwd+bwd step that took ev_ms_step (HIP events), plus the floor this plan can reach
+    on this part with its one-line derivation."""
+    from hyena_dna_amd import _lib
+    s = 4 if dtype_name == "fp32" else 2
+    abytes = algorithmic_bytes(B, D, L, s)
+    achieved = abytes / (ev_ms_step * 1e-3) / 1e9
+    M = int(_lib.lib().hyena_fftconv_fft_size(L))
+    onchip = int(_lib.lib().hyena_fftconv_plan(L)) == _lib.PLAN_ONCHIP
+    plan = "onchip" if onchip else "twolevel"
+    aflops = algorithmic_flops(B, D, L, M)
+    tflops = aflops / (ev_ms_step * 1e-3) / 1e12
+    lds_b = lds_exchange_bytes(B, D, M)
+    traffic, src = measured_traffic(L, D, B, dtype_name, save, plan)
+    if onchip:
+        # the row never leaves the CU: traffic is the algorithmic bytes, the kernels are bound by VALU issue.  Floor = the transforms'
+        # nominal instruction count at the fp32 issue rate the part sustains (v_fma_f32: 117 of the 157 TF, profiles/valu_rate_r2.txt)
+        floor_ms = aflops / (117.0e12) * 1e3
+        floor_how = "VALU issue: algorithmic flops / 117 TF (measured v_fma_f32 rate, profiles/valu_rate_r2.txt); the row stays on chip"
+    elif traffic is not None:
+        floor_ms = traffic / (MIXED_STREAM_TBS * 1e12) * 1e3
+        floor_how = (f"two-pass exact-fp32 transform: measured HBM traffic {traffic / 1e9:.2f} GB (six transform units x 2 crossings of 8 M B "
+                     f"+ saved spectra + I/O = 128 M B per row) / {MIXED_STREAM_TBS} TB/s, the best mixed read+write rate measured on this part "
+                     f"(profiles/cpol_bw_r2.txt); DESIGN.md section 5")
+    else:
+        floor_ms, floor_how = None, "no PMC traffic record for this configuration"
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src,
+            "floor_frac": None if floor_ms is None else abytes / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "floor_ms": floor_ms, "floor_derivation": floor_how,
+            "kernel": "all launches of one fftconv fwd+bwd step (" +
+                      ("spec / conv / dk kernels of the workspace-free plan)" if onchip
+                       else "col_fwd / row_* / col_inv chain of the two-level plan)"),
+            "algorithmic_bytes_per_step": abytes, "event_ms_per_step": ev_ms_step}
+    # the second roofline of SURVEY.md 8d: the fused op sits at / above the fp32 ridge, so VALU (and LDS) co-bind
+    valu = {"bound": "valu_fp32", "achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / VALU_PEAK_TFLOPS,
+            "algorithmic_flops_per_step": aflops, "fft_points": M, "transforms_per_step": (5 * B + 2) * D,
+            "lds_bytes_per_step": lds_b, "lds_achieved_TBs": lds_b / (ev_ms_step * 1e-3) / 1e12, "lds_peak_TBs": LDS_PEAK_TBS}
+    return roof, valu
+
+
+def sweep_configs(dtype, dtype_name, dev, steps, warmup, graph_ok, emu=False, configs=None):
+    """The other BASELINE.json configurations through the same timed loop as the headline (HIP events around `steps` steps after
+    `warmup`, operands resident): {ms_per_step, nt/s, both roofline fractions, floor, PMC traffic} each.  N = 1 only."""
+    res = []
+    for (L, B, D) in (configs or SWEEP):
+        try:
+            step = make_conv_step(L, B, D, dtype, dev, seed=2222)
+            for _ in range(warmup):
+                step()
+            run, graphed = (step, False) if emu else maybe_graph(step, L, B, D, dtype, dev, warmup, graph_ok)
+            if emu:
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    run()
+                ms = (time.perf_counter() - t0) * 1e3 / steps
+            else:
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(steps):
+                    run()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                ms = e0.elapsed_time(e1) / steps
+            roof, valu = conv_rooflines(L, B, D, dtype_name, True, ms)
+            res.append({"seq_len": L, "batch_per_gpu": B, "channels": D, "io_dtype": dtype_name, "steps": steps, "warmup": warmup,
+                        "hipgraph_replay": bool(graphed), "ms_per_step": ms, "value": B * L / ms * 1e3, "unit": "nt/s",
+                        "frac": roof["frac"], "valu_frac": valu["frac"], "floor_frac": roof["floor_frac"],
+                        "traffic": roof["traffic"], "traffic_source": roof["traffic_source"],
+                        "algorithmic_bytes_per_step": roof["algorithmic_bytes_per_step"]})
+            del step, run
+            if not emu:
+                torch.cuda.empty_cache()
+        except Exception as e:                                       # a secondary figure never costs the contract line
+            res.append({"seq_len": L, "batch_per_gpu": B, "channels": D, "error": repr(e)[:200]})
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -290,25 +430,9 @@ def main():
 
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     B, D, L = args.batch, args.d_model, args.seq_len
-    g = torch.Generator(device=dev).manual_seed(2222 + rank)            # 2222 = the reference's train seed
-    u = torch.randn(B, D, L, generator=g, device=dev).to(dtype)
-    k = torch.randn(D, L, generator=g, device=dev) * torch.exp(-5.0 * torch.linspace(0, 1, L, device=dev))[None] * 0.1
-    bias = torch.randn(D, generator=g, device=dev)
-    dout = torch.randn(B, D, L, generator=g, device=dev).to(dtype)
     chunk = args.chunk if args.chunk > 0 else None
     save = not args.no_save_spectra and not args.fwd_only
-
-    def step():
-        # what hyena_dna_amd.fftconv.FFTConvFunc does per layer call: forward (keeping its column spectra for the
-        # backward unless --no-save-spectra), then the backward for a given upstream gradient
-        if save:
-            out, saved = _lib.fftconv_fwd(u, k, bias, chunk=chunk, save=True)
-        else:
-            out, saved = _lib.fftconv_fwd(u, k, bias, chunk=chunk), None
-        if args.fwd_only:
-            return out
-        res = _lib.fftconv_bwd(dout, u, k, bias, chunk=chunk, saved=saved)
-        return res
+    step = make_conv_step(L, B, D, dtype, dev, seed=2222 + rank, chunk=chunk, save=save, fwd_only=args.fwd_only)   # 2222 = the reference's train seed
 
     def sync():
         if not args.emu:
@@ -321,26 +445,9 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    # Launch-bound sizes (a hyenadna-tiny-1k layer call is ~15 us of GPU work behind ~35 us of Python + ctypes per call): the step
-    # is captured into ONE hipGraph and replayed -- the same launches on the same buffers, issued by the runtime instead of the
-    # interpreter (what lm.GraphedTrainStep does for the whole training step).  --no-graph times the eager calls.
-    graphed = False
-    run_step = step
-    if not args.emu and not args.no_graph and algorithmic_bytes(B, D, L, 2 if dtype != torch.float32 else 4) <= 64 * 2 ** 20:
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):                       # this stream's workspace and the allocator's blocks exist before the capture
-                step()
-            side.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        run_step, graphed = graph.replay, True
-        for _ in range(args.warmup):
-            run_step()
-        sync()
+    # --no-graph times the eager calls at the launch-bound sizes too
+    run_step, graphed = (step, False) if args.emu else maybe_graph(step, L, B, D, dtype, dev, args.warmup, not args.no_graph)
+    sync()
     if not args.emu:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -357,6 +464,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = tmax.item()
 
+    sweep = None
+    if world == 1 and not args.no_sweep and not args.fwd_only:
+        # the four other contract configurations, same loop (rank 0 of an N = 1 run only: a sweep is not part of the scaling legs)
+        sweep = sweep_configs(dtype, args.dtype, dev, max(args.steps, 20) if not args.emu else 1, args.warmup if not args.emu else 0,
+                              not args.no_graph, emu=args.emu, configs=[(256, 2, 64)] if args.emu else None)
+
     model_res = None
     if not args.no_model and not args.fwd_only and (world > 1 or not args.emu):
         # every rank takes part (DDP's collectives); a failure must not lose the contract line, nor leave the other ranks
@@ -367,17 +480,10 @@ def main():
             model_res = {"error": repr(e)[:300]}
 
     if rank == 0:
-        s = 4 if dtype == torch.float32 else 2
         ms_per_step = wall * 1e3 / args.steps
         nt_per_s = B * L * world / (wall / args.steps)
-        abytes = algorithmic_bytes(B, D, L, s)
         ev_ms_step = ev_ms / args.steps
-        achieved = abytes / (ev_ms_step * 1e-3) / 1e9
-        M = int(_lib.lib().hyena_fftconv_fft_size(L))
-        onchip = int(_lib.lib().hyena_fftconv_plan(L)) == _lib.PLAN_ONCHIP
-        aflops = algorithmic_flops(B, D, L, M)
-        tflops = aflops / (ev_ms_step * 1e-3) / 1e12
-        lds_b = lds_exchange_bytes(B, D, M)
+        roof, valu = conv_rooflines(L, B, D, args.dtype, save, ev_ms_step)
         line = {
             "metric": METRIC, "value": nt_per_s, "unit": "nt/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -392,18 +498,10 @@ def main():
                                       f"timed region; the DDP gradient all-reduce is measured in `model_step`)"
                                       if world > 1 else "single GPU",
                        "unit_of_work": "one nucleotide through one Hyena long-conv layer call (fwd+bwd), all d channels"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(L, D, B, args.dtype, save),
-                         "kernel": "all launches of one fftconv fwd+bwd step (" +
-                                   ("spec / conv / dk kernels of the workspace-free plan)" if onchip
-                                    else "col_fwd / row_* / col_inv chain of the two-level plan)"),
-                         "algorithmic_bytes_per_step": abytes, "event_ms_per_step": ev_ms_step},
-            # the second roofline of SURVEY.md 8d: the fused op sits at / above the fp32 ridge, so VALU (and LDS) co-bind
-            "roofline_valu": {"bound": "valu_fp32", "achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": tflops / VALU_PEAK_TFLOPS, "algorithmic_flops_per_step": aflops, "fft_points": M,
-                              "transforms_per_step": (5 * B + 2) * D,
-                              "lds_bytes_per_step": lds_b, "lds_achieved_TBs": lds_b / (ev_ms_step * 1e-3) / 1e12,
-                              "lds_peak_TBs": LDS_PEAK_TBS},
+            "roofline": roof,
+            "roofline_valu": valu,
+            # the other four BASELINE.json configurations through the same loop (N = 1 runs; null otherwise)
+            "sweep": sweep,
         }
         if world == 1 and not args.emu and not args.no_operator and not args.fwd_only:
             try:

@@ -9,6 +9,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import KERNEL_SET  # noqa: E402  (the generation of each plan's kernels in this tree: the record is valid for it only)
 STEPS = 4
 out = []
 for spec in sys.argv[1:]:
@@ -31,13 +33,21 @@ for spec in sys.argv[1:]:
     alg = 5 * B * D * L * 2 + 12 * D * L + 8 * D
     out.append({"config": {"seq_len": L, "channels": D, "batch_per_gpu": B, "io_dtype": "bf16", "save_spectra": True},
                 "traffic_bytes_per_step": total, "algorithmic_bytes_per_step": alg, "ratio": total / alg,
-                "source": f"gpurun_out/{tag}/FETCH_SIZE.csv, WRITE_SIZE.csv (scripts/gpu_pmc_cfg.sh)", "per_kernel": per})
+                "source": f"gpurun_out/{tag}/FETCH_SIZE.csv, WRITE_SIZE.csv (scripts/gpu_pmc_cfg.sh)",
+                "kernel_set": ("onchip-" + KERNEL_SET["onchip"]) if L <= 32768 else ("twolevel-" + KERNEL_SET["twolevel"]), "per_kernel": per})
 doc = {"method": __doc__.split("usage")[0].strip() + "  " + __doc__.split("Counter unit")[1].strip().join(["Counter unit", ""]) if False else
        "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of bench.py, summed over all hyena kernels of one "
        "fwd+bwd step; counter unit KB; FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md HBM section) "
        "except for col_fwd<1024, bf16> (4-byte pair loads, calibrated x1 against the tensor size in round 1); scripts/gpu_pmc_cfg.sh, "
        "scripts/pmc_traffic_json.py",
        "configs": out}
-json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+# configurations not re-measured in this call keep their records (each carries the kernel generation it was taken on)
+path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+if os.path.exists(path):
+    fresh = [json.dumps(c["config"], sort_keys=True) for c in out]
+    for c in json.load(open(path)).get("configs", []):
+        if json.dumps(c["config"], sort_keys=True) not in fresh:
+            doc["configs"].append(c)
+json.dump(doc, open(path, "w"), indent=1)
 for c in out:
     print(c["config"], "traffic %.3f GB" % (c["traffic_bytes_per_step"] / 1e9), "algorithmic %.3f GB" % (c["algorithmic_bytes_per_step"] / 1e9), "ratio %.2f" % c["ratio"])

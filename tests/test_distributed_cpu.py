@@ -24,6 +24,7 @@ def _run(nproc, port):
 def test_bench_world_size_2_gloo():
     r = _run(2, 29611)
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["sweep"] is None                          # the sweep belongs to the N = 1 run only
     assert r["unit"] == "nt/s" and r["higher_is_better"] is True and r["vs_baseline"] is None
     assert r["config"]["seq_len"] == 3000 and "dp2" in r["config"]["parallelism"]
     # whole-job aggregate: 2 ranks x 1 sequence x 3000 nt per step
@@ -47,6 +48,35 @@ def test_bench_single_process_line_shape():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in r
     assert r["n_gpus"] == 1 and r["data"] == "synthetic" and "workload" in r["config"]
+    # roofline: the floor this plan can reach and where the traffic figure comes from travel with the line
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "floor_frac", "floor_derivation"):
+        assert key in r["roofline"], key
+    # `sweep`: the other BASELINE.json configurations through the same timed loop (N = 1 runs; the emulated run times one small stand-in)
+    assert isinstance(r["sweep"], list) and len(r["sweep"]) >= 1
+    for c in r["sweep"]:
+        assert "error" not in c, c
+        for key in ("seq_len", "batch_per_gpu", "channels", "steps", "ms_per_step", "value", "unit", "frac", "valu_frac", "floor_frac",
+                    "traffic", "traffic_source", "hipgraph_replay"):
+            assert key in c, key
+        assert c["unit"] == "nt/s" and c["ms_per_step"] > 0
+        assert abs(c["value"] - c["batch_per_gpu"] * c["seq_len"] / (c["ms_per_step"] * 1e-3)) / c["value"] < 1e-6
+
+
+def test_bench_sweep_names_the_four_other_contract_configurations():
+    """BASELINE.json configs 1-4 (the headline is config 5), as (L, B per GPU, d)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.SWEEP == [(1024, 8, 128), (32768, 8, 256), (160000, 2, 256), (450560, 1, 256)]
+    # a PMC record taken on another generation of a plan's kernels is reported as stale, not as a measurement
+    t, why = bench.measured_traffic(1048576, 256, 1, "bf16", True, "twolevel")
+    assert (t is None) == why.startswith(("stale", "no PMC"))
+    saved = dict(bench.KERNEL_SET)
+    try:
+        bench.KERNEL_SET["twolevel"] = "never"
+        t, why = bench.measured_traffic(1048576, 256, 1, "bf16", True, "twolevel")
+        assert t is None and why.startswith("stale")
+    finally:
+        bench.KERNEL_SET.update(saved)
 
 
 def test_ddp_operator_world_size_2():
