@@ -71,7 +71,11 @@ class Mlp(nn.Module):
             return False
         dt = _mlp_dtype(x, self.fc1.weight)
         rows = x.numel() // max(x.shape[-1], 1)
-        return dt is not None and rows >= 1 and _lib.mlp_supported(rows, self.fc1.in_features, self.fc1.out_features, dt)
+        # fc1's kernel contracts over in_features, the fused backward (`mlp_dh_dgelu_bwd`) over fc2.out_features: both must be a width the
+        # kernels are built for, whatever `out_features` the caller chose (the reference's Mlp accepts any; other widths take the library path)
+        return (dt is not None and rows >= 1 and self.fc2.in_features == self.fc1.out_features
+                and _lib.mlp_supported(rows, self.fc1.in_features, self.fc1.out_features, dt)
+                and _lib.mlp_supported(rows, self.fc2.out_features, self.fc1.out_features, dt))
 
 
 FUSED_MLP = os.environ.get("HYENA_FUSED_MLP", "1") != "0"          # A/B knob: 0 = two library GEMMs + PyTorch's GELU

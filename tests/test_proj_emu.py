@@ -137,6 +137,24 @@ def test_fused_mlp_module_matches_the_unfused_graph(emu_backend, monkeypatch):
         assert err < 1e-2, err
 
 
+def test_mlp_with_an_output_width_the_backward_kernel_is_not_built_for_takes_the_library_path(emu_backend):
+    """`Mlp(128, hidden_features=256, out_features=64)` passed fc1's check, ran the fused forward and then failed in the fused
+    backward (it contracts over fc2.out_features).  The reference's Mlp accepts any out_features: such a module must work end to end."""
+    from functools import partial
+
+    import torch.nn.functional as F
+
+    import hyena_dna_amd.lm as LM
+    torch.manual_seed(2)
+    mlp = LM.Mlp(128, hidden_features=256, out_features=64, activation=partial(F.gelu, approximate="tanh")).to(torch.bfloat16)
+    x = torch.randn(2, 40, 128).to(torch.bfloat16).requires_grad_(True)
+    assert not mlp._fused_ok(x)
+    y = mlp(x)
+    y.backward(torch.randn_like(y))
+    assert y.shape == (2, 40, 64) and x.grad is not None and mlp.fc2.weight.grad is not None
+    assert LM.Mlp(128, hidden_features=512, activation=partial(F.gelu, approximate="tanh")).to(torch.bfloat16)._fused_ok(x)
+
+
 @pytest.mark.parametrize("P,N,dtype", [(1, 128, torch.bfloat16), (700, 256, torch.bfloat16), (5000, 1024, torch.float16), (33, 64, torch.bfloat16)])
 def test_colsum_kernel(emu_backend, P, N, dtype):
     x = torch.randn(P, N, generator=torch.Generator().manual_seed(P)).to(dtype)
