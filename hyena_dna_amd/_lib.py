@@ -265,6 +265,29 @@ def workspace_for(device, nbytes):
     return w, stream
 
 
+def release_stream_state(device, stream):
+    """Drop what this module keeps for one (device, stream): its workspace, the record that captured launches point at it, and any
+    outgrown buffers retired on its behalf.  Called by the owner of a hipGraph when the graph is released (GraphedTrainStep.release(),
+    a sequence-length stage re-capturing): without it every discarded capture stream leaks one workspace."""
+    key = (getattr(device, "index", None), stream)
+    w = _workspace.pop(key, None)
+    _captured.discard(key)
+    if w is not None:
+        _retired[:] = [r for r in _retired if r.data_ptr() != w.data_ptr()]
+    return w is not None
+
+
+def reset_save_decisions(device=None):
+    """Forget the cached keep-the-spectra decisions (all, or one device's): they are taken against the memory that was free when a shape
+    was first seen -- re-evaluate them once model + optimizer state exist, at a new GraphedTrainStep, or at a new sequence-length stage."""
+    if device is None:
+        _save_decision.clear()
+        return
+    idx = getattr(device, "index", None)
+    for key in [k for k in _save_decision if k[0] == idx]:
+        del _save_decision[key]
+
+
 def _chunk_override():
     v = os.environ.get("HYENA_FFTCONV_CHUNK")
     return int(v) if v else 0

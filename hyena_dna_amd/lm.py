@@ -386,7 +386,9 @@ class HyenaDNALM(nn.Module, GenerationMixin):
         # no counterpart for are accepted at their "off" values only: a config asking for attention layers, tensor parallelism
         # or flash_attn's FusedMLP must not silently get a different model.
         off = {"attn_layer_idx": None, "attn_cfg": None, "process_group": None, "fused_mlp": False, "identity_mlp": False,
-               "sequence_parallel": (True, False), "device": None, "dtype": None, "return_hidden_state": False}
+               "sequence_parallel": (True, False), "return_hidden_state": False}
+        # the factory keywords every reference module takes (long_conv_lm.py:266: factory_kwargs): applied after construction
+        device, dtype = unused.pop("device", None), unused.pop("dtype", None)
         for key, val in unused.items():
             allowed = off.get(key, KeyError)
             if allowed is KeyError:
@@ -422,6 +424,8 @@ class HyenaDNALM(nn.Module, GenerationMixin):
         self.lm_head = nn.Linear(d_model, vocab_size, bias=False)
         self.apply(partial(_init_weights, n_layer=n_layer, **(initializer_cfg or {})))
         self.tie_weights()
+        if device is not None or dtype is not None:
+            self.to(device=device, dtype=dtype)
 
     def tie_weights(self):
         self.lm_head.weight = self.backbone.embeddings.word_embeddings.weight
@@ -501,14 +505,39 @@ class GraphedTrainStep:
         # OUTSIDE the capture: drop them, and warm up on the very stream the capture uses.
         import gc
         gc.collect()
+        from . import _lib
+        # keep-the-spectra decisions are re-taken during this warm-up, with the model (and, from its second step on, the optimizer state)
+        # already allocated -- not inherited from whatever memory was free when a shape was first seen; they then stay fixed for the capture
+        _lib.reset_save_decisions(input_ids.device)
         side = torch.cuda.Stream(input_ids.device)
+        self._side = side
         side.wait_stream(torch.cuda.current_stream(input_ids.device))
         with torch.cuda.stream(side):                 # twiddle tables, workspaces, optimizer state, GEMM heuristics: all created here
+            # The warm-up runs REAL optimizer updates (the optimizer's state tensors must exist, on this stream, before the capture).  They
+            # are not training steps: parameters, Adam moments and step counters are put back afterwards, in place (the graph will hold
+            # these very tensors), so that a graphed run and an eager run of the same config + seed start from the same state.
+            params = [p for g in optimizer.param_groups for p in g["params"]]
+            with torch.no_grad():
+                snap_p = [p.detach().clone() for p in params]
+            had_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state.get(p, {}).items()}
+                         for p in params}
             for _ in range(max(1, int(warmup))):
                 optimizer.zero_grad(set_to_none=True)
                 self._fwd_bwd()
                 optimizer.step()
             optimizer.zero_grad(set_to_none=True)      # the gradients of the captured step live in the graph's pool
+            with torch.no_grad():
+                for p, q in zip(params, snap_p):
+                    p.copy_(q)
+                for p in params:
+                    st, old = optimizer.state.get(p, {}), had_state[id(p)]
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            if k in old and torch.is_tensor(old[k]):
+                                v.copy_(old[k])
+                            else:
+                                v.zero_()                  # fresh optimizer: moments and the step counter start at zero
+            del snap_p, had_state
             gc.collect()
             side.synchronize()
             self.graph = torch.cuda.CUDAGraph()
@@ -516,6 +545,17 @@ class GraphedTrainStep:
                 self.loss = self._fwd_bwd().detach()
                 optimizer.step()
         torch.cuda.current_stream(input_ids.device).wait_stream(side)
+
+    def release(self):
+        """Drop the graph and what the long-convolution binding keeps for its capture stream (workspace, tables stay: they are per length).
+        Call before building the next GraphedTrainStep of a sequence-length stage."""
+        from . import _lib
+        dev = self.ids.device
+        self.graph = None
+        self.loss = None
+        torch.cuda.synchronize(dev)
+        _lib.release_stream_state(dev, self._side.cuda_stream)
+        self._side = None
 
     def _fwd_bwd(self):
         enabled = self.autocast_dtype is not None and self.autocast_dtype != torch.float32

@@ -26,6 +26,7 @@ Not reproduced (out of scope): Lightning's logging 
 epochs, fault-tolerant samplers.
 """
 import math
+import contextlib
 import os
 import re
 import time
@@ -376,8 +377,16 @@ def build_dataset(cfg, split="train"):
     d = cfg["dataset"]
     max_len = {"train": d["max_length"], "valid": d.get("max_length_val") or d["max_length"],
                "test": d.get("max_length_test") or d["max_length"]}[split]
+    # src/dataloaders/genomics.py:78-82: unset paths fall back to <data dir>/hg38/{human-sequences.bed, hg38.ml.fa}
+    data_dir = os.environ.get("DATA_PATH") or os.path.join(os.getcwd(), "data")
+    bed = d.get("bed_file") or os.path.join(data_dir, "hg38", "human-sequences.bed")
+    fasta = d.get("fasta_file") or os.path.join(data_dir, "hg38", "hg38.ml.fa")
+    for what, path, key in (("interval list", bed, "dataset.bed_file"), ("genome", fasta, "dataset.fasta_file")):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"hg38 {what} not found at {path!r}: pass {key}=<path> (the reference's default location is "
+                                    f"data/hg38/, src/dataloaders/genomics.py:78-82), or use --synthetic-genome")
     # src/dataloaders/genomics.py:127-141
-    return HG38Dataset(split=split, bed_file=d["bed_file"], fasta_file=d["fasta_file"], max_length=max_len, tokenizer=None,
+    return HG38Dataset(split=split, bed_file=bed, fasta_file=fasta, max_length=max_len, tokenizer=None,
                        tokenizer_name=d.get("tokenizer_name") or "char", add_eos=d.get("add_eos", True), return_seq_indices=False,
                        shift_augs=None, rc_aug=d.get("rc_aug", False), return_augs=False,
                        replace_N_token=d.get("replace_N_token", False), pad_interval=d.get("pad_interval", False))
@@ -405,7 +414,8 @@ def train(cfg, max_steps, device, graphed=False, log_every=10, log=print):
     sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=cfg["dataset"].get("shuffle", True), seed=seed) if world > 1 else None
     loader = torch.utils.data.DataLoader(ds, batch_size=int(cfg["dataset"]["batch_size"]), sampler=sampler,
                                          shuffle=(sampler is None and bool(cfg["dataset"].get("shuffle", True))),
-                                         drop_last=bool(cfg.get("loader", {}).get("drop_last", True)), num_workers=0)
+                                         drop_last=bool(cfg.get("loader", {}).get("drop_last", True)),
+                                         num_workers=int(cfg["dataset"].get("num_workers", 0) or 0))
     tr = cfg.get("trainer", {})
     accum = max(1, int(tr.get("accumulate_grad_batches", 1) or 1))
     clip = float(tr.get("gradient_clip_val", 0.0) or 0.0)
@@ -433,9 +443,12 @@ def train(cfg, max_steps, device, graphed=False, log_every=10, log=print):
             raise NotImplementedError("graphed=True captures one micro-batch per update on one GPU")
         from .lm import GraphedTrainStep
         x, y = next(it)
+        # the capture's warm-up updates are undone (parameters, moments, step counters: lm.GraphedTrainStep), and the batch it warmed up on
+        # is the first counted step's batch: a graphed and an eager run of the same config + seed follow the same trajectory
         step = GraphedTrainStep(model, opt, x, y, autocast_dtype=torch.bfloat16 if amp else None, warmup=2, clip_grad_norm=clip)
         for i in range(max_steps):
-            x, y = next(it)
+            if i > 0:
+                x, y = next(it)
             loss = step(x, y)
             if sched is not None:
                 sched.step()
@@ -448,10 +461,14 @@ def train(cfg, max_steps, device, graphed=False, log_every=10, log=print):
         total = 0.0
         for a in range(accum):
             x, y = next(it)
-            with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=amp and dev_type == "cuda"):
-                logits = net(x)[0].logits
-                loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), y.reshape(-1))
-            (loss / accum).backward()
+            # gradients cross the ranks once per update, on the last micro-batch (what Lightning does with accumulate_grad_batches;
+            # hg38_hyena resolves it to >= 64, so all-reducing every micro-batch would multiply the collective traffic by that)
+            hold = net.no_sync() if (world > 1 and a + 1 < accum) else contextlib.nullcontext()
+            with hold:
+                with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=amp and dev_type == "cuda"):
+                    logits = net(x)[0].logits
+                    loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), y.reshape(-1))
+                (loss / accum).backward()
             total += float(loss.detach()) / accum
         if clip > 0:
             torch.nn.utils.clip_grad_norm_(model.parameters(), clip)

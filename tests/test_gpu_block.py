@@ -116,17 +116,20 @@ def test_graphed_train_step_matches_eager(gpu_lib):
 
     m_e, o_e = make()
     eager = []
-    for i, ids in enumerate([batches[0]] * warm + batches):         # the graphed step's warm-up trains on its first batch too
+    for ids in batches:         # (the graphed step's warm-up updates are undone before the capture: both runs start from the same state)
         o_e.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             loss = m_e.loss(ids, torch.roll(ids, -1, 1))
         loss.backward()
         o_e.step()
-        if i >= warm:
-            eager.append(float(loss))
+        eager.append(float(loss))
 
     m_g, o_g = make()
+    before = [p.detach().clone() for p in m_g.parameters()]
     step = GraphedTrainStep(m_g, o_g, batches[0], torch.roll(batches[0], -1, 1), warmup=warm)
+    # the warm-up's optimizer updates are not training steps: parameters, moments and step counters are back where they were
+    assert all(torch.equal(a, b) for a, b in zip(before, m_g.parameters()))
+    assert all(float(st["step"]) == 0.0 and not bool(st["exp_avg"].any()) for st in o_g.state.values())
     graphed = []
     for ids in batches:
         graphed.append(float(step(ids, torch.roll(ids, -1, 1))))
@@ -139,3 +142,8 @@ def test_graphed_train_step_matches_eager(gpu_lib):
 
     with pytest.raises(RuntimeError, match="capturable"):
         GraphedTrainStep(m_g, torch.optim.AdamW(m_g.parameters(), lr=1e-3), batches[0], batches[0])
+    # releasing the step gives back what the binding kept for its capture stream
+    from hyena_dna_amd import _lib
+    n_ws = len(_lib._workspace)
+    step.release()
+    assert len(_lib._workspace) == n_ws - 1

@@ -326,3 +326,31 @@ def test_k_rev_and_bidirectional_match_the_reference_definition(emu_backend, L):
     assert _rel(yo, ref) < 5e-6
     yo.sum().backward()
     assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+def test_advice_r3_host_side_fixes(tmp_path, monkeypatch):
+    """ADVICE r3 (low): unset hg38 paths fall back to the reference's default location and fail with an error that names the overrides;
+    HyenaDNALM applies the `device` / `dtype` factory keywords the reference's modules take; the cached keep-the-spectra decisions can be
+    dropped per device; a released capture stream gives its workspace back."""
+    import os
+    from hyena_dna_amd import _lib, runner
+    from hyena_dna_amd.lm import HyenaDNALM
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = runner.compose(os.path.join(root, "tests", "golden", "hg38_hyena_composed.json"))
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError, match="dataset.bed_file"):
+        runner.build_dataset(cfg)
+    m = HyenaDNALM(d_model=64, n_layer=1, d_inner=256, vocab_size=12, layer=dict(l_max=66, order=2, filter_order=64, emb_dim=5),
+                   dtype=torch.bfloat16, device="cpu")
+    assert all(p.dtype == torch.bfloat16 for p in m.parameters())
+    monkeypatch.setattr(_lib, "_save_decision", {(0, 1, 2, 3): True, (1, 1, 2, 3): False})
+    _lib.reset_save_decisions(torch.device("cuda", 0))
+    assert _lib._save_decision == {(1, 1, 2, 3): False}
+    _lib.reset_save_decisions()
+    assert _lib._save_decision == {}
+    w = torch.empty(16, dtype=torch.uint8)
+    monkeypatch.setattr(_lib, "_workspace", {(0, 77): w})
+    monkeypatch.setattr(_lib, "_captured", {(0, 77)})
+    monkeypatch.setattr(_lib, "_retired", [w])
+    assert _lib.release_stream_state(torch.device("cuda", 0), 77) and not _lib._workspace and not _lib._captured and not _lib._retired
+    assert not _lib.release_stream_state(torch.device("cuda", 0), 77)

@@ -38,6 +38,34 @@ def test_experiment_config_resolves_like_hydra():
     assert big["trainer"]["accumulate_grad_batches"] == 256 // 8
 
 
+def _flatten(tree, prefix=""):
+    out = {}
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            out.update(_flatten(v, prefix + k + "."))
+        else:
+            out[prefix + k] = v
+    return out
+
+
+def test_resolved_config_equals_the_hand_derived_tree_key_by_key():
+    """the composition used to be pinned only to a file the runner itself wrote.  tests/golden/hg38_hyena_resolved_by_hand.py
+    is the resolved tree derived by hand from the reference's yaml files with Hydra's merge rules (its docstring lists them): every key and
+    every value -- including the types (3815.0 is a float, 381500 an int) -- must agree, and neither side may have a key the other lacks."""
+    import importlib.util
+    from hyena_dna_amd import runner
+    spec = importlib.util.spec_from_file_location("by_hand", os.path.join(ROOT, "tests", "golden", "hg38_hyena_resolved_by_hand.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = _flatten(mod.RESOLVED)
+    got = _flatten(runner.compose(COMPOSED))
+    gpu_mem = got.pop("train.gpu_mem")                    # run-time (nvidia-smi in the reference, the HIP runtime here)
+    assert isinstance(gpu_mem, int)
+    assert sorted(got) == sorted(want), (sorted(set(got) - set(want)), sorted(set(want) - set(got)))
+    for key in want:
+        assert got[key] == want[key] and type(got[key]) is type(want[key]), (key, got[key], want[key])
+
+
 @needs_ref
 def test_composed_json_is_what_the_reference_configs_compose_to():
     from hyena_dna_amd import runner
