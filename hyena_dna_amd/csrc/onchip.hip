@@ -6,7 +6,6 @@
 #include "../../include/hyena_fftconv.h"
 
 #include <cmath>
-#include <cstdint>
 #include <cstdlib>
 
 namespace hyena {
@@ -63,20 +62,6 @@ void build_tables(int R, float* h) {
     }
 }
 
-#ifdef HIPEMU
-extern "C" { int hyena_emu_wide_launches = 0; }          // tests only: how many launches took the 16-byte path
-#endif
-bool wide_ok(int which, int R, int L, int dtype, const void* p0, const void* p1, const void* p2) {
-    const char* e = std::getenv("HYENA_FFTCONV_WIDE");            // (read per call, like the other A/B knobs: tests flip it)
-    const int mask = (e != nullptr && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
-    if ((mask & which) == 0 || dtype == DT_F32 || R < 2 || (L & 7) != 0) return false;
-    const bool ok = ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15u) == 0;
-#ifdef HIPEMU
-    hyena_emu_wide_launches += ok ? 1 : 0;
-#endif
-    return ok;
-}
-
 size_t spectrum_bytes(int D, int R) { return (size_t)D * 1024 * R * sizeof(c32); }
 
 // dk owns one workgroup (512 threads, the whole register file of a CU) per channel; with fewer channels than the MI355X has CUs
@@ -102,14 +87,6 @@ size_t dk_partial_bytes(int R, int B, int D, int L) {
 template <int R, bool HALF>
 static int spec_rh(const SpecArgs& a, void* stream) {
     typedef WgCfg<R> W;
-    if constexpr (HALF && R >= 2) {
-        if (wide_ok(WIDE_CONV, R, a.L, a.dtype, a.k)) {
-            static thread_local int donew = -1;
-            hy_allow_lds(spec_kernel<R, true, true>, W::LDS, &donew);
-            HY_LAUNCH((spec_kernel<R, true, true>), dim3(a.D), dim3(W::WGT), W::LDS, stream, a);
-            return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
-        }
-    }
     static thread_local int done = -1;
     hy_allow_lds(spec_kernel<R, HALF>, W::LDS, &done);
     HY_LAUNCH((spec_kernel<R, HALF>), dim3((a.D + W::RPW - 1) / W::RPW), dim3(W::WGT), W::LDS, stream, a);
@@ -124,14 +101,6 @@ static int spec_r(const SpecArgs& a, void* stream) {
 template <int R, bool HALF>
 static int conv_f32out_rh(const ConvArgs& a, void* stream) {
     typedef WgCfg<R> W;
-    if constexpr (HALF && R >= 2) {
-        if (wide_ok(WIDE_CONV, R, a.L, a.dtype, a.x)) {          // (the fp32 output rows keep their 4-byte stores)
-            static thread_local int donew = -1;
-            hy_allow_lds(conv_kernel<R, true, true, true>, W::LDS, &donew);
-            HY_LAUNCH((conv_kernel<R, true, true, true>), dim3(a.B * a.D), dim3(W::WGT), W::LDS, stream, a);
-            return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
-        }
-    }
     static thread_local int done = -1;
     hy_allow_lds(conv_kernel<R, HALF, true>, W::LDS, &done);
     const int rows = a.B * a.D;
@@ -145,14 +114,6 @@ static int conv_f32out_r(const ConvArgs& a, void* stream) {
 template <int R, bool HALF>
 static int conv_rh(const ConvArgs& a, void* stream) {
     typedef WgCfg<R> W;
-    if constexpr (HALF && R >= 2) {
-        if (wide_ok(WIDE_CONV, R, a.L, a.dtype, a.x, a.out)) {
-            static thread_local int donew = -1;
-            hy_allow_lds(conv_kernel<R, true, false, true>, W::LDS, &donew);
-            HY_LAUNCH((conv_kernel<R, true, false, true>), dim3(a.B * a.D), dim3(W::WGT), W::LDS, stream, a);
-            return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
-        }
-    }
     static thread_local int done = -1;
     hy_allow_lds(conv_kernel<R, HALF>, W::LDS, &done);
     const int rows = a.B * a.D;

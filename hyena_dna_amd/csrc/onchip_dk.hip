@@ -17,20 +17,6 @@ namespace oc {
 template <int R, int NP, bool HALF>
 static int dk_rh(const DkArgs& a, void* stream) {
     typedef DkCfg<R, NP> K;
-    if constexpr (HALF && R >= 2) {
-        if (wide_ok(WIDE_DK, NP == 2 ? 2 * R : R, a.L, a.dtype, a.dout, a.u)) {           // 16-byte row fetches (onchip_kernels.h)
-            static thread_local int donew = -1;
-            hy_allow_lds(dk_kernel<R, NP, true, 0, true>, K::LDS, &donew);
-            HY_LAUNCH((dk_kernel<R, NP, true, 0, true>), dim3(a.D, a.S), dim3(K::WGT), K::LDS, stream, a);
-            if constexpr (NP == 2) {
-                static thread_local int donew1 = -1;
-                hy_allow_lds(dk_kernel<R, NP, true, 1, true>, K::LDS, &donew1);
-                HY_LAUNCH((dk_kernel<R, NP, true, 1, true>), dim3(a.D, a.S), dim3(K::WGT), K::LDS, stream, a);
-            }
-            if (a.S > 1) HY_LAUNCH((dk_sum_kernel<0>), dim3((a.L + 255) / 256, a.D), dim3(256), 0, stream, a);
-            return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
-        }
-    }
     static thread_local int done = -1;
     hy_allow_lds(dk_kernel<R, NP, HALF, 0>, K::LDS, &done);
     HY_LAUNCH((dk_kernel<R, NP, HALF, 0>), dim3(a.D, a.S), dim3(K::WGT), K::LDS, stream, a);

@@ -16,12 +16,6 @@ void build_tables(int R, float* host_c32);
 // device memory for the filter spectrum H [D][M] (the only intermediate of this path)
 size_t spectrum_bytes(int D, int R);
 
-// 16-byte row I/O (WIDE kernels, onchip_kernels.h): 16-bit rows that are whole wavefronts wide (R >= 2), L % 8 == 0, every tensor 16-byte
-// aligned.  HYENA_FFTCONV_WIDE = bit mask of the kernel families allowed to use it (1: conv / spectrum, 2: dk; default 3; 0 keeps the
-// 2-byte-access kernels reachable -- A/B, tests).
-enum { WIDE_CONV = 1, WIDE_DK = 2 };
-bool wide_ok(int which, int R, int L, int dtype, const void* p0, const void* p1 = nullptr, const void* p2 = nullptr);
-
 // H = (FFT(k) + bias) / M into `H`
 int launch_spec(int R, const float* k, const float* bias, void* H, const void* tab, int D, int L, void* stream);
 // out = conv(x, H) (conj = 0) or corr(x, H) (conj = 1)

@@ -256,9 +256,7 @@ struct Ctx {
 
 // (Issuing the twiddle-table loads of a pass ahead of the butterflies that precede their use was tried -- no gain on the
 // conv kernels, more spills in the 256-register dk kernels; profiles/r2_attribution.txt.)
-// PRESYNC: the input came through the staging areas inside the exchange buffer (wide row I/O) -- one workgroup barrier before exchange 1
-// may write over them.
-template <int R, bool PRESYNC = false>
+template <int R>
 __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
     OC_DFT((dft_reg<32, false>(v)));
     OC_FENCE();
@@ -268,7 +266,6 @@ __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
         apply_tw<false, true>(v, w);
     }
     OC_FENCE();
-    if constexpr (PRESYNC) row_sync<Cfg<R>::T>();
     OC_X1(x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp));
     OC_FENCE();
     OC_DFT((dft_reg<32, false>(v)));
@@ -421,101 +418,6 @@ __device__ __forceinline__ void store_row(GBuf ob, bool bf, int tid, unsigned ro
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row I/O in 16-byte pieces (WIDE kernels: 16-bit rows, whole wavefronts per row -- T >= 64 --, L % 8 == 0 and 16-byte aligned tensors;
-// the host checks and otherwise launches the 2-byte-access kernels above).
-//
-// A wavefront's 64 lanes x 32 samples (n = tid + T s) are 256 chunks of 8 consecutive samples: chunk (g, s) = samples
-// 64 w + 8 g .. + 7 of block s, g = 0..7, w = wavefront of the row.  Lane l moves chunks (g = l & 7, s = (l >> 3) + 8 j), j = 0..3 -- eight
-// lanes cover 128 contiguous bytes of the row, an access 1 KB per wavefront where the 2-byte path moves 128 B -- and the 8 x 8 transposition
-// between "lane owns 8 consecutive samples" and "lane owns sample 8 g + i of every block" goes through a wavefront-private staging area in
-// LDS: chunk (g, s) at byte (8 s + g) 16, so that the 16-byte side is linear in the lane (l 16 + j 1024) and the 2-byte side reads /
-// writes 128 contiguous bytes per block s -- both conflict-free.  No workgroup barrier: LDS operations of one wavefront execute in order.
-//
-// The staging area is the wavefront's own slice of the exchange buffer: the region its lanes use in exchange 2 ((64 / R) groups of 33 R
-// floats = 8448 bytes for every R >= 2; rows of dk's parity split stage two 4 KB halves there).  Exchange 1 writes anywhere in the buffer,
-// so a transform whose input was staged passes one workgroup barrier before its exchange-1 writes (fft_fwd<R, true>); the store side needs
-// none (the last exchange of fft_inv ends with a barrier and nothing but staging touches LDS after it).
-// ---------------------------------------------------------------------------------------------
-static constexpr int OC_STAGE_BYTES = 8448;            // per wavefront: (64 / R) 33 R floats
-static constexpr int OC_STAGE_HALF = 4096;             // one staged row piece: 64 lanes x 32 samples x 2 bytes
-
-#ifdef HIPEMU
-struct oc_u4 { uint32_t w[4]; };
-#else
-typedef hy_u4 oc_u4;
-#endif
-
-__device__ __forceinline__ HY_LDS char* stage_of(const HY_LDS char* xb, int tid) {
-    return const_cast<HY_LDS char*>(xb) + (tid >> 6) * OC_STAGE_BYTES;
-}
-
-// NH row pieces (samples tid + T s + extra[h]) -> x[h][s]; all 4 NH fetches are issued before the first LDS access
-template <int T, int NH>
-__device__ __forceinline__ void load_raw_wide(float (&x)[NH][32], GBuf xb, bool bf, int tid, unsigned row_off, int L, const int (&extra)[NH],
-                                              HY_LDS char* stage) {
-    static_assert(T >= 64 && NH * OC_STAGE_HALF <= OC_STAGE_BYTES, "wide row I/O: whole wavefronts, at most two staged pieces");
-    const int l = tid & 63, wv = tid >> 6;
-    const unsigned c0 = (unsigned)(8 * wv + (l & 7) + (T / 8) * (l >> 3));                 // chunk of sweep 0
-    oc_u4 raw[NH][4];
-    HY_UNROLL
-    for (int h = 0; h < NH; ++h) {
-        const unsigned vo = row_off + (c0 * 8u + (unsigned)extra[h]) * 2u;
-        HY_UNROLL
-        for (int j = 0; j < 4; ++j) {
-#ifdef HIPEMU
-            const int n0 = (int)(c0 * 8u) + extra[h] + j * T * 8;
-            if (n0 < L) __builtin_memcpy(&raw[h][j], xb.p + vo + (unsigned)(j * T * 16), 16);
-            else raw[h][j] = oc_u4{{0u, 0u, 0u, 0u}};
-#else
-            raw[h][j] = __builtin_amdgcn_raw_buffer_load_b128(xb.r, vo, (unsigned)(j * T * 16), OC_POL_LD);    // n >= L: hardware bounds check
-#endif
-        }
-    }
-    HY_UNROLL
-    for (int h = 0; h < NH; ++h) {
-        HY_UNROLL
-        for (int j = 0; j < 4; ++j) *HY_LDS_CAST(oc_u4, stage + h * OC_STAGE_HALF + l * 16 + j * 1024) = raw[h][j];
-    }
-    HY_WAVE_SYNC();
-    const HY_LDS char* rd = stage + (l >> 3) * 16 + (l & 7) * 2;
-    HY_UNROLL
-    for (int h = 0; h < NH; ++h) {
-        HY_UNROLL
-        for (int s = 0; s < 32; ++s) x[h][s] = half_to_f32(*HY_LDS_CAST(const uint16_t, rd + h * OC_STAGE_HALF + s * 128), bf);
-    }
-    HY_WAVE_SYNC();
-}
-template <int R, int PHI8>
-__device__ __forceinline__ void load_row_wide(c32 (&v)[32], GBuf xb, bool bf, int tid, unsigned row_off, int L, HY_LDS char* stage) {
-    float x[1][32];
-    const int extra[1] = {0};
-    load_raw_wide<Cfg<R>::T, 1>(x, xb, bf, tid, row_off, L, extra, stage);
-    HY_UNROLL
-    for (int s = 0; s < 32; ++s) v[s] = rmul(x[0][s], twist_const<PHI8>(s));
-}
-// y[s] -> sample tid + T s of the 16-bit row
-template <int T>
-__device__ __forceinline__ void store_row_wide(GBuf ob, bool bf, int tid, unsigned row_off, int L, const float (&y)[32], HY_LDS char* stage) {
-    const int l = tid & 63, wv = tid >> 6;
-    HY_LDS char* wr = stage + (l >> 3) * 16 + (l & 7) * 2;
-    HY_UNROLL
-    for (int s = 0; s < 32; ++s) *HY_LDS_CAST(uint16_t, wr + s * 128) = f32_to_half(y[s], bf);
-    HY_WAVE_SYNC();
-    const unsigned c0 = (unsigned)(8 * wv + (l & 7) + (T / 8) * (l >> 3));
-    const unsigned vo = row_off + c0 * 16u;
-    HY_UNROLL
-    for (int j = 0; j < 4; ++j) {
-        const oc_u4 w = *HY_LDS_CAST(const oc_u4, stage + l * 16 + j * 1024);
-#ifdef HIPEMU
-        if ((int)(c0 * 8u) + j * T * 8 < L) __builtin_memcpy(ob.p + vo + (unsigned)(j * T * 16), &w, 16);
-#else
-        __builtin_amdgcn_raw_buffer_store_b128(w, ob.r, vo + (unsigned)(j * T * 16), 0, OC_POL_ST);       // no scalar offset on stores (gb_st)
-#endif
-    }
-    HY_WAVE_SYNC();
-}
-
-// ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
 struct SpecArgs {          // row spectrum: H[d] = (FFT(c_k) + bias) / M -- of the filter rows (fp32), or, for dk at B = 1, of the u rows
@@ -568,9 +470,8 @@ __device__ __forceinline__ Ctx make_ctx(HY_LDS char* smem, int rg, int tid, cons
     return c;
 }
 
-template <int R, bool HALF = false, bool WIDE = false>
+template <int R, bool HALF = false>
 __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) spec_kernel(SpecArgs a) {
-    static_assert(!WIDE || (HALF && WgCfg<R>::RPW == 1), "wide row I/O: 16-bit rows, whole wavefronts per row");
     typedef Cfg<R> C;
     constexpr int T = C::T, RPW = WgCfg<R>::RPW;
     constexpr unsigned ES = HALF ? 2u : 4u;
@@ -585,9 +486,8 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) spec_kernel(SpecArgs a
     const int nrows = (a.D - d0) < RPW ? (a.D - d0) : RPW;
     const GBuf kb = make_gbuf(reinterpret_cast<const char*>(a.k) + (size_t)d0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
     c32 v[32];
-    if constexpr (WIDE) load_row_wide<R, 2>(v, kb, bf, tid, (unsigned)(d - d0) * (unsigned)a.L * ES, a.L, stage_of(c.xb, tid));
-    else load_row<R, 2, HALF, (RPW > 1)>(v, kb, bf, tid, (unsigned)(d - d0) * (unsigned)a.L * ES, a.L);
-    fft_fwd<R, WIDE>(v, c);
+    load_row<R, 2, HALF, (RPW > 1)>(v, kb, bf, tid, (unsigned)(d - d0) * (unsigned)a.L * ES, a.L);
+    fft_fwd<R>(v, c);
     const float bias = (a.bias != nullptr) ? a.bias[d] : 0.f;
     const float sc = 1.0f / (float)C::M;
     if (valid) {
@@ -597,9 +497,8 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) spec_kernel(SpecArgs a
     }
 }
 
-template <int R, bool HALF, bool OUTF32 = false, bool WIDE = false>
+template <int R, bool HALF, bool OUTF32 = false>
 __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a) {
-    static_assert(!WIDE || (HALF && WgCfg<R>::RPW == 1), "wide row I/O: 16-bit rows, whole wavefronts per row");
     typedef Cfg<R> C;
     constexpr int T = C::T, RPW = WgCfg<R>::RPW;
     constexpr unsigned ES = HALF ? 2u : 4u;
@@ -631,9 +530,8 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a
     const unsigned row_off = (unsigned)(r - r0) * (unsigned)a.L * ES, orow_off = (unsigned)(r - r0) * (unsigned)a.L * EO;
     const GBuf hb = make_gbuf(a.H, (unsigned)a.D * (unsigned)C::M * 8u);
     c32 v[32];
-    if constexpr (WIDE) load_row_wide<R, 2>(v, xb, bf, tid, row_off, a.L, stage_of(c.xb, tid));
-    else load_row<R, 2, HALF, (RPW > 1)>(v, xb, bf, tid, row_off, a.L);
-    fft_fwd<R, WIDE>(v, c);
+    load_row<R, 2, HALF, (RPW > 1)>(v, xb, bf, tid, row_off, a.L);
+    fft_fwd<R>(v, c);
     {
         const unsigned ho = ((unsigned)d * (unsigned)C::M + (unsigned)tid) * 8u;
         HY_UNROLL
@@ -660,8 +558,7 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a
     }
     // (one row per workgroup: the grid is exactly B D blocks, every block is valid; a conditional epilogue costs hipcc 36
     // spilled registers at T = 1024)
-    if constexpr (WIDE && OHALF) store_row_wide<T>(ob, bf, tid, orow_off, a.L, y, stage_of(c.xb, tid));
-    else if (RPW == 1 || valid) store_row<T, OHALF, (RPW > 1)>(ob, bf, tid, orow_off, a.L, y);
+    if (RPW == 1 || valid) store_row<T, OHALF, (RPW > 1)>(ob, bf, tid, orow_off, a.L, y);
 }
 
 // dbias[d] = dk[d][0] (after a dk that came out of conv_kernel)
@@ -697,36 +594,29 @@ template <int R, int NP> struct DkCfg {
 };
 
 // spectrum input of sub-problem e (NP = 2: PHI8 = 1 + 4 e, sigma = +-1) or of the whole row (NP = 1)
-template <int R, int NP, bool HALF, int PHI8, bool WIDE>
-__device__ __forceinline__ void dk_load(c32 (&v)[32], GBuf xb, bool bf, int tid, unsigned row_off, int L, float sigma, HY_LDS char* stage) {
+template <int R, int NP, bool HALF, int PHI8>
+__device__ __forceinline__ void dk_load(c32 (&v)[32], GBuf xb, bool bf, int tid, unsigned row_off, int L, float sigma) {
     if constexpr (NP == 1) {
         // T = 32: two row groups share a wavefront, hence one descriptor (the whole tensor) and a per-lane row offset
-        if constexpr (WIDE) load_row_wide<R, PHI8>(v, xb, bf, tid, row_off, L, stage);
-        else load_row<R, PHI8, HALF, (Cfg<R>::T < 64)>(v, xb, bf, tid, row_off, L);
+        load_row<R, PHI8, HALF, (Cfg<R>::T < 64)>(v, xb, bf, tid, row_off, L);
     } else {
         constexpr int T = Cfg<R>::T, MS = Cfg<R>::M;
         const float r = 0.70710678118654752440f * sigma;
-        // all loads of the thread in one batch (one memory round trip; 8-pair batches measured 4x slower on MI355X:
+        // all 64 loads of the thread in one batch (one memory round trip; 8-pair batches measured 4x slower on MI355X:
         // with 2 wavefronts per SIMD nothing hides the latency between batches)
-        float x[2][32];
-        if constexpr (WIDE) {
-            const int extra[2] = {0, MS};
-            load_raw_wide<T, 2>(x, xb, bf, tid, 0u, L, extra, stage);          // 8 sixteen-byte fetches instead of 64 two-byte ones
-        } else {
-            load_raw<T, HALF, false>(x[0], xb, bf, tid, 0u, L, 0);
-            load_raw<T, HALF, false>(x[1], xb, bf, tid, 0u, L, MS);
-        }
+        float xa[32], xc[32];
+        load_raw<T, HALF, false>(xa, xb, bf, tid, 0u, L, 0);
+        load_raw<T, HALF, false>(xc, xb, bf, tid, 0u, L, MS);
         HY_UNROLL
         for (int s = 0; s < 32; ++s) {
-            const c32 y = mk(x[0][s] + r * x[1][s], -r * x[1][s]);           // x[n] + sigma e^(-i pi/4) x[n + M/2]
+            const c32 y = mk(xa[s] + r * xc[s], -r * xc[s]);           // x[n] + sigma e^(-i pi/4) x[n + M/2]
             v[s] = cmul(y, twist_const<PHI8>(s));
         }
     }
 }
 
-template <int R, int NP, bool HALF, int E0, bool WIDE = false>
+template <int R, int NP, bool HALF, int E0>
 __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
-    static_assert(!WIDE || (HALF && Cfg<R>::T >= 64), "wide row I/O: 16-bit rows, whole wavefronts per row");
     typedef Cfg<R> C;
     typedef DkCfg<R, NP> K;
     constexpr int T = C::T, BP = K::BP;
@@ -768,14 +658,13 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
             const GBuf ub = WHOLE ? make_gbuf(a.u, (unsigned)((size_t)a.B * a.D * a.L * ES)) : make_gbuf(reinterpret_cast<const char*>(a.u) + row, rowbytes);
             const unsigned row_off = WHOLE ? (unsigned)row : 0u;
             c32 u[32], v[32];
-            HY_LDS char* const stage = stage_of(c.xb, tid);
-            if (e == 0) dk_load<R, NP, HALF, PHI_A, WIDE>(u, ub, bf, tid, row_off, a.L, sigma, stage);
-            else dk_load<R, NP, HALF, PHI_B, WIDE>(u, ub, bf, tid, row_off, a.L, sigma, stage);
-            fft_fwd<R, WIDE>(u, c);
+            if (e == 0) dk_load<R, NP, HALF, PHI_A>(u, ub, bf, tid, row_off, a.L, sigma);
+            else dk_load<R, NP, HALF, PHI_B>(u, ub, bf, tid, row_off, a.L, sigma);
+            fft_fwd<R>(u, c);
             HY_SCHED_FENCE();
-            if (e == 0) dk_load<R, NP, HALF, PHI_A, WIDE>(v, gb, bf, tid, row_off, a.L, sigma, stage);
-            else dk_load<R, NP, HALF, PHI_B, WIDE>(v, gb, bf, tid, row_off, a.L, sigma, stage);
-            fft_fwd<R, WIDE>(v, c);
+            if (e == 0) dk_load<R, NP, HALF, PHI_A>(v, gb, bf, tid, row_off, a.L, sigma);
+            else dk_load<R, NP, HALF, PHI_B>(v, gb, bf, tid, row_off, a.L, sigma);
+            fft_fwd<R>(v, c);
             HY_SCHED_FENCE();
             const float lv = live ? 1.f : 0.f;
             HY_UNROLL

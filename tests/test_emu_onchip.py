@@ -199,53 +199,3 @@ def test_dk_at_batch_one_is_spectrum_plus_conjugate_conv(emu_backend, monkeypatc
     assert torch.equal(dbias, dk[:, 0]) and (dbias - r_db).abs().max() < 1e-5 * L ** 0.5 + 1e-5
     du1, dk1, db1 = emu_backend.fftconv_bwd(dout, u, k, bias, need_du=False, need_dk=True)
     assert du1 is None and torch.equal(dk1, dk) and torch.equal(db1, dbias)
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,D,L", [(3, 2, 1032), (2, 3, 2048), (5, 2, 4096), (2, 2, 3000), (3, 1, 8192), (2, 2, 9000), (2, 1, 16384),
-                                   (9, 2, 12000), (2, 1, 32768), (3, 1, 20000), (1, 2, 32768), (1, 1, 24000)])
-def test_sixteen_byte_row_io_gives_the_bits_of_the_two_byte_path(emu_backend, monkeypatch, B, D, L, dtype):
-    """WIDE kernels (16-byte global accesses + the wavefront-private 8 x 8 transposition through LDS, onchip_kernels.h) move the same
-    samples into the same registers as the 2-byte-access kernels: every output bit for bit -- forward, du, dk (its parity launches at
-    M = 32768, batch slices, the B = 1 spectrum + conjugate-convolution form), ragged L < M (the hardware bounds check's job on the GPU)."""
-    import ctypes
-    u, k, bias, dout = _inputs(B, D, L, dtype, seed=3 * L + B)
-    counter = ctypes.c_int.in_dll(emu_backend.lib(), "hyena_emu_wide_launches")
-    monkeypatch.setenv("HYENA_FFTCONV_SMALL", "0")       # (short rows: the general kernels, not the one-launch pair)
-    monkeypatch.setenv("HYENA_FFTCONV_WIDE", "3")
-    n0 = counter.value
-    out_w = emu_backend.fftconv_fwd(u, k, bias)
-    g_w = emu_backend.fftconv_bwd(dout, u, k, bias)
-    assert counter.value - n0 >= 3                      # forward, du and dk launches all took the 16-byte kernels
-    monkeypatch.setenv("HYENA_FFTCONV_WIDE", "0")
-    n0 = counter.value
-    out_n = emu_backend.fftconv_fwd(u, k, bias)
-    g_n = emu_backend.fftconv_bwd(dout, u, k, bias)
-    assert counter.value == n0
-    assert torch.equal(out_w, out_n)
-    for a, b in zip(g_w, g_n):
-        assert torch.equal(a, b)
-    # and both are the operator: against the fp32 oracle on the same 16-bit inputs
-    _, f_du, f_dk, _ = _oracle(u.float(), k, bias, dout.float())
-    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
-    assert ((g_w[0].float() - f_du).abs() <= 0.5 * eps * f_du.abs() * 1.01 + 2e-5).all() and _rel(g_w[1], f_dk) < 2e-6
-
-
-def test_misaligned_or_ragged_tensors_fall_back_to_the_two_byte_path(emu_backend, monkeypatch):
-    """The 16-byte path needs L % 8 == 0 and 16-byte aligned tensors; anything else must silently take the 2-byte kernels (same results)."""
-    monkeypatch.setenv("HYENA_FFTCONV_WIDE", "3")
-    B, D, L = 2, 2, 4096
-    u, k, bias, dout = _inputs(B, D, L, torch.bfloat16, seed=11)
-    ref = emu_backend.fftconv_fwd(u, k, bias)
-    pad = torch.zeros(B * D * L + 1, dtype=torch.bfloat16)
-    pad[1:] = u.reshape(-1)
-    u_off = pad[1:].view(B, D, L)                        # same values, base address 2 bytes off a 16-byte boundary
-    assert u_off.data_ptr() % 16 != 0 and u_off.is_contiguous()
-    import ctypes
-    counter = ctypes.c_int.in_dll(emu_backend.lib(), "hyena_emu_wide_launches")
-    n0 = counter.value
-    assert torch.equal(emu_backend.fftconv_fwd(u_off, k, bias), ref)
-    assert counter.value == n0
-    u2, k2, b2, d2 = _inputs(B, D, 4100, torch.bfloat16, seed=12)          # L % 8 = 4
-    out = emu_backend.fftconv_fwd(u2, k2, b2)
-    assert _rel(out.float(), O.fftconv_ref(u2.float(), k2, b2)) < 1e-2
