@@ -8,6 +8,13 @@
 #include <cmath>
 #include <cstdlib>
 
+#if defined(OC_PROFILE)
+// profiling builds only: hand the device a buffer for conv_kernel's time stamps ([workgroup][wavefront][32] uint64)
+extern "C" int hyena_oc_prof_set(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hyena::oc::oc_prof_buf), &buf, sizeof(buf));
+}
+#endif
+
 namespace hyena {
 namespace oc {
 

@@ -46,6 +46,22 @@ namespace oc {
 #define HY_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
+// -DOC_PROFILE (profiling builds only, scripts/build_variant.sh): wavefront time stamps (s_memtime: shader clock) at the phase boundaries of
+// conv_kernel, written by lane 0 of every wavefront to a buffer the host hands over through hyena_oc_prof_set (onchip.hip);
+// scripts/oc_phase_profile.py turns them into a per-phase timeline.  The product build contains none of it.
+#if defined(OC_PROFILE) && !defined(HIPEMU)
+__device__ unsigned long long* oc_prof_buf = nullptr;
+struct Prof { unsigned long long t[32]; };
+#define OC_MARK(c, i)                                                                                               \
+    do {                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if ((c).prof != nullptr) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"((c).prof->t[i])::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    } while (0)
+#else
+#define OC_MARK(c, i) do {} while (0)
+#endif
+
 // cos / sin (2 pi j / 256): the per-register part of the input twist, e^(-2 pi i s phi / 32) with phi = PHI8 / 8
 HY_CONST_TABLE float OC_COS256[256] = {1.000000000e+00f, 9.996988177e-01f, 9.987954497e-01f, 9.972904325e-01f, 9.951847196e-01f, 9.924795628e-01f, 9.891765118e-01f, 9.852776527e-01f, 9.807852507e-01f, 9.757021070e-01f, 9.700312614e-01f, 9.637760520e-01f, 9.569403529e-01f, 9.495281577e-01f, 9.415440559e-01f, 9.329928160e-01f, 9.238795042e-01f, 9.142097831e-01f, 9.039893150e-01f, 8.932242990e-01f, 8.819212914e-01f, 8.700869679e-01f, 8.577286005e-01f, 8.448535800e-01f, 8.314695954e-01f, 8.175848126e-01f, 8.032075167e-01f, 7.883464098e-01f, 7.730104327e-01f, 7.572088242e-01f, 7.409511209e-01f, 7.242470980e-01f, 7.071067691e-01f, 6.895405650e-01f, 6.715589762e-01f, 6.531728506e-01f, 6.343932748e-01f, 6.152315736e-01f, 5.956993103e-01f, 5.758081675e-01f, 5.555702448e-01f, 5.349976420e-01f, 5.141027570e-01f, 4.928981960e-01f, 4.713967443e-01f, 4.496113360e-01f, 4.275550842e-01f, 4.052413106e-01f, 3.826834261e-01f, 3.598950505e-01f, 3.368898630e-01f, 3.136817515e-01f, 2.902846634e-01f, 2.667127550e-01f, 2.429801822e-01f, 2.191012353e-01f, 1.950903237e-01f, 1.709618866e-01f, 1.467304677e-01f, 1.224106774e-01f, 9.801714122e-02f, 7.356456667e-02f, 4.906767607e-02f, 2.454122901e-02f, 6.123234263e-17f, -2.454122901e-02f, -4.906767607e-02f, -7.356456667e-02f, -9.801714122e-02f, -1.224106774e-01f, -1.467304677e-01f, -1.709618866e-01f, -1.950903237e-01f, -2.191012353e-01f, -2.429801822e-01f, -2.667127550e-01f, -2.902846634e-01f, -3.136817515e-01f, -3.368898630e-01f, -3.598950505e-01f, -3.826834261e-01f, -4.052413106e-01f, -4.275550842e-01f, -4.496113360e-01f, -4.713967443e-01f, -4.928981960e-01f, -5.141027570e-01f, -5.349976420e-01f, -5.555702448e-01f, -5.758081675e-01f, -5.956993103e-01f, -6.152315736e-01f, -6.343932748e-01f, -6.531728506e-01f, -6.715589762e-01f, -6.895405650e-01f, -7.071067691e-01f, -7.242470980e-01f, -7.409511209e-01f, -7.572088242e-01f, -7.730104327e-01f, -7.883464098e-01f, -8.032075167e-01f, -8.175848126e-01f, -8.314695954e-01f, -8.448535800e-01f, -8.577286005e-01f, -8.700869679e-01f, -8.819212914e-01f, -8.932242990e-01f, -9.039893150e-01f, -9.142097831e-01f, -9.238795042e-01f, -9.329928160e-01f, -9.415440559e-01f, -9.495281577e-01f, -9.569403529e-01f, -9.637760520e-01f, -9.700312614e-01f, -9.757021070e-01f, -9.807852507e-01f, -9.852776527e-01f, -9.891765118e-01f, -9.924795628e-01f, -9.951847196e-01f, -9.972904325e-01f, -9.987954497e-01f, -9.996988177e-01f, -1.000000000e+00f, -9.996988177e-01f, -9.987954497e-01f, -9.972904325e-01f, -9.951847196e-01f, -9.924795628e-01f, -9.891765118e-01f, -9.852776527e-01f, -9.807852507e-01f, -9.757021070e-01f, -9.700312614e-01f, -9.637760520e-01f, -9.569403529e-01f, -9.495281577e-01f, -9.415440559e-01f, -9.329928160e-01f, -9.238795042e-01f, -9.142097831e-01f, -9.039893150e-01f, -8.932242990e-01f, -8.819212914e-01f, -8.700869679e-01f, -8.577286005e-01f, -8.448535800e-01f, -8.314695954e-01f, -8.175848126e-01f, -8.032075167e-01f, -7.883464098e-01f, -7.730104327e-01f, -7.572088242e-01f, -7.409511209e-01f, -7.242470980e-01f, -7.071067691e-01f, -6.895405650e-01f, -6.715589762e-01f, -6.531728506e-01f, -6.343932748e-01f, -6.152315736e-01f, -5.956993103e-01f, -5.758081675e-01f, -5.555702448e-01f, -5.349976420e-01f, -5.141027570e-01f, -4.928981960e-01f, -4.713967443e-01f, -4.496113360e-01f, -4.275550842e-01f, -4.052413106e-01f, -3.826834261e-01f, -3.598950505e-01f, -3.368898630e-01f, -3.136817515e-01f, -2.902846634e-01f, -2.667127550e-01f, -2.429801822e-01f, -2.191012353e-01f, -1.950903237e-01f, -1.709618866e-01f, -1.467304677e-01f, -1.224106774e-01f, -9.801714122e-02f, -7.356456667e-02f, -4.906767607e-02f, -2.454122901e-02f, -1.836970147e-16f, 2.454122901e-02f, 4.906767607e-02f, 7.356456667e-02f, 9.801714122e-02f, 1.224106774e-01f, 1.467304677e-01f, 1.709618866e-01f, 1.950903237e-01f, 2.191012353e-01f, 2.429801822e-01f, 2.667127550e-01f, 2.902846634e-01f, 3.136817515e-01f, 3.368898630e-01f, 3.598950505e-01f, 3.826834261e-01f, 4.052413106e-01f, 4.275550842e-01f, 4.496113360e-01f, 4.713967443e-01f, 4.928981960e-01f, 5.141027570e-01f, 5.349976420e-01f, 5.555702448e-01f, 5.758081675e-01f, 5.956993103e-01f, 6.152315736e-01f, 6.343932748e-01f, 6.531728506e-01f, 6.715589762e-01f, 6.895405650e-01f, 7.071067691e-01f, 7.242470980e-01f, 7.409511209e-01f, 7.572088242e-01f, 7.730104327e-01f, 7.883464098e-01f, 8.032075167e-01f, 8.175848126e-01f, 8.314695954e-01f, 8.448535800e-01f, 8.577286005e-01f, 8.700869679e-01f, 8.819212914e-01f, 8.932242990e-01f, 9.039893150e-01f, 9.142097831e-01f, 9.238795042e-01f, 9.329928160e-01f, 9.415440559e-01f, 9.495281577e-01f, 9.569403529e-01f, 9.637760520e-01f, 9.700312614e-01f, 9.757021070e-01f, 9.807852507e-01f, 9.852776527e-01f, 9.891765118e-01f, 9.924795628e-01f, 9.951847196e-01f, 9.972904325e-01f, 9.987954497e-01f, 9.996988177e-01f};
 HY_CONST_TABLE float OC_SIN256[256] = {0.000000000e+00f, 2.454122901e-02f, 4.906767607e-02f, 7.356456667e-02f, 9.801714122e-02f, 1.224106774e-01f, 1.467304677e-01f, 1.709618866e-01f, 1.950903237e-01f, 2.191012353e-01f, 2.429801822e-01f, 2.667127550e-01f, 2.902846634e-01f, 3.136817515e-01f, 3.368898630e-01f, 3.598950505e-01f, 3.826834261e-01f, 4.052413106e-01f, 4.275550842e-01f, 4.496113360e-01f, 4.713967443e-01f, 4.928981960e-01f, 5.141027570e-01f, 5.349976420e-01f, 5.555702448e-01f, 5.758081675e-01f, 5.956993103e-01f, 6.152315736e-01f, 6.343932748e-01f, 6.531728506e-01f, 6.715589762e-01f, 6.895405650e-01f, 7.071067691e-01f, 7.242470980e-01f, 7.409511209e-01f, 7.572088242e-01f, 7.730104327e-01f, 7.883464098e-01f, 8.032075167e-01f, 8.175848126e-01f, 8.314695954e-01f, 8.448535800e-01f, 8.577286005e-01f, 8.700869679e-01f, 8.819212914e-01f, 8.932242990e-01f, 9.039893150e-01f, 9.142097831e-01f, 9.238795042e-01f, 9.329928160e-01f, 9.415440559e-01f, 9.495281577e-01f, 9.569403529e-01f, 9.637760520e-01f, 9.700312614e-01f, 9.757021070e-01f, 9.807852507e-01f, 9.852776527e-01f, 9.891765118e-01f, 9.924795628e-01f, 9.951847196e-01f, 9.972904325e-01f, 9.987954497e-01f, 9.996988177e-01f, 1.000000000e+00f, 9.996988177e-01f, 9.987954497e-01f, 9.972904325e-01f, 9.951847196e-01f, 9.924795628e-01f, 9.891765118e-01f, 9.852776527e-01f, 9.807852507e-01f, 9.757021070e-01f, 9.700312614e-01f, 9.637760520e-01f, 9.569403529e-01f, 9.495281577e-01f, 9.415440559e-01f, 9.329928160e-01f, 9.238795042e-01f, 9.142097831e-01f, 9.039893150e-01f, 8.932242990e-01f, 8.819212914e-01f, 8.700869679e-01f, 8.577286005e-01f, 8.448535800e-01f, 8.314695954e-01f, 8.175848126e-01f, 8.032075167e-01f, 7.883464098e-01f, 7.730104327e-01f, 7.572088242e-01f, 7.409511209e-01f, 7.242470980e-01f, 7.071067691e-01f, 6.895405650e-01f, 6.715589762e-01f, 6.531728506e-01f, 6.343932748e-01f, 6.152315736e-01f, 5.956993103e-01f, 5.758081675e-01f, 5.555702448e-01f, 5.349976420e-01f, 5.141027570e-01f, 4.928981960e-01f, 4.713967443e-01f, 4.496113360e-01f, 4.275550842e-01f, 4.052413106e-01f, 3.826834261e-01f, 3.598950505e-01f, 3.368898630e-01f, 3.136817515e-01f, 2.902846634e-01f, 2.667127550e-01f, 2.429801822e-01f, 2.191012353e-01f, 1.950903237e-01f, 1.709618866e-01f, 1.467304677e-01f, 1.224106774e-01f, 9.801714122e-02f, 7.356456667e-02f, 4.906767607e-02f, 2.454122901e-02f, 1.224646853e-16f, -2.454122901e-02f, -4.906767607e-02f, -7.356456667e-02f, -9.801714122e-02f, -1.224106774e-01f, -1.467304677e-01f, -1.709618866e-01f, -1.950903237e-01f, -2.191012353e-01f, -2.429801822e-01f, -2.667127550e-01f, -2.902846634e-01f, -3.136817515e-01f, -3.368898630e-01f, -3.598950505e-01f, -3.826834261e-01f, -4.052413106e-01f, -4.275550842e-01f, -4.496113360e-01f, -4.713967443e-01f, -4.928981960e-01f, -5.141027570e-01f, -5.349976420e-01f, -5.555702448e-01f, -5.758081675e-01f, -5.956993103e-01f, -6.152315736e-01f, -6.343932748e-01f, -6.531728506e-01f, -6.715589762e-01f, -6.895405650e-01f, -7.071067691e-01f, -7.242470980e-01f, -7.409511209e-01f, -7.572088242e-01f, -7.730104327e-01f, -7.883464098e-01f, -8.032075167e-01f, -8.175848126e-01f, -8.314695954e-01f, -8.448535800e-01f, -8.577286005e-01f, -8.700869679e-01f, -8.819212914e-01f, -8.932242990e-01f, -9.039893150e-01f, -9.142097831e-01f, -9.238795042e-01f, -9.329928160e-01f, -9.415440559e-01f, -9.495281577e-01f, -9.569403529e-01f, -9.637760520e-01f, -9.700312614e-01f, -9.757021070e-01f, -9.807852507e-01f, -9.852776527e-01f, -9.891765118e-01f, -9.924795628e-01f, -9.951847196e-01f, -9.972904325e-01f, -9.987954497e-01f, -9.996988177e-01f, -1.000000000e+00f, -9.996988177e-01f, -9.987954497e-01f, -9.972904325e-01f, -9.951847196e-01f, -9.924795628e-01f, -9.891765118e-01f, -9.852776527e-01f, -9.807852507e-01f, -9.757021070e-01f, -9.700312614e-01f, -9.637760520e-01f, -9.569403529e-01f, -9.495281577e-01f, -9.415440559e-01f, -9.329928160e-01f, -9.238795042e-01f, -9.142097831e-01f, -9.039893150e-01f, -8.932242990e-01f, -8.819212914e-01f, -8.700869679e-01f, -8.577286005e-01f, -8.448535800e-01f, -8.314695954e-01f, -8.175848126e-01f, -8.032075167e-01f, -7.883464098e-01f, -7.730104327e-01f, -7.572088242e-01f, -7.409511209e-01f, -7.242470980e-01f, -7.071067691e-01f, -6.895405650e-01f, -6.715589762e-01f, -6.531728506e-01f, -6.343932748e-01f, -6.152315736e-01f, -5.956993103e-01f, -5.758081675e-01f, -5.555702448e-01f, -5.349976420e-01f, -5.141027570e-01f, -4.928981960e-01f, -4.713967443e-01f, -4.496113360e-01f, -4.275550842e-01f, -4.052413106e-01f, -3.826834261e-01f, -3.598950505e-01f, -3.368898630e-01f, -3.136817515e-01f, -2.902846634e-01f, -2.667127550e-01f, -2.429801822e-01f, -2.191012353e-01f, -1.950903237e-01f, -1.709618866e-01f, -1.467304677e-01f, -1.224106774e-01f, -9.801714122e-02f, -7.356456667e-02f, -4.906767607e-02f, -2.454122901e-02f};
@@ -148,9 +164,11 @@ __device__ __forceinline__ void row_sync() {
 }
 
 // (every exchange moves one float plane at a time: real parts, then imaginary parts)
-template <int R, bool INV>
-__device__ __forceinline__ void x1p(c32 (&v)[32], HY_LDS float* xb, int tid, int ka, int tp) {
+template <int R, bool INV, class CTX>
+__device__ __forceinline__ void x1p(c32 (&v)[32], HY_LDS float* xb, int tid, int ka, int tp, const CTX& c) {
     constexpr int T = Cfg<R>::T, ROW1 = Cfg<R>::ROW1;
+    constexpr int MB = INV ? 17 : 3;                    // (profiling builds: stamps MB .. MB + 3 after the four barriers)
+    (void)c;
     HY_LDS float* const pa = xb + tid;
     HY_LDS float* const pb = xb + ka * ROW1 + tp;
     HY_UNROLL
@@ -159,16 +177,19 @@ __device__ __forceinline__ void x1p(c32 (&v)[32], HY_LDS float* xb, int tid, int
             HY_UNROLL
             for (int q = 0; q < 32; ++q) pa[q * ROW1] = part ? v[q].y : v[q].x;
             row_sync<T>();
+            if (part) OC_MARK(c, MB + 2); else OC_MARK(c, MB + 0);
             HY_UNROLL
             for (int s = 0; s < 32; ++s) { if (part) v[s].y = pb[R * s]; else v[s].x = pb[R * s]; }
         } else {
             HY_UNROLL
             for (int s = 0; s < 32; ++s) pb[R * s] = part ? v[s].y : v[s].x;
             row_sync<T>();
+            if (part) OC_MARK(c, MB + 2); else OC_MARK(c, MB + 0);
             HY_UNROLL
             for (int q = 0; q < 32; ++q) { if (part) v[q].y = pa[q * ROW1]; else v[q].x = pa[q * ROW1]; }
         }
         row_sync<T>();
+        if (part) OC_MARK(c, MB + 3); else OC_MARK(c, MB + 1);
     }
 }
 template <int R, bool INV>
@@ -232,6 +253,9 @@ struct Ctx {
     HY_LDS char* xb;        // exchange buffer of this row
     GBuf tab;               // twiddle tables of this transform size (tw1 | tw2)
     int tid, ka, tp;
+#if defined(OC_PROFILE) && !defined(HIPEMU)
+    Prof* prof;             // time stamps of this wavefront (profiling builds)
+#endif
 };
 
 // v[s] = c[tid + T s] e^(+2 pi i tid phi / M) on entry (i.e. the raw samples times the per-register twist constants);
@@ -260,16 +284,19 @@ template <int R>
 __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
     OC_DFT((dft_reg<32, false>(v)));
     OC_FENCE();
+    OC_MARK(c, 1);
     {
         Tw w;
         load_tw1<R>(w, c.tab, c.tid);
         apply_tw<false, true>(v, w);
     }
     OC_FENCE();
-    OC_X1(x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp));
+    OC_MARK(c, 2);
+    OC_X1(x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp, c));
     OC_FENCE();
     OC_DFT((dft_reg<32, false>(v)));
     OC_FENCE();
+    OC_MARK(c, 7);
     if constexpr (R > 1) {
         {
             Tw w;
@@ -277,10 +304,13 @@ __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
             apply_tw<false, false>(v, w);
         }
         OC_FENCE();
+        OC_MARK(c, 8);
         OC_X2(x2p<R, false>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp));
         OC_FENCE();
+        OC_MARK(c, 9);
         OC_DFT((pass3<R, false>(v)));
         OC_FENCE();
+        OC_MARK(c, 10);
     }
 }
 // inverse (unnormalised); on exit v[s] = result[tid + T s] e^(-2 pi i (tid + T s) phi / M) e^(+2 pi i s phi / 32),
@@ -290,18 +320,23 @@ __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
     if constexpr (R > 1) {
         OC_DFT((pass3<R, true>(v)));
         OC_FENCE();
+        OC_MARK(c, 12);
         OC_X2(x2p<R, true>(v, HY_LDS_CAST(float, c.xb), c.ka, c.tp));
         OC_FENCE();
+        OC_MARK(c, 13);
         Tw w;
         load_tw2<R>(w, c.tab, c.tp);
         apply_tw<true, false>(v, w);
     }
     OC_FENCE();
+    OC_MARK(c, 14);
     OC_DFT((dft_reg<32, true>(v)));
     OC_FENCE();
+    OC_MARK(c, 15);
     // exchange 1 writes anywhere in the buffer: every wavefront must be done with its exchange-2 region
     if constexpr (R > 1) row_sync<Cfg<R>::T>();
-    OC_X1(x1p<R, true>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp));
+    OC_MARK(c, 16);
+    OC_X1(x1p<R, true>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp, c));
     OC_FENCE();
     {
         Tw w;
@@ -309,8 +344,10 @@ __device__ __forceinline__ void fft_inv(c32 (&v)[32], const Ctx& c) {
         apply_tw<true, true>(v, w);
     }
     OC_FENCE();
+    OC_MARK(c, 21);
     OC_DFT((dft_reg<32, true>(v)));
     OC_FENCE();
+    OC_MARK(c, 22);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,6 +504,9 @@ __device__ __forceinline__ Ctx make_ctx(HY_LDS char* smem, int rg, int tid, cons
     c.tid = tid;
     c.ka = tid / R;
     c.tp = tid % R;
+#if defined(OC_PROFILE) && !defined(HIPEMU)
+    c.prof = nullptr;
+#endif
     return c;
 }
 
@@ -529,6 +569,15 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a
     const GBuf ob = make_gbuf(reinterpret_cast<char*>(a.out) + (size_t)r0 * a.L * EO, (unsigned)nrows * (unsigned)a.L * EO);
     const unsigned row_off = (unsigned)(r - r0) * (unsigned)a.L * ES, orow_off = (unsigned)(r - r0) * (unsigned)a.L * EO;
     const GBuf hb = make_gbuf(a.H, (unsigned)a.D * (unsigned)C::M * 8u);
+#if defined(OC_PROFILE) && !defined(HIPEMU)
+    Prof prof;
+    HY_UNROLL
+    for (int i = 0; i < 32; ++i) prof.t[i] = 0;
+    const_cast<Ctx&>(c).prof = &prof;
+    unsigned long long rt0, rt1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");       // 100 MHz reference: calibrates s_memtime
+    OC_MARK(c, 0);
+#endif
     c32 v[32];
     load_row<R, 2, HALF, (RPW > 1)>(v, xb, bf, tid, row_off, a.L);
     fft_fwd<R>(v, c);
@@ -549,6 +598,7 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a
             HY_SCHED_FENCE();
         }
     }
+    OC_MARK(c, 11);
     fft_inv<R>(v, c);
     float y[32];
     HY_UNROLL
@@ -559,6 +609,24 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a
     // (one row per workgroup: the grid is exactly B D blocks, every block is valid; a conditional epilogue costs hipcc 36
     // spilled registers at T = 1024)
     if (RPW == 1 || valid) store_row<T, OHALF, (RPW > 1)>(ob, bf, tid, orow_off, a.L, y);
+#if defined(OC_PROFILE) && !defined(HIPEMU)
+    OC_MARK(c, 23);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OC_MARK(c, 24);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+    if (oc_prof_buf != nullptr && (threadIdx.x & 63) == 0) {
+        unsigned long long* o = oc_prof_buf + ((size_t)blockIdx.x * (WgCfg<R>::WGT / 64) + (threadIdx.x >> 6)) * 32;
+        HY_UNROLL
+        for (int i = 0; i < 25; ++i) o[i] = prof.t[i];
+        // which CU / XCD ran this workgroup (HW_ID register: CU id bits 8-11, SE 13-15 ...; XCC_ID separately)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[25] = ((unsigned long long)xcc << 32) | hw;
+        o[26] = rt0;
+        o[27] = rt1;
+    }
+#endif
 }
 
 // dbias[d] = dk[d][0] (after a dk that came out of conv_kernel)
