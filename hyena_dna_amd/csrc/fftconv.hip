@@ -143,11 +143,73 @@ const size_t ROW0_SMEM = ROW0_LDS * sizeof(c32);
 int self_paired_rows(int M1) { return (M1 >= 2 && M1 % 2 == 0) ? 2 : 1; }
 int regular_pairs(int M1) { return (M1 - 1) / 2; }
 
+// The self-paired rows (k1 = 0 and M1 / 2: 2 / M1 of the work) are dependent chains of ~25 us per launch on a grid that fills a fraction of
+// the chip -- three serial launches of them were 3 - 4 % of a step at L = 160000 / 450560 (profiles/r3a_kernel_tables.md).  They touch rows
+// no other row kernel touches, so they run BESIDE the regular pairs on a side stream: fork after the column transforms, join before the
+// inverse column transforms.  The side stream and its two events are created once per calling thread and device (the only state this
+// library keeps); inside a hipGraph capture the fork / join become graph edges.  HYENA_FFTCONV_SIDE=0 keeps everything on the caller's stream.
+#ifndef HIPEMU
+struct SideStream {
+    bool tried = false;
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static SideStream* side_for(void* stream) {
+    static const bool enabled = [] { const char* e = std::getenv("HYENA_FFTCONV_SIDE"); return !(e != nullptr && e[0] == '0'); }();
+    if (!enabled) return nullptr;
+    static thread_local SideStream tab[32];
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+    int dev = cur;
+    hipDevice_t sd;
+    if (stream != nullptr && hipStreamGetDevice((hipStream_t)stream, &sd) == hipSuccess) dev = (int)sd;
+    if (dev < 0 || dev >= 32) return nullptr;
+    SideStream& t = tab[dev];
+    if (!t.tried) {
+        t.tried = true;
+        if (dev != cur) (void)hipSetDevice(dev);
+        const bool ok = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&t.join, hipEventDisableTiming) == hipSuccess;
+        if (dev != cur) (void)hipSetDevice(cur);
+        if (!ok) { t.s = nullptr; (void)hipGetLastError(); }
+    }
+    return t.s != nullptr ? &t : nullptr;
+}
+// fork: the side stream waits for everything the caller's stream holds so far; returns the stream the self-paired rows go to
+static void* side_fork(void* stream, SideStream** out) {
+    SideStream* t = side_for(stream);
+    *out = nullptr;
+    if (t == nullptr) return stream;
+    if (hipEventRecord(t->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(t->s, t->fork, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return stream;
+    }
+    *out = t;
+    return t->s;
+}
+static void side_mark(SideStream* t) {                  // the side work is complete behind this point of the side stream
+    if (t != nullptr) (void)hipEventRecord(t->join, t->s);
+}
+static void side_join(void* stream, SideStream* t) {    // the caller's stream continues only after it
+    if (t != nullptr) (void)hipStreamWaitEvent((hipStream_t)stream, t->join, 0);
+}
+#else
+struct SideStream {};
+static void* side_fork(void* stream, SideStream** out) { *out = nullptr; return stream; }
+static void side_mark(SideStream*) {}
+static void side_join(void*, SideStream*) {}
+#endif
+
 template <int MODE>
 int launch_row_prod2(const RowArgs& a, void* stream) {
-    HY_LAUNCH((row0_prod2_kernel<MODE>), dim3(self_paired_rows(a.M1), (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, stream, a);
+    SideStream* sd;
+    void* s0 = regular_pairs(a.M1) > 0 ? side_fork(stream, &sd) : (sd = nullptr, stream);
+    HY_LAUNCH((row0_prod2_kernel<MODE>), dim3(self_paired_rows(a.M1), (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, s0, a);
+    side_mark(sd);
     if (regular_pairs(a.M1) > 0)
         HY_LAUNCH((row_prod2_kernel<MODE>), dim3(regular_pairs(a.M1), a.inner), dim3(64), ROW_SMEM, stream, a);
+    side_join(stream, sd);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
@@ -158,8 +220,11 @@ const int ROW_BWD_SPLIT_BATCH = 2;     // measured: B = 1 fused 6.62 vs split 7.
 
 template <bool DO_DU>
 int launch_row_bwd(const RowArgs& a, void* stream) {
-    HY_LAUNCH((row0_bwd_kernel<DO_DU>), dim3(self_paired_rows(a.M1), (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, stream, a);
-    HY_LAUNCH(row0_dk_reduce_kernel, dim3(self_paired_rows(a.M1), a.inner), dim3(256), 0, stream, a);
+    SideStream* sd;
+    void* s0 = regular_pairs(a.M1) > 0 ? side_fork(stream, &sd) : (sd = nullptr, stream);
+    HY_LAUNCH((row0_bwd_kernel<DO_DU>), dim3(self_paired_rows(a.M1), (a.inner + 1) / 2, a.B), dim3(64), ROW0_SMEM, s0, a);
+    HY_LAUNCH(row0_dk_reduce_kernel, dim3(self_paired_rows(a.M1), a.inner), dim3(256), 0, s0, a);
+    side_mark(sd);
     if (regular_pairs(a.M1) > 0) {
         const dim3 grid(regular_pairs(a.M1), a.inner);
         if (a.B >= ROW_BWD_SPLIT_BATCH) {
@@ -173,6 +238,7 @@ int launch_row_bwd(const RowArgs& a, void* stream) {
             HY_LAUNCH((row_bwd_kernel<DO_DU>), grid, dim3(64), ROW_SMEM, stream, a);
         }
     }
+    side_join(stream, sd);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
