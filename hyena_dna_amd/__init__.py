@@ -21,21 +21,33 @@ import torch as _torch
 # hipGraph replays on ROCm 7.2: with the runtime's "graph packet capture" optimisation (pre-built AQL packets) a replayed graph
 # of ~1 000 kernels reads clobbered kernel arguments once a few hundred eager launches have run between two replays -- NaNs,
 # or HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION; reproduced with plain torch.nn.Linear, none of this package's kernels
-# (scripts/graph_bisect.py, scripts/graph_debug3.py; gpurun_out/r2g*).  The knob is read when the HIP runtime initialises,
-# so it is set here, at import, unless the user has decided otherwise; lm.GraphedTrainStep refuses to capture when it could
-# not take effect.  Eager launches are not affected by it.
-# Side effect, stated: this sets a PROCESS-WIDE ROCm runtime knob for every hipGraph user in the process (graphs stay
-# correct, launches inside a replay are dispatched the ordinary way); export DEBUG_CLR_GRAPH_PACKET_CAPTURE=1 before the
-# import to keep the runtime's default -- GraphedTrainStep then refuses to capture.
+# (scripts/graph_bisect.py, scripts/graph_debug3.py; gpurun_out/r2g*).  Whole-step replays (lm.GraphedTrainStep) therefore need
+# DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, and the knob is read when the HIP runtime initialises.
+#
+# Round 4: importing this package no longer touches the environment (the knob is process-wide, and most users of
+# the package -- the overlay seams, eager training -- never capture a graph).  Whoever wants graphed steps says so, BEFORE the first
+# torch.cuda call: `hyena_dna_amd.prepare_graph_runtime()` (or export the variable; bench.py, scripts/train_hg38.py and the tests set it
+# at their very top).  GraphedTrainStep refuses to capture when the knob could not have taken effect.  Eager launches never need it.
 _K = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
-_was_init = _torch.cuda.is_initialized()
-_prev = _os.environ.get(_K)
-_os.environ.setdefault(_K, "0")
-# safe = the variable reads "0" AND the HIP runtime reads it after it was set: either it was not initialised yet, or the
-# user had exported "0" before starting the process (a value placed in os.environ after initialisation is never seen).
-GRAPH_SAFE = _os.environ[_K] == "0" and ((not _was_init) or _prev == "0")
+# safe = the variable reads "0" AND the HIP runtime reads it after it was set: found "0" at import (exported before the process started,
+# or set by the caller ahead of its imports), or set by prepare_graph_runtime() while the runtime was still uninitialised
+GRAPH_SAFE = _os.environ.get(_K) == "0"
+
+
+def prepare_graph_runtime():
+    """Opt in to hipGraph replays of whole training steps: sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 for this process if the HIP runtime has
+    not been initialised yet and the user has not chosen a value.  Returns whether graphed steps are safe to use."""
+    global GRAPH_SAFE
+    if _os.environ.get(_K) == "0":
+        return GRAPH_SAFE
+    if _K in _os.environ or _torch.cuda.is_initialized():      # the user decided otherwise / too late to take effect
+        return False
+    _os.environ[_K] = "0"
+    GRAPH_SAFE = True
+    return True
+
 
 from . import _lib  # noqa: F401,E402
 
-__all__ = ["fftconv", "hyena", "mixer", "filter", "projection", "block", "tokenizer", "build"]
+__all__ = ["fftconv", "hyena", "mixer", "filter", "projection", "block", "tokenizer", "build", "prepare_graph_runtime", "GRAPH_SAFE"]
 __version__ = "0.1.0"

@@ -494,8 +494,8 @@ class GraphedTrainStep:
         if not hyena_dna_amd.GRAPH_SAFE or os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
             raise RuntimeError("GraphedTrainStep: hipGraph replays of a whole step are only reliable on this ROCm runtime with "
                                "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP runtime initialises "
-                               "(import hyena_dna_amd before the first torch.cuda call, or export the variable); see "
-                               "hyena_dna_amd/__init__.py")
+                               "(call hyena_dna_amd.prepare_graph_runtime() before the first torch.cuda call, or export the "
+                               "variable); see hyena_dna_amd/__init__.py")
         self.model, self.optimizer = model, optimizer
         self.ids, self.targets = input_ids.clone(), targets.clone()
         self.autocast_dtype, self.ignore_index = autocast_dtype, ignore_index

@@ -1,5 +1,7 @@
 """Host side above the C ABI -- the autograd function and the module mirrors -- on the CPU-emulated kernels,
 against the oracle and the golden vectors minted from the reference's own classes.  No GPU needed."""
+import os
+
 import pytest
 import torch
 
@@ -217,8 +219,8 @@ def test_block_glue_refuses_cpu_tensors_without_the_test_double():
 
 
 def test_graphed_train_step_refuses_what_it_cannot_capture():
-    """lm.GraphedTrainStep fails loudly, before touching the device, on a CPU batch and on a non-capturable optimizer; the
-    package sets the ROCm graph knob at import (hyena_dna_amd/__init__.py)."""
+    """lm.GraphedTrainStep fails loudly, before touching the device, on a CPU batch and on a non-capturable optimizer.  The ROCm graph
+    knob is the caller's business since round 4 (the test session sets it in conftest.py, ahead of every import)."""
     import os
 
     import hyena_dna_amd
@@ -354,3 +356,21 @@ def test_advice_r3_host_side_fixes(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "_retired", [w])
     assert _lib.release_stream_state(torch.device("cuda", 0), 77) and not _lib._workspace and not _lib._captured and not _lib._retired
     assert not _lib.release_stream_state(torch.device("cuda", 0), 77)
+
+
+def test_importing_the_package_leaves_the_process_environment_alone():
+    """`import hyena_dna_amd` used to set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 for the whole process.  It is opt-in now:
+    prepare_graph_runtime() sets it (only while the HIP runtime is uninitialised, only if the user has not chosen a value)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os; os.environ.pop('DEBUG_CLR_GRAPH_PACKET_CAPTURE', None)\n"
+            "import hyena_dna_amd as h\n"
+            "assert 'DEBUG_CLR_GRAPH_PACKET_CAPTURE' not in os.environ and h.GRAPH_SAFE is False\n"
+            "assert h.prepare_graph_runtime() is True and os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] == '0' and h.GRAPH_SAFE is True\n"
+            "os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = '1'; h.GRAPH_SAFE = False\n"
+            "assert h.prepare_graph_runtime() is False and os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] == '1'\n"
+            "print('ENV_OK')")
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ENV_OK" in p.stdout, (p.stdout, p.stderr[-1500:])
