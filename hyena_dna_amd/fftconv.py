@@ -16,8 +16,15 @@ Differences from the reference's fused op (all lifts of restrictions, SURVEY.md 
 * ``k_rev`` (src/ops/fftconv.py:64-66: ``k_f + conj(rfft(k_rev))`` = an anti-causal convolution added to the causal one) and
   ``bidirectional`` (hyena.py:67-73: the input centred in the 2L window = the causal result delayed by L // 2) are served by the same
   kernels through flips / shifts (``fftconv_func`` / ``fftconv_ref`` below);
-* options no HyenaDNA config enables (``gelu``, ``dropout_mask``, ``v``/``q``/``head_dim``,
-  ``output_hbl_layout``, ``fftfp16``) raise ``NotImplementedError`` instead of silently running something else.
+* the H3-form options of the reference op that no HyenaDNA config enables -- ``gelu``, ``dropout_mask``, ``v`` / ``q`` / ``head_dim``,
+  ``output_hbl_layout``, ``force_fp16_output``, ``fftfp16`` (src/ops/fftconv.py:37-55, 58-108; the kernel's order of operations
+  csrc/fftconv/fftconv_cuda.cu:420-500) -- are served by ``fftconv_func`` since round 4: the long convolution runs on the HIP kernels
+  with fp32 rows, the element-wise parts around it (the ``k (x) v`` outer product, GELU, the dropout mask, ``* q`` and the sum over the
+  head dimension) are PyTorch ops on the fp32 result, rounded once at the end like the fused reference kernel (``fftfp16`` asks the
+  reference for a faster, less exact half-precision FFT: here the transform stays fp32).  ``FFTConvFunc.apply`` itself takes the plain
+  form only and says so;
+* sequences longer than the kernels' 2^20 positions (the reference's torch.fft path takes any L) are served by splitting the causal
+  convolution into four half-length ones (``_conv_long``); slower than a native transform of that size would be, but exact.
 There is no CPU / torch.fft fallback in this module.
 """
 import torch
@@ -123,7 +130,51 @@ class FFTConvFunc(torch.autograd.Function):
 
 
 def _conv(u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, head_dim, q, fftfp16):
+    if u.shape[-1] > _lib.MAX_L and not (dropout_mask is not None or gelu or output_hbl_layout or v is not None or q is not None
+                                         or head_dim != 1 or fftfp16):
+        out = _conv_long(u, k, D)
+        return out.to(torch.float16) if (force_fp16_output and u.dtype == torch.float32) else out
     return FFTConvFunc.apply(u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, head_dim, q, fftfp16, None)
+
+
+def _plain(u, k, D):
+    """causal convolution + D u on the HIP kernels, any length, plain form"""
+    return _conv(u, k, D, None, False, False, False, None, 1, None, False)
+
+
+def _conv_long(u, k, D):
+    """L > 2^20 (the kernels' largest transform; the reference's torch.fft path, hyena.py:61, takes any L): with u = [u_lo | u_hi],
+    k = [k_lo | k_hi] split at h = ceil(L / 2), and C(a, b) the causal convolution of two length-h rows truncated to h outputs (the
+    kernels' primitive, any h <= 2^20; longer halves recurse),
+
+        out[:h] = C(u_lo, k_lo) + D u_lo
+        out[h:] = upper(u_lo * k_lo) + C(u_lo, k_hi) + C(u_hi, k_lo) + D u_hi
+
+    where upper(a * b)[n] = (a * b)[h + n] -- the half of the linear convolution that C drops -- is itself a causal convolution of the
+    flipped rows read backwards: upper[n] = C(flip a, flip b)[h - 2 - n] (and 0 at n = h - 1).  Four half-length calls, i.e. twice the
+    work of one transform of the full length, all through FFTConvFunc (gradients come from autograd over this composition); the halves are
+    convolved as fp32 rows and the sum is rounded once, like the reference's single irfft."""
+    L = u.shape[-1]
+    h = (L + 1) // 2
+    uf = u.float()
+    kf = k.float()
+    if L % 2:                                              # odd L: one zero behind each row; the extra output is dropped
+        uf = torch.nn.functional.pad(uf, (0, 1))
+        kf = torch.nn.functional.pad(kf, (0, 1))
+    u_lo, u_hi = uf[..., :h].contiguous(), uf[..., h:].contiguous()
+    k_lo, k_hi = kf[..., :h].contiguous(), kf[..., h:].contiguous()
+    lo = _plain(u_lo, k_lo, D)
+    w = _plain(u_lo.flip(-1), k_lo.flip(-1), None)                             # C(flip u_lo, flip k_lo)
+    upper = torch.nn.functional.pad(w.flip(-1)[..., 1:], (0, 1))               # upper[n] = w[h - 2 - n], upper[h - 1] = 0
+    hi = upper + _plain(u_lo, k_hi, None) + _plain(u_hi, k_lo, D)
+    return torch.cat([lo, hi], dim=-1)[..., :L].to(u.dtype)
+
+
+def _bcast_D(D, ref):
+    """D as the reference broadcasts it against a (..., H, L) tensor: (H,) -> (H, 1); (1, H, 1) as HyenaOperator passes it stays"""
+    if D is None:
+        return None
+    return D.unsqueeze(-1) if D.dim() == 1 else D
 
 
 def fftconv_func(u, k, D, dropout_mask=None, gelu=True, force_fp16_output=False, output_hbl_layout=False, v=None,
@@ -133,14 +184,49 @@ def fftconv_func(u, k, D, dropout_mask=None, gelu=True, force_fp16_output=False,
     ``k_rev`` (src/ops/fftconv.py:64-66; hyena.py:63-65): the reference adds ``conj(rfft(k_rev, 2L))`` to the filter spectrum, i.e. the
     circularly time-reversed ``k_rev``: ``out[t] += sum_{s >= t} k_rev[s - t] u[s]`` -- an anti-causal convolution, which is the causal
     one of the flipped input, flipped back.  Both run on the HIP kernels; 16-bit inputs are convolved in fp32 so that the sum is
-    rounded once, as in the reference."""
-    if k_rev is None:
-        return _conv(u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, head_dim, q, fftfp16)
-    _unsupported(dropout_mask=dropout_mask is not None, gelu=bool(gelu), force_fp16_output=bool(force_fp16_output))
-    uf = u.float()
-    out = _conv(uf, k, D, None, False, False, output_hbl_layout, v, head_dim, q, fftfp16)
-    out = out + _conv(uf.flip(-1), k_rev, None, None, False, False, output_hbl_layout, v, head_dim, q, fftfp16).flip(-1)
-    return out.to(u.dtype)
+    rounded once, as in the reference.
+
+    The H3 form (``v`` and ``q`` given; src/ops/fftconv.py:37-55, fftconv_cuda.cu:405-500): with ``u`` (b, h d1, l), ``v`` (b, h d2, l),
+    ``q`` (b, h d1, l), ``k`` (h, l), ``D`` (h,):  kv = u (x) v over (d1, d2);  y = conv(kv, k) + D kv;  [GELU];  out = sum_d1 y q  ->
+    (b, h d2, l).  ``dropout_mask`` (b, H) scales the rows after the GELU (plain form).  ``output_hbl_layout`` returns the same (b, h, l)
+    tensor laid out as (h, b, l) in memory, as the reference kernel writes it."""
+    plain = (dropout_mask is None and not gelu and not output_hbl_layout and v is None and q is None and head_dim == 1 and not fftfp16)
+    if plain and k_rev is None:
+        return _conv(u, k, D, None, False, force_fp16_output, False, None, 1, None, False)
+    if (v is None) != (q is None):
+        raise ValueError("fftconv_func: the H3 form needs both v and q (src/ops/fftconv.py:37)")
+    if v is None and head_dim != 1:
+        raise ValueError("fftconv_func: head_dim > 1 without v / q")
+    if v is not None and dropout_mask is not None:
+        raise NotImplementedError("fftconv_func: dropout_mask together with the H3 form (v, q) -- no caller in the reference builds it")
+
+    def conv32(x32):            # causal (+ anti-causal) convolution and the D term on fp32 rows
+        y = _plain(x32, k, D)
+        if k_rev is not None:
+            y = y + _plain(x32.flip(-1), k_rev, None).flip(-1)
+        return y
+
+    if v is None:
+        out = conv32(u.float())
+    else:
+        from einops import rearrange
+        kv = (rearrange(u, "b (h d1) l -> b d1 1 h l", d1=head_dim).float()
+              * rearrange(v, "b (h d2) l -> b 1 d2 h l", d2=head_dim).float())             # b d1 d2 h l   (fftconv.py:40-41)
+        b, d1, d2, h, l = kv.shape
+        out = conv32(kv.reshape(b * d1 * d2, h, l)).reshape(b, d1, d2, h, l)               # y + kv D      (fftconv.py:48-49)
+    if gelu:
+        out = torch.nn.functional.gelu(out)                                                # fftconv_cuda.cu:473
+    if dropout_mask is not None:
+        out = out * dropout_mask.to(out.dtype).unsqueeze(-1)                               # (b, H) -> rows
+    if v is not None:
+        from einops import rearrange
+        qr = rearrange(q, "b (h d1) l -> b d1 1 h l", d1=head_dim).float()
+        out = rearrange((out * qr).sum(dim=1), "b d2 h l -> b (h d2) l")                   # fftconv.py:50-55
+    odt = torch.float16 if (force_fp16_output and u.dtype == torch.float32) else u.dtype
+    out = out.to(odt)
+    if output_hbl_layout:                                                                  # (b, h, l) values, (h, b, l) memory order
+        out = out.transpose(0, 1).contiguous().transpose(0, 1)
+    return out
 
 
 def fftconv_ref(u, k, D, dropout_mask=None, gelu=True, k_rev=None, bidirectional=False):

@@ -205,6 +205,13 @@ class HyenaFilter(_OptimModule):
         return y.to(dtype=x.dtype)
 
 
+def _lib_max_l():
+    """the longest sequence the fused core's kernels take; beyond it the generic path below runs, whose long convolution
+    (fftconv_func) splits into half-length calls"""
+    from . import _lib
+    return _lib.MAX_L
+
+
 class HyenaOperator(nn.Module):
     """Hyena operator (hyena.py:270-448): in_proj -> short depthwise conv -> order-N gated long-conv
     recurrence -> out_proj.  ``forward(u)``: (B, L, D) -> (B, min(L, l_max), D)."""
@@ -264,7 +271,7 @@ class HyenaOperator(nn.Module):
     def forward(self, u, *args, **kwargs):
         l = u.size(-2)
         l_filter = min(l, self.l_max)
-        if self._fused_ok():
+        if self._fused_ok() and l_filter <= _lib_max_l():
             k = self.filter_fn.filter_dl(l_filter)                              # (D, l), rows contiguous along l
             fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
             if CHANNEL_MAJOR:

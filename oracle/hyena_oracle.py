@@ -10,6 +10,8 @@ into ``/root/reference``:
 
 * ``fftconv_ref``           <- src/models/sequence/hyena.py:59-88
                                (dup: src/ops/fftconv.py:15-34, standalone_hyenadna.py:45-60)
+* ``fftconv_h3_ref``        <- src/ops/fftconv.py:37-55 (the H3 form of the fused op: k (x) v, SSM-kernel convolution, q gate;
+                               pinned to the reference's own function by tests/test_overlay_reference.py)
 * ``positional_embedding``  <- src/models/sequence/hyena.py:109-131
 * ``filter_mlp`` / ``Sin``  <- src/models/sequence/hyena.py:96-106, 199-215
 * ``exp_modulation``        <- src/models/sequence/hyena.py:134-155
@@ -72,6 +74,28 @@ def fftconv_ref(u, k, D, dropout_mask=None, gelu=False, k_rev=None, bidirectiona
     if dropout_mask is not None:                                  # hyena.py:85-86
         return (out * dropout_mask[..., None]).to(dtype=u.dtype)
     return out.to(dtype=u.dtype)                                  # hyena.py:88
+
+
+def fftconv_h3_ref(k, ssm_kernel, D, q, v, head_dim=1, ssm_kernel_rev=None):
+    """The H3 form of the fused op (src/ops/fftconv.py:37-55), restated line by line: kv = k (x) v over the head dimension, long
+    convolution with the SSM kernel (+ its time reversal), the D term, then the q gate and the sum over d1.
+    k, q: (b, h d1, l); v: (b, h d2, l); ssm_kernel: (h, l); D: (h,)."""
+    from einops import rearrange
+    seqlen = k.shape[-1]
+    fft_size = 2 * seqlen                                                               # fftconv.py:39
+    kv = (rearrange(k, "b (h d1) l -> b d1 1 h l", d1=head_dim)
+          * rearrange(v, "b (h d2) l -> b 1 d2 h l", d2=head_dim))                       # fftconv.py:40-41
+    kv_f = torch.fft.rfft(kv.to(dtype=ssm_kernel.dtype), n=fft_size) / fft_size         # fftconv.py:42
+    ssm_kernel_f = torch.fft.rfft(ssm_kernel, n=fft_size)                               # fftconv.py:43
+    if ssm_kernel_rev is not None:                                                      # fftconv.py:44-46
+        ssm_kernel_f = ssm_kernel_f + torch.fft.rfft(ssm_kernel_rev, n=fft_size).conj()
+    y = torch.fft.irfft(kv_f * ssm_kernel_f, n=fft_size, norm="forward")[..., :seqlen]  # fftconv.py:47
+    out = y + kv * D.unsqueeze(-1)                                                      # fftconv.py:48
+    q = rearrange(q, "b (h d1) l -> b d1 1 h l", d1=head_dim)                           # fftconv.py:49
+    if head_dim > 1:                                                                    # fftconv.py:50-52
+        out = (out * q).sum(dim=1)
+        return rearrange(out, "b d2 h l -> b (h d2) l").to(dtype=k.dtype)
+    return rearrange(out * q, "b 1 1 h l -> b h l").to(dtype=k.dtype)                   # fftconv.py:53-54
 
 
 def causal_conv_direct_f64(u, k, D):

@@ -44,12 +44,37 @@ def main():
             e = ((x - r).norm() / r.norm().clamp_min(1e-30)).item()
             worst = max(worst, e) if dtype == torch.float32 else worst
             assert e < tol, (B, H, L, dtype, e)
-    # options outside the HyenaDNA path are refused, not mis-computed
+    # the 14-argument native seam itself serves the plain form only: the reference's autograd class with gelu=True is refused there,
+    # not mis-computed (fftconv_func of this package composes the H3-form options around the kernels: below)
     try:
         ref_ops.FFTConvFunc.apply(u, k, D, None, True)
         raise SystemExit("gelu=True should have raised")
     except NotImplementedError:
         pass
+    # The H3 form and the element-wise options (round 4): the REFERENCE's own fftconv_h3_ref / fftconv_ref (src/ops/fftconv.py:15-55)
+    # against this package's fftconv_func on the same kernels, and against the oracle's restatement (which this pins).
+    from hyena_dna_amd.fftconv import fftconv_func
+    from oracle import hyena_oracle as O
+    rel = lambda x, r: ((x.double() - r.double()).norm() / r.double().norm().clamp_min(1e-30)).item()
+    for head_dim in (1, 8):
+        b, h, L = 2, 3, 300
+        g = torch.Generator().manual_seed(40 + head_dim)
+        kin, v, q = (torch.randn(b, h * head_dim, L, generator=g) for _ in range(3))
+        ssm = torch.randn(h, L, generator=g) * torch.exp(-3.0 * torch.linspace(0, 1, L))[None] * 0.3
+        rev = torch.randn(h, L, generator=g) * 0.05
+        D = torch.randn(h, generator=g)
+        for r_ in (None, rev):
+            want = ref_ops.fftconv_h3_ref(kin, ssm, D, q, v, head_dim, r_)
+            assert torch.equal(O.fftconv_h3_ref(kin, ssm, D, q, v, head_dim, r_), want)              # the restatement, bit for bit
+            assert rel(fftconv_func(kin, ssm, D, gelu=False, v=v, head_dim=head_dim, q=q, k_rev=r_), want) < 1e-5
+    mask = (torch.rand(2, 4, generator=g) > 0.4).float() * 1.5
+    u4 = torch.randn(2, 4, 600, generator=g)
+    k4 = torch.randn(4, 600, generator=g) * 0.05
+    D4 = torch.randn(4, generator=g)
+    for gelu in (True, False):
+        want = ref_ops.fftconv_ref(u4, k4, D4, mask, gelu=gelu)
+        assert torch.equal(O.fftconv_ref(u4, k4, D4, dropout_mask=mask, gelu=gelu), want)
+        assert rel(fftconv_func(u4, k4, D4, dropout_mask=mask, gelu=gelu), want) < 3e-6
     print(f"B3_OK worst_rel_fp32={worst:.2e}", flush=True)
 
 

@@ -28,10 +28,18 @@ def test_product_refuses_cpu_tensors_and_missing_library(monkeypatch, tmp_path):
 def test_unsupported_options_raise(emu_backend):
     from hyena_dna_amd.fftconv import fftconv_func, fftconv_heads_ref
     u, k, D = torch.randn(1, 2, 16), torch.randn(2, 16), torch.randn(2)
-    for kw in (dict(gelu=True), dict(gelu=False, dropout_mask=torch.ones(1, 2)), dict(gelu=False, head_dim=8),
-               dict(gelu=True, k_rev=k), dict(gelu=False, fftfp16=True), dict(gelu=False, output_hbl_layout=True)):
+    # since round 4 fftconv_func serves the H3-form options (tests/test_fftconv_options.py); what stays refused: the autograd class
+    # called directly with them, head_dim > 1 without v / q, half of the H3 form, a dropout mask on top of the H3 form
+    from hyena_dna_amd.fftconv import FFTConvFunc
+    for kw in (dict(gelu=True), dict(gelu=False, dropout_mask=torch.ones(1, 2)), dict(gelu=False, output_hbl_layout=True)):
         with pytest.raises(NotImplementedError):
-            fftconv_func(u, k, D, **kw)
+            FFTConvFunc.apply(u, k, D, kw.get("dropout_mask"), kw["gelu"], False, kw.get("output_hbl_layout", False))
+    with pytest.raises(ValueError):
+        fftconv_func(u, k, D, gelu=False, head_dim=8)
+    with pytest.raises(ValueError):
+        fftconv_func(u, k, D, gelu=False, q=u)
+    with pytest.raises(NotImplementedError):
+        fftconv_func(u, k, D, gelu=False, v=u, q=u, dropout_mask=torch.ones(1, 2))
     with pytest.raises(NotImplementedError):
         fftconv_heads_ref()
     with pytest.raises(ValueError):
