@@ -154,6 +154,11 @@ def lib():
         L.hyena_inproj_pre_fwd.restype = c_int
         L.hyena_inproj_pre_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_outproj_supported.restype = c_int
+        L.hyena_outproj_supported.argtypes = [c_int, c_int, c_int, c_int]
+        L.hyena_outproj_gate_fwd.restype = c_int
+        L.hyena_outproj_gate_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_int, c_int, c_int, c_int, c_int, c_void_p]
         L.hyena_colsum_supported.restype = c_int
         L.hyena_colsum_supported.argtypes = [ctypes.c_long, c_int, c_int]
         L.hyena_colsum_partial_floats.restype = c_size_t
@@ -505,6 +510,28 @@ def inproj_pre_fwd(u, W, bin_, w, b, L):
         check(lib().hyena_inproj_pre_fwd(u.data_ptr(), W.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
                                          xT.data_ptr(), vg.data_ptr(), B, Lx, int(L), D, dtype_code(u.dtype), _backend.stream(u.device)))
     return xT, vg
+
+
+def outproj_supported(B, L, Lx, D, dtype):
+    code = _DTYPES.get(dtype)
+    return code is not None and code != 0 and Lx % 8 == 0 and bool(lib().hyena_outproj_supported(int(B), int(L), int(D), code))
+
+
+def outproj_gate_fwd(y, xT, bin_, w, b, W, bias, want_z):
+    """y (B, D, L) conv output, xT (3D, B, Lx), bin_ / w / b as cm_post_fwd, W (D, D) out_proj weight (element type of y), bias (D,) fp32
+    [values already rounded to the element type] or None -> out (B, L, D) = (y * x0)^T W^T + bias, zT (D, B, L) = y * x0 if want_z else
+    None (bit-identical to cm_post_fwd).  One launch: the gate rides on the operand load of the matrix-core product."""
+    _require_gpu(y, "y")
+    B, D, L = y.shape
+    assert W.shape == (D, D) and W.dtype == y.dtype and xT.dtype == y.dtype and W.is_contiguous() and y.is_contiguous() and xT.is_contiguous()
+    out = torch.empty((B, L, D), dtype=y.dtype, device=y.device)
+    zT = torch.empty((D, B, L), dtype=y.dtype, device=y.device) if want_z else None
+    with _backend.guard(y.device):
+        check(lib().hyena_outproj_gate_fwd(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                           W.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(),
+                                           None if zT is None else zT.data_ptr(), B, L, xT.shape[2], D, dtype_code(y.dtype),
+                                           _backend.stream(y.device)))
+    return out, zT
 
 
 def colsum(x2):

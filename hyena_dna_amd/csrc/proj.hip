@@ -34,6 +34,14 @@ void mlp_schedule(size_t P, int ncg, pj::MlpArgs* a, int* runs_out, int* grid_ou
     *runs_out = runs;
     *grid_out = ((runs + 7) / 8) * 8 * ncg;
 }
+template <int K, int DT>
+int launch_outproj(const pj::OutProjArgs& a, int grid, void* stream) {
+    typedef pj::OpCfg<K> C;
+    static thread_local int done = -1;
+    hy_allow_lds(pj::outproj_gate_fwd_kernel<K, DT>, C::LDS, &done);
+    HY_LAUNCH((pj::outproj_gate_fwd_kernel<K, DT>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
 template <int MODE>
 int dispatch_mlp(const pj::MlpArgs& a, int K, int dtype, int grid, void* stream) {
     if (K == 256) return dtype == HYENA_BF16 ? launch_mlp<256, DT_BF16, MODE>(a, grid, stream) : launch_mlp<256, DT_F16, MODE>(a, grid, stream);
@@ -101,6 +109,32 @@ int hyena_mlp_dh_dgelu_bwd(const void* dy, const void* W2T, const void* a_in, vo
     int runs, grid;
     mlp_schedule((size_t)P, N / 256, &a, &runs, &grid);
     return dispatch_mlp<1>(a, K, dtype, grid, stream);
+}
+
+int hyena_outproj_supported(int B, int L, int D, int dtype) {
+    if (!(D == 128 || D == 256) || !(dtype == HYENA_BF16 || dtype == HYENA_F16)) return 0;
+    if (B < 1 || L < 64 || L % 64 != 0) return 0;          // whole 64-position tiles, 16-byte aligned row pieces
+    return (size_t)B * (size_t)L < ((size_t)1 << 31) ? 1 : 0;
+}
+
+int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
+                           const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int dtype, void* stream) {
+    if (y == nullptr || xT == nullptr || w == nullptr || b == nullptr || W == nullptr || out == nullptr || L > Lx || Lx % 8 != 0 ||
+        !hyena_outproj_supported(B, L, D, dtype))
+        return HYENA_ERR_BAD_ARG;
+    pj::OutProjArgs a;
+    a.y = y; a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.W = W; a.bias = bias; a.out = out; a.zT = zT;
+    a.B = B; a.L = L; a.Lx = Lx; a.D = D;
+    a.tiles_per_seq = (L + pj::PJ_NT - 1) / pj::PJ_NT;
+    a.tiles = B * a.tiles_per_seq;
+    // two workgroups per CU are resident; a few runs per slot balance the tail, runs of >= 8 tiles amortise the weight load
+    int runs = 256 * 8;
+    if (runs > a.tiles) runs = a.tiles;
+    a.tiles_per_wg = (a.tiles + runs - 1) / runs;
+    if (a.tiles_per_wg < 8 && a.tiles >= 8) a.tiles_per_wg = 8;
+    runs = (a.tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    if (D == 256) return dtype == HYENA_BF16 ? launch_outproj<256, DT_BF16>(a, runs, stream) : launch_outproj<256, DT_F16>(a, runs, stream);
+    return dtype == HYENA_BF16 ? launch_outproj<128, DT_BF16>(a, runs, stream) : launch_outproj<128, DT_F16>(a, runs, stream);
 }
 
 int hyena_proj_supported(int B, int Lx, int D, int dtype) {

@@ -681,5 +681,207 @@ __global__ void __launch_bounds__(PJ_THREADS) colsum_final_kernel(ColsumArgs a) 
     if (q == 0 && col < a.N) a.out[col] = ((red[threadIdx.x] + red[threadIdx.x + 64]) + red[threadIdx.x + 128]) + red[threadIdx.x + 192];
 }
 
+
+// =============================================================================================================================
+// The output projection with the second gate on its operand load (round 4).  hyena.py:432-440 (order 2):
+//     y = y * x[0]                                   (b, d, l) element-wise, x[0] = short_filter(in_proj(u))[0:D]      hyena.py:432
+//     y = rearrange(y, 'b d l -> b l d');  y = self.out_proj(y)                                                        hyena.py:439-440
+// Until round 4: cm_post_fwd (cm_kernels.h) wrote zT = y x0 channel-major and a library GEMM read it back.  Here ONE kernel reads the
+// long convolution's output y (B, D, L) and the x0 third of xT (3D, B, Lx) -- both rows contiguous along l -- and writes
+// out (B, L, N) = z W^T + b; zT (D, B, L) is written on the side only when the caller keeps it for the weight gradient.
+//
+// The product contracts over the channels, the operands arrive position-contiguous: the 64 x K tile of z has to be transposed on its
+// way to the matrix cores.  A wavefront fetches 8 channel rows x 128 bytes per access (lane = (row r, 16-byte piece c): every access
+// is 8 whole 128-byte lines), forms z = round(y * shortconv(x0)) for its 8 positions (the arithmetic of cm_post_fwd, FMA by FMA), swaps
+// half of them with the lane holding the neighbouring channel (lane ^ 8) so that it owns (k, k + 1) pairs for 4 positions, and writes
+// 4-byte pairs into the LDS tile.  Tile layout: chunk-major, swizzled --
+//     element (pos, k) at byte  (k / 8) * 1024 + (pos ^ (pos >> 3)) * 16 + (k % 8) * 2
+// i.e. for every 8 channels one 1 KB block of 64 sixteen-byte slots, the slot of a position XOR-ed with its octet: an MFMA A-fragment
+// (8 consecutive channels of one position) is ONE aligned 16-byte read, conflict-free for the 16-lane groups of ds_read_b128 (checked
+// group by group for both 32-position halves), and the 4-byte writes of a wavefront hit every bank exactly twice (free for ds_write_b32).
+// No padding: 64 x K x 2 bytes.  The rest is the weights-stationary scheme of mlp_kernel: a wavefront keeps N / 4 output channels x K
+// weights as B fragments, the four wavefronts share the z tile, accumulators leave through a wavefront-private [position][channel]
+// tile as 16-byte row pieces.  76 KB of LDS at K = 256: two workgroups per CU.
+// =============================================================================================================================
+#ifndef OP_NB256
+#define OP_NB256 4
+#endif
+template <int K> struct OpCfg {
+    static_assert(K == 128 || K == 256, "d_model of the HyenaDNA models");
+    static constexpr int KS = K / 16;
+    static constexpr int UW = K / PJ_WAVES;                   // output channels per wavefront (N = K)
+    static constexpr int UT = UW / 32;                        // 32-channel MFMA tiles per wavefront
+    static constexpr int RND = K / 32;                        // staging rounds: 4 wavefronts x 8 rows each
+    static constexpr int NB = K == 256 ? OP_NB256 : 2;        // ... fetched and transposed in NB batches (register budget, see the kernel)
+    static constexpr int ZBUF = PJ_NT * K * 2;                // the z tile
+    static constexpr int TAPB = K * 8 * 4;                    // per channel 8 floats: w0 w1 w2 b_sc b_in - - -
+    static constexpr int EROW = (UW + 8) * 2;                 // epilogue tile row [position][channel], +16 bytes: conflict-free 16-byte reads
+    static constexpr int EBUF = 32 * EROW;                    // 32 positions at a time
+    static constexpr int PCS = UW / 8;                        // 16-byte pieces per position and wavefront
+    static constexpr size_t LDS = (size_t)ZBUF + TAPB + PJ_WAVES * (size_t)EBUF;
+};
+
+struct OutProjArgs {
+    const void* y;        // (B, D, L) long-convolution output
+    const void* xT;       // (3D, B, Lx) in_proj output without its bias; rows [0, D) are used
+    const float* bin;     // (3D,) in_proj bias or null
+    const float* w;       // (3D, 3) short-filter taps
+    const float* b;       // (3D,) short-filter bias
+    const void* W;        // (N, K) out_proj weight, N = K = D
+    const float* bias;    // (N,) fp32 (values already rounded to the element type) or null
+    void* out;            // (B, L, N)
+    void* zT;             // (D, B, L) or null
+    int B, L, Lx, D;
+    int tiles_per_seq, tiles, tiles_per_wg;
+};
+
+__device__ __forceinline__ int op_slot(int pos) { return pos ^ (pos >> 3); }
+
+template <int K, int DT>
+__global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProjArgs a) {
+    typedef OpCfg<K> C;
+    typedef typename Elem<DT>::type elem_t;
+    HY_SMEM(smem);
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hb = lane >> 5;
+    const int r = lane >> 3, c = lane & 7;                    // staging role: row of the round, 16-byte piece (8 positions)
+    const int run = blockIdx.x;
+    const int t_begin = run * a.tiles_per_wg;
+    if (t_begin >= a.tiles) return;
+    const int t_end = (t_begin + a.tiles_per_wg < a.tiles) ? t_begin + a.tiles_per_wg : a.tiles;
+    const int n0 = wave * C::UW;                              // first output channel of this wavefront
+    const int N = K;
+
+    HY_LDS char* const zt = HY_LDS_CAST(char, smem);
+    HY_LDS float* const taps = reinterpret_cast<HY_LDS float*>(HY_LDS_CAST(char, smem) + C::ZBUF);
+    HY_LDS char* const et = HY_LDS_CAST(char, smem) + C::ZBUF + C::TAPB + wave * C::EBUF;
+
+    // short-filter taps of the x0 channels -> LDS (read per round below; 5 of 8 floats per channel)
+    for (int k = tid; k < K; k += PJ_THREADS) {
+        taps[k * 8 + 0] = a.w[k * 3]; taps[k * 8 + 1] = a.w[k * 3 + 1]; taps[k * 8 + 2] = a.w[k * 3 + 2];
+        taps[k * 8 + 3] = a.b[k];
+        taps[k * 8 + 4] = a.bin != nullptr ? a.bin[k] : 0.f;
+    }
+    // stationary operand: UW weight rows as B fragments (column = output channel j of tile ut, k = 16 ks + 8 hb ...)
+    Frag wf[C::UT][C::KS];
+    HY_UNROLL
+    for (int ut = 0; ut < C::UT; ++ut) {
+        const char* row = reinterpret_cast<const char*>(a.W) + ((size_t)(n0 + ut * 32 + j) * K + 8 * hb) * 2;
+        HY_UNROLL
+        for (int ks = 0; ks < C::KS; ++ks) wf[ut][ks] = ld16(row + ks * 32);
+    }
+    float bias[C::UT];
+    HY_UNROLL
+    for (int ut = 0; ut < C::UT; ++ut) bias[ut] = a.bias != nullptr ? a.bias[n0 + ut * 32 + j] : 0.f;
+
+    const elem_t* const yb = reinterpret_cast<const elem_t*>(a.y);
+    const elem_t* const xb = reinterpret_cast<const elem_t*>(a.xT);
+    elem_t* const zb = reinterpret_cast<elem_t*>(a.zT);
+    elem_t* const ob = reinterpret_cast<elem_t*>(a.out);
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int b = t / a.tiles_per_seq, l0 = (t - b * a.tiles_per_seq) * PJ_NT;
+        const int lp = l0 + 8 * c;                                    // this lane's first position
+        // The rounds go in NB batches (fetch a batch, transpose it into the tile, fetch the next): all 8 rounds of K = 256 in flight at
+        // once are 72 registers next to the 128 that hold the weights -- hipcc spilled 61 - 126 registers; 14 with two batches, none
+        // with four.  The CU's other workgroup covers the extra round trips.
+        HY_UNROLL
+        for (int half = 0; half < C::NB; ++half) {
+            constexpr int HR = C::RND / C::NB;
+            // ---- global -> registers: y and x0 pieces of this half's rounds (+ the two positions before the tile for piece 0) ----
+            Frag yr[HR], xr[HR];
+            uint32_t halo[HR];
+            HY_UNROLL
+            for (int ii = 0; ii < HR; ++ii) {
+                const int i = half * HR + ii;
+                const int k = 32 * i + 8 * wave + r;
+                const elem_t* yrow = yb + ((size_t)b * a.D + k) * a.L;
+                const elem_t* xrow = xb + ((size_t)k * a.B + b) * a.Lx;
+                yr[ii] = ld16(yrow + lp);                           // (L is a multiple of 64: every tile is whole, every piece aligned)
+                xr[ii] = ld16(xrow + lp);
+                uint32_t h2 = 0u;
+                if (c == 0 && l0 >= 2) __builtin_memcpy(&h2, xrow + (l0 - 2), 4);
+                halo[ii] = h2;
+            }
+            if (half == 0) __syncthreads();                          // every wavefront is done with the previous z tile (first tile: the taps are in LDS)
+            // ---- z = round(y * shortconv(x0)) -> pairs of channels -> the swizzled tile ----
+            HY_UNROLL
+            for (int ii = 0; ii < HR; ++ii) {
+                const int i = half * HR + ii;
+                const int k = 32 * i + 8 * wave + r;
+                const uint32_t prev = HY_SHFL_U32(xr[ii].w[3], lane - 1);        // positions lp - 2, lp - 1 (lane - 1 = same row, piece c - 1)
+                const uint32_t hw = c == 0 ? halo[ii] : prev;
+                elem_t xe[10], ye[8];
+                __builtin_memcpy(xe, &hw, 4);
+                __builtin_memcpy(xe + 2, xr[ii].w, 16);
+                __builtin_memcpy(ye, yr[ii].w, 16);
+                const float w0 = taps[k * 8], w1 = taps[k * 8 + 1], w2 = taps[k * 8 + 2], bsc = taps[k * 8 + 3], bin = taps[k * 8 + 4];
+                elem_t ze[8];
+                HY_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int l = lp + e;
+                    const float x0 = l >= 2 ? Elem<DT>::dec(xe[e]) + bin : 0.f, x1 = l >= 1 ? Elem<DT>::dec(xe[e + 1]) + bin : 0.f,
+                                x2 = Elem<DT>::dec(xe[e + 2]) + bin;
+                    const float c0 = __builtin_fmaf(w2, x2, __builtin_fmaf(w1, x1, __builtin_fmaf(w0, x0, bsc)));   // = cm_sc
+                    ze[e] = Elem<DT>::cvt(Elem<DT>::dec(ye[e]) * c0);                                                  // = cm_post_fwd
+                }
+                Frag zp;
+                __builtin_memcpy(zp.w, ze, 16);
+                if (zb != nullptr) st16(zb + ((size_t)k * a.B + b) * a.L + lp, zp);
+                // lanes r (even) and r + 1 (= lane ^ 8) hold channels k, k + 1 for the same 8 positions: the even one takes positions
+                // 0..3 of both, the odd one positions 4..7
+                const bool odd = (r & 1) != 0;
+                const uint32_t s0 = odd ? zp.w[0] : zp.w[2], s1 = odd ? zp.w[1] : zp.w[3];
+                const uint32_t g0 = HY_SHFL_U32(s0, lane ^ 8), g1 = HY_SHFL_U32(s1, lane ^ 8);
+                const uint32_t m0 = odd ? zp.w[2] : zp.w[0], m1 = odd ? zp.w[3] : zp.w[1];      // my own channel's 4 positions
+                const uint32_t lo0 = odd ? g0 : m0, lo1 = odd ? g1 : m1;                         // even channel (k & ~1)
+                const uint32_t hi0 = odd ? m0 : g0, hi1 = odd ? m1 : g1;                         // odd channel
+                const uint32_t pr[4] = {(lo0 & 0xffffu) | (hi0 << 16), (lo0 >> 16) | (hi0 & 0xffff0000u),
+                                        (lo1 & 0xffffu) | (hi1 << 16), (lo1 >> 16) | (hi1 & 0xffff0000u)};
+                const int kk = k & ~1, pp = 8 * c + (odd ? 4 : 0);
+                HY_LDS char* const base = zt + (kk >> 3) * 1024 + (kk & 7) * 2;
+                HY_UNROLL
+                for (int e = 0; e < 4; ++e) *reinterpret_cast<HY_LDS uint32_t*>(base + op_slot(pp + e) * 16) = pr[e];
+                HY_SCHED_FENCE();                                   // one round at a time: interleaved, their temporaries spill
+            }
+        }
+        __syncthreads();
+        // ---- out tile = z W^T on the matrix cores, 32 positions at a time (both halves' accumulators at once -- 64 registers next
+        //      to the 128 of the weights -- made hipcc spill a quarter of the weights) ----
+        HY_UNROLL
+        for (int pt = 0; pt < 2; ++pt) {
+            acc_t acc[C::UT];
+            HY_UNROLL
+            for (int ut = 0; ut < C::UT; ++ut) {
+                HY_UNROLL
+                for (int q = 0; q < 16; ++q) acc[ut][q] = 0.f;
+            }
+            HY_UNROLL
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const Frag af = lds_ld16(zt + (2 * ks + hb) * 1024 + op_slot(pt * 32 + j) * 16);
+                HY_UNROLL
+                for (int ut = 0; ut < C::UT; ++ut) acc[ut] = mfma<DT>(af, wf[ut][ks], acc[ut]);
+            }
+            // epilogue, wavefront-private: register q of lane (j, hb) = position pt 32 + pj_row(q, hb), channel ut 32 + j
+            HY_WAVE_SYNC_PJ();
+            HY_UNROLL
+            for (int ut = 0; ut < C::UT; ++ut) {
+                HY_UNROLL
+                for (int q = 0; q < 16; ++q) {
+                    const int pos = pj_row(q, hb), un = ut * 32 + j;
+                    *(reinterpret_cast<HY_LDS elem_t*>(et + pos * C::EROW) + un) = Elem<DT>::cvt(acc[ut][q] + bias[ut]);
+                }
+            }
+            HY_WAVE_SYNC_PJ();
+            HY_UNROLL
+            for (int m = 0; m < C::PCS / 2; ++m) {
+                const int pos = lane / C::PCS + (64 / C::PCS) * m, pc = lane % C::PCS;        // 32 positions x PCS pieces = 64 lanes x PCS / 2
+                st16(ob + (((size_t)b * a.L + l0 + pt * 32 + pos) * N + n0 + 8 * pc), lds_ld16(et + pos * C::EROW + pc * 16));
+            }
+            HY_SCHED_FENCE();
+        }
+        HY_WAVE_SYNC_PJ();
+    }
+}
+
 }  // namespace pj
 }  // namespace hyena

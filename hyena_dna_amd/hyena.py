@@ -20,7 +20,7 @@ from .fftconv import fftconv_func, fftconv_ref
 from .filter import fused_filter_ok, hyena_filter_dl
 import os
 
-from .mixer import hyena_mixer_core, hyena_mixer_core_cm
+from .mixer import hyena_mixer_core, hyena_mixer_core_cm, hyena_mixer_out_cm, mixer_out_supported
 from .projection import hyena_linear, in_proj_cm, in_proj_pre_cm, out_proj_cm
 
 # Layout of the tensors between the operator's two projections: channel-major (x^T written by the in_proj GEMM, z^T read by
@@ -280,9 +280,14 @@ class HyenaOperator(nn.Module):
                 # from its epilogue -- csrc/proj_kernels.h; otherwise the library GEMM and vg = None)
                 xT, vg = in_proj_pre_cm(u, self.in_proj.weight, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias,
                                         l_filter)
-                zT = hyena_mixer_core_cm(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter,
-                                         vg=vg)
-                y = out_proj_cm(zT, self.out_proj.weight, self.out_proj.bias)   # activation is the identity (_fused_ok)
+                if l_filter > 0 and xT.shape[1] > 0 and mixer_out_supported(xT, l_filter, self.out_proj.weight):
+                    # out_proj as this package's matrix-core kernel, the `* x0` gate on its operand load (csrc/proj_kernels.h, round 4)
+                    y = hyena_mixer_out_cm(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter,
+                                           vg, self.out_proj.weight, self.out_proj.bias)
+                else:
+                    zT = hyena_mixer_core_cm(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter,
+                                             vg=vg)
+                    y = out_proj_cm(zT, self.out_proj.weight, self.out_proj.bias)   # activation is the identity (_fused_ok)
             else:
                 x = hyena_linear(u, self.in_proj.weight, self.in_proj.bias)     # (B, L, 3D), hipBLASLt GEMM
                 z = hyena_mixer_core(x, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter)

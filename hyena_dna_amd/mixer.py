@@ -15,7 +15,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["hyena_mixer_core", "HyenaMixerFunc", "hyena_mixer_core_cm", "HyenaMixerCMFunc"]
+__all__ = ["hyena_mixer_core", "HyenaMixerFunc", "hyena_mixer_core_cm", "HyenaMixerCMFunc", "hyena_mixer_out_cm", "HyenaMixerOutCMFunc",
+           "mixer_out_supported"]
 
 
 class HyenaMixerFunc(torch.autograd.Function):
@@ -136,3 +137,102 @@ def hyena_mixer_core_cm(xT, b_in, sf_weight, sf_bias, k, bias, L, vg=None):
         zero = 0 * (b_in.sum() + sf_weight.sum() + sf_bias.sum() + k.sum() + bias.sum())
         return xT[:D, :, :L] * 0 + zero.to(xT.dtype)
     return HyenaMixerCMFunc.apply(xT, b_in, sf_weight, sf_bias, k, bias, L, vg)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The channel-major core WITH out_proj (round 4): the second gate rides on the operand load of a hand-written matrix-core kernel
+# (csrc/proj_kernels.h::outproj_gate_fwd_kernel, include/hyena_proj.h) instead of cm_post_fwd writing zT for a library GEMM to read back.
+# ---------------------------------------------------------------------------------------------------------------------
+import os as _os
+
+OUTPROJ_MFMA = _os.environ.get("HYENA_OUTPROJ_MFMA", "1") != "0"      # A/B knob: 0 = cm_post_fwd + library GEMM
+
+
+def mixer_out_supported(xT, L, out_weight):
+    """16-bit channel-major tensors, d_model 128 / 256, whole 64-position tiles (L % 64 == 0, Lx % 8 == 0)"""
+    D3, B, Lx = xT.shape
+    D = D3 // 3
+    return (OUTPROJ_MFMA and xT.dtype in (torch.bfloat16, torch.float16) and tuple(out_weight.shape) == (D, D)
+            and (xT.is_cuda or _lib._backend.name != "hip") and _lib.outproj_supported(B, L, Lx, D, xT.dtype))
+
+
+class HyenaMixerOutCMFunc(torch.autograd.Function):
+    """out (B, L, D) = out_proj(fftconv(v * x1, k, bias) * x0): HyenaMixerCMFunc followed by projection.OutProjCMFunc, with the forward's
+    ``zT = y * x0`` formed inside the projection kernel (and written out only when out_proj's weight gradient will need it).  The backward
+    is the two functions' backward unchanged: dzT and the weight gradient are library GEMMs (contractions over d_model / the positions)."""
+
+    @staticmethod
+    def forward(ctx, xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out):
+        D3, B, Lx = xT.shape
+        D = D3 // 3
+        xc = xT.contiguous()
+        bi = b_in.detach().to(torch.float32).contiguous()
+        w = sf_weight.detach().to(torch.float32).reshape(D3, 3).contiguous()
+        b = sf_bias.detach().to(torch.float32).contiguous()
+        kf = k.detach().to(torch.float32).contiguous()
+        bf = bias.detach().to(torch.float32).reshape(D).contiguous()
+        if vg is None:
+            vg = _lib.cm_pre_fwd(xc, bi, w, b, L)
+        want_grad = any(ctx.needs_input_grad[:6]) or ctx.needs_input_grad[8] or ctx.needs_input_grad[9]
+        spectra = None
+        if want_grad and _lib.save_spectra_default(B, D, L, device=vg.device):
+            y, spectra = _lib.fftconv_fwd(vg, kf, bf, save=True)
+        else:
+            y = _lib.fftconv_fwd(vg, kf, bf, grad=want_grad)
+        wo = w_out.detach().to(xc.dtype).contiguous()
+        bo = None if b_out is None else b_out.detach().to(xc.dtype).to(torch.float32).contiguous()      # rounded as autocast rounds it
+        out, zT = _lib.outproj_gate_fwd(y, xc, bi, w, b, wo, bo, want_z=bool(ctx.needs_input_grad[8]))
+        ctx.save_for_backward(xc, bi, w, b, kf, bf, y, wo, zT if zT is not None else torch.empty(0, device=xc.device))
+        ctx.has_z = zT is not None
+        ctx.spectra = spectra
+        ctx.meta = (b_in.dtype, sf_weight.shape, sf_weight.dtype, sf_bias.dtype, k.dtype, bias.shape, bias.dtype, L, w_out.dtype,
+                    None if b_out is None else b_out.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .projection import _bmm_f32, split_count
+        xc, bi, w, b, kf, bf, y, wo, zT = ctx.saved_tensors
+        bin_dtype, w_shape, w_dtype, b_dtype, k_dtype, bias_shape, bias_dtype, L, wo_dtype, bo_dtype = ctx.meta
+        D3, B, Lx = xc.shape
+        D = D3 // 3
+        rows = B * L
+        dy2 = dout.to(xc.dtype).reshape(rows, D).contiguous()
+        # ---- out_proj's backward (projection.OutProjCMFunc.backward) ----
+        dW = dbo = None
+        if ctx.needs_input_grad[8]:
+            z2 = (zT if ctx.has_z else _lib.cm_post_fwd(y, xc, bi, w, b)).reshape(D, rows)
+            s = split_count(rows)
+            body = (rows // s) * s
+            dW = _bmm_f32(dy2[:body].view(s, rows // s, D).transpose(1, 2), z2[:, :body].reshape(D, s, rows // s).permute(1, 2, 0)).sum(0)
+            if body < rows:
+                dW = dW + torch.mm(dy2[body:].t().float(), z2[:, body:].t().float())
+            dW = dW.to(wo_dtype)
+        if bo_dtype is not None and ctx.needs_input_grad[9]:
+            dbo = _lib.colsum(dy2).to(bo_dtype)
+        if not any(ctx.needs_input_grad[:6]):
+            return None, None, None, None, None, None, None, None, dW, dbo
+        dzT = torch.mm(wo.t(), dy2.t()).view(D, B, L)                      # channel-major, straight from the GEMM
+        # ---- the core's backward (HyenaMixerCMFunc.backward) ----
+        dxT = torch.zeros_like(xc) if Lx > L else torch.empty_like(xc)
+        part = _lib.cm_partials(xc, L)
+        dy = _lib.cm_post_bwd(dzT.contiguous(), y, xc, bi, w, b, dxT, part)
+        need_vg = ctx.spectra is None or _lib.lib().hyena_fftconv_plan(int(L)) == _lib.PLAN_ONCHIP
+        vg = _lib.cm_pre_fwd(xc, bi, w, b, L) if need_vg else None
+        need_dk = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
+        dvg, dk, dbias = _lib.fftconv_bwd(dy, vg, kf, bf, need_du=True, need_dk=need_dk, saved=ctx.spectra)
+        ctx.spectra = None
+        _lib.cm_pre_bwd(dvg, xc, bi, w, b, dxT, part)
+        red = part[:, :, :5].sum(dim=1)
+        dw = red[:, :3].reshape(w_shape).to(w_dtype)
+        db = red[:, 3].to(b_dtype)
+        dbin = red[:, 4].to(bin_dtype)
+        return (dxT, dbin, dw, db, dk.to(k_dtype) if dk is not None else None,
+                dbias.reshape(bias_shape).to(bias_dtype) if dbias is not None else None, None, None, dW, dbo)
+
+
+def hyena_mixer_out_cm(xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out):
+    """(3D, B, Lx) -> (B, L, D): the channel-major core and out_proj in one autograd function (see HyenaMixerOutCMFunc); the caller
+    checks mixer_out_supported first.  Runs with autocast disabled on tensors already in the compute type, like projection.out_proj_cm."""
+    with torch.autocast("cuda" if xT.is_cuda else "cpu", enabled=False):
+        return HyenaMixerOutCMFunc.apply(xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out)

@@ -31,6 +31,23 @@ int hyena_inproj_pre_fwd(const void* u, const void* W, const float* bin, const f
                          int B, int Lx, int Lc, int D, int dtype, void* stream);
 
 
+/* ---- out_proj with the second gate on its operand load (round 4) -----------------------------------------------------------------
+ * Replaces, for the same operator configuration, these lines of HyenaOperator.forward in ONE launch (until round 4:
+ * hyena_cm_post_fwd + a library GEMM):
+ *     y = y * x[0]                                      hyena.py:432   (x[0] = the first third of short_filter(in_proj(u)))
+ *     y = rearrange(y, 'b d l -> b l d')                hyena.py:439
+ *     y = self.out_proj(y)                              hyena.py:440   nn.Linear(D, D)
+ * Tensors: y (B, D, L) the long convolution's output; xT (3D, B, Lx) as above (rows [0, D) are read, bin / w / b likewise);
+ * W (D, D) out_proj weight, bias (D,) fp32 [values already rounded to the element type] or NULL;
+ * out (B, L, D);  zT (D, B, L) = y * x0 or NULL -- written only if the caller keeps it for the weight gradient (bit-identical to
+ * hyena_cm_post_fwd).  L <= Lx, L a multiple of 64 and Lx of 8 (whole tiles, aligned 16-byte pieces: hyena_outproj_supported; other
+ * lengths keep hyena_cm_post_fwd + the library GEMM).  Arithmetic: z = round(y * shortconv(xT + bin)) exactly as hyena_cm_post_fwd, then 16-bit operands with
+ * fp32 accumulation on v_mfma_f32_32x32x16, out = one rounding of (sum + bias).  Asynchronous on `stream`; no workspace; no state. */
+int hyena_outproj_supported(int B, int L, int D, int dtype);
+int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
+                           const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int dtype, void* stream);
+
+
 /* ---- the block's MLP (flash_attn.modules.mlp.Mlp = simple_lm.py:191-211; long_conv_lm.py:117-123: fc1 -> tanh-GELU -> fc2) ---------
  * The two products contracting over d_model, position-major, with the reference's element-wise passes in their epilogues:
  *   forward   a = x W1^T + b1,  h = gelu_tanh(a)          x (P, K), W1 (N, K), b1 (N,) fp32 or NULL [values already rounded to the

@@ -137,3 +137,62 @@ def test_colsum_on_gpu(gpu_lib, P, N, dtype):
     ref = x.double().sum(0)
     assert out.dtype == torch.float32 and ((out.double() - ref).abs() <= 2e-6 * x.double().abs().sum(0) + 1e-5).all()
     assert torch.equal(out, gpu_lib.colsum(x))
+
+
+@pytest.mark.parametrize("B,L,Lx,D,dtype", [(8, 1024, 1024, 128, torch.bfloat16), (8, 32768, 32768, 256, torch.bfloat16),
+                                            (2, 160000, 160000, 256, torch.bfloat16), (1, 1048576, 1048576, 256, torch.bfloat16),
+                                            (3, 4096, 4104, 128, torch.float16), (2, 70016, 70016, 256, torch.float16)])
+def test_outproj_gate_fwd_on_gpu(gpu_lib, B, L, Lx, D, dtype):
+    """The fused out_proj kernel (round 4) on the MI355X through the C ABI: zT BIT-IDENTICAL to cm_post_fwd, out against the library
+    GEMM on that zT (one rounding of an fp32 sum either way: at most an ulp apart, almost everywhere identical), a slice against the
+    fp64 product, determinism, the contract shapes."""
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(L + D)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
+    y = rn(B, D, L).to(dtype)
+    xT = (rn(3 * D, B, Lx) * 0.5).to(dtype)
+    bin_, w, b = rn(3 * D) * 0.1, rn(3 * D, 3) * 0.5, rn(3 * D) * 0.1
+    W = (rn(D, D) / D ** 0.5).to(dtype)
+    bias = (rn(D) * 0.1).to(dtype)
+    assert gpu_lib.outproj_supported(B, L, Lx, D, dtype)
+    out, zT = gpu_lib.outproj_gate_fwd(y, xT, bin_, w, b, W, bias.float(), want_z=True)
+    z_ref = gpu_lib.cm_post_fwd(y, xT, bin_, w, b)
+    assert torch.equal(zT, z_ref)
+    lib = torch.addmm(bias, z_ref.reshape(D, B * L).t(), W.t()).view(B, L, D)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert ((out.float() - lib.float()).abs() <= 2 * eps * lib.float().abs() + 1e-5).all()
+    assert (out != lib).float().mean().item() < 0.02
+    pos = torch.arange(0, B * L, max(1, B * L // 997), device=dev)
+    z64 = z_ref.reshape(D, B * L)[:, pos].t().double()
+    ref = z64 @ W.double().t() + bias.double()
+    got = out.reshape(B * L, D)[pos].double()
+    assert ((got - ref).abs() <= 1.01 * eps * ref.abs() + 2e-6 * z64.abs().sum(1, keepdim=True) + 1e-30).all()
+    out2, z2 = gpu_lib.outproj_gate_fwd(y, xT, bin_, w, b, W, bias.float(), want_z=False)
+    assert z2 is None and torch.equal(out2, out)
+
+
+def test_operator_uses_the_fused_out_proj_and_matches_the_library_path(gpu_lib, monkeypatch):
+    """HyenaOperator under bf16 autocast: HyenaMixerOutCMFunc (the kernel really runs) vs HYENA_OUTPROJ_MFMA=0, output and every
+    gradient to 16-bit rounding."""
+    import hyena_dna_amd.mixer as MX
+    from hyena_dna_amd.hyena import HyenaOperator
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(6)
+    B, L, D = 2, 8192, 256
+    op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10).to(dev)
+    u0 = torch.randn(B, L, D, device=dev)
+    dy = torch.randn(B, L, D, device=dev)
+    calls, real = [], gpu_lib.outproj_gate_fwd
+    monkeypatch.setattr(gpu_lib, "outproj_gate_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(MX, "OUTPROJ_MFMA", on)
+        op.zero_grad(set_to_none=True)
+        u = u0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yy = op(u)
+        yy.float().backward(dy)
+        res.append([yy.float(), u.grad.float()] + [p.grad.float() for _, p in sorted(op.named_parameters()) if p.grad is not None])
+    assert len(calls) == 1 and len(res[0]) == len(res[1])
+    for a, b_ in zip(*res):
+        assert ((a - b_).norm() / b_.norm().clamp_min(1e-20)).item() < 1.5e-2

@@ -165,3 +165,69 @@ def test_colsum_kernel(emu_backend, P, N, dtype):
     # shapes the kernel does not serve fall back to torch's reduction
     y = torch.randn(10, 96).to(dtype)
     assert torch.allclose(emu_backend.colsum(y), y.float().sum(0))
+
+
+@pytest.mark.parametrize("B,L,Lx,D,dtype", [(1, 64, 64, 128, torch.bfloat16), (2, 192, 200, 128, torch.float16), (1, 128, 128, 256, torch.bfloat16),
+                                            (3, 64, 72, 256, torch.float16)])
+def test_outproj_gate_fwd_vs_cm_post_and_gemm(emu_backend, B, L, Lx, D, dtype):
+    """The fused out_proj kernel (csrc/proj_kernels.h::outproj_gate_fwd_kernel): zT bit-identical to cm_post_fwd, out = the library
+    product of that zT with the weight (+ bias), one rounding; with and without the zT side output; L < Lx (l_max cut)."""
+    g = torch.Generator().manual_seed(B * 1000 + L + D)
+    y = torch.randn(B, D, L, generator=g).to(dtype)
+    xT = (torch.randn(3 * D, B, Lx, generator=g) * 0.5).to(dtype)
+    bin_ = torch.randn(3 * D, generator=g) * 0.1
+    w = torch.randn(3 * D, 3, generator=g) * 0.5
+    b = torch.randn(3 * D, generator=g) * 0.1
+    W = (torch.randn(D, D, generator=g) / D ** 0.5).to(dtype)
+    bias = (torch.randn(D, generator=g) * 0.1).to(dtype).float()
+    assert emu_backend.outproj_supported(B, L, Lx, D, dtype) and not emu_backend.outproj_supported(B, L + 1, Lx + 8, D, dtype)
+    out, zT = emu_backend.outproj_gate_fwd(y, xT, bin_, w, b, W, bias, want_z=True)
+    z_ref = emu_backend.cm_post_fwd(y, xT, bin_, w, b)
+    assert torch.equal(zT, z_ref)
+    want = (z_ref.reshape(D, B * L).t().float() @ W.float().t() + bias).reshape(B, L, D)
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert out.shape == (B, L, D) and out.dtype == dtype
+    assert ((out.float() - want).abs() <= eps * want.abs() + 1e-3 * eps).all()              # one rounding of the fp32 sum
+    assert (out != want.to(dtype)).float().mean() < 0.02                                    # (another summation order: a few rounding flips)
+    out2, z2 = emu_backend.outproj_gate_fwd(y, xT, None, w, b, W, None, want_z=False)
+    assert z2 is None
+    want2 = (emu_backend.cm_post_fwd(y, xT, None, w, b).reshape(D, B * L).t().float() @ W.float().t()).reshape(B, L, D)
+    assert ((out2.float() - want2).abs() <= eps * want2.abs() + 1e-3 * eps).all()
+
+
+def test_operator_with_and_without_the_fused_out_proj(emu_backend, monkeypatch):
+    """HyenaOperator (bf16 tensors) through HyenaMixerOutCMFunc vs the round-3 path (cm_post_fwd + library GEMM): output and every
+    gradient agree to 16-bit rounding; the kernel really ran; out_proj's weight gradient with and without the saved zT."""
+    import hyena_dna_amd.mixer as MX
+    from hyena_dna_amd.hyena import HyenaOperator
+    torch.manual_seed(4)
+    B, L, D = 2, 128, 128
+    op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10)
+    with torch.no_grad():
+        op.in_proj.bias.normal_(0, 0.1)
+        op.out_proj.bias.normal_(0, 0.1)
+    op = op.to(torch.bfloat16)
+    u0 = torch.randn(B, L, D).to(torch.bfloat16)
+    dy = torch.randn(B, L, D).to(torch.bfloat16)
+    calls, real = [], emu_backend.outproj_gate_fwd
+    monkeypatch.setattr(emu_backend, "outproj_gate_fwd", lambda *a, **k: (calls.append(k.get("want_z")), real(*a, **k))[1])
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(MX, "OUTPROJ_MFMA", on)
+        op.zero_grad(set_to_none=True)
+        u = u0.clone().requires_grad_(True)
+        y = op(u)
+        y.backward(dy)
+        res.append([y.float(), u.grad.float()] + [p.grad.float() for _, p in sorted(op.named_parameters())])
+    assert calls == [True] and len(res[0]) == len(res[1])          # ran once, keeping zT for out_proj's weight gradient
+    for a, b_ in zip(*res):
+        err = ((a - b_).norm() / b_.norm().clamp_min(1e-20)).item()
+        assert err < 2e-2, err
+    # frozen out_proj weight: no zT is written, the other gradients are unchanged
+    monkeypatch.setattr(MX, "OUTPROJ_MFMA", True)
+    op.out_proj.weight.requires_grad_(False)
+    op.zero_grad(set_to_none=True)
+    u = u0.clone().requires_grad_(True)
+    op(u).backward(dy)
+    assert calls == [True, False] and op.out_proj.weight.grad is None
+    assert ((u.grad.float() - res[0][1]).norm() / res[0][1].norm()).item() < 1e-6
