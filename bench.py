@@ -92,6 +92,8 @@ def measured_traffic(L, D, B, io_dtype, save, plan):
 
 # The other four BASELINE.json configurations (L, B per GPU, d): timed by the same loop as the headline in the default N = 1 run
 SWEEP = [(1024, 8, 128), (32768, 8, 256), (160000, 2, 256), (450560, 1, 256)]
+# ... and one length between the plans' home grounds (the former cliff above 32768: VERDICT r3 item 8), not a contract configuration
+SWEEP_EXTRA = [(65536, 4, 256)]
 # What the part sustains for the mixed read + write streams of the two-level plan (profiles/cpol_bw_r2.txt: 5.0-5.3 TB/s typical, 5.8 TB/s
 # the single best case): the floor of ANY exact-fp32 two-pass transform is its real traffic / this rate
 MIXED_STREAM_TBS = 5.8
@@ -464,11 +466,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = tmax.item()
 
-    sweep = None
+    sweep = sweep_extra = None
     if world == 1 and not args.no_sweep and not args.fwd_only:
         # the four other contract configurations, same loop (rank 0 of an N = 1 run only: a sweep is not part of the scaling legs)
         sweep = sweep_configs(dtype, args.dtype, dev, max(args.steps, 20) if not args.emu else 1, args.warmup if not args.emu else 0,
                               not args.no_graph, emu=args.emu, configs=[(256, 2, 64)] if args.emu else None)
+        if not args.emu:
+            sweep_extra = sweep_configs(dtype, args.dtype, dev, max(args.steps, 20), args.warmup, not args.no_graph, configs=SWEEP_EXTRA)
 
     model_res = None
     if not args.no_model and not args.fwd_only and (world > 1 or not args.emu):
@@ -502,6 +506,7 @@ def main():
             "roofline_valu": valu,
             # the other four BASELINE.json configurations through the same loop (N = 1 runs; null otherwise)
             "sweep": sweep,
+            "sweep_extra": sweep_extra,
         }
         if world == 1 and not args.emu and not args.no_operator and not args.fwd_only:
             try:

@@ -6,6 +6,9 @@
 // pair 34.4 -> 29.9 us at 1024 x 8 x 128.  The conv / spectrum kernels of onchip.hip run at four wavefronts per SIMD, where packed
 // instructions (half issue rate) change nothing, and stay unpacked.
 #define HY_PACKED_F32 1
+#ifndef OC_X1_HALVES
+#define OC_X1_HALVES 0          // exchange 1 as complex halves (onchip_kernels.h) fits these kernels' 256-register budget -- and gains nothing: off
+#endif
 #include "onchip_kernels.h"
 #include "launch.h"
 #include "onchip_host.h"

@@ -165,7 +165,7 @@ __device__ __forceinline__ void row_sync() {
 
 // (every exchange moves one float plane at a time: real parts, then imaginary parts)
 template <int R, bool INV, class CTX>
-__device__ __forceinline__ void x1p(c32 (&v)[32], HY_LDS float* xb, int tid, int ka, int tp, const CTX& c) {
+__device__ __forceinline__ void x1p_planes(c32 (&v)[32], HY_LDS float* xb, int tid, int ka, int tp, const CTX& c) {
     constexpr int T = Cfg<R>::T, ROW1 = Cfg<R>::ROW1;
     constexpr int MB = INV ? 17 : 3;                    // (profiling builds: stamps MB .. MB + 3 after the four barriers)
     (void)c;
@@ -191,6 +191,89 @@ __device__ __forceinline__ void x1p(c32 (&v)[32], HY_LDS float* xb, int tid, int
         row_sync<T>();
         if (part) OC_MARK(c, MB + 3); else OC_MARK(c, MB + 1);
     }
+}
+// OC_X1_HALVES (opt-in, per translation unit; measured and NOT adopted: profiles/r4f_x1_halves_not_kept.txt).  A thread that reads its 32 new
+// values in round 0 still holds 16 unsent old ones: 96 data registers live -- 32 - 43 spilled registers under the 128 of the conv / spectrum
+// kernels (+34 % time), none under the 256 of the dk / one-launch kernels, where it changes nothing (they are not LDS bound).
+#ifndef OC_X1_HALVES
+#define OC_X1_HALVES 0
+#endif
+// Exchange 1 in COMPLEX halves (round 4).  The same LDS footprint as one float plane -- 16 rows of T + R complex slots -- holds half
+// of the registers (q = 16 h ... 16 h + 15) as complex values: round h = every thread writes those 16 values (ds_write_b64), barrier,
+// the threads whose ka lies in that half read all their 32 values (ds_read_b64), barrier.  Against the two float planes: the same 32
+// 8-byte writes per thread (6 LDS cycles per wavefront instruction either way), but the reads are 32 ds_read_b64 (2 cycles each) where
+// the planes need 32 ds_read2_b32 (4 cycles each) -- exchange 1 is LDS-throughput bound (profiles/r4b_conv_phase_timeline.txt: its four
+// phases take exactly the cycles the LDS needs for their instructions), so a quarter of its time goes.  Still four barriers.  The halves
+// are wave-uniform for T >= 128 (a wavefront's ka values lie in one half); below that the other half's lanes sit the reads out.
+// Bank check (64 banks = 32 slots for b64): writes go to consecutive slots; a reading half-wave covers 32 / R rows of R slots at stride
+// T + R = R mod 32 slots -- all 32 distinct.
+template <int R, bool INV, class CTX>
+__device__ __forceinline__ void x1p(c32 (&v)[32], HY_LDS float* xbf, int tid, int ka, int tp, const CTX& c) {
+#if !OC_X1_HALVES
+    x1p_planes<R, INV>(v, xbf, tid, ka, tp, c);
+#else
+    if constexpr (R < 2) {                              // T = 32: both halves inside every half-wave -- the planes stay (the halves spill)
+        x1p_planes<R, INV>(v, xbf, tid, ka, tp, c);
+        return;
+    }
+    constexpr int T = Cfg<R>::T, ROW1 = Cfg<R>::ROW1;
+    constexpr int MB = INV ? 17 : 3;
+    (void)c;
+    HY_LDS lc32* const xb = HY_LDS_CAST(lc32, xbf);
+    HY_LDS lc32* const pa = xb + tid;                                   // (q, tid) of the half at (q - 16 h) ROW1 + tid
+    HY_LDS lc32* const pb = xb + (ka & 15) * ROW1 + tp;                 // (ka, R s + tp)
+    const int myhalf = ka >> 4;
+    if (!INV) {
+        // round 0: everyone writes q < 16, the ka < 16 threads read their 32 values -- into `w`: their own q >= 16 are still to be written
+        c32 w[32];
+        HY_UNROLL
+        for (int q = 0; q < 16; ++q) lds_st(pa + q * ROW1, v[q]);
+        row_sync<T>();
+        OC_MARK(c, MB + 0);
+        if (myhalf == 0) {
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) w[s] = lds_ld(pb + R * s);
+        }
+        row_sync<T>();
+        OC_MARK(c, MB + 1);
+        HY_UNROLL
+        for (int q = 0; q < 16; ++q) lds_st(pa + q * ROW1, v[16 + q]);
+        row_sync<T>();
+        OC_MARK(c, MB + 2);
+        if (myhalf == 0) {
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) v[s] = w[s];
+        } else {
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) v[s] = lds_ld(pb + R * s);
+        }
+        row_sync<T>();
+        OC_MARK(c, MB + 3);
+    } else {
+        // round 0: the ka < 16 threads write their 32 values, everyone reads q < 16 -- into `w`: the ka >= 16 threads still hold theirs
+        c32 w[16];
+        if (myhalf == 0) {
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) lds_st(pb + R * s, v[s]);
+        }
+        row_sync<T>();
+        OC_MARK(c, MB + 0);
+        HY_UNROLL
+        for (int q = 0; q < 16; ++q) w[q] = lds_ld(pa + q * ROW1);
+        row_sync<T>();
+        OC_MARK(c, MB + 1);
+        if (myhalf != 0) {
+            HY_UNROLL
+            for (int s = 0; s < 32; ++s) lds_st(pb + R * s, v[s]);
+        }
+        row_sync<T>();
+        OC_MARK(c, MB + 2);
+        HY_UNROLL
+        for (int q = 0; q < 16; ++q) { v[q] = w[q]; v[16 + q] = lds_ld(pa + q * ROW1); }
+        row_sync<T>();
+        OC_MARK(c, MB + 3);
+    }
+#endif
 }
 template <int R, bool INV>
 __device__ __forceinline__ void x2p(c32 (&v)[32], HY_LDS float* xb, int ka, int tp) {
