@@ -198,6 +198,9 @@ __device__ __forceinline__ void x1p_planes(c32 (&v)[32], HY_LDS float* xb, int t
 #ifndef OC_X1_HALVES
 #define OC_X1_HALVES 0
 #endif
+#ifndef OC_DK_PRESYNC
+#define OC_DK_PRESYNC 1
+#endif
 // Exchange 1 in COMPLEX halves (round 4).  The same LDS footprint as one float plane -- 16 rows of T + R complex slots -- holds half
 // of the registers (q = 16 h ... 16 h + 15) as complex values: round h = every thread writes those 16 values (ds_write_b64), barrier,
 // the threads whose ka lies in that half read all their 32 values (ds_read_b64), barrier.  Against the two float planes: the same 32
@@ -363,7 +366,14 @@ struct Ctx {
 
 // (Issuing the twiddle-table loads of a pass ahead of the butterflies that precede their use was tried -- no gain on the
 // conv kernels, more spills in the 256-register dk kernels; profiles/r2_attribution.txt.)
-template <int R>
+// PRESYNC: this transform follows ANOTHER transform on the same exchange buffer without a workgroup barrier in between (dk: u, then dout,
+// then the next item's u).  Exchange 1 writes anywhere in the buffer while exchange 2 of the previous transform is wave-local, so a fast
+// wavefront could in principle overwrite the exchange-2 slice a slow one is still reading (it would have to be a whole transform's worth of
+// instructions ahead; never observed -- 1 042 + 4 816 double-run stress cases bitwise reproducible -- but nothing in the code ruled it out
+// until round 4, and a wavefront CAN be held up that long on its own: a retried page fault under XNACK with migratable memory).  One
+// barrier before exchange 1 does (fft_inv has always had it).  Measured cost: dk 302 -> 311 us at 32768 x 8, 111.5 -> 116 us at 16384 x 8
+// (profiles/r4h_dk_presync_ab.txt); -DOC_DK_PRESYNC=0 builds without it.
+template <int R, bool PRESYNC = false>
 __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
     OC_DFT((dft_reg<32, false>(v)));
     OC_FENCE();
@@ -375,6 +385,7 @@ __device__ __forceinline__ void fft_fwd(c32 (&v)[32], const Ctx& c) {
     }
     OC_FENCE();
     OC_MARK(c, 2);
+    if constexpr (PRESYNC && OC_DK_PRESYNC) row_sync<Cfg<R>::T>();
     OC_X1(x1p<R, false>(v, HY_LDS_CAST(float, c.xb), c.tid, c.ka, c.tp, c));
     OC_FENCE();
     OC_DFT((dft_reg<32, false>(v)));
@@ -811,11 +822,11 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
             c32 u[32], v[32];
             if (e == 0) dk_load<R, NP, HALF, PHI_A>(u, ub, bf, tid, row_off, a.L, sigma);
             else dk_load<R, NP, HALF, PHI_B>(u, ub, bf, tid, row_off, a.L, sigma);
-            fft_fwd<R>(u, c);
+            fft_fwd<R, true>(u, c);
             HY_SCHED_FENCE();
             if (e == 0) dk_load<R, NP, HALF, PHI_A>(v, gb, bf, tid, row_off, a.L, sigma);
             else dk_load<R, NP, HALF, PHI_B>(v, gb, bf, tid, row_off, a.L, sigma);
-            fft_fwd<R>(v, c);
+            fft_fwd<R, true>(v, c);
             HY_SCHED_FENCE();
             const float lv = live ? 1.f : 0.f;
             HY_UNROLL

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 4, call I: L2 prefetch of the next row inside dk's running transform (regular = prefetch + presync; nopf = presync only;
+# pf_nosync = prefetch only; nopf_nosync = round 3's dk)
+TAG=${1:-r4i}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+cd $R
+CFGS='"32768 8 256" "16384 8 256" "8192 8 256" "4096 16 256" "2048 64 128" "32768 2 256"'
+for v in regular nopf pf_nosync nopf_nosync regular nopf pf_nosync nopf_nosync; do
+  echo "== $v" | tee -a $OUT/ab.txt
+  if [ $v = regular ]; then unset HYENA_FFTCONV_LIB; else export HYENA_FFTCONV_LIB=$R/build/libhyena_$v.so; fi
+  eval timeout 300 python scripts/oc_times.py $CFGS 2>&1 | grep "L=" | tee -a $OUT/ab.txt
+done
+unset HYENA_FFTCONV_LIB
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_small.py -m gpu -x -q 2>&1 | tail -3 | tee $OUT/pytest_gpu.txt
