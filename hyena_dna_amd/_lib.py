@@ -514,7 +514,7 @@ def inproj_pre_fwd(u, W, bin_, w, b, L):
 
 def outproj_supported(B, L, Lx, D, dtype):
     code = _DTYPES.get(dtype)
-    return code is not None and code != 0 and Lx % 8 == 0 and bool(lib().hyena_outproj_supported(int(B), int(L), int(D), code))
+    return code is not None and code != 0 and Lx >= L and bool(lib().hyena_outproj_supported(int(B), int(L), int(D), code))
 
 
 def outproj_gate_fwd(y, xT, bin_, w, b, W, bias, want_z):

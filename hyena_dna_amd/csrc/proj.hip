@@ -113,13 +113,13 @@ int hyena_mlp_dh_dgelu_bwd(const void* dy, const void* W2T, const void* a_in, vo
 
 int hyena_outproj_supported(int B, int L, int D, int dtype) {
     if (!(D == 128 || D == 256) || !(dtype == HYENA_BF16 || dtype == HYENA_F16)) return 0;
-    if (B < 1 || L < 64 || L % 64 != 0) return 0;          // whole 64-position tiles, 16-byte aligned row pieces
+    if (B < 1 || L < 64) return 0;                          // at least one whole 64-position tile per sequence
     return (size_t)B * (size_t)L < ((size_t)1 << 31) ? 1 : 0;
 }
 
 int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
                            const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int dtype, void* stream) {
-    if (y == nullptr || xT == nullptr || w == nullptr || b == nullptr || W == nullptr || out == nullptr || L > Lx || Lx % 8 != 0 ||
+    if (y == nullptr || xT == nullptr || w == nullptr || b == nullptr || W == nullptr || out == nullptr || L > Lx ||
         !hyena_outproj_supported(B, L, D, dtype))
         return HYENA_ERR_BAD_ARG;
     pj::OutProjArgs a;

@@ -779,7 +779,10 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
     elem_t* const ob = reinterpret_cast<elem_t*>(a.out);
 
     for (int t = t_begin; t < t_end; ++t) {
-        const int b = t / a.tiles_per_seq, l0 = (t - b * a.tiles_per_seq) * PJ_NT;
+        // a sequence's last tile is pulled back to end at L when L is not a multiple of 64: it recomputes (and rewrites, identically) up to
+        // 63 positions of its neighbour instead of taking a ragged path -- every tile is whole, and rows may start at any even byte offset
+        const int b = t / a.tiles_per_seq, l0raw = (t - b * a.tiles_per_seq) * PJ_NT;
+        const int l0 = l0raw + PJ_NT <= a.L ? l0raw : a.L - PJ_NT;
         const int lp = l0 + 8 * c;                                    // this lane's first position
         // The rounds go in NB batches (fetch a batch, transpose it into the tile, fetch the next): all 8 rounds of K = 256 in flight at
         // once are 72 registers next to the 128 that hold the weights -- hipcc spilled 61 - 126 registers; 14 with two batches, none
@@ -796,10 +799,11 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
                 const int k = 32 * i + 8 * wave + r;
                 const elem_t* yrow = yb + ((size_t)b * a.D + k) * a.L;
                 const elem_t* xrow = xb + ((size_t)k * a.B + b) * a.Lx;
-                yr[ii] = ld16(yrow + lp);                           // (L is a multiple of 64: every tile is whole, every piece aligned)
+                yr[ii] = ld16(yrow + lp);                           // (every tile is whole; gfx950 global memory takes under-aligned 16-byte accesses)
                 xr[ii] = ld16(xrow + lp);
                 uint32_t h2 = 0u;
                 if (c == 0 && l0 >= 2) __builtin_memcpy(&h2, xrow + (l0 - 2), 4);
+                else if (c == 0 && l0 == 1) { uint16_t h1; __builtin_memcpy(&h1, xrow, 2); h2 = (uint32_t)h1 << 16; }   // L = 65: the pulled-back tile starts at 1
                 halo[ii] = h2;
             }
             if (half == 0) __syncthreads();                          // every wavefront is done with the previous z tile (first tile: the taps are in LDS)

@@ -29,7 +29,7 @@ There is no CPU / torch.fft fallback in this module.
 """
 import torch
 
-from . import _lib
+from . import _gradmode, _lib
 
 __all__ = ["fftconv_func", "FFTConvFunc", "fftconv_ref", "fftconv_heads_ref"]
 
@@ -92,7 +92,7 @@ class FFTConvFunc(torch.autograd.Function):
             bias = D.detach().to(torch.float32).reshape(H).contiguous()
         # keep the forward's column spectra for the backward when any gradient is wanted (time-for-memory trade,
         # _lib.save_spectra_default); otherwise the backward recomputes them from (u, k)
-        want_grad = any(ctx.needs_input_grad[:3])
+        want_grad = any(_gradmode.needs(ctx)[:3])
         saved = None
         if want_grad and _lib.save_spectra_default(*rows.shape, device=rows.device):
             out, saved = _lib.fftconv_fwd(rows, kf, bias, save=True)
@@ -134,7 +134,7 @@ def _conv(u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, 
                                          or head_dim != 1 or fftfp16):
         out = _conv_long(u, k, D)
         return out.to(torch.float16) if (force_fp16_output and u.dtype == torch.float32) else out
-    return FFTConvFunc.apply(u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, head_dim, q, fftfp16, None)
+    return _gradmode.apply(FFTConvFunc, u, k, D, dropout_mask, gelu, force_fp16_output, output_hbl_layout, v, head_dim, q, fftfp16, None)
 
 
 def _plain(u, k, D):

@@ -20,7 +20,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _gradmode, _lib
 
 __all__ = ["hyena_filter_dl", "HyenaFilterFunc", "fused_filter_ok"]
 
@@ -40,8 +40,9 @@ class HyenaFilterFunc(torch.autograd.Function):
         """z (L, E), t (L,), w0 (64, E), b0 (64,), w1/w2 (64, 64), b1/b2 (64,), w3 (D, 64), freq (64,), deltas (D,)
         -> k (D, L) fp32.  ``compute_dtype``: None (fp32 graph) or the autocast type whose graph is to be computed."""
         args = [_f32(x) for x in (z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas)]
-        want_grad = any(ctx.needs_input_grad)
-        if any(ctx.needs_input_grad[i] for i in (1, 10)):
+        need = _gradmode.needs(ctx)
+        want_grad = any(need)
+        if any(need[i] for i in (1, 10)):
             raise NotImplementedError("gradients w.r.t. pos_emb.t / modulation.deltas are not provided by the fused "
                                       "filter kernels (both are buffers in every HyenaDNA configuration)")
         if want_grad:
@@ -79,4 +80,4 @@ def autocast_compute_dtype(device_type="cuda"):
 def hyena_filter_dl(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift=0.0, modulate=True, compute_dtype="auto"):
     if compute_dtype == "auto":
         compute_dtype = autocast_compute_dtype(z.device.type)
-    return HyenaFilterFunc.apply(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate, compute_dtype)
+    return _gradmode.apply(HyenaFilterFunc, z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate, compute_dtype)

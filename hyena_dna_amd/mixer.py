@@ -13,7 +13,7 @@ backward kernels (3 taps) instead of being stored.
 """
 import torch
 
-from . import _lib
+from . import _gradmode, _lib
 
 __all__ = ["hyena_mixer_core", "HyenaMixerFunc", "hyena_mixer_core_cm", "HyenaMixerCMFunc", "hyena_mixer_out_cm", "HyenaMixerOutCMFunc",
            "mixer_out_supported"]
@@ -31,7 +31,7 @@ class HyenaMixerFunc(torch.autograd.Function):
         kf = k.detach().to(torch.float32).contiguous()
         bf = bias.detach().to(torch.float32).reshape(D).contiguous()
         vg = _lib.mixer_pre_fwd(xc, w, b, L)
-        want_grad = any(ctx.needs_input_grad[:5])
+        want_grad = any(_gradmode.needs(ctx)[:5])
         spectra = None
         if want_grad and _lib.save_spectra_default(B, D, L, device=vg.device):
             y, spectra = _lib.fftconv_fwd(vg, kf, bf, save=True)
@@ -74,7 +74,7 @@ def hyena_mixer_core(x, sf_weight, sf_bias, k, bias, L):
         D = x.shape[-1] // 3
         zero = 0 * (sf_weight.sum() + sf_bias.sum() + k.sum() + bias.sum())
         return x[:, :L, :D] * 0 + zero.to(x.dtype)
-    return HyenaMixerFunc.apply(x, sf_weight, sf_bias, k, bias, L)
+    return _gradmode.apply(HyenaMixerFunc, x, sf_weight, sf_bias, k, bias, L)
 
 
 class HyenaMixerCMFunc(torch.autograd.Function):
@@ -95,7 +95,7 @@ class HyenaMixerCMFunc(torch.autograd.Function):
         bf = bias.detach().to(torch.float32).reshape(D).contiguous()
         if vg is None:
             vg = _lib.cm_pre_fwd(xc, bi, w, b, L)
-        want_grad = any(ctx.needs_input_grad[:6])
+        want_grad = any(_gradmode.needs(ctx)[:6])
         spectra = None
         if want_grad and _lib.save_spectra_default(B, D, L, device=vg.device):
             y, spectra = _lib.fftconv_fwd(vg, kf, bf, save=True)
@@ -136,7 +136,7 @@ def hyena_mixer_core_cm(xT, b_in, sf_weight, sf_bias, k, bias, L, vg=None):
         D = xT.shape[0] // 3
         zero = 0 * (b_in.sum() + sf_weight.sum() + sf_bias.sum() + k.sum() + bias.sum())
         return xT[:D, :, :L] * 0 + zero.to(xT.dtype)
-    return HyenaMixerCMFunc.apply(xT, b_in, sf_weight, sf_bias, k, bias, L, vg)
+    return _gradmode.apply(HyenaMixerCMFunc, xT, b_in, sf_weight, sf_bias, k, bias, L, vg)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -149,9 +149,14 @@ OUTPROJ_MFMA = _os.environ.get("HYENA_OUTPROJ_MFMA", "1") != "0"      # A/B knob
 
 
 def mixer_out_supported(xT, L, out_weight):
-    """16-bit channel-major tensors, d_model 128 / 256, whole 64-position tiles (L % 64 == 0, Lx % 8 == 0)"""
+    """16-bit channel-major tensors, d_model 128 / 256, sequences of at least one 64-position tile"""
     D3, B, Lx = xT.shape
     D = D3 // 3
+    if L % 8 != 0 and out_weight.requires_grad and torch.is_grad_enabled():
+        # out_proj's weight gradient wants zT in HBM, whose rows then start at odd element offsets: the kernel's 16-byte stores to them are
+        # split and cost more than the fusion saves (872 vs 564 us at L = 2^20 - 1, profiles/r4i_outproj_ragged.txt) -- such training calls keep
+        # cm_post_fwd + the library GEMM; inference, and any L that is a multiple of 8, take the kernel
+        return False
     return (OUTPROJ_MFMA and xT.dtype in (torch.bfloat16, torch.float16) and tuple(out_weight.shape) == (D, D)
             and (xT.is_cuda or _lib._backend.name != "hip") and _lib.outproj_supported(B, L, Lx, D, xT.dtype))
 
@@ -173,7 +178,8 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
         bf = bias.detach().to(torch.float32).reshape(D).contiguous()
         if vg is None:
             vg = _lib.cm_pre_fwd(xc, bi, w, b, L)
-        want_grad = any(ctx.needs_input_grad[:6]) or ctx.needs_input_grad[8] or ctx.needs_input_grad[9]
+        need = _gradmode.needs(ctx)
+        want_grad = any(need[:6]) or need[8] or need[9]
         spectra = None
         if want_grad and _lib.save_spectra_default(B, D, L, device=vg.device):
             y, spectra = _lib.fftconv_fwd(vg, kf, bf, save=True)
@@ -181,7 +187,7 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
             y = _lib.fftconv_fwd(vg, kf, bf, grad=want_grad)
         wo = w_out.detach().to(xc.dtype).contiguous()
         bo = None if b_out is None else b_out.detach().to(xc.dtype).to(torch.float32).contiguous()      # rounded as autocast rounds it
-        out, zT = _lib.outproj_gate_fwd(y, xc, bi, w, b, wo, bo, want_z=bool(ctx.needs_input_grad[8]))
+        out, zT = _lib.outproj_gate_fwd(y, xc, bi, w, b, wo, bo, want_z=bool(need[8]))
         ctx.save_for_backward(xc, bi, w, b, kf, bf, y, wo, zT if zT is not None else torch.empty(0, device=xc.device))
         ctx.has_z = zT is not None
         ctx.spectra = spectra
@@ -235,4 +241,4 @@ def hyena_mixer_out_cm(xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_ou
     """(3D, B, Lx) -> (B, L, D): the channel-major core and out_proj in one autograd function (see HyenaMixerOutCMFunc); the caller
     checks mixer_out_supported first.  Runs with autocast disabled on tensors already in the compute type, like projection.out_proj_cm."""
     with torch.autocast("cuda" if xT.is_cuda else "cpu", enabled=False):
-        return HyenaMixerOutCMFunc.apply(xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out)
+        return _gradmode.apply(HyenaMixerOutCMFunc, xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out)

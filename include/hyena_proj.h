@@ -40,8 +40,8 @@ int hyena_inproj_pre_fwd(const void* u, const void* W, const float* bin, const f
  * Tensors: y (B, D, L) the long convolution's output; xT (3D, B, Lx) as above (rows [0, D) are read, bin / w / b likewise);
  * W (D, D) out_proj weight, bias (D,) fp32 [values already rounded to the element type] or NULL;
  * out (B, L, D);  zT (D, B, L) = y * x0 or NULL -- written only if the caller keeps it for the weight gradient (bit-identical to
- * hyena_cm_post_fwd).  L <= Lx, L a multiple of 64 and Lx of 8 (whole tiles, aligned 16-byte pieces: hyena_outproj_supported; other
- * lengths keep hyena_cm_post_fwd + the library GEMM).  Arithmetic: z = round(y * shortconv(xT + bin)) exactly as hyena_cm_post_fwd, then 16-bit operands with
+ * hyena_cm_post_fwd).  64 <= L <= Lx (hyena_outproj_supported; any such L: a sequence's last tile is pulled back to end at L and rewrites up to
+ * 63 positions identically; shorter sequences keep hyena_cm_post_fwd + the library GEMM).  Arithmetic: z = round(y * shortconv(xT + bin)) exactly as hyena_cm_post_fwd, then 16-bit operands with
  * fp32 accumulation on v_mfma_f32_32x32x16, out = one rounding of (sum + bias).  Asynchronous on `stream`; no workspace; no state. */
 int hyena_outproj_supported(int B, int L, int D, int dtype);
 int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,

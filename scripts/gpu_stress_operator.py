@@ -48,7 +48,7 @@ while time.time() - t0 < budget:
     B = ri(1, 4 if L < 9000 else 2)
     autocast = bool(n % 3 == 2)
     if autocast and n % 2 == 0:
-        L = max(64, L // 64 * 64)      # whole 64-position tiles: the fused out_proj kernel of round 4 is on the path (csrc/proj_kernels.h)
+        L = max(64, L // 64 * 64)      # multiples of 64 as well as ragged lengths through the fused out_proj kernel (csrc/proj_kernels.h; any L >= 64)
     torch.manual_seed(1000 * seed + n)
     op = HyenaOperator(d_model=D, l_max=L + ri(0, 3), order=2, filter_order=64, emb_dim=[3, 5][ri(0, 1)], short_filter_order=3,
                        modulate=True, w=10).to(dev)

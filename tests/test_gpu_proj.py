@@ -141,7 +141,8 @@ def test_colsum_on_gpu(gpu_lib, P, N, dtype):
 
 @pytest.mark.parametrize("B,L,Lx,D,dtype", [(8, 1024, 1024, 128, torch.bfloat16), (8, 32768, 32768, 256, torch.bfloat16),
                                             (2, 160000, 160000, 256, torch.bfloat16), (1, 1048576, 1048576, 256, torch.bfloat16),
-                                            (3, 4096, 4104, 128, torch.float16), (2, 70016, 70016, 256, torch.float16)])
+                                            (3, 4096, 4104, 128, torch.float16), (2, 70016, 70016, 256, torch.float16),
+                                            (1, 999999, 999999, 256, torch.bfloat16), (3, 4099, 4101, 128, torch.float16), (2, 32767, 32767, 256, torch.bfloat16)])
 def test_outproj_gate_fwd_on_gpu(gpu_lib, B, L, Lx, D, dtype):
     """The fused out_proj kernel (round 4) on the MI355X through the C ABI: zT BIT-IDENTICAL to cm_post_fwd, out against the library
     GEMM on that zT (one rounding of an fp32 sum either way: at most an ulp apart, almost everywhere identical), a slice against the
@@ -171,14 +172,15 @@ def test_outproj_gate_fwd_on_gpu(gpu_lib, B, L, Lx, D, dtype):
     assert z2 is None and torch.equal(out2, out)
 
 
-def test_operator_uses_the_fused_out_proj_and_matches_the_library_path(gpu_lib, monkeypatch):
+@pytest.mark.parametrize("L", [8192, 8200])
+def test_operator_uses_the_fused_out_proj_and_matches_the_library_path(gpu_lib, monkeypatch, L):
     """HyenaOperator under bf16 autocast: HyenaMixerOutCMFunc (the kernel really runs) vs HYENA_OUTPROJ_MFMA=0, output and every
     gradient to 16-bit rounding."""
     import hyena_dna_amd.mixer as MX
     from hyena_dna_amd.hyena import HyenaOperator
     dev = torch.device("cuda", 0)
     torch.manual_seed(6)
-    B, L, D = 2, 8192, 256
+    B, D = 2, 256
     op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10).to(dev)
     u0 = torch.randn(B, L, D, device=dev)
     dy = torch.randn(B, L, D, device=dev)

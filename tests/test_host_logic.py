@@ -382,3 +382,31 @@ def test_importing_the_package_leaves_the_process_environment_alone():
     env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
     p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "ENV_OK" in p.stdout, (p.stdout, p.stderr[-1500:])
+
+
+def test_no_grad_forward_keeps_nothing_for_a_backward(emu_backend, monkeypatch):
+    """ctx.needs_input_grad ignores torch.no_grad(): the wrappers pass the caller's grad mode on (hyena_dna_amd._gradmode), so serving a
+    model whose parameters still require grad neither saves the column spectra nor asks the filter for its backward state."""
+    import hyena_dna_amd.fftconv as FC
+    from hyena_dna_amd.hyena import HyenaOperator
+    seen = {"save": [], "filter_save": []}
+    real_fwd, real_filter = emu_backend.fftconv_fwd, emu_backend.filter_fwd
+    monkeypatch.setattr(emu_backend, "fftconv_fwd", lambda *a, **k: (seen["save"].append((k.get("save", False), k.get("grad"))), real_fwd(*a, **k))[1])
+    monkeypatch.setattr(emu_backend, "filter_fwd", lambda *a, **k: (seen["filter_save"].append(k.get("save", False)), real_filter(*a, **k))[1])
+    monkeypatch.setattr(emu_backend, "save_spectra_default", lambda *a, **k: True)
+    torch.manual_seed(0)
+    op = HyenaOperator(d_model=64, l_max=96, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10)
+    u = torch.randn(2, 96, 64)
+    y_train = op(u)
+    assert seen["save"] == [(True, None)] and seen["filter_save"] == [True]
+    seen["save"].clear(), seen["filter_save"].clear()
+    with torch.no_grad():
+        y_serve = op(u)
+    assert seen["save"] == [(False, False)] and seen["filter_save"] == [False]
+    assert torch.equal(y_train.detach(), y_serve)
+    # the H3-form entry point alike
+    seen["save"].clear()
+    k = torch.randn(64, 96, requires_grad=True)
+    with torch.no_grad():
+        FC.fftconv_func(torch.randn(2, 64, 96), k, torch.randn(64), None, False)
+    assert seen["save"] == [(False, False)]

@@ -168,7 +168,8 @@ def test_colsum_kernel(emu_backend, P, N, dtype):
 
 
 @pytest.mark.parametrize("B,L,Lx,D,dtype", [(1, 64, 64, 128, torch.bfloat16), (2, 192, 200, 128, torch.float16), (1, 128, 128, 256, torch.bfloat16),
-                                            (3, 64, 72, 256, torch.float16)])
+                                            (3, 64, 72, 256, torch.float16), (2, 127, 127, 128, torch.bfloat16), (3, 65, 67, 128, torch.float16),
+                                            (1, 255, 255, 256, torch.bfloat16)])
 def test_outproj_gate_fwd_vs_cm_post_and_gemm(emu_backend, B, L, Lx, D, dtype):
     """The fused out_proj kernel (csrc/proj_kernels.h::outproj_gate_fwd_kernel): zT bit-identical to cm_post_fwd, out = the library
     product of that zT with the weight (+ bias), one rounding; with and without the zT side output; L < Lx (l_max cut)."""
@@ -180,7 +181,7 @@ def test_outproj_gate_fwd_vs_cm_post_and_gemm(emu_backend, B, L, Lx, D, dtype):
     b = torch.randn(3 * D, generator=g) * 0.1
     W = (torch.randn(D, D, generator=g) / D ** 0.5).to(dtype)
     bias = (torch.randn(D, generator=g) * 0.1).to(dtype).float()
-    assert emu_backend.outproj_supported(B, L, Lx, D, dtype) and not emu_backend.outproj_supported(B, L + 1, Lx + 8, D, dtype)
+    assert emu_backend.outproj_supported(B, L, Lx, D, dtype) and not emu_backend.outproj_supported(B, 63, 64, D, dtype)
     out, zT = emu_backend.outproj_gate_fwd(y, xT, bin_, w, b, W, bias, want_z=True)
     z_ref = emu_backend.cm_post_fwd(y, xT, bin_, w, b)
     assert torch.equal(zT, z_ref)
@@ -195,13 +196,14 @@ def test_outproj_gate_fwd_vs_cm_post_and_gemm(emu_backend, B, L, Lx, D, dtype):
     assert ((out2.float() - want2).abs() <= eps * want2.abs() + 1e-3 * eps).all()
 
 
-def test_operator_with_and_without_the_fused_out_proj(emu_backend, monkeypatch):
+@pytest.mark.parametrize("L", [128, 136])
+def test_operator_with_and_without_the_fused_out_proj(emu_backend, monkeypatch, L):
     """HyenaOperator (bf16 tensors) through HyenaMixerOutCMFunc vs the round-3 path (cm_post_fwd + library GEMM): output and every
     gradient agree to 16-bit rounding; the kernel really ran; out_proj's weight gradient with and without the saved zT."""
     import hyena_dna_amd.mixer as MX
     from hyena_dna_amd.hyena import HyenaOperator
     torch.manual_seed(4)
-    B, L, D = 2, 128, 128
+    B, D = 2, 128
     op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10)
     with torch.no_grad():
         op.in_proj.bias.normal_(0, 0.1)
@@ -231,3 +233,26 @@ def test_operator_with_and_without_the_fused_out_proj(emu_backend, monkeypatch):
     op(u).backward(dy)
     assert calls == [True, False] and op.out_proj.weight.grad is None
     assert ((u.grad.float() - res[0][1]).norm() / res[0][1].norm()).item() < 1e-6
+
+
+def test_ragged_length_policy_of_the_fused_out_proj(emu_backend, monkeypatch):
+    """L not a multiple of 8: inference (and a frozen out_proj weight) takes the kernel -- its pulled-back last tile -- and gives the library
+    path's bits; a training call, whose zT rows would start at odd offsets, keeps cm_post_fwd + the library GEMM (mixer.mixer_out_supported)."""
+    import hyena_dna_amd.mixer as MX
+    from hyena_dna_amd.hyena import HyenaOperator
+    torch.manual_seed(5)
+    B, L, D = 2, 127, 128
+    op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10).to(torch.bfloat16)
+    u = torch.randn(B, L, D).to(torch.bfloat16)
+    calls, real = [], emu_backend.outproj_gate_fwd
+    monkeypatch.setattr(emu_backend, "outproj_gate_fwd", lambda *a, **k: (calls.append(k.get("want_z")), real(*a, **k))[1])
+    monkeypatch.setattr(MX, "OUTPROJ_MFMA", True)
+    op(u).float().sum().backward()
+    assert calls == []                                    # training, ragged: library path
+    with torch.no_grad():
+        y_k = op(u)
+    assert calls == [False]                               # inference: the kernel, no zT
+    monkeypatch.setattr(MX, "OUTPROJ_MFMA", False)
+    with torch.no_grad():
+        y_l = op(u)
+    assert torch.equal(y_k, y_l)
