@@ -49,6 +49,13 @@ int dispatch_mlp(const pj::MlpArgs& a, int K, int dtype, int grid, void* stream)
 }
 }  // namespace
 
+#if defined(PJ_PROFILE)
+// profiling builds only: hand the device a buffer for mlp_kernel's phase times ([workgroup][wavefront][16] uint64)
+extern "C" int hyena_pj_prof_set(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(hyena::pj::pj_prof_buf), &buf, sizeof(buf));
+}
+#endif
+
 extern "C" {
 
 static int colsum_groups(long P) {

@@ -43,6 +43,22 @@ enum { PJ_THREADS = 256, PJ_WAVES = 4, PJ_NT = 64 /* positions per tile */,
 #define HY_WAVE_SYNC_PJ() __builtin_amdgcn_wave_barrier()
 #endif
 
+// -DPJ_PROFILE (profiling builds only, FULL=1 scripts/build_variant.sh): per-wavefront time (s_memtime, shader clock) spent between the
+// phase boundaries of mlp_kernel, summed over its tiles and written by lane 0 to a buffer the host hands over through hyena_pj_prof_set
+// (proj.hip); scripts/pj_phase_profile.py prints the table.  The product build contains none of it.
+#if defined(PJ_PROFILE) && !defined(HIPEMU)
+__device__ unsigned long long* pj_prof_buf = nullptr;
+#define PJ_NOW(v)                                                                                       \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");                       \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    } while (0)
+#define PJ_MARK(i) do { unsigned long long now_; PJ_NOW(now_); pj_d[i] += now_ - pj_t; pj_t = now_; } while (0)
+#else
+#define PJ_MARK(i) do {} while (0)
+#endif
+
 struct Frag { uint32_t w[4]; };                       // eight 16-bit values: one A or B operand of v_mfma_f32_32x32x16
 #ifdef HIPEMU
 typedef hipemu::floatx16 acc_t;
@@ -407,18 +423,59 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
 // Numerics follow the autocast graph they replace: a is the rounded GEMM result (bias added in fp32 before the one rounding, as
 // the library's epilogue does), h = round(gelu(a)) from the ROUNDED a, da = round(round(dh) * gelu'(a)).
 // =============================================================================================================================
-enum { PM_UW = 64 /* hidden units per wavefront */, PM_EW = PM_UW + 8 };
+enum { PM_UW = 64 /* hidden units per wavefront */ };
 
+// Round 4: the operand tile (and MODE 1's a tile) reach LDS by gfx950's LDS-direct 16-byte loads (global_load_lds_dwordx4: no registers, no
+// ds_write pass, asynchronous).  An instruction fills 1 KB of LDS lane by lane (wave-uniform base + 16 * lane) from per-lane global
+// addresses, so the tiles are unpadded and a bank-conflict-free image is obtained by permuting the SOURCE pieces:
+//     operand tile [position][K]:   piece c of position pos at slot c ^ (pos mod PCS)          (PCS = K / 8 pieces per row)
+//     wavefront tile [position][64 units]:  piece c at slot c ^ (4 * bit 2 of pos)
+// What this buys: tile t + 1 is requested as soon as every wavefront has read tile t's last fragment and lands behind tile t's whole
+// epilogue (s_memtime stamps of the round-3 kernel, profiles/r4j_mlp_phases.txt: of 9.5 us per tile and wavefront 2.3 us were spent issuing
+// the operand's loads into registers and waiting for them -- 250 of 256 registers hold weights, accumulators and the staged tile, there is
+// no room to prefetch through registers).  vmcnt counts loads and stores in issue order: the waits name how many younger operations may
+// stay in flight (a tile's own stores), never a blanket vmcnt(0) inside the steady state.
 template <int K> struct PmCfg {
     static constexpr int KS = K / 16;
-    static constexpr int UROW = PjCfg<K>::UROW, UBUF = PjCfg<K>::UBUF, CH = PjCfg<K>::CH;
-    static constexpr int EROW = PM_EW * 2;                    // bytes per row of the epilogue tile [position][unit]
-    static constexpr int EBUF = PJ_NT * EROW;                 // one tile per wavefront
-    // ONE staging buffer and ONE epilogue tile per wavefront: 70 KB, so that TWO workgroups share a CU (2 wavefronts per SIMD,
-    // <= 256 registers each).  A lone wavefront issues an instruction every ~7 cycles here (LDS and transcendental latencies in
-    // a dependent chain); the second one fills the gaps -- and covers the first one's barriers and global-load waits.
+    static constexpr int PCS = K / 8;                           // 16-byte pieces per operand row (32 / 16)
+    static constexpr int UROWB = K * 2;                         // bytes per operand row
+    static constexpr int UBUF = PJ_NT * UROWB;                  // the operand tile: 32 / 16 KB
+    static constexpr int NX = UBUF / 1024 / PJ_WAVES;           // LDS-direct loads per wavefront and operand tile (8 / 4)
+    static constexpr int EROW = PM_UW * 2;                      // bytes per row of a wavefront's tile [position][unit]
+    static constexpr int EBUF = PJ_NT * EROW;                   // 8 KB
+    static constexpr int NE = EBUF / 1024;                      // 16-byte row pieces per lane of that tile = LDS-direct loads of MODE 1's a tile (8)
+    // 64 / 48 KB: two workgroups share a CU (2 wavefronts per SIMD, <= 256 registers each); the second one fills the first one's
+    // dependent chains (LDS and transcendental latencies), barriers and store back-pressure.
     static constexpr size_t LDS = (size_t)UBUF + PJ_WAVES * (size_t)EBUF;
 };
+
+#ifdef HIPEMU
+// the test double copies at issue (LDS-direct loads are asynchronous on the hardware: the kernel's waits and barriers are what make that equal)
+__device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane) { __builtin_memcpy(wave_base + 16 * lane, base + voff, 16); }
+#define PJ_VMWAIT(n) do {} while (0)
+#define PJ_LGKMWAIT() do {} while (0)
+#define PJ_BARRIER() __syncthreads()
+#else
+// global_load_lds_dwordx4 voffset, sbase: 16 bytes from base + voff (per lane) to LDS byte M0 + 16 * lane.  Written as inline assembly on
+// purpose: hipcc tracks the built-in's LDS writes on vmcnt and, having no alias information for them, drains EVERY outstanding memory
+// operation before any later LDS read of the kernel -- the wavefront tile's reads in the epilogue would wait for the next operand tile and
+// for each preceding global store.  Here the kernel's own counted waits (PJ_VMWAIT) are the only ones; the compiler's waits for the memory
+// operations it knows can only come out stricter for the extra ones in the queue, never laxer.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane) {
+    (void)lane;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(base), "s"((uint32_t)(size_t)wave_base) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+#define PJ_VMWAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define PJ_LGKMWAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PJ_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#endif
+
+struct True_ { static constexpr bool value = true; };      // compile-time flags handed to the kernels' generic lambdas
+struct False_ { static constexpr bool value = false; };
 
 struct MlpArgs {
     const void* x;        // fc1: x (P, K);  dh: dy (P, K)
@@ -468,7 +525,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     typedef PmCfg<K> C;
     typedef typename Elem<DT>::type elem_t;
     HY_SMEM(smem);
-    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, hb = lane >> 5;
+    const int tid = (int)threadIdx.x, wave = HY_SGPR(tid >> 6), lane = tid & 63, j = lane & 31, hb = lane >> 5;
     const int N = a.N;
     const unsigned P = a.P;
     const int ncg = N / (PJ_WAVES * PM_UW);
@@ -486,6 +543,37 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     HY_LDS char* const ubuf = HY_LDS_CAST(char, smem);
     HY_LDS char* const et = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::EBUF;      // this wavefront's tile [position][unit]
 
+    const char* const xbase = reinterpret_cast<const char*>(a.x);
+    // LDS-direct load i of this wavefront fills chunk i * 4 + wave of the operand tile: lane -> 16-byte slot S = 64 chunk + lane
+    // = (position S / PCS, slot S mod PCS), which holds the source piece (slot ^ position mod PCS).  FULL = false: the last, partial tile
+    // of the matrix (positions >= P are not fetched: their rows of the tile keep older, finite values and are never stored).
+    auto issue_x = [&](int t, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const unsigned p0 = (unsigned)t * PJ_NT;
+        const char* const tb = HY_UNIFORM_PTR(const char, xbase + (size_t)p0 * K * 2);
+        HY_UNROLL
+        for (int i = 0; i < C::NX; ++i) {
+            const int chunk = i * PJ_WAVES + wave, S = chunk * 64 + lane, pos = S / C::PCS, c = (S % C::PCS) ^ (pos % C::PCS);
+            if (FULL || p0 + (unsigned)pos < P) glds16(tb, (uint32_t)(pos * K * 2 + c * 16), ubuf + chunk * 1024, lane);
+        }
+    };
+    // A wavefront's tile: 16-byte slot S = 64 m + lane = (position 8 m + lane / 8, slot lane mod 8) <-> piece (lane mod 8) ^ 4 hb of the global
+    // row (bit 2 of the position is hb for every m).  Same map for the a tile coming in (MODE 1) and the results going out.
+    const uint32_t eoff0 = (uint32_t)(((lane >> 3) * N + n0 + 8 * ((lane & 7) ^ (hb << 2))) * 2);          // bytes; + (p0 + 8 m) N 2: wave-uniform
+    auto issue_a = [&](int t, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const unsigned p0 = (unsigned)t * PJ_NT;
+        HY_UNROLL
+        for (int m = 0; m < C::NE; ++m) {
+            const char* const rb = HY_UNIFORM_PTR(const char, reinterpret_cast<const char*>(a.a_in) + ((size_t)p0 + 8u * m) * N * 2);
+            if (FULL || p0 + (unsigned)(lane >> 3) + 8u * m < P) glds16(rb, eoff0, et + m * 1024, lane);
+        }
+    };
+    const int t_whole = (int)(P / PJ_NT) < t_end ? (int)(P / PJ_NT) : t_end;                 // tiles [t_begin, t_whole) are whole
+    if (t_begin < t_whole) { issue_x(t_begin, True_()); if (MODE == 1) issue_a(t_begin, True_()); }
+    else { issue_x(t_begin, False_()); if (MODE == 1) issue_a(t_begin, False_()); }
+
+
     // stationary operand: 64 weight rows as B fragments (column = unit j of unit tile ut, k = 16 ks + 8 hb ...)
     Frag wf[2][C::KS];
     HY_UNROLL
@@ -498,46 +586,30 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     if (MODE == 0 && a.bias != nullptr) { bias[0] = a.bias[n0 + j]; bias[1] = a.bias[n0 + 32 + j]; }
     float colsum[2] = {0.f, 0.f};
 
-    const char* const xbase = reinterpret_cast<const char*>(a.x);
-    // Piece m of a lane in the [position][unit] tile: position (lane >> 3) + 8 m, piece lane & 7 -- the m-dependent part of its
-    // global address is wave-uniform.
-    const size_t eoff0 = (size_t)(lane >> 3) * N + n0 + 8 * (lane & 7);
+    // A fragment of (position tile pt, step ks): 16 bytes at row pt 32 + j, piece (2 ks + hb) ^ (j mod PCS) = (2 ks) ^ (hb ^ j mod PCS)
+    const int ua = j * C::UROWB, ux = (hb ^ (j % C::PCS)) * 16;
+    // accumulator register r of lane (j, hb) = position pt 32 + pj_row(r, hb), unit ut 32 + j: byte (ut ^ hb) 64 + 2 j of that row
+    HY_LDS char* const eacc = et + hb * 4 * C::EROW + 2 * j;
 
-    for (int t = t_begin; t < t_end; ++t) {
+#if defined(PJ_PROFILE) && !defined(HIPEMU)
+    unsigned long long pj_d[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pj_t, pj_start, pj_rt0, pj_rt1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pj_rt0)::"memory");
+    PJ_NOW(pj_t);
+    pj_start = pj_t;
+#endif
+    // one tile; FULL (compile time): whole tiles carry no per-position predicate and no branch around a memory instruction, so that the
+    // number of operations in flight behind a given one is known
+    auto tile = [&](int t, auto full_c) {
+        constexpr bool full = decltype(full_c)::value;
         const unsigned p0 = (unsigned)t * PJ_NT;
-        const bool full = p0 + PJ_NT <= P;                       // wave-uniform: whole tiles skip every per-position predicate
-        {
-            // the operand tile (64 x K, one contiguous block) and, MODE 1, this wavefront's a tile: global -> registers -> LDS.
-            // (No register double-buffering across the matrix-core phase: the CU's other workgroup covers these waits.)
-            Frag st[C::CH];
-            HY_UNROLL
-            for (int c = 0; c < C::CH; ++c) {
-                const int q = tid + PJ_THREADS * c;
-                const unsigned p = p0 + (unsigned)(q / (K / 8));
-                Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
-                st[c] = (full || p < P) ? ld16(xbase + ((size_t)p0 * K * 2 + (size_t)q * 16)) : z;
-            }
-            Frag at[MODE == 1 ? PJ_NT * 8 / 64 : 1];
-            if (MODE == 1) {
-                HY_UNROLL
-                for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
-                    Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
-                    at[m] = (full || p0 + (unsigned)(lane >> 3) + 8u * m < P)
-                                ? ld16(reinterpret_cast<const elem_t*>(a.a_in) + (eoff0 + ((size_t)p0 + 8u * m) * N)) : z;
-                }
-            }
-            __syncthreads();                                     // every wavefront is done with the previous operand tile
-            HY_UNROLL
-            for (int c = 0; c < C::CH; ++c) {
-                const int q = tid + PJ_THREADS * c;
-                lds_st16(ubuf + (q / (K / 8)) * C::UROW + (q % (K / 8)) * 16, st[c]);
-            }
-            if (MODE == 1) {
-                HY_UNROLL
-                for (int m = 0; m < PJ_NT * 8 / 64; ++m) lds_st16(et + ((lane >> 3) + 8 * m) * C::EROW + (lane & 7) * 16, at[m]);
-            }
-        }
-        __syncthreads();
+        const bool next_full = t + 1 < t_whole;
+        // (1) this tile's operand is in LDS: my share has landed (younger: the previous tile's 16 stores, or its 8 stores and this tile's
+        //     8 a loads), then everybody's
+        if (t == t_begin || !full) PJ_VMWAIT(0);
+        else PJ_VMWAIT(16);
+        PJ_MARK(0);
+        PJ_BARRIER();
+        PJ_MARK(1);
         acc_t acc[2][2];                           // [position tile][unit tile]
         HY_UNROLL
         for (int pt = 0; pt < 2; ++pt) {
@@ -547,16 +619,28 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
                 for (int r = 0; r < 16; ++r) acc[pt][ut][r] = 0.f;
             }
         }
-        const HY_LDS char* const ub = ubuf + j * C::UROW + hb * 16;
         HY_UNROLL
         for (int ks = 0; ks < C::KS; ++ks) {
             HY_UNROLL
             for (int pt = 0; pt < 2; ++pt) {
-                const Frag af = lds_ld16(ub + pt * 32 * C::UROW + ks * 32);
+                const Frag af = lds_ld16(ubuf + pt * 32 * C::UROWB + ua + (ux ^ (ks * 32)));
                 HY_UNROLL
                 for (int ut = 0; ut < 2; ++ut) acc[pt][ut] = mfma<DT>(af, wf[ut][ks], acc[pt][ut]);
             }
         }
+        PJ_MARK(2);
+        // (2) every wavefront has read its last fragment: the next tile may land, behind this tile's epilogue
+        PJ_BARRIER();
+        PJ_MARK(3);
+        if (next_full) issue_x(t + 1, True_());
+        else if (t + 1 < t_end) issue_x(t + 1, False_());
+        if (MODE == 1) {
+            // this tile's a values (requested one tile ago; younger: the operand loads just issued)
+            if (!next_full) PJ_VMWAIT(0);
+            else if (C::NX == 8) PJ_VMWAIT(8);
+            else PJ_VMWAIT(4);
+        }
+        PJ_MARK(4);
         // ---- epilogue, wavefront-private: register r of lane (j, hb) = position pt 32 + pj_row(r, hb), unit ut 32 + j ----
         // The tile is used twice in MODE 0 (a, then h -- recomputed from the accumulators rather than held in 32 more registers)
         // and in place in MODE 1 (every lane overwrites the a values it read with its da values).
@@ -567,10 +651,11 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
             for (int pt = 0; pt < 2; ++pt) {
                 HY_UNROLL
                 for (int ut = 0; ut < 2; ++ut) {
+                    HY_LDS char* const eb = eacc + ((ut ^ hb) * 64);
                     HY_UNROLL
                     for (int r = 0; r < 16; ++r) {
-                        const int pos = pt * 32 + pj_row(r, hb), un = ut * 32 + j;
-                        HY_LDS elem_t* slot = reinterpret_cast<HY_LDS elem_t*>(et + pos * C::EROW) + un;
+                        const int prow = pt * 32 + (r & 3) + 8 * (r >> 2);              // + 4 hb: in eacc
+                        HY_LDS elem_t* slot = reinterpret_cast<HY_LDS elem_t*>(eb + prow * C::EROW);
                         if (MODE == 0) {
                             const elem_t av = Elem<DT>::cvt(acc[pt][ut][r] + bias[ut]);
                             *slot = pass == 0 ? av : Elem<DT>::cvt(pm_gelu(Elem<DT>::dec(av)));
@@ -578,22 +663,51 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
                             const float dh = Elem<DT>::dec(Elem<DT>::cvt(acc[pt][ut][r]));          // the rounding of the unfused dh tensor
                             const elem_t dv = Elem<DT>::cvt(dh * pm_dgelu(Elem<DT>::dec(*slot)));
                             *slot = dv;
-                            if (full || p0 + pos < P) colsum[ut] += Elem<DT>::dec(dv);
+                            if (full || p0 + (unsigned)(prow + 4 * hb) < P) colsum[ut] += Elem<DT>::dec(dv);
                         }
                     }
                 }
             }
             HY_WAVE_SYNC_PJ();
+            PJ_MARK(5 + 2 * pass);                               // accumulators (waits for the matrix cores) -> element-wise -> tile
             elem_t* const dst = reinterpret_cast<elem_t*>(pass == 0 ? a.o0 : a.o1);
             HY_UNROLL
-            for (int m = 0; m < PJ_NT * 8 / 64; ++m) {
-                const int pos = (lane >> 3) + 8 * m, pc = lane & 7;
-                if (!full && p0 + pos >= P) continue;
-                st16(dst + (eoff0 + ((size_t)p0 + 8u * m) * N), lds_ld16(et + pos * C::EROW + pc * 16));      // (second term wave-uniform)
+            for (int m = 0; m < C::NE; ++m) {
+                if (!full && p0 + (unsigned)(lane >> 3) + 8u * m >= P) continue;
+                st16(reinterpret_cast<char*>(dst) + ((size_t)p0 + 8u * m) * N * 2 + eoff0, lds_ld16(et + m * 1024 + lane * 16));
             }
+            PJ_MARK(6 + 2 * pass);                               // stores issued
         }
         HY_WAVE_SYNC_PJ();
+        if (MODE == 1 && t + 1 < t_end) {
+            PJ_LGKMWAIT();                                       // the tile's rows have been read out: the next a tile may land in it
+            if (next_full) issue_a(t + 1, True_());
+            else issue_a(t + 1, False_());
+        }
+    };
+    {
+        int t = t_begin;
+        for (; t < t_whole; ++t) tile(t, True_());
+        if (t < t_end) tile(t, False_());
     }
+#if defined(PJ_PROFILE) && !defined(HIPEMU)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PJ_MARK(9);                                                  // last stores acknowledged
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pj_rt1)::"memory");
+    if (pj_prof_buf != nullptr && lane == 0) {
+        unsigned long long* o = pj_prof_buf + ((size_t)blockIdx.x * PJ_WAVES + wave) * 16;
+        HY_UNROLL
+        for (int i = 0; i < 10; ++i) o[i] = pj_d[i];
+        o[10] = (unsigned long long)(t_end - t_begin);
+        o[11] = pj_t - pj_start;
+        o[12] = pj_rt1 - pj_rt0;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[13] = ((unsigned long long)xcc << 32) | hw;
+        o[14] = pj_start;
+    }
+#endif
     if (MODE == 1) {
         // column sums of da over this run: the two half-waves hold different positions of the same unit
         HY_LDS float* red = reinterpret_cast<HY_LDS float*>(et);

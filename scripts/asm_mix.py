@@ -1,28 +1,41 @@
-"""Instruction mix of one kernel in gfx950 assembly: python scripts/asm_mix.py x.s <mangled-name-substring>"""
+"""Instruction mix per kernel from hipcc -S output: python scripts/asm_mix.py file.s substring [substring ...]"""
 import collections
 import re
 import sys
 
 txt = open(sys.argv[1]).read().splitlines()
-key = sys.argv[2]
-start = next(i for i, l in enumerate(txt) if l.startswith("_Z") and key in l)
-mix = collections.Counter()
-n = 0
-for l in txt[start + 1:]:
-    t = l.strip()
-    if t.startswith("s_endpgm"):
-        break
-    if not l.startswith("\t") or t.startswith((";", ".")):
-        continue
-    op = t.split()[0]
-    n += 1
-    cls = ("VALU" if op.startswith("v_") else "SALU" if op.startswith("s_") and not op.startswith(("s_waitcnt", "s_barrier", "s_load", "s_buffer", "s_nop"))
-           else "LDS" if op.startswith("ds_") else "VMEM" if op.startswith(("buffer_", "global_", "scratch_", "flat_")) else op)
-    mix[cls] += 1
-    if cls in ("VALU",):
-        mix["  " + re.sub(r"_e(32|64)$", "", op)] += 1
-print("total", n)
-for k, v in sorted(mix.items(), key=lambda kv: (-kv[1] if not kv[0].startswith("  ") else 0, kv[0])):
-    if not k.startswith("  "):
-        print(f"{k:12s} {v}")
-print("top VALU ops:", ", ".join(f"{k.strip()}={v}" for k, v in sorted(((k, v) for k, v in mix.items() if k.startswith("  ")), key=lambda kv: -kv[1])[:14]))
+starts = [(i, l.split(":")[0]) for i, l in enumerate(txt) if re.match(r"^_Z\w+:", l)]
+for pat in sys.argv[2:]:
+    for n, (i, name) in enumerate(starts):
+        if pat not in name:
+            continue
+        end = starts[n + 1][0] if n + 1 < len(starts) else len(txt)
+        c = collections.Counter()
+        for line in txt[i + 1:end]:
+            line = line.strip()
+            if not line or line[0] in ".;/" or line.endswith(":"):
+                continue
+            op = line.split()[0]
+            if op == "s_endpgm":
+                break
+            if op.startswith("v_mfma"):
+                c["mfma"] += 1
+            elif op.startswith(("v_exp", "v_rcp", "v_log", "v_sqrt", "v_rsq")):
+                c["trans"] += 1
+            elif op.startswith("v_cvt"):
+                c["cvt:" + op] += 1
+            elif op.startswith("v_"):
+                c["valu"] += 1
+            elif op.startswith("ds_"):
+                c["lds:" + op] += 1
+            elif op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+                c["mem:" + op] += 1
+            elif op.startswith("s_waitcnt"):
+                c["waitcnt"] += 1
+            elif op.startswith("s_barrier"):
+                c["barrier"] += 1
+            elif op.startswith("s_"):
+                c["salu"] += 1
+        print(name)
+        for k, v in sorted(c.items(), key=lambda kv: -kv[1]):
+            print(f"    {k:40s} {v}")
