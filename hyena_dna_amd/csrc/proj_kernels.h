@@ -441,12 +441,13 @@ template <int K> struct PmCfg {
     static constexpr int UROWB = K * 2;                         // bytes per operand row
     static constexpr int UBUF = PJ_NT * UROWB;                  // the operand tile: 32 / 16 KB
     static constexpr int NX = UBUF / 1024 / PJ_WAVES;           // LDS-direct loads per wavefront and operand tile (8 / 4)
-    static constexpr int EROW = PM_UW * 2;                      // bytes per row of a wavefront's tile [position][unit]
-    static constexpr int EBUF = PJ_NT * EROW;                   // 8 KB
-    static constexpr int NE = EBUF / 1024;                      // 16-byte row pieces per lane of that tile = LDS-direct loads of MODE 1's a tile (8)
-    // 64 / 48 KB: two workgroups share a CU (2 wavefronts per SIMD, <= 256 registers each); the second one fills the first one's
-    // dependent chains (LDS and transcendental latencies), barriers and store back-pressure.
-    static constexpr size_t LDS = (size_t)UBUF + PJ_WAVES * (size_t)EBUF;
+    static constexpr int EROW = PM_UW * 2;                      // bytes per row of a wavefront's [position][unit] images
+    static constexpr int NE = PJ_NT * EROW / 1024;              // 16-byte row pieces per lane of a 64-position tile = LDS-direct loads of MODE 1's a tile (8)
+    // a wavefront's LDS: MODE 0 two double-buffered 1 KB chunk images (a, h): 4 KB; MODE 1 the whole a tile: 8 KB
+    static constexpr int ebuf(int mode) { return mode == 0 ? 4096 : PJ_NT * EROW; }
+    // 48 / 64 KB at K = 256: two workgroups share a CU (2 wavefronts per SIMD, <= 256 registers each); the second one fills the first
+    // one's dependent chains (LDS and transcendental latencies), barriers and store back-pressure.
+    static constexpr size_t lds(int mode) { return (size_t)UBUF + PJ_WAVES * (size_t)ebuf(mode); }
 };
 
 #ifdef HIPEMU
@@ -490,33 +491,38 @@ struct MlpArgs {
     int tiles, tiles_per_wg;
 };
 
-// 0.5 (1 + tanh(z)) = sigmoid(2 z) = 1 / (1 + exp(-2 z)): no cancellation in the negative tail (where 1 + tanh loses its digits),
-// exact limits 0 and 1.
-__device__ __forceinline__ float pm_sigmoid2(float z) {
+// The tanh approximation PyTorch's F.gelu(approximate="tanh") evaluates (aten/src/ATen/native/cuda/ActivationGeluKernel.cu):
+//     gelu(x) = 0.5 x (1 + tanh(z)),  z = sqrt(2 / pi) (x + 0.044715 x^3),  in fp32.
+// 0.5 (1 + tanh(z)) = sigmoid(2 z) = 1 / (1 + exp(-2 z)): no cancellation in the negative tail (where 1 + tanh loses its digits), exact
+// limits 0 and 1.  exp(-2 z) = exp2(x (c1 + c2 x^2)) with the constants folded (c1 = -2 sqrt(2 / pi) log2(e), c2 = 0.044715 c1): five
+// fp32 operations and two transcendentals per value -- the element-wise part is what these kernels' wavefronts spend their time on
+// (profiles/r4j_mlp_phases.txt).
+#define PM_C1 (-2.302208198f)                 /* -2 * 0.7978845608028654 * 1.4426950408889634 */
+#define PM_C2 (-0.1029432396f)                /* 0.044715 * PM_C1 */
+__device__ __forceinline__ float pm_exp2(float w) {
 #ifdef HIPEMU
-    const float s = expf(-2.0f * z);
+    return exp2f(w);
 #else
-    const float s = __expf(-2.0f * z);
-#endif
-#ifdef HIPEMU
-    return 1.0f / (1.0f + s);
-#else
-    return __builtin_amdgcn_rcpf(1.0f + s);          // v_rcp_f32 (1 ulp): a correctly rounded division costs ten instructions
+    return __builtin_amdgcn_exp2f(w);                 // v_exp_f32
 #endif
 }
-// the tanh approximation PyTorch's F.gelu(approximate="tanh") evaluates (aten/src/ATen/native/cuda/ActivationGeluKernel.cu):
-// 0.5 x (1 + tanh(z)), z = sqrt(2 / pi) (x + 0.044715 x^3); fp32
+__device__ __forceinline__ float pm_rcp(float d) {
+#ifdef HIPEMU
+    return 1.0f / d;
+#else
+    return __builtin_amdgcn_rcpf(d);                  // v_rcp_f32 (1 ulp): a correctly rounded division costs ten instructions
+#endif
+}
 __device__ __forceinline__ float pm_gelu(float x) {
-    const float kBeta = 0.7978845608028654f /* sqrt(2 / pi) */, kKappa = 0.044715f;
-    return x * pm_sigmoid2(kBeta * (x + kKappa * x * x * x));
+    const float e = pm_exp2(x * __builtin_fmaf(x * x, PM_C2, PM_C1));
+    return x * pm_rcp(1.0f + e);
 }
-// its derivative: 0.5 (1 + t) + 0.5 x (1 - t^2) z'  with  0.5 (1 + t) = sg,  1 - t^2 = 4 sg (1 - sg)
+// its derivative: sg + x sg (1 - sg) (2 z'),  sg = sigmoid(2 z),  2 z' = 2 sqrt(2 / pi) (1 + 3 * 0.044715 x^2)
 __device__ __forceinline__ float pm_dgelu(float x) {
-    const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
     const float x2 = x * x;
-    const float sg = pm_sigmoid2(kBeta * (x + kKappa * x2 * x));
-    const float dz = kBeta * (1.0f + 3.0f * kKappa * x2);
-    return sg + 2.0f * x * sg * (1.0f - sg) * dz;
+    const float sg = pm_rcp(1.0f + pm_exp2(x * __builtin_fmaf(x2, PM_C2, PM_C1)));
+    const float q = x * __builtin_fmaf(x2, 0.2140644488f /* 6 * 0.044715 * sqrt(2 / pi) */, 1.5957691216f /* 2 sqrt(2 / pi) */);
+    return __builtin_fmaf(q * sg, 1.0f - sg, sg);
 }
 
 // MODE 0: fc1 + bias + GELU (outputs a, h);  MODE 1: dh = dy W2, da = dh gelu'(a) (+ partial column sums)
@@ -541,7 +547,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     const int n0 = cg * PJ_WAVES * PM_UW + wave * PM_UW;                   // first hidden unit of this wavefront
 
     HY_LDS char* const ubuf = HY_LDS_CAST(char, smem);
-    HY_LDS char* const et = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::EBUF;      // this wavefront's tile [position][unit]
+    HY_LDS char* const et = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::ebuf(MODE);      // this wavefront's images [position][unit]
 
     const char* const xbase = reinterpret_cast<const char*>(a.x);
     // LDS-direct load i of this wavefront fills chunk i * 4 + wave of the operand tile: lane -> 16-byte slot S = 64 chunk + lane
@@ -588,8 +594,6 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
 
     // A fragment of (position tile pt, step ks): 16 bytes at row pt 32 + j, piece (2 ks + hb) ^ (j mod PCS) = (2 ks) ^ (hb ^ j mod PCS)
     const int ua = j * C::UROWB, ux = (hb ^ (j % C::PCS)) * 16;
-    // accumulator register r of lane (j, hb) = position pt 32 + pj_row(r, hb), unit ut 32 + j: byte (ut ^ hb) 64 + 2 j of that row
-    HY_LDS char* const eacc = et + hb * 4 * C::EROW + 2 * j;
 
 #if defined(PJ_PROFILE) && !defined(HIPEMU)
     unsigned long long pj_d[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pj_t, pj_start, pj_rt0, pj_rt1;
@@ -641,42 +645,54 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
             else PJ_VMWAIT(4);
         }
         PJ_MARK(4);
-        // ---- epilogue, wavefront-private: register r of lane (j, hb) = position pt 32 + pj_row(r, hb), unit ut 32 + j ----
-        // The tile is used twice in MODE 0 (a, then h -- recomputed from the accumulators rather than held in 32 more registers)
-        // and in place in MODE 1 (every lane overwrites the a values it read with its da values).
-        HY_UNROLL
-        for (int pass = 0; pass < (MODE == 0 ? 2 : 1); ++pass) {
-            HY_WAVE_SYNC_PJ();
+        // ---- epilogue, wavefront-private, in 8 chunks of 8 positions x 64 units (1 KB = one 16-byte row piece per lane) ----
+        // Register r of lane (j, hb) = position pt 32 + pj_row(r, hb), unit ut 32 + j: chunk m = positions 8 m .. 8 m + 7 is registers
+        // 4 (m mod 4) + i, i < 4, of position tile m / 4, both unit tiles -- 8 values per lane.  A chunk is computed, parked in LDS in the
+        // [position][unit] image (byte q 128 + (ut ^ hb) 64 + 2 j, q = i + 4 hb), read back as row pieces while the NEXT chunk is computed
+        // and stored after it: two stores (MODE 1: one) every eighth of the element-wise work instead of bursts of eight that block the
+        // wavefront at the memory pipeline's queue (1.7 of a tile's 8.0 us: profiles/r4j_mlp_phases.txt).  MODE 0 parks a and h side by side
+        // (two 1 KB images, double-buffered: 4 KB per wavefront); MODE 1 works in place in the a tile that the LDS-direct loads brought.
+        {
+            Frag r0, r1;
+            r0.w[0] = r0.w[1] = r0.w[2] = r0.w[3] = 0u;
+            r1 = r0;
+            char* const dst0 = reinterpret_cast<char*>(a.o0) + (size_t)p0 * N * 2 + eoff0;
+            char* const dst1 = MODE == 0 ? reinterpret_cast<char*>(a.o1) + (size_t)p0 * N * 2 + eoff0 : nullptr;
             HY_UNROLL
-            for (int pt = 0; pt < 2; ++pt) {
+            for (int m = 0; m < 8; ++m) {
+                HY_LDS char* const ca = MODE == 0 ? et + (m & 1) * 2048 : et + m * 1024;          // this chunk's image (MODE 0: a, then h at + 1024)
                 HY_UNROLL
                 for (int ut = 0; ut < 2; ++ut) {
-                    HY_LDS char* const eb = eacc + ((ut ^ hb) * 64);
                     HY_UNROLL
-                    for (int r = 0; r < 16; ++r) {
-                        const int prow = pt * 32 + (r & 3) + 8 * (r >> 2);              // + 4 hb: in eacc
-                        HY_LDS elem_t* slot = reinterpret_cast<HY_LDS elem_t*>(eb + prow * C::EROW);
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = acc[m >> 2][ut][4 * (m & 3) + i];
+                        HY_LDS elem_t* slot = reinterpret_cast<HY_LDS elem_t*>(ca + (i + 4 * hb) * C::EROW + (ut ^ hb) * 64 + 2 * j);
                         if (MODE == 0) {
-                            const elem_t av = Elem<DT>::cvt(acc[pt][ut][r] + bias[ut]);
-                            *slot = pass == 0 ? av : Elem<DT>::cvt(pm_gelu(Elem<DT>::dec(av)));
+                            const elem_t av = Elem<DT>::cvt(v + bias[ut]);
+                            slot[0] = av;
+                            slot[512] = Elem<DT>::cvt(pm_gelu(Elem<DT>::dec(av)));                   // + 1024 bytes: the h image
                         } else {
-                            const float dh = Elem<DT>::dec(Elem<DT>::cvt(acc[pt][ut][r]));          // the rounding of the unfused dh tensor
+                            const float dh = Elem<DT>::dec(Elem<DT>::cvt(v));                        // the rounding of the unfused dh tensor
                             const elem_t dv = Elem<DT>::cvt(dh * pm_dgelu(Elem<DT>::dec(*slot)));
                             *slot = dv;
-                            if (full || p0 + (unsigned)(prow + 4 * hb) < P) colsum[ut] += Elem<DT>::dec(dv);
+                            if (full || p0 + (unsigned)(8 * m + i + 4 * hb) < P) colsum[ut] += Elem<DT>::dec(dv);
                         }
                     }
                 }
+                if (m > 0 && (full || p0 + (unsigned)(lane >> 3) + 8u * (m - 1) < P)) {
+                    st16(dst0 + (size_t)(8 * (m - 1)) * N * 2, r0);
+                    if (MODE == 0) st16(dst1 + (size_t)(8 * (m - 1)) * N * 2, r1);
+                }
+                HY_WAVE_SYNC_PJ();
+                r0 = lds_ld16(ca + lane * 16);
+                if (MODE == 0) r1 = lds_ld16(ca + 1024 + lane * 16);
+                HY_WAVE_SYNC_PJ();
             }
-            HY_WAVE_SYNC_PJ();
-            PJ_MARK(5 + 2 * pass);                               // accumulators (waits for the matrix cores) -> element-wise -> tile
-            elem_t* const dst = reinterpret_cast<elem_t*>(pass == 0 ? a.o0 : a.o1);
-            HY_UNROLL
-            for (int m = 0; m < C::NE; ++m) {
-                if (!full && p0 + (unsigned)(lane >> 3) + 8u * m >= P) continue;
-                st16(reinterpret_cast<char*>(dst) + ((size_t)p0 + 8u * m) * N * 2 + eoff0, lds_ld16(et + m * 1024 + lane * 16));
+            if (full || p0 + (unsigned)(lane >> 3) + 56u < P) {
+                st16(dst0 + (size_t)56 * N * 2, r0);
+                if (MODE == 0) st16(dst1 + (size_t)56 * N * 2, r1);
             }
-            PJ_MARK(6 + 2 * pass);                               // stores issued
+            PJ_MARK(5);                                          // accumulators (waits for the matrix cores) -> element-wise -> rows stored
         }
         HY_WAVE_SYNC_PJ();
         if (MODE == 1 && t + 1 < t_end) {

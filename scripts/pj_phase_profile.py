@@ -2,8 +2,8 @@
 HYENA_FFTCONV_LIB=build/libhyena_pjprof.so).  usage: python scripts/pj_phase_profile.py [P K N]
 Phases (s_memtime deltas summed over a wavefront's tiles): 0 wait for my share of the operand tile (vmcnt) | 1 barrier: everybody's share |
 2 matrix-core instructions issued | 3 barrier: every wavefront has read its last fragment | 4 next operand tile requested (+ MODE 1: wait for the
-a tile) | 5 pass-0 element-wise (incl. the wait for the matrix cores) | 6 pass-0 stores issued | 7 pass-1 element-wise | 8 pass-1 stores issued
-(MODE 1: + next a tile requested) | 9 last stores acknowledged."""
+a tile) | 5 the epilogue's eight chunks: element-wise work, rows parked in LDS, stores (incl. the wait for the matrix cores; MODE 1: + next a
+tile requested) | 9 last stores acknowledged.  (The round-3 kernel and the first LDS-direct version had other phases: profiles/r4j_mlp_phases.txt.)"""
 import ctypes
 import os
 import sys
@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hyena_dna_amd import _lib  # noqa: E402
 
 NAMES = ["wait: my operand share", "barrier 1 (operand complete)", "MFMA issue", "barrier 2 (operand read)", "request next operand (+ wait a)",
-         "pass 0 element-wise (+MFMA drain)", "pass 0 store issue", "pass 1 element-wise", "pass 1 store issue", "final store ack"]
+         "epilogue: 8 chunks (+MFMA drain)", "-", "-", "-", "final store ack"]
 dev = torch.device("cuda", 0)
 L_ = _lib.lib()
 L_.hyena_pj_prof_set.argtypes = [ctypes.c_void_p]
