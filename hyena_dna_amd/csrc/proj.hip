@@ -168,6 +168,9 @@ int hyena_inproj_pre_fwd(const void* u, const void* W, const float* bin, const f
     if (runs > a.tiles) runs = a.tiles;
     a.tiles_per_wg = (a.tiles + runs - 1) / runs;
     if (a.tiles_per_wg < 8 && a.tiles >= 8) a.tiles_per_wg = 8;
+#ifdef PJ_DBG_TPW
+    if (const char* e = getenv("HYENA_PJ_TPW")) a.tiles_per_wg = atoi(e);        // experiments only: run length override
+#endif
     runs = (a.tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     const int grid = ((runs + 7) / 8) * 8 * ncg;
     if (D == 256) return dtype == HYENA_BF16 ? launch_inproj<256, DT_BF16>(a, grid, stream) : launch_inproj<256, DT_F16>(a, grid, stream);

@@ -117,6 +117,49 @@ __device__ __forceinline__ Frag lds_ld16(const HY_LDS char* p) { return __builti
 __device__ __forceinline__ void lds_st16(HY_LDS char* p, const Frag& f) { *reinterpret_cast<HY_LDS pj_lvec16*>(p) = __builtin_bit_cast(pj_lvec16, f); }
 #endif
 
+#ifdef HIPEMU
+// the test double copies at issue (LDS-direct loads are asynchronous on the hardware: the kernel's waits and barriers are what make that equal)
+__device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane) { __builtin_memcpy(wave_base + 16 * lane, base + voff, 16); }
+#define PJ_VMWAIT(n) do {} while (0)
+#define PJ_LGKMWAIT() do {} while (0)
+#define PJ_BARRIER() __syncthreads()
+#else
+// global_load_lds_dwordx4 voffset, sbase: 16 bytes from base + voff (per lane) to LDS byte M0 + 16 * lane.  Written as inline assembly on
+// purpose: hipcc tracks the built-in's LDS writes on vmcnt and, having no alias information for them, drains EVERY outstanding memory
+// operation before any later LDS read of the kernel -- the wavefront tile's reads in the epilogue would wait for the next operand tile and
+// for each preceding global store.  Here the kernel's own counted waits (PJ_VMWAIT) are the only ones; the compiler's waits for the memory
+// operations it knows can only come out stricter for the extra ones in the queue, never laxer.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane) {
+    (void)lane;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(base), "s"((uint32_t)(size_t)wave_base) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+#define PJ_VMWAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define PJ_LGKMWAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PJ_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#endif
+
+struct True_ { static constexpr bool value = true; };      // compile-time flags handed to the kernels' generic lambdas
+struct False_ { static constexpr bool value = false; };
+
+// The operand tile [64 positions][K] of the weights-stationary kernels, brought to LDS by LDS-direct loads: load i of wavefront `wave` fills
+// the 1 KB chunk i * 4 + wave; lane -> 16-byte slot S = 64 chunk + lane = (position S / PCS, slot S mod PCS), which holds the source piece
+// (slot ^ position mod PCS), PCS = K / 8 pieces per row -- a fragment read of 16 neighbouring rows at one piece index then touches 16
+// different bank groups.  FULL = false: rows of positions >= P are not fetched (they keep older values; their results are never stored).
+template <int K, bool FULL>
+__device__ __forceinline__ void issue_operand_tile(const char* xbase, unsigned p0, unsigned P, HY_LDS char* ubuf, int wave, int lane) {
+    constexpr int PCS = K / 8, NX = PJ_NT * K * 2 / 1024 / PJ_WAVES;
+    const char* const tb = HY_UNIFORM_PTR(const char, xbase + (size_t)p0 * K * 2);
+    HY_UNROLL
+    for (int i = 0; i < NX; ++i) {
+        const int chunk = i * PJ_WAVES + wave, S = chunk * 64 + lane, pos = S / PCS, c = (S % PCS) ^ (pos % PCS);
+        if (FULL || p0 + (unsigned)pos < P) glds16(tb, (uint32_t)(pos * K * 2 + c * 16), ubuf + chunk * 1024, lane);
+    }
+}
+
 template <int K> struct PjCfg {
     static_assert(K == 128 || K == 256, "d_model of the HyenaDNA models");
     static constexpr int KS = K / 16;                         // MFMA steps over the contraction
@@ -173,7 +216,8 @@ __device__ __forceinline__ acc4_t mfma16(const Frag& a, const Frag& b, acc4_t c)
 enum { IP_CB = 16, IP_NT4 = PJ_NT / 16 };
 template <int K> struct IpCfg {
     static constexpr int KS = K / 32;                         // v_mfma_f32_16x16x32 steps over the contraction
-    static constexpr int UROW = PjCfg<K>::UROW, UBUF = PjCfg<K>::UBUF, CH = PjCfg<K>::CH;
+    static constexpr int PCS = K / 8;                         // 16-byte pieces per row of the u tile
+    static constexpr int UROWB = K * 2, UBUF = PJ_NT * UROWB; // the u tile, unpadded: filled by LDS-direct loads, source pieces permuted (issue_operand_tile)
     static constexpr int EROW = PJ_EW * 2;
     static constexpr int EBUF = 3 * IP_CB * EROW;             // per wavefront: [group][channel][PJ_EW]
     static constexpr int TAPS = 2 * IP_CB * 5 * 4;
@@ -186,7 +230,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
     typedef typename Elem<DT>::type elem_t;
     static_assert(sizeof(elem_t) == 2, "16-bit element types only");
     HY_SMEM(smem);
-    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, kq = lane >> 4;
+    const int tid = (int)threadIdx.x, wave = HY_SGPR(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
     const int D = a.D;
     const unsigned P = (unsigned)a.B * (unsigned)a.Lx;                       // flattened positions (< 2^31, checked by the host)
     // workgroup -> (channel group of 64, run of tiles).  Workgroups are dealt to the 8 XCDs round-robin; the channel groups of
@@ -232,28 +276,20 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
     // (sequence, position within it) of the first position of the current tile, carried along instead of divided out per tile
     unsigned sb = ((unsigned)t_first * PJ_NT) / (unsigned)a.Lx;
     int sl0 = (int)((unsigned)t_first * PJ_NT - sb * (unsigned)a.Lx);
+    // The u tile of positions [64 t, 64 t + 64) -- one contiguous block of 64 K 2 bytes -- reaches LDS by LDS-direct loads (round 4; until
+    // then global -> registers -> LDS with the wait for it on every tile's critical path: the staged tile, the weights and the accumulators
+    // fill the register file, there was nothing to prefetch into).  Tile t + 1 is requested when every wavefront has read tile t's last
+    // fragment and lands behind tile t's epilogue; the wait at the top names the stores that may stay in flight behind it.
+    const int t_whole = (int)(P / PJ_NT);                                    // tiles below this one are whole
+    if (t_first < t_whole) issue_operand_tile<K, true>(ubase, (unsigned)t_first * PJ_NT, P, ubuf, wave, lane);
+    else issue_operand_tile<K, false>(ubase, (unsigned)t_first * PJ_NT, P, ubuf, wave, lane);
+    bool counted = false;                                                    // the previous tile left exactly IP_ST stores behind the loads
     for (int t = t_first; t < t_end; ++t, sl0 += PJ_NT) {
         while (sl0 >= a.Lx) { sl0 -= a.Lx; ++sb; }
         const unsigned p0 = (unsigned)t * PJ_NT;
-        {
-            // the u tile of positions [64 t, 64 t + 64): one contiguous block of 64 K 2 bytes, global -> registers -> LDS
-            // (no register double-buffering across the matrix-core phase: the CU's other workgroup covers these waits)
-            Frag st[C::CH];
-            HY_UNROLL
-            for (int c = 0; c < C::CH; ++c) {
-                const int q = tid + PJ_THREADS * c;
-                const unsigned p = p0 + (unsigned)(q / (K / 8));
-                Frag z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
-                st[c] = p < P ? ld16(ubase + ((size_t)p0 * K * 2 + (size_t)q * 16)) : z;
-            }
-            __syncthreads();                                     // every wavefront is done with the previous u tile
-            HY_UNROLL
-            for (int c = 0; c < C::CH; ++c) {
-                const int q = tid + PJ_THREADS * c;
-                lds_st16(ubuf + (q / (K / 8)) * C::UROW + (q % (K / 8)) * 16, st[c]);
-            }
-        }
-        __syncthreads();
+        if (counted) PJ_VMWAIT(8);                                           // (IP_ST = 8: six xT stores, two vg stores)
+        else PJ_VMWAIT(0);
+        PJ_BARRIER();                                                        // everybody's share of the tile has landed
         acc4_t acc[3][IP_NT4];
         HY_UNROLL
         for (int g = 0; g < 3; ++g) {
@@ -263,16 +299,24 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                 for (int r = 0; r < 4; ++r) acc[g][nt][r] = 0.f;
             }
         }
-        const HY_LDS char* const ub = ubuf + j * C::UROW + kq * 16;
+        // B fragment of (position tile nt, step ks): 16 bytes of row 16 nt + j, piece 4 ks + kq -> slot (4 ks + kq) ^ ((16 nt + j) mod PCS)
+        // = (kq ^ j) ^ (4 ks ^ (16 nt mod PCS)): a per-lane part and a compile-time part
+        const int ua = j * C::UROWB, ux = (kq ^ j) * 16;
         HY_UNROLL
         for (int ks = 0; ks < C::KS; ++ks) {
             HY_UNROLL
             for (int nt = 0; nt < IP_NT4; ++nt) {
-                const Frag bf = lds_ld16(ub + nt * 16 * C::UROW + ks * 64);
+                const Frag bf = lds_ld16(ubuf + nt * 16 * C::UROWB + ua + (ux ^ (((4 * ks) ^ ((16 * nt) % C::PCS)) * 16)));
                 HY_UNROLL
                 for (int g = 0; g < 3; ++g) acc[g][nt] = mfma16<DT>(wf[g][ks], bf, acc[g][nt]);
             }
         }
+        PJ_BARRIER();                                                        // every wavefront has read its last fragment
+        if (t + 1 < t_end) {
+            if (t + 1 < t_whole) issue_operand_tile<K, true>(ubase, p0 + PJ_NT, P, ubuf, wave, lane);
+            else issue_operand_tile<K, false>(ubase, p0 + PJ_NT, P, ubuf, wave, lane);
+        }
+        counted = false;
         // ---- epilogue, wavefront-private ---------------------------------------------------------------------------
         // (1) the previous tile's last two positions become this tile's halo (slots 6, 7: one dword per row)
         if (lane < 3 * IP_CB) {
@@ -280,9 +324,13 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
             row[3] = row[3 + PJ_NT / 2];
         }
         HY_WAVE_SYNC_PJ();
-        // (2) accumulators -> storage type -> [group][channel 4 kq + r][8 + position 16 nt + j]
-        HY_UNROLL
-        for (int g = 0; g < 3; ++g) {
+        // (2) accumulators -> storage type -> [group][channel 4 kq + r][8 + position 16 nt + j], group by group; on the straight-line path
+        //     of interior tiles a group's rows are read back while the next group is converted and stored after it -- the stores leave one
+        //     or two at a time between the element-wise work instead of as a burst of eight at the end of the tile.
+        // Interior tiles -- whole, inside one sequence, at least two positions into it, inside the convolved length -- take a
+        // straight-line path: no per-element predicates, no divisions, addresses from offsets hoisted out of the loop.
+        const bool fast = t >= t_begin && p0 + PJ_NT <= P && sl0 >= 2 && sl0 + PJ_NT <= a.Lc;
+        auto park = [&](int g) {
             HY_UNROLL
             for (int nt = 0; nt < IP_NT4; ++nt) {
                 HY_UNROLL
@@ -291,53 +339,69 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                     e[8 + nt * 16 + j] = Elem<DT>::cvt(acc[g][nt][r]);
                 }
             }
-        }
-        HY_WAVE_SYNC_PJ();
-        if (t >= t_begin) {
-            // Interior tiles -- whole, inside one sequence, at least two positions into it, inside the convolved length -- take a
-            // straight-line path: no per-element predicates, no divisions, addresses from offsets hoisted out of the loop.
-            const bool fast = p0 + PJ_NT <= P && sl0 >= 2 && sl0 + PJ_NT <= a.Lc;
-            if (fast) {
-                // (3) xT: 3 x 16 rows x 8 pieces of 8 positions
-                HY_UNROLL
-                for (int m = 0; m < 3 * IP_CB * 8 / 64; ++m) {
-                    const int g = m >> 1, ch = (lane >> 3) + 8 * (m & 1), pc = lane & 7;
-                    const size_t rowm = (size_t)(g * D + 8 * (m & 1)) * P + p0;                     // wave-uniform
-                    st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), lds_ld16(ebuf + (g * IP_CB + ch) * C::EROW + 16 + pc * 16));
+        };
+        if (fast) {
+            counted = t + 1 < t_whole;                                       // eight stores, no branch around any of them; the next tile's loads whole
+            // (3) xT: 3 x 16 rows x 8 pieces of 8 positions; piece m of a lane: group m >> 1, channel (lane >> 3) + 8 (m & 1), piece lane & 7
+            Frag ra, rb;
+            HY_UNROLL
+            for (int g = 0; g < 3; ++g) {
+                park(g);
+                if (g > 0) {
+                    const size_t rowm = (size_t)((g - 1) * D) * P + p0;                               // wave-uniform
+                    st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), ra);
+                    st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm + (size_t)8 * P), rb);
                 }
-                // (4) vg = shortconv(v) * shortconv(x1): 16 channels x 8 pieces
-                const size_t vbase = (size_t)sb * D * a.Lc + (size_t)sl0;
+                HY_WAVE_SYNC_PJ();
+                ra = lds_ld16(ebuf + (g * IP_CB + (lane >> 3)) * C::EROW + 16 + (lane & 7) * 16);
+                rb = lds_ld16(ebuf + (g * IP_CB + (lane >> 3) + 8) * C::EROW + 16 + (lane & 7) * 16);
+            }
+            // (4) vg = shortconv(v) * shortconv(x1): 16 channels x 8 pieces
+            const size_t vbase = (size_t)sb * D * a.Lc + (size_t)sl0;
+            Frag vf[IP_CB * 8 / 64];
+            HY_UNROLL
+            for (int m = 0; m < IP_CB * 8 / 64; ++m) {
+                const int ch = (lane >> 3) + 8 * m, pc = lane & 7;
+                float prod[8];
                 HY_UNROLL
-                for (int m = 0; m < IP_CB * 8 / 64; ++m) {
-                    const int ch = (lane >> 3) + 8 * m, pc = lane & 7;
-                    float prod[8];
+                for (int gi = 0; gi < 2; ++gi) {                    // gi = 0: x1 (group 1), gi = 1: v (group 2)
+                    const HY_LDS char* row = ebuf + ((1 + gi) * IP_CB + ch) * C::EROW + pc * 16;
+                    const Frag lo = lds_ld16(row), hi = lds_ld16(row + 16);
+                    elem_t pl[8], ph[8];
+                    __builtin_memcpy(pl, lo.w, 16);
+                    __builtin_memcpy(ph, hi.w, 16);
+                    float xs[10];
+                    const HY_LDS float* tp = taps + (gi * IP_CB + ch) * 5;
+                    const float w0 = tp[0], w1 = tp[1], w2 = tp[2], bsc = tp[3], bin = tp[4];
+                    xs[0] = Elem<DT>::dec(pl[6]) + bin; xs[1] = Elem<DT>::dec(pl[7]) + bin;
                     HY_UNROLL
-                    for (int gi = 0; gi < 2; ++gi) {                    // gi = 0: x1 (group 1), gi = 1: v (group 2)
-                        const HY_LDS char* row = ebuf + ((1 + gi) * IP_CB + ch) * C::EROW + pc * 16;
-                        const Frag lo = lds_ld16(row), hi = lds_ld16(row + 16);
-                        elem_t pl[8], ph[8];
-                        __builtin_memcpy(pl, lo.w, 16);
-                        __builtin_memcpy(ph, hi.w, 16);
-                        float xs[10];
-                        const HY_LDS float* tp = taps + (gi * IP_CB + ch) * 5;
-                        const float w0 = tp[0], w1 = tp[1], w2 = tp[2], bsc = tp[3], bin = tp[4];
-                        xs[0] = Elem<DT>::dec(pl[6]) + bin; xs[1] = Elem<DT>::dec(pl[7]) + bin;
-                        HY_UNROLL
-                        for (int i = 0; i < 8; ++i) xs[2 + i] = Elem<DT>::dec(ph[i]) + bin;
-                        HY_UNROLL
-                        for (int i = 0; i < 8; ++i) {
-                            const float c = __builtin_fmaf(w2, xs[i + 2], __builtin_fmaf(w1, xs[i + 1], __builtin_fmaf(w0, xs[i], bsc)));   // = cm_sc
-                            prod[i] = gi == 0 ? c : prod[i] * c;
-                        }
+                    for (int i = 0; i < 8; ++i) xs[2 + i] = Elem<DT>::dec(ph[i]) + bin;
+                    HY_UNROLL
+                    for (int i = 0; i < 8; ++i) {
+                        const float c = __builtin_fmaf(w2, xs[i + 2], __builtin_fmaf(w1, xs[i + 1], __builtin_fmaf(w0, xs[i], bsc)));   // = cm_sc
+                        prod[i] = gi == 0 ? c : prod[i] * c;
                     }
-                    elem_t out[8];
-                    HY_UNROLL
-                    for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
-                    Frag f;
-                    __builtin_memcpy(f.w, out, 16);
-                    st16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * m) * (unsigned)a.Lc), f);
                 }
-            } else {
+                elem_t out[8];
+                HY_UNROLL
+                for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
+                __builtin_memcpy(vf[m].w, out, 16);
+                if (m == 0) {                                       // the v rows of xT, behind the first half of the window arithmetic
+                    const size_t rowm = (size_t)(2 * D) * P + p0;
+                    st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), ra);
+                    st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm + (size_t)8 * P), rb);
+                } else {
+                    st16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * (m - 1)) * (unsigned)a.Lc), vf[m - 1]);
+                }
+            }
+            st16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * (IP_CB * 8 / 64 - 1)) * (unsigned)a.Lc), vf[IP_CB * 8 / 64 - 1]);
+        } else {
+            HY_UNROLL
+            for (int g = 0; g < 3; ++g) park(g);
+            HY_WAVE_SYNC_PJ();
+        }
+        if (t >= t_begin && !fast) {
+            {
                 // generic path: ragged tiles, sequence boundaries inside the tile, the first two positions of a sequence,
                 // positions beyond the convolved length
                 HY_UNROLL
@@ -450,34 +514,6 @@ template <int K> struct PmCfg {
     static constexpr size_t lds(int mode) { return (size_t)UBUF + PJ_WAVES * (size_t)ebuf(mode); }
 };
 
-#ifdef HIPEMU
-// the test double copies at issue (LDS-direct loads are asynchronous on the hardware: the kernel's waits and barriers are what make that equal)
-__device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane) { __builtin_memcpy(wave_base + 16 * lane, base + voff, 16); }
-#define PJ_VMWAIT(n) do {} while (0)
-#define PJ_LGKMWAIT() do {} while (0)
-#define PJ_BARRIER() __syncthreads()
-#else
-// global_load_lds_dwordx4 voffset, sbase: 16 bytes from base + voff (per lane) to LDS byte M0 + 16 * lane.  Written as inline assembly on
-// purpose: hipcc tracks the built-in's LDS writes on vmcnt and, having no alias information for them, drains EVERY outstanding memory
-// operation before any later LDS read of the kernel -- the wavefront tile's reads in the epilogue would wait for the next operand tile and
-// for each preceding global store.  Here the kernel's own counted waits (PJ_VMWAIT) are the only ones; the compiler's waits for the memory
-// operations it knows can only come out stricter for the extra ones in the queue, never laxer.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane) {
-    (void)lane;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(voff), "s"(base), "s"((uint32_t)(size_t)wave_base) : "memory", "m0");
-}
-#pragma clang diagnostic pop
-#define PJ_VMWAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define PJ_LGKMWAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define PJ_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
-#endif
-
-struct True_ { static constexpr bool value = true; };      // compile-time flags handed to the kernels' generic lambdas
-struct False_ { static constexpr bool value = false; };
-
 struct MlpArgs {
     const void* x;        // fc1: x (P, K);  dh: dy (P, K)
     const void* W;        // fc1: W1 (N, K);  dh: W2^T (N, K)        [K contiguous]
@@ -550,18 +586,8 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     HY_LDS char* const et = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::ebuf(MODE);      // this wavefront's images [position][unit]
 
     const char* const xbase = reinterpret_cast<const char*>(a.x);
-    // LDS-direct load i of this wavefront fills chunk i * 4 + wave of the operand tile: lane -> 16-byte slot S = 64 chunk + lane
-    // = (position S / PCS, slot S mod PCS), which holds the source piece (slot ^ position mod PCS).  FULL = false: the last, partial tile
-    // of the matrix (positions >= P are not fetched: their rows of the tile keep older, finite values and are never stored).
     auto issue_x = [&](int t, auto full_c) {
-        constexpr bool FULL = decltype(full_c)::value;
-        const unsigned p0 = (unsigned)t * PJ_NT;
-        const char* const tb = HY_UNIFORM_PTR(const char, xbase + (size_t)p0 * K * 2);
-        HY_UNROLL
-        for (int i = 0; i < C::NX; ++i) {
-            const int chunk = i * PJ_WAVES + wave, S = chunk * 64 + lane, pos = S / C::PCS, c = (S % C::PCS) ^ (pos % C::PCS);
-            if (FULL || p0 + (unsigned)pos < P) glds16(tb, (uint32_t)(pos * K * 2 + c * 16), ubuf + chunk * 1024, lane);
-        }
+        issue_operand_tile<K, decltype(full_c)::value>(xbase, (unsigned)t * PJ_NT, P, ubuf, wave, lane);
     };
     // A wavefront's tile: 16-byte slot S = 64 m + lane = (position 8 m + lane / 8, slot lane mod 8) <-> piece (lane mod 8) ^ 4 hb of the global
     // row (bit 2 of the position is hb for every m).  Same map for the a tile coming in (MODE 1) and the results going out.
