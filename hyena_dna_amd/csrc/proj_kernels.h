@@ -121,8 +121,14 @@ __device__ __forceinline__ void lds_st16(HY_LDS char* p, const Frag& f) { *reint
 // the test double copies at issue (LDS-direct loads are asynchronous on the hardware: the kernel's waits and barriers are what make that equal)
 __device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane) { __builtin_memcpy(wave_base + 16 * lane, base + voff, 16); }
 #define PJ_VMWAIT(n) do {} while (0)
+#define PJ_VMWAIT_FOR(n, f) do {} while (0)
 #define PJ_LGKMWAIT() do {} while (0)
 #define PJ_BARRIER() __syncthreads()
+typedef Frag AReg;                                            // (device: a raw register quadruple an asynchronous load is in flight to)
+__device__ __forceinline__ void gld16_async(const char* base, uint32_t voff, AReg& d) { __builtin_memcpy(d.w, base + voff, 16); }
+__device__ __forceinline__ void gld16_sync(const char* base, uint32_t voff, AReg& d) { __builtin_memcpy(d.w, base + voff, 16); }
+__device__ __forceinline__ Frag areg_frag(const AReg& r) { return r; }
+__device__ __forceinline__ AReg areg_zero() { AReg z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u; return z; }
 #else
 // global_load_lds_dwordx4 voffset, sbase: 16 bytes from base + voff (per lane) to LDS byte M0 + 16 * lane.  Written as inline assembly on
 // purpose: hipcc tracks the built-in's LDS writes on vmcnt and, having no alias information for them, drains EVERY outstanding memory
@@ -138,6 +144,22 @@ __device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS c
 }
 #pragma clang diagnostic pop
 #define PJ_VMWAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// 16 bytes from base + voff (per lane) into registers WITHOUT the compiler's bookkeeping: its own wait for an ordinary load counts only the
+// memory operations it knows of and would drain the LDS-direct loads queued behind.  The registers are in flight from gld16_async to the
+// PJ_VMWAIT_FOR on the SAME variable (which names how many younger operations may stay in the queue): the compiler sees two opaque
+// definitions of that variable and nothing in between, and the code between the two must be straight-line -- no branch, no loop edge, no
+// other use -- so that it has no reason to copy the registers before the data has landed (checked in the generated code:
+// scripts/check_async_loads.py).  gld16_sync waits inside the same statement (ragged tiles, where lanes are predicated off).
+typedef unsigned AReg __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gld16_async(const char* base, uint32_t voff, AReg& d) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void gld16_sync(const char* base, uint32_t voff, AReg& d) {
+    asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "+v"(d) : "v"(voff), "s"(base) : "memory");
+}
+#define PJ_VMWAIT_FOR(n, r) asm volatile("s_waitcnt vmcnt(" #n ") ; releases %0" : "+v"(r)::"memory")
+__device__ __forceinline__ Frag areg_frag(const AReg& r) { return __builtin_bit_cast(Frag, r); }
+__device__ __forceinline__ AReg areg_zero() { AReg z = {0u, 0u, 0u, 0u}; return z; }
 #define PJ_LGKMWAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define PJ_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #endif
@@ -153,6 +175,7 @@ template <int K, bool FULL>
 __device__ __forceinline__ void issue_operand_tile(const char* xbase, unsigned p0, unsigned P, HY_LDS char* ubuf, int wave, int lane) {
     constexpr int PCS = K / 8, NX = PJ_NT * K * 2 / 1024 / PJ_WAVES;
     const char* const tb = HY_UNIFORM_PTR(const char, xbase + (size_t)p0 * K * 2);
+    HY_OPAQUE(lane);                             // the NX per-lane offsets are recomputed per tile (a handful of operations) instead of being held in NX registers
     HY_UNROLL
     for (int i = 0; i < NX; ++i) {
         const int chunk = i * PJ_WAVES + wave, S = chunk * 64 + lane, pos = S / PCS, c = (S % PCS) ^ (pos % PCS);
@@ -505,13 +528,12 @@ template <int K> struct PmCfg {
     static constexpr int UROWB = K * 2;                         // bytes per operand row
     static constexpr int UBUF = PJ_NT * UROWB;                  // the operand tile: 32 / 16 KB
     static constexpr int NX = UBUF / 1024 / PJ_WAVES;           // LDS-direct loads per wavefront and operand tile (8 / 4)
-    static constexpr int EROW = PM_UW * 2;                      // bytes per row of a wavefront's [position][unit] images
-    static constexpr int NE = PJ_NT * EROW / 1024;              // 16-byte row pieces per lane of a 64-position tile = LDS-direct loads of MODE 1's a tile (8)
-    // a wavefront's LDS: MODE 0 two double-buffered 1 KB chunk images (a, h): 4 KB; MODE 1 the whole a tile: 8 KB
-    static constexpr int ebuf(int mode) { return mode == 0 ? 4096 : PJ_NT * EROW; }
-    // 48 / 64 KB at K = 256: two workgroups share a CU (2 wavefronts per SIMD, <= 256 registers each); the second one fills the first
-    // one's dependent chains (LDS and transcendental latencies), barriers and store back-pressure.
-    static constexpr size_t lds(int mode) { return (size_t)UBUF + PJ_WAVES * (size_t)ebuf(mode); }
+    static constexpr int EROW = PM_UW * 2;                      // bytes per row of a wavefront's [position][unit] chunk image
+    // a wavefront's LDS: two 1 KB chunk images (8 positions x 64 units), double-buffered
+    static constexpr int EBUF = 2048;
+    // 40 / 24 KB: two workgroups share a CU (2 wavefronts per SIMD, <= 256 registers each); the second one fills the first one's
+    // dependent chains (LDS and transcendental latencies), barriers and store back-pressure.
+    static constexpr size_t LDS = (size_t)UBUF + PJ_WAVES * (size_t)EBUF;
 };
 
 struct MlpArgs {
@@ -583,7 +605,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     const int n0 = cg * PJ_WAVES * PM_UW + wave * PM_UW;                   // first hidden unit of this wavefront
 
     HY_LDS char* const ubuf = HY_LDS_CAST(char, smem);
-    HY_LDS char* const et = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::ebuf(MODE);      // this wavefront's images [position][unit]
+    HY_LDS char* const et = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::EBUF;             // this wavefront's chunk images [position][unit]
 
     const char* const xbase = reinterpret_cast<const char*>(a.x);
     auto issue_x = [&](int t, auto full_c) {
@@ -592,19 +614,21 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     // A wavefront's tile: 16-byte slot S = 64 m + lane = (position 8 m + lane / 8, slot lane mod 8) <-> piece (lane mod 8) ^ 4 hb of the global
     // row (bit 2 of the position is hb for every m).  Same map for the a tile coming in (MODE 1) and the results going out.
     const uint32_t eoff0 = (uint32_t)(((lane >> 3) * N + n0 + 8 * ((lane & 7) ^ (hb << 2))) * 2);          // bytes; + (p0 + 8 m) N 2: wave-uniform
-    auto issue_a = [&](int t, auto full_c) {
+    // MODE 1: the a values arrive as the same row pieces, straight into registers, two chunks ahead of their use (asynchronously on whole
+    // tiles; the ragged last tile loads them one by one)
+    auto load_a = [&](int t, int c, AReg& d, auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
-        const unsigned p0 = (unsigned)t * PJ_NT;
-        HY_UNROLL
-        for (int m = 0; m < C::NE; ++m) {
-            const char* const rb = HY_UNIFORM_PTR(const char, reinterpret_cast<const char*>(a.a_in) + ((size_t)p0 + 8u * m) * N * 2);
-            if (FULL || p0 + (unsigned)(lane >> 3) + 8u * m < P) glds16(rb, eoff0, et + m * 1024, lane);
+        const unsigned p = (unsigned)t * PJ_NT + 8u * (unsigned)c;
+        const char* const rb = HY_UNIFORM_PTR(const char, reinterpret_cast<const char*>(a.a_in) + (size_t)p * N * 2);
+        if (FULL) gld16_async(rb, eoff0, d);
+        else {
+            d = areg_zero();
+            if (p + (unsigned)(lane >> 3) < P) gld16_sync(rb, eoff0, d);
         }
     };
     const int t_whole = (int)(P / PJ_NT) < t_end ? (int)(P / PJ_NT) : t_end;                 // tiles [t_begin, t_whole) are whole
-    if (t_begin < t_whole) { issue_x(t_begin, True_()); if (MODE == 1) issue_a(t_begin, True_()); }
-    else { issue_x(t_begin, False_()); if (MODE == 1) issue_a(t_begin, False_()); }
-
+    if (t_begin < t_whole) issue_x(t_begin, True_());
+    else issue_x(t_begin, False_());
 
     // stationary operand: 64 weight rows as B fragments (column = unit j of unit tile ut, k = 16 ks + 8 hb ...)
     Frag wf[2][C::KS];
@@ -616,7 +640,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     }
     float bias[2] = {0.f, 0.f};
     if (MODE == 0 && a.bias != nullptr) { bias[0] = a.bias[n0 + j]; bias[1] = a.bias[n0 + 32 + j]; }
-    float colsum[2] = {0.f, 0.f};
+    float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                 // MODE 1: units n0 + 8 ((lane & 7) ^ 4 hb) + i of the positions this lane's row pieces cover
 
     // A fragment of (position tile pt, step ks): 16 bytes at row pt 32 + j, piece (2 ks + hb) ^ (j mod PCS) = (2 ks) ^ (hb ^ j mod PCS)
     const int ua = j * C::UROWB, ux = (hb ^ (j % C::PCS)) * 16;
@@ -629,17 +653,20 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
 #endif
     // one tile; FULL (compile time): whole tiles carry no per-position predicate and no branch around a memory instruction, so that the
     // number of operations in flight behind a given one is known
-    auto tile = [&](int t, auto full_c) {
-        constexpr bool full = decltype(full_c)::value;
+    // FULL: a whole tile; NEXT: the next tile exists and is whole (both compile time: see above)
+    auto tile = [&](int t, auto full_c, auto next_c) {
+        constexpr bool full = decltype(full_c)::value, next_full = decltype(next_c)::value;
         const unsigned p0 = (unsigned)t * PJ_NT;
-        const bool next_full = t + 1 < t_whole;
-        // (1) this tile's operand is in LDS: my share has landed (younger: the previous tile's 16 stores, or its 8 stores and this tile's
-        //     8 a loads), then everybody's
+        // (1) this tile's operand is in LDS: my share has landed (younger: the previous tile's 16 stores -- MODE 1: 8 stores and 6 a loads),
+        //     then everybody's
         if (t == t_begin || !full) PJ_VMWAIT(0);
-        else PJ_VMWAIT(16);
+        else if (MODE == 0) PJ_VMWAIT(16);
+        else PJ_VMWAIT(14);
         PJ_MARK(0);
         PJ_BARRIER();
         PJ_MARK(1);
+        AReg ab0 = areg_zero(), ab1 = ab0;                                     // MODE 1: the a pieces of row phases r (even / odd)
+        if (MODE == 1) { load_a(t, 0, ab0, full_c); load_a(t, 1, ab1, full_c); }      // land behind the matrix-core phase
         acc_t acc[2][2];                           // [position tile][unit tile]
         HY_UNROLL
         for (int pt = 0; pt < 2; ++pt) {
@@ -664,73 +691,88 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
         PJ_MARK(3);
         if (next_full) issue_x(t + 1, True_());
         else if (t + 1 < t_end) issue_x(t + 1, False_());
-        if (MODE == 1) {
-            // this tile's a values (requested one tile ago; younger: the operand loads just issued)
-            if (!next_full) PJ_VMWAIT(0);
-            else if (C::NX == 8) PJ_VMWAIT(8);
-            else PJ_VMWAIT(4);
-        }
         PJ_MARK(4);
         // ---- epilogue, wavefront-private, in 8 chunks of 8 positions x 64 units (1 KB = one 16-byte row piece per lane) ----
         // Register r of lane (j, hb) = position pt 32 + pj_row(r, hb), unit ut 32 + j: chunk m = positions 8 m .. 8 m + 7 is registers
-        // 4 (m mod 4) + i, i < 4, of position tile m / 4, both unit tiles -- 8 values per lane.  A chunk is computed, parked in LDS in the
-        // [position][unit] image (byte q 128 + (ut ^ hb) 64 + 2 j, q = i + 4 hb), read back as row pieces while the NEXT chunk is computed
-        // and stored after it: two stores (MODE 1: one) every eighth of the element-wise work instead of bursts of eight that block the
-        // wavefront at the memory pipeline's queue (1.7 of a tile's 8.0 us: profiles/r4j_mlp_phases.txt).  MODE 0 parks a and h side by side
-        // (two 1 KB images, double-buffered: 4 KB per wavefront); MODE 1 works in place in the a tile that the LDS-direct loads brought.
+        // 4 (m mod 4) + i, i < 4, of position tile m / 4, both unit tiles -- 8 values per lane.  The GEMM result of a chunk (MODE 0: a =
+        // round(acc + bias); MODE 1: round(dh)) is parked in LDS in the [position][unit] image (byte q 128 + (ut ^ hb) 64 + 2 j, q = i + 4 hb)
+        // and read back as row pieces: from there on a lane holds 8 neighbouring units of ONE position, exactly what one 16-byte piece of
+        // the outputs (and of MODE 1's a operand) is, and the element-wise part runs in that layout -- eight independent chains per lane,
+        // nothing but the GEMM result ever crosses LDS (the first chunked version parked h as well and MODE 1 picked its a values out of
+        // an LDS tile one 2-byte read at a time, each with its latency exposed: 30 % of a wavefront's life, profiles/r4l_mlp_sq_counters.txt).
+        // Row phase r = m - 1 runs between chunk m's parking and the request for its rows, which are used behind the parking of chunk m + 1: the
+        // read-back's latency and the stores' back-pressure hide behind arithmetic.
         {
-            Frag r0, r1;
-            r0.w[0] = r0.w[1] = r0.w[2] = r0.w[3] = 0u;
-            r1 = r0;
+            Frag rp;
+            rp.w[0] = rp.w[1] = rp.w[2] = rp.w[3] = 0u;
             char* const dst0 = reinterpret_cast<char*>(a.o0) + (size_t)p0 * N * 2 + eoff0;
             char* const dst1 = MODE == 0 ? reinterpret_cast<char*>(a.o1) + (size_t)p0 * N * 2 + eoff0 : nullptr;
             HY_UNROLL
-            for (int m = 0; m < 8; ++m) {
-                HY_LDS char* const ca = MODE == 0 ? et + (m & 1) * 2048 : et + m * 1024;          // this chunk's image (MODE 0: a, then h at + 1024)
-                HY_UNROLL
-                for (int ut = 0; ut < 2; ++ut) {
+            for (int m = 0; m <= 8; ++m) {
+                if (m < 8) {
+                    HY_LDS char* const img = et + (m & 1) * 1024;
                     HY_UNROLL
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = acc[m >> 2][ut][4 * (m & 3) + i];
-                        HY_LDS elem_t* slot = reinterpret_cast<HY_LDS elem_t*>(ca + (i + 4 * hb) * C::EROW + (ut ^ hb) * 64 + 2 * j);
-                        if (MODE == 0) {
-                            const elem_t av = Elem<DT>::cvt(v + bias[ut]);
-                            slot[0] = av;
-                            slot[512] = Elem<DT>::cvt(pm_gelu(Elem<DT>::dec(av)));                   // + 1024 bytes: the h image
-                        } else {
-                            const float dh = Elem<DT>::dec(Elem<DT>::cvt(v));                        // the rounding of the unfused dh tensor
-                            const elem_t dv = Elem<DT>::cvt(dh * pm_dgelu(Elem<DT>::dec(*slot)));
-                            *slot = dv;
-                            if (full || p0 + (unsigned)(8 * m + i + 4 * hb) < P) colsum[ut] += Elem<DT>::dec(dv);
+                    for (int ut = 0; ut < 2; ++ut) {
+                        HY_UNROLL
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = acc[m >> 2][ut][4 * (m & 3) + i];
+                            HY_LDS elem_t* slot = reinterpret_cast<HY_LDS elem_t*>(img + (i + 4 * hb) * C::EROW + (ut ^ hb) * 64 + 2 * j);
+                            *slot = Elem<DT>::cvt(MODE == 0 ? v + bias[ut] : v);                     // MODE 1: the rounding of the unfused dh tensor
                         }
                     }
+                    HY_WAVE_SYNC_PJ();
                 }
-                if (m > 0 && (full || p0 + (unsigned)(lane >> 3) + 8u * (m - 1) < P)) {
-                    st16(dst0 + (size_t)(8 * (m - 1)) * N * 2, r0);
-                    if (MODE == 0) st16(dst1 + (size_t)(8 * (m - 1)) * N * 2, r1);
+                if (m > 0) {
+                    const int r = m - 1;
+                    const bool on = full || p0 + (unsigned)(lane >> 3) + 8u * r < P;
+                    elem_t ge[8], oe[8];
+                    __builtin_memcpy(ge, rp.w, 16);
+                    if (MODE == 0) {
+                        HY_UNROLL
+                        for (int i = 0; i < 8; ++i) oe[i] = Elem<DT>::cvt(pm_gelu(Elem<DT>::dec(ge[i])));
+                        Frag rh;
+                        __builtin_memcpy(rh.w, oe, 16);
+                        if (on) {
+                            st16(dst0 + (size_t)(8 * r) * N * 2, rp);
+                            st16(dst1 + (size_t)(8 * r) * N * 2, rh);
+                        }
+                    } else {
+                        // a(r): requested two row phases ago (r < 2: before the matrix-core phase); younger in the queue: a store and an a
+                        // load -- for r < 2 the next tile's operand loads and a(1) / store(0), a(2)
+                        AReg& ar = (r & 1) ? ab1 : ab0;
+                        if (full) {
+                            if (r == 0) { if (!next_full) PJ_VMWAIT_FOR(0, ar); else if (C::NX == 8) PJ_VMWAIT_FOR(9, ar); else PJ_VMWAIT_FOR(5, ar); }
+                            else if (r == 1) { if (!next_full) PJ_VMWAIT_FOR(0, ar); else if (C::NX == 8) PJ_VMWAIT_FOR(10, ar); else PJ_VMWAIT_FOR(6, ar); }
+                            else if (r == 7) PJ_VMWAIT_FOR(1, ar);
+                            else PJ_VMWAIT_FOR(2, ar);
+                        }
+                        const Frag af = areg_frag(ar);
+                        elem_t ae[8];
+                        __builtin_memcpy(ae, af.w, 16);
+                        Frag rd;
+                        HY_UNROLL
+                        for (int i = 0; i < 8; ++i) {
+                            oe[i] = Elem<DT>::cvt(Elem<DT>::dec(ge[i]) * pm_dgelu(Elem<DT>::dec(ae[i])));
+                            if (on) colsum[i] += Elem<DT>::dec(oe[i]);
+                            if (i & 1) rd.w[i >> 1] = (uint32_t)oe[i - 1] | ((uint32_t)oe[i] << 16);      // packed as they come: eight loose 16-bit results and the fp16 kernel spills
+                            if (i == 3) HY_SCHED_FENCE();          // four chains at a time
+                        }
+                        if (on) st16(dst0 + (size_t)(8 * r) * N * 2, rd);
+                        if (r + 2 < 8) load_a(t, r + 2, ar, full_c);
+                    }
                 }
+                // chunk m's rows: requested now, used behind the parking of chunk m + 1
+                if (m < 8) rp = lds_ld16(et + (m & 1) * 1024 + lane * 16);
                 HY_WAVE_SYNC_PJ();
-                r0 = lds_ld16(ca + lane * 16);
-                if (MODE == 0) r1 = lds_ld16(ca + 1024 + lane * 16);
-                HY_WAVE_SYNC_PJ();
-            }
-            if (full || p0 + (unsigned)(lane >> 3) + 56u < P) {
-                st16(dst0 + (size_t)56 * N * 2, r0);
-                if (MODE == 0) st16(dst1 + (size_t)56 * N * 2, r1);
             }
             PJ_MARK(5);                                          // accumulators (waits for the matrix cores) -> element-wise -> rows stored
-        }
-        HY_WAVE_SYNC_PJ();
-        if (MODE == 1 && t + 1 < t_end) {
-            PJ_LGKMWAIT();                                       // the tile's rows have been read out: the next a tile may land in it
-            if (next_full) issue_a(t + 1, True_());
-            else issue_a(t + 1, False_());
         }
     };
     {
         int t = t_begin;
-        for (; t < t_whole; ++t) tile(t, True_());
-        if (t < t_end) tile(t, False_());
+        for (; t + 1 < t_whole; ++t) tile(t, True_(), True_());
+        if (t < t_whole) { tile(t, True_(), False_()); ++t; }                  // the last whole tile: nothing, or a ragged tile, behind it
+        if (t < t_end) tile(t, False_(), False_());
     }
 #if defined(PJ_PROFILE) && !defined(HIPEMU)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -751,15 +793,17 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     }
 #endif
     if (MODE == 1) {
-        // column sums of da over this run: the two half-waves hold different positions of the same unit
+        // column sums of da over this run: the 8 lanes that share a piece index hold different positions of the same 8 units -- through
+        // LDS ([row lane >> 3][unit]: 2 KB), added in row order
         HY_LDS float* red = reinterpret_cast<HY_LDS float*>(et);
         HY_WAVE_SYNC_PJ();
-        if (hb == 1) { red[j] = colsum[0]; red[32 + j] = colsum[1]; }
+        HY_UNROLL
+        for (int i = 0; i < 8; ++i) red[(lane >> 3) * 64 + 8 * ((lane & 7) ^ (hb << 2)) + i] = colsum[i];
         HY_WAVE_SYNC_PJ();
-        if (hb == 0) {
-            a.part[(size_t)run * N + n0 + j] = colsum[0] + red[j];
-            a.part[(size_t)run * N + n0 + 32 + j] = colsum[1] + red[32 + j];
-        }
+        float sum = 0.f;
+        HY_UNROLL
+        for (int q = 0; q < 8; ++q) sum += red[q * 64 + lane];
+        a.part[(size_t)run * N + n0 + lane] = sum;
     }
 }
 

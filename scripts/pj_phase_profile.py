@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hyena_dna_amd import _lib  # noqa: E402
 
 NAMES = ["wait: my operand share", "barrier 1 (operand complete)", "MFMA issue", "barrier 2 (operand read)", "request next operand (+ wait a)",
-         "epilogue: 8 chunks (+MFMA drain)", "-", "-", "-", "final store ack"]
+         "epilogue: 8 chunks, row layout (+MFMA drain)", "-", "-", "-", "final store ack"]
 dev = torch.device("cuda", 0)
 L_ = _lib.lib()
 L_.hyena_pj_prof_set.argtypes = [ctypes.c_void_p]
