@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
         // and read back as row pieces: from there on a lane holds 8 neighbouring units of ONE position, exactly what one 16-byte piece of
         // the outputs (and of MODE 1's a operand) is, and the element-wise part runs in that layout -- eight independent chains per lane,
         // nothing but the GEMM result ever crosses LDS (the first chunked version parked h as well and MODE 1 picked its a values out of
-        // an LDS tile one 2-byte read at a time, each with its latency exposed: 30 % of a wavefront's life, profiles/r4l_mlp_sq_counters.txt).
+        // an LDS tile one 2-byte read at a time, each with its latency exposed: 30 % of a wavefront's life, profiles/r4l_mlp_sq_counters.csv).
         // Row phase r = m - 1 runs between chunk m's parking and the request for its rows, which are used behind the parking of chunk m + 1: the
         // read-back's latency and the stores' back-pressure hide behind arithmetic.
         {
