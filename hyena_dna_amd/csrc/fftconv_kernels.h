@@ -1358,6 +1358,7 @@ __global__ void __launch_bounds__(64, 2) row0_bwd_kernel(RowArgs a) {
             const int pk2 = (pk_base - (j + 32 * q)) & 1023;
             h[q] = cscale(packed_product<MODE_CORR>(v[q], lds_ld(imx + row_idx(pk2)), h[q], lds_ld(imh + row_idx(pk2)), pw_tw(wkj, q), 0.f),
                           a.scale);
+            if (DO_DU && (q & 3) == 3) HY_SCHED_FENCE();         // G stays live for du: four products at a time, not 32 partner reads + twiddles up front
         }
         __syncthreads();
         row_fft1024<true>(h, imh, j, rtw);
@@ -1373,11 +1374,21 @@ __global__ void __launch_bounds__(64, 2) row0_bwd_kernel(RowArgs a) {
             HY_UNROLL
             for (int q = 0; q < 32; ++q) lds_st(imh + j + 33 * q, h[q]);       // K image; the G image is still in imx
             __syncthreads();
+            // the partner indices and the 32 twiddles are recomputed for this second product (from copies the optimiser cannot identify
+            // with the first product's): kept live across the three transforms in between they were 81 spilled registers
+            int j2 = j;
+            c32 wk2 = wkj;
+            HY_OPAQUE(j2);
+            HY_OPAQUE(wk2.x);
+            HY_OPAQUE(wk2.y);
+            // ... and this lane's own G values come back from the G image (they were 64 more registers live across those transforms)
             HY_UNROLL
             for (int q = 0; q < 32; ++q) {
-                const int pk2 = (pk_base - (j + 32 * q)) & 1023;
-                v[q] = cscale(packed_product<MODE_CORR>(v[q], lds_ld(imx + row_idx(pk2)), h[q], lds_ld(imh + row_idx(pk2)), pw_tw(wkj, q), bias),
+                const int pk2 = (pk_base - (j2 + 32 * q)) & 1023;
+                v[q] = cscale(packed_product<MODE_CORR>(lds_ld(imx + j2 + 33 * q), lds_ld(imx + row_idx(pk2)), h[q], lds_ld(imh + row_idx(pk2)),
+                                                        pw_tw(wk2, q), bias),
                               a.scale);
+                if ((q & 3) == 3) HY_SCHED_FENCE();
             }
             __syncthreads();
             row_fft1024<true>(v, imx, j, rtw);
