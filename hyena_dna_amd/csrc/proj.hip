@@ -19,8 +19,8 @@ template <int K, int DT, int MODE>
 int launch_mlp(const pj::MlpArgs& a, int grid, void* stream) {
     typedef pj::PmCfg<K> C;
     static thread_local int done = -1;
-    hy_allow_lds(pj::mlp_kernel<K, DT, MODE>, C::LDS, &done);
-    HY_LAUNCH((pj::mlp_kernel<K, DT, MODE>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS, stream, a);
+    hy_allow_lds(pj::mlp_kernel<K, DT, MODE>, C::lds(MODE), &done);
+    HY_LAUNCH((pj::mlp_kernel<K, DT, MODE>), dim3(grid), dim3(pj::PJ_THREADS), C::lds(MODE), stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 // runs of tiles per unit group: a few per workgroup slot (2 per CU; tail balance), at least 8 tiles long (weight load amortised)

@@ -118,23 +118,43 @@ __device__ __forceinline__ void lds_st16(HY_LDS char* p, const Frag& f) { *reint
 #endif
 
 #ifdef HIPEMU
-// the test double copies at issue (LDS-direct loads are asynchronous on the hardware: the kernel's waits and barriers are what make that equal)
-__device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane) { __builtin_memcpy(wave_base + 16 * lane, base + voff, 16); }
-#define PJ_VMWAIT(n) do {} while (0)
-#define PJ_VMWAIT_FOR(n, f) do {} while (0)
+// The test double models the memory pipeline's queue the way the kernels' counted waits assume it: operations retire in issue order, an
+// LDS-direct or asynchronous register load delivers its 16 bytes only when it retires, `s_waitcnt vmcnt(n)` retires the oldest operations until
+// n are left.  A wait that names too many younger operations therefore leaves the data stale under the emulator as well -- on the hardware such
+// a mistake is a race that may or may not show.  (One queue per thread: the stack of its fibre.  Stores are performed at issue and only counted.)
+struct EmuVmq {
+    struct Op { const void* src; void* dst; };
+    Op q[128];
+    int head = 0, n = 0;
+    void push(const void* src, void* dst) { q[(head + n++) & 127] = Op{src, dst}; }
+    void retire_to(int keep) {
+        while (n > keep) {
+            const Op& o = q[head];
+            if (o.dst != nullptr) __builtin_memcpy(o.dst, o.src, 16);
+            head = (head + 1) & 127;
+            --n;
+        }
+    }
+    ~EmuVmq() { retire_to(0); }
+};
+#define PJ_VMQ_DECL EmuVmq pj_vmq
+#define PJ_VMQ_PARAM , EmuVmq& pj_vmq
+#define PJ_VMQ_ARG , pj_vmq
+__device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane, EmuVmq& q) { q.push(base + voff, wave_base + 16 * lane); }
+#define PJ_VMWAIT(n) pj_vmq.retire_to(n)
 #define PJ_LGKMWAIT() do {} while (0)
 #define PJ_BARRIER() __syncthreads()
-typedef Frag AReg;                                            // (device: a raw register quadruple an asynchronous load is in flight to)
-__device__ __forceinline__ void gld16_async(const char* base, uint32_t voff, AReg& d) { __builtin_memcpy(d.w, base + voff, 16); }
-__device__ __forceinline__ void gld16_sync(const char* base, uint32_t voff, AReg& d) { __builtin_memcpy(d.w, base + voff, 16); }
-__device__ __forceinline__ Frag areg_frag(const AReg& r) { return r; }
-__device__ __forceinline__ AReg areg_zero() { AReg z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u; return z; }
+#define PJ_ST16(p, f) do { st16((p), (f)); pj_vmq.push(nullptr, nullptr); } while (0)
 #else
 // global_load_lds_dwordx4 voffset, sbase: 16 bytes from base + voff (per lane) to LDS byte M0 + 16 * lane.  Written as inline assembly on
 // purpose: hipcc tracks the built-in's LDS writes on vmcnt and, having no alias information for them, drains EVERY outstanding memory
 // operation before any later LDS read of the kernel -- the wavefront tile's reads in the epilogue would wait for the next operand tile and
 // for each preceding global store.  Here the kernel's own counted waits (PJ_VMWAIT) are the only ones; the compiler's waits for the memory
 // operations it knows can only come out stricter for the extra ones in the queue, never laxer.
+#define PJ_VMQ_DECL do {} while (0)
+#define PJ_VMQ_PARAM
+#define PJ_VMQ_ARG
+#define PJ_ST16(p, f) st16((p), (f))
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane) {
@@ -144,22 +164,6 @@ __device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS c
 }
 #pragma clang diagnostic pop
 #define PJ_VMWAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-// 16 bytes from base + voff (per lane) into registers WITHOUT the compiler's bookkeeping: its own wait for an ordinary load counts only the
-// memory operations it knows of and would drain the LDS-direct loads queued behind.  The registers are in flight from gld16_async to the
-// PJ_VMWAIT_FOR on the SAME variable (which names how many younger operations may stay in the queue): the compiler sees two opaque
-// definitions of that variable and nothing in between, and the code between the two must be straight-line -- no branch, no loop edge, no
-// other use -- so that it has no reason to copy the registers before the data has landed (checked in the generated code:
-// scripts/check_async_loads.py).  gld16_sync waits inside the same statement (ragged tiles, where lanes are predicated off).
-typedef unsigned AReg __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void gld16_async(const char* base, uint32_t voff, AReg& d) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(base) : "memory");
-}
-__device__ __forceinline__ void gld16_sync(const char* base, uint32_t voff, AReg& d) {
-    asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "+v"(d) : "v"(voff), "s"(base) : "memory");
-}
-#define PJ_VMWAIT_FOR(n, r) asm volatile("s_waitcnt vmcnt(" #n ") ; releases %0" : "+v"(r)::"memory")
-__device__ __forceinline__ Frag areg_frag(const AReg& r) { return __builtin_bit_cast(Frag, r); }
-__device__ __forceinline__ AReg areg_zero() { AReg z = {0u, 0u, 0u, 0u}; return z; }
 #define PJ_LGKMWAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define PJ_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #endif
@@ -172,14 +176,14 @@ struct False_ { static constexpr bool value = false; };
 // (slot ^ position mod PCS), PCS = K / 8 pieces per row -- a fragment read of 16 neighbouring rows at one piece index then touches 16
 // different bank groups.  FULL = false: rows of positions >= P are not fetched (they keep older values; their results are never stored).
 template <int K, bool FULL>
-__device__ __forceinline__ void issue_operand_tile(const char* xbase, unsigned p0, unsigned P, HY_LDS char* ubuf, int wave, int lane) {
+__device__ __forceinline__ void issue_operand_tile(const char* xbase, unsigned p0, unsigned P, HY_LDS char* ubuf, int wave, int lane PJ_VMQ_PARAM) {
     constexpr int PCS = K / 8, NX = PJ_NT * K * 2 / 1024 / PJ_WAVES;
     const char* const tb = HY_UNIFORM_PTR(const char, xbase + (size_t)p0 * K * 2);
     HY_OPAQUE(lane);                             // the NX per-lane offsets are recomputed per tile (a handful of operations) instead of being held in NX registers
     HY_UNROLL
     for (int i = 0; i < NX; ++i) {
         const int chunk = i * PJ_WAVES + wave, S = chunk * 64 + lane, pos = S / PCS, c = (S % PCS) ^ (pos % PCS);
-        if (FULL || p0 + (unsigned)pos < P) glds16(tb, (uint32_t)(pos * K * 2 + c * 16), ubuf + chunk * 1024, lane);
+        if (FULL || p0 + (unsigned)pos < P) glds16(tb, (uint32_t)(pos * K * 2 + c * 16), ubuf + chunk * 1024, lane PJ_VMQ_ARG);
     }
 }
 
@@ -253,6 +257,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
     typedef typename Elem<DT>::type elem_t;
     static_assert(sizeof(elem_t) == 2, "16-bit element types only");
     HY_SMEM(smem);
+    PJ_VMQ_DECL;
     const int tid = (int)threadIdx.x, wave = HY_SGPR(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
     const int D = a.D;
     const unsigned P = (unsigned)a.B * (unsigned)a.Lx;                       // flattened positions (< 2^31, checked by the host)
@@ -304,8 +309,8 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
     // fill the register file, there was nothing to prefetch into).  Tile t + 1 is requested when every wavefront has read tile t's last
     // fragment and lands behind tile t's epilogue; the wait at the top names the stores that may stay in flight behind it.
     const int t_whole = (int)(P / PJ_NT);                                    // tiles below this one are whole
-    if (t_first < t_whole) issue_operand_tile<K, true>(ubase, (unsigned)t_first * PJ_NT, P, ubuf, wave, lane);
-    else issue_operand_tile<K, false>(ubase, (unsigned)t_first * PJ_NT, P, ubuf, wave, lane);
+    if (t_first < t_whole) issue_operand_tile<K, true>(ubase, (unsigned)t_first * PJ_NT, P, ubuf, wave, lane PJ_VMQ_ARG);
+    else issue_operand_tile<K, false>(ubase, (unsigned)t_first * PJ_NT, P, ubuf, wave, lane PJ_VMQ_ARG);
     bool counted = false;                                                    // the previous tile left exactly IP_ST stores behind the loads
     for (int t = t_first; t < t_end; ++t, sl0 += PJ_NT) {
         while (sl0 >= a.Lx) { sl0 -= a.Lx; ++sb; }
@@ -336,8 +341,8 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
         }
         PJ_BARRIER();                                                        // every wavefront has read its last fragment
         if (t + 1 < t_end) {
-            if (t + 1 < t_whole) issue_operand_tile<K, true>(ubase, p0 + PJ_NT, P, ubuf, wave, lane);
-            else issue_operand_tile<K, false>(ubase, p0 + PJ_NT, P, ubuf, wave, lane);
+            if (t + 1 < t_whole) issue_operand_tile<K, true>(ubase, p0 + PJ_NT, P, ubuf, wave, lane PJ_VMQ_ARG);
+            else issue_operand_tile<K, false>(ubase, p0 + PJ_NT, P, ubuf, wave, lane PJ_VMQ_ARG);
         }
         counted = false;
         // ---- epilogue, wavefront-private ---------------------------------------------------------------------------
@@ -372,8 +377,8 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                 park(g);
                 if (g > 0) {
                     const size_t rowm = (size_t)((g - 1) * D) * P + p0;                               // wave-uniform
-                    st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), ra);
-                    st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm + (size_t)8 * P), rb);
+                    PJ_ST16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), ra);
+                    PJ_ST16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm + (size_t)8 * P), rb);
                 }
                 HY_WAVE_SYNC_PJ();
                 ra = lds_ld16(ebuf + (g * IP_CB + (lane >> 3)) * C::EROW + 16 + (lane & 7) * 16);
@@ -411,13 +416,13 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                 __builtin_memcpy(vf[m].w, out, 16);
                 if (m == 0) {                                       // the v rows of xT, behind the first half of the window arithmetic
                     const size_t rowm = (size_t)(2 * D) * P + p0;
-                    st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), ra);
-                    st16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm + (size_t)8 * P), rb);
+                    PJ_ST16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), ra);
+                    PJ_ST16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm + (size_t)8 * P), rb);
                 } else {
-                    st16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * (m - 1)) * (unsigned)a.Lc), vf[m - 1]);
+                    PJ_ST16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * (m - 1)) * (unsigned)a.Lc), vf[m - 1]);
                 }
             }
-            st16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * (IP_CB * 8 / 64 - 1)) * (unsigned)a.Lc), vf[IP_CB * 8 / 64 - 1]);
+            PJ_ST16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * (IP_CB * 8 / 64 - 1)) * (unsigned)a.Lc), vf[IP_CB * 8 / 64 - 1]);
         } else {
             HY_UNROLL
             for (int g = 0; g < 3; ++g) park(g);
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                     const unsigned p = p0 + 8u * (unsigned)pc;
                     const Frag v = lds_ld16(ebuf + (g * IP_CB + ch) * C::EROW + 16 + pc * 16);
                     elem_t* dst = reinterpret_cast<elem_t*>(a.xT) + (size_t)(g * D + d0 + ch) * P + p;
-                    if (p + 8 <= P) st16(dst, v);
+                    if (p + 8 <= P) PJ_ST16(dst, v);
                     else {
                         elem_t sv[8];
                         __builtin_memcpy(sv, v.w, 16);
@@ -478,7 +483,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                     if (l + 8 <= a.Lc) {
                         Frag f;
                         __builtin_memcpy(f.w, out, 16);
-                        st16(vrow + l, f);
+                        PJ_ST16(vrow + l, f);
                     } else {
                         for (int i = 0; i < 8; ++i) {
                             int li = l + i;
@@ -529,11 +534,12 @@ template <int K> struct PmCfg {
     static constexpr int UBUF = PJ_NT * UROWB;                  // the operand tile: 32 / 16 KB
     static constexpr int NX = UBUF / 1024 / PJ_WAVES;           // LDS-direct loads per wavefront and operand tile (8 / 4)
     static constexpr int EROW = PM_UW * 2;                      // bytes per row of a wavefront's [position][unit] chunk image
-    // a wavefront's LDS: two 1 KB chunk images (8 positions x 64 units), double-buffered
-    static constexpr int EBUF = 2048;
-    // 40 / 24 KB: two workgroups share a CU (2 wavefronts per SIMD, <= 256 registers each); the second one fills the first one's
+    // a wavefront's LDS: two 1 KB chunk images (8 positions x 64 units), double-buffered; MODE 1: + the tile of a values (64 positions x 64 units)
+    static constexpr int IMG = 2048, ATILE = PJ_NT * EROW;
+    static constexpr int ebuf(int mode) { return mode == 0 ? IMG : IMG + ATILE; }
+    // 40 / 72 KB at K = 256: two workgroups share a CU (2 wavefronts per SIMD, <= 256 registers each); the second one fills the first one's
     // dependent chains (LDS and transcendental latencies), barriers and store back-pressure.
-    static constexpr size_t LDS = (size_t)UBUF + PJ_WAVES * (size_t)EBUF;
+    static constexpr size_t lds(int mode) { return (size_t)UBUF + PJ_WAVES * (size_t)ebuf(mode); }
 };
 
 struct MlpArgs {
@@ -589,6 +595,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     typedef PmCfg<K> C;
     typedef typename Elem<DT>::type elem_t;
     HY_SMEM(smem);
+    PJ_VMQ_DECL;
     const int tid = (int)threadIdx.x, wave = HY_SGPR(tid >> 6), lane = tid & 63, j = lane & 31, hb = lane >> 5;
     const int N = a.N;
     const unsigned P = a.P;
@@ -605,30 +612,33 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     const int n0 = cg * PJ_WAVES * PM_UW + wave * PM_UW;                   // first hidden unit of this wavefront
 
     HY_LDS char* const ubuf = HY_LDS_CAST(char, smem);
-    HY_LDS char* const et = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::EBUF;             // this wavefront's chunk images [position][unit]
+    HY_LDS char* const et = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::ebuf(MODE);       // this wavefront's chunk images [position][unit] (+ MODE 1: its a tile)
 
     const char* const xbase = reinterpret_cast<const char*>(a.x);
     auto issue_x = [&](int t, auto full_c) {
-        issue_operand_tile<K, decltype(full_c)::value>(xbase, (unsigned)t * PJ_NT, P, ubuf, wave, lane);
+        issue_operand_tile<K, decltype(full_c)::value>(xbase, (unsigned)t * PJ_NT, P, ubuf, wave, lane PJ_VMQ_ARG);
     };
     // A wavefront's tile: 16-byte slot S = 64 m + lane = (position 8 m + lane / 8, slot lane mod 8) <-> piece (lane mod 8) ^ 4 hb of the global
     // row (bit 2 of the position is hb for every m).  Same map for the a tile coming in (MODE 1) and the results going out.
     const uint32_t eoff0 = (uint32_t)(((lane >> 3) * N + n0 + 8 * ((lane & 7) ^ (hb << 2))) * 2);          // bytes; + (p0 + 8 m) N 2: wave-uniform
-    // MODE 1: the a values arrive as the same row pieces, straight into registers, two chunks ahead of their use (asynchronously on whole
-    // tiles; the ragged last tile loads them one by one)
-    auto load_a = [&](int t, int c, AReg& d, auto full_c) {
+    // MODE 1: the a values arrive as the same row pieces by LDS-direct loads into a wavefront-private tile (slot 64 m + lane = the piece this
+    // lane turns into a piece of da), half a tile (chunks 4 h .. 4 h + 3) at a time: a half is requested as soon as the previous tile's row
+    // phases have read it out, a whole half-tile of epilogue before it is needed.  (They first came straight into registers, two chunks
+    // ahead; the queue retires in order, so every wait for such a load also waited for the next tile's operand loads issued before it --
+    // the emulator's queue model showed the operand prefetch being drained two chunks into the epilogue.)
+    HY_LDS char* const atile = et + C::IMG;
+    auto issue_a_half = [&](int t, int h, auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
-        const unsigned p = (unsigned)t * PJ_NT + 8u * (unsigned)c;
-        const char* const rb = HY_UNIFORM_PTR(const char, reinterpret_cast<const char*>(a.a_in) + (size_t)p * N * 2);
-        if (FULL) gld16_async(rb, eoff0, d);
-        else {
-            d = areg_zero();
-            if (p + (unsigned)(lane >> 3) < P) gld16_sync(rb, eoff0, d);
+        const unsigned p0 = (unsigned)t * PJ_NT;
+        HY_UNROLL
+        for (int m = 4 * h; m < 4 * h + 4; ++m) {
+            const char* const rb = HY_UNIFORM_PTR(const char, reinterpret_cast<const char*>(a.a_in) + ((size_t)p0 + 8u * m) * N * 2);
+            if (FULL || p0 + (unsigned)(lane >> 3) + 8u * m < P) glds16(rb, eoff0, atile + m * 1024, lane PJ_VMQ_ARG);
         }
     };
     const int t_whole = (int)(P / PJ_NT) < t_end ? (int)(P / PJ_NT) : t_end;                 // tiles [t_begin, t_whole) are whole
-    if (t_begin < t_whole) issue_x(t_begin, True_());
-    else issue_x(t_begin, False_());
+    if (t_begin < t_whole) { issue_x(t_begin, True_()); if (MODE == 1) { issue_a_half(t_begin, 0, True_()); issue_a_half(t_begin, 1, True_()); } }
+    else { issue_x(t_begin, False_()); if (MODE == 1) { issue_a_half(t_begin, 0, False_()); issue_a_half(t_begin, 1, False_()); } }
 
     // stationary operand: 64 weight rows as B fragments (column = unit j of unit tile ut, k = 16 ks + 8 hb ...)
     Frag wf[2][C::KS];
@@ -657,16 +667,13 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
     auto tile = [&](int t, auto full_c, auto next_c) {
         constexpr bool full = decltype(full_c)::value, next_full = decltype(next_c)::value;
         const unsigned p0 = (unsigned)t * PJ_NT;
-        // (1) this tile's operand is in LDS: my share has landed (younger: the previous tile's 16 stores -- MODE 1: 8 stores and 6 a loads),
-        //     then everybody's
+        // (1) this tile's operand is in LDS: my share has landed (younger: the previous tile's 16 stores -- MODE 1: 8 stores and the 8 loads
+        //     of this tile's a values), then everybody's
         if (t == t_begin || !full) PJ_VMWAIT(0);
-        else if (MODE == 0) PJ_VMWAIT(16);
-        else PJ_VMWAIT(14);
+        else PJ_VMWAIT(16);
         PJ_MARK(0);
         PJ_BARRIER();
         PJ_MARK(1);
-        AReg ab0 = areg_zero(), ab1 = ab0;                                     // MODE 1: the a pieces of row phases r (even / odd)
-        if (MODE == 1) { load_a(t, 0, ab0, full_c); load_a(t, 1, ab1, full_c); }      // land behind the matrix-core phase
         acc_t acc[2][2];                           // [position tile][unit tile]
         HY_UNROLL
         for (int pt = 0; pt < 2; ++pt) {
@@ -733,20 +740,18 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
                         Frag rh;
                         __builtin_memcpy(rh.w, oe, 16);
                         if (on) {
-                            st16(dst0 + (size_t)(8 * r) * N * 2, rp);
-                            st16(dst1 + (size_t)(8 * r) * N * 2, rh);
+                            PJ_ST16(dst0 + (size_t)(8 * r) * N * 2, rp);
+                            PJ_ST16(dst1 + (size_t)(8 * r) * N * 2, rh);
                         }
                     } else {
-                        // a(r): requested two row phases ago (r < 2: before the matrix-core phase); younger in the queue: a store and an a
-                        // load -- for r < 2 the next tile's operand loads and a(1) / store(0), a(2)
-                        AReg& ar = (r & 1) ? ab1 : ab0;
-                        if (full) {
-                            if (r == 0) { if (!next_full) PJ_VMWAIT_FOR(0, ar); else if (C::NX == 8) PJ_VMWAIT_FOR(9, ar); else PJ_VMWAIT_FOR(5, ar); }
-                            else if (r == 1) { if (!next_full) PJ_VMWAIT_FOR(0, ar); else if (C::NX == 8) PJ_VMWAIT_FOR(10, ar); else PJ_VMWAIT_FOR(6, ar); }
-                            else if (r == 7) PJ_VMWAIT_FOR(1, ar);
-                            else PJ_VMWAIT_FOR(2, ar);
+                        // the a values of this half tile have landed (requested half a tile of epilogue ago; younger in the queue: 4 stores, the 4
+                        // loads of the other half and the next tile's operand loads)
+                        if ((r & 3) == 0) {
+                            if (!full || !next_full) PJ_VMWAIT(0);
+                            else if (C::NX == 8) PJ_VMWAIT(16);
+                            else PJ_VMWAIT(12);
                         }
-                        const Frag af = areg_frag(ar);
+                        const Frag af = lds_ld16(atile + r * 1024 + lane * 16);
                         elem_t ae[8];
                         __builtin_memcpy(ae, af.w, 16);
                         Frag rd;
@@ -757,8 +762,12 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) mlp_kernel(MlpArgs a) {
                             if (i & 1) rd.w[i >> 1] = (uint32_t)oe[i - 1] | ((uint32_t)oe[i] << 16);      // packed as they come: eight loose 16-bit results and the fp16 kernel spills
                             if (i == 3) HY_SCHED_FENCE();          // four chains at a time
                         }
-                        if (on) st16(dst0 + (size_t)(8 * r) * N * 2, rd);
-                        if (r + 2 < 8) load_a(t, r + 2, ar, full_c);
+                        if (on) PJ_ST16(dst0 + (size_t)(8 * r) * N * 2, rd);
+                        if ((r & 3) == 3) {                                  // this half of the a tile is read out: the next tile's may land in it
+                            PJ_LGKMWAIT();
+                            if (next_full) issue_a_half(t + 1, r >> 2, True_());
+                            else if (t + 1 < t_end) issue_a_half(t + 1, r >> 2, False_());
+                        }
                     }
                 }
                 // chunk m's rows: requested now, used behind the parking of chunk m + 1
