@@ -197,7 +197,7 @@ def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=3, warmup=
     embedding -> n_layer x [add+LayerNorm -> HyenaOperator -> add+LayerNorm -> MLP (d -> 4d -> d, tanh-GELU)] -> LayerNorm ->
     tied LM head -> cross entropy, backward, AdamW step -- random init, autocast (hg38_hyena.yaml: d_model 256, n_layer 8,
     d_inner 1024, vocab 12 padded to 16)."""
-    from hyena_dna_amd.lm import HyenaDNALM
+    from hyena_dna_amd.lm import HyenaDNALM, token_cross_entropy
     torch.manual_seed(0)
     layer = dict(l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10, lr=6e-4, wd=0.0,
                  lr_pos_emb=0.0)
@@ -220,7 +220,7 @@ def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=3, warmup=
         opt.zero_grad(set_to_none=True)
         with torch.autocast(dev_type, dtype=dtype, enabled=dtype != torch.float32 and not emu):   # (the CPU test double runs fp32)
             logits = net(ids)[0].logits              # through DDP's forward, so that its reducer is armed for the backward
-            loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), tgt.reshape(-1))
+            loss = token_cross_entropy(logits, tgt)           # = F.cross_entropy over the flattened logits (lm.py)
         loss.backward()
         opt.step()
         return loss

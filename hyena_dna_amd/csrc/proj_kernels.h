@@ -843,7 +843,21 @@ __global__ void __launch_bounds__(PJ_THREADS) colsum_kernel(ColsumArgs a) {
     HY_UNROLL
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     const elem_t* base = reinterpret_cast<const elem_t*>(a.x) + 8 * pc;
-    for (unsigned r = r0 + (unsigned)ro; r < r1; r += (unsigned)rstep) {
+    unsigned r = r0 + (unsigned)ro;
+    // eight rows' loads in flight per thread, added in row order (one load per trip left the pass at 3.4 TB/s: 158 us for 0.54 GB)
+    for (; r + 7u * (unsigned)rstep < r1; r += 8u * (unsigned)rstep) {
+        Frag f[8];
+        HY_UNROLL
+        for (int u = 0; u < 8; ++u) f[u] = ld16(base + (size_t)(r + (unsigned)(u * rstep)) * a.N);
+        HY_UNROLL
+        for (int u = 0; u < 8; ++u) {
+            elem_t e[8];
+            __builtin_memcpy(e, f[u].w, 16);
+            HY_UNROLL
+            for (int i = 0; i < 8; ++i) acc[i] += Elem<DT>::dec(e[i]);
+        }
+    }
+    for (; r < r1; r += (unsigned)rstep) {
         const Frag f = ld16(base + (size_t)r * a.N);
         elem_t e[8];
         __builtin_memcpy(e, f.w, 16);

@@ -444,13 +444,27 @@ class HyenaDNALM(nn.Module, GenerationMixin):
         return bb.ln_f(residual.to(dtype=bb.ln_f.weight.dtype))
 
     def forward(self, input_ids, position_ids=None, inference_params=None, state=None):
-        lm_logits = self.lm_head(self.hidden(input_ids, position_ids))
+        # (the head through projection.hyena_linear: its weight gradient contracts 16 x 256 outputs over 10^6 tokens, which the GEMM library
+        # runs on 16 workgroups -- 1.19 ms per step at 2^20 tokens, profiles/r4y_model_stats.csv -- and the split-K form does not)
+        lm_logits = hyena_linear(self.hidden(input_ids, position_ids), self.lm_head.weight, self.lm_head.bias)
         return namedtuple("CausalLMOutput", ["logits"])(logits=lm_logits), None
 
     def loss(self, input_ids, targets, ignore_index=-100):
         """next-token cross entropy (src/tasks/metrics.py cross_entropy over the flattened logits), logits in fp32"""
         logits = self.forward(input_ids)[0].logits
-        return F.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), targets.reshape(-1), ignore_index=ignore_index)
+        return token_cross_entropy(logits, targets, ignore_index=ignore_index)
+
+
+def token_cross_entropy(logits, targets, ignore_index=-100):
+    """``F.cross_entropy(logits.float().reshape(-1, V), targets.reshape(-1), ignore_index=ignore_index)`` -- the mean of -log p[target] over
+    the tokens that are not ignored -- written as log-softmax + gather + masked mean.  Same value and gradients to fp32 summation order; on
+    ROCm PyTorch's own reduction for this 2-D case (nll_loss_forward_reduce_cuda_kernel_2d) runs in ONE workgroup: 1.07 ms forward and 0.8 ms
+    backward per step at 2^20 tokens x 16 classes (profiles/r4y_model_stats.csv) for 64 MB of logits; these are streaming kernels."""
+    lp = torch.log_softmax(logits.float().reshape(-1, logits.shape[-1]), dim=-1)
+    t = targets.reshape(-1)
+    valid = t != ignore_index
+    picked = lp.gather(1, t.clamp_min(0).unsqueeze(1)).squeeze(1)
+    return -(picked * valid).sum() / valid.sum()
 
 
 class CheckpointedModule(nn.Module):

@@ -33,6 +33,11 @@ import time
 
 import torch
 
+
+def _token_cross_entropy():
+    from .lm import token_cross_entropy          # (imported late, like the other model pieces: lm pulls the kernels' library in)
+    return token_cross_entropy
+
 __all__ = ["compose", "compose_raw", "apply_overrides", "resolve", "gpu_mem_gb", "set_affinity", "build_model", "build_optimizer", "optimizer_groups",
            "TimmCosineSchedule", "make_synthetic_genome", "train"]
 
@@ -467,7 +472,7 @@ def train(cfg, max_steps, device, graphed=False, log_every=10, log=print):
             with hold:
                 with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=amp and dev_type == "cuda"):
                     logits = net(x)[0].logits
-                    loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), y.reshape(-1))
+                    loss = _token_cross_entropy()(logits, y)
                 (loss / accum).backward()
             total += float(loss.detach()) / accum
         if clip > 0:

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 4: model-level effect of the head / loss / column-sum changes: LM tests, the model step, its kernel stats
+TAG=${1:-r4x}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+cd $R
+timeout 900 python -m pytest tests/test_gpu_block.py tests/test_gpu_runner.py tests/test_gpu_proj.py -q -m gpu 2>&1 | tail -3 | tee $OUT/pytest.txt
+timeout 600 python bench.py --no-sweep --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err; python -c "
+import json; d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1]); print('headline', d['ms_per_step'], 'layer', d['operator_layer']['ms_per_step'], 'model', d['model_step']['ms_per_step'], d['model_step'].get('graphed'))"
+bash scripts/gpu_prof_model.sh ${TAG}_model 1048576 1 256 | head -12 | cut -c1-150

@@ -410,3 +410,19 @@ def test_no_grad_forward_keeps_nothing_for_a_backward(emu_backend, monkeypatch):
     with torch.no_grad():
         FC.fftconv_func(torch.randn(2, 64, 96), k, torch.randn(64), None, False)
     assert seen["save"] == [(False, False)]
+
+
+def test_token_cross_entropy_is_f_cross_entropy():
+    """lm.token_cross_entropy (log-softmax + gather + masked mean) == F.cross_entropy with ignore_index: value and gradient"""
+    from hyena_dna_amd.lm import token_cross_entropy
+    torch.manual_seed(0)
+    logits = torch.randn(3, 50, 16, requires_grad=True)
+    tgt = torch.randint(0, 16, (3, 50))
+    tgt[0, :7] = -100
+    ref = torch.nn.functional.cross_entropy(logits.float().reshape(-1, 16), tgt.reshape(-1), ignore_index=-100)
+    g_ref, = torch.autograd.grad(ref, logits)
+    got = token_cross_entropy(logits, tgt)
+    g_got, = torch.autograd.grad(got, logits)
+    assert torch.allclose(got, ref, rtol=1e-6, atol=1e-7) and torch.allclose(g_got, g_ref, rtol=1e-5, atol=1e-8)
+    lb = logits.detach().to(torch.bfloat16)                    # 16-bit logits are evaluated in fp32, like the reference's metric
+    assert torch.allclose(token_cross_entropy(lb, tgt), torch.nn.functional.cross_entropy(lb.float().reshape(-1, 16), tgt.reshape(-1)), rtol=1e-6)
