@@ -199,6 +199,12 @@ def lib():
         L.hyena_add_norm_fwd.restype = c_int
         L.hyena_add_norm_fwd.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p,
                                          c_void_p, c_void_p, c_long, c_int, c_void_p]
+        L.hyena_dropout_add_norm_fwd.restype = c_int
+        L.hyena_dropout_add_norm_fwd.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int,
+                                                 c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]
+        L.hyena_dropout_add_norm_bwd.restype = c_int
+        L.hyena_dropout_add_norm_bwd.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                                 c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]
         L.hyena_add_norm_partial_floats.restype = c_size_t
         L.hyena_add_norm_partial_floats.argtypes = [c_long, c_int]
         L.hyena_add_norm_bwd.restype = c_int
@@ -651,9 +657,12 @@ def add_norm_supported(D, x_dtype, out_dtype):
         return False
 
 
-def add_norm_fwd(x0, residual, weight, bias, eps, out_dtype):
-    """x0 (rows, D), residual (rows, D) fp32 or None -> out (rows, D) out_dtype, residual' fp32, mean, rstd (rows,)."""
+def add_norm_fwd(x0, residual, weight, bias, eps, out_dtype, dropout_p=0.0, seed=None):
+    """x0 (rows, D), residual (rows, D) fp32 or None -> out (rows, D) out_dtype, residual' fp32, mean, rstd (rows,).
+    ``dropout_p`` > 0: dropout(x0) inside the pass, decided per element from ``seed`` (a one-element int64 tensor on x0's device)."""
     _require_gpu(x0, "x0")
+    if dropout_p > 0.0:
+        assert seed is not None and seed.dtype == torch.int64 and seed.numel() == 1 and seed.device == x0.device
     rows, D = x0.shape
     out = torch.empty((rows, D), dtype=out_dtype, device=x0.device)
     res_out = torch.empty((rows, D), dtype=torch.float32, device=x0.device)
@@ -662,14 +671,15 @@ def add_norm_fwd(x0, residual, weight, bias, eps, out_dtype):
     if rows == 0:
         return out, res_out, mean, rstd
     with _backend.guard(x0.device):
-        check(lib().hyena_add_norm_fwd(x0.data_ptr(), dtype_code(x0.dtype), None if residual is None else residual.data_ptr(),
-                                       weight.data_ptr(), bias.data_ptr(), float(eps), out.data_ptr(), dtype_code(out_dtype),
-                                       res_out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, _backend.stream(x0.device)))
+        check(lib().hyena_dropout_add_norm_fwd(x0.data_ptr(), dtype_code(x0.dtype), None if residual is None else residual.data_ptr(),
+                                               weight.data_ptr(), bias.data_ptr(), float(eps), float(dropout_p),
+                                               seed.data_ptr() if dropout_p > 0.0 else None, out.data_ptr(), dtype_code(out_dtype),
+                                               res_out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, _backend.stream(x0.device)))
     return out, res_out, mean, rstd
 
 
-def add_norm_bwd(dout, d_res_out, res_out, weight, mean, rstd, dx_dtype, need_dres):
-    """-> dx0 (rows, D) dx_dtype, d_residual_in fp32 or None, dweight (D,), dbias (D,)."""
+def add_norm_bwd(dout, d_res_out, res_out, weight, mean, rstd, dx_dtype, need_dres, dropout_p=0.0, seed=None):
+    """-> dx0 (rows, D) dx_dtype, d_residual_in fp32 or None, dweight (D,), dbias (D,).  (``dropout_p``, ``seed``): the forward's."""
     _require_gpu(dout, "dout")
     rows, D = dout.shape
     dev = dout.device
@@ -681,8 +691,9 @@ def add_norm_bwd(dout, d_res_out, res_out, weight, mean, rstd, dx_dtype, need_dr
         return dx, dres, dw, db
     part = torch.empty(lib().hyena_add_norm_partial_floats(rows, D), dtype=torch.float32, device=dev)
     with _backend.guard(dev):
-        check(lib().hyena_add_norm_bwd(dout.data_ptr(), dtype_code(dout.dtype), None if d_res_out is None else d_res_out.data_ptr(),
-                                       res_out.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                                       dtype_code(dx_dtype), None if dres is None else dres.data_ptr(), dw.data_ptr(),
-                                       db.data_ptr(), part.data_ptr(), rows, D, _backend.stream(dev)))
+        check(lib().hyena_dropout_add_norm_bwd(dout.data_ptr(), dtype_code(dout.dtype), None if d_res_out is None else d_res_out.data_ptr(),
+                                               res_out.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), float(dropout_p),
+                                               seed.data_ptr() if dropout_p > 0.0 else None, dx.data_ptr(), dtype_code(dx_dtype),
+                                               None if dres is None else dres.data_ptr(), dw.data_ptr(), db.data_ptr(), part.data_ptr(),
+                                               rows, D, _backend.stream(dev)))
     return dx, dres, dw, db

@@ -8,8 +8,10 @@ restated unfused at ``src/models/sequence/simple_lm.py:267-271, 280-284``).
     out, residual' = LayerNorm(dropout(x0) + residual), dropout(x0) + residual   prenorm=True
 
 ``residual'`` is fp32 (``residual_in_fp32=True``, what HyenaDNA trains with); ``out`` has ``x0``'s dtype, computed in
-fp32 and rounded once.  The dropout itself (p > 0 only: HyenaDNA's ``resid_dropout`` is 0) is PyTorch's, applied before the
-kernel.  Shapes outside the kernels' coverage (D not a multiple of 64, or > 1024) take the same graph in PyTorch ops on
+fp32 and rounded once.  Dropout (p > 0: HyenaDNA's embedding dropout, which the reference applies as the first block's) is part of
+the same pass since round 4: a 64-bit seed is drawn from PyTorch's generator of the device per call (so ``torch.manual_seed`` and graph
+capture behave as with ``F.dropout``), the keep / drop decision of an element is a pure function of (seed, index) and the backward
+regenerates it -- no mask tensor, no extra pass (csrc/block_kernels.h); the draws are NOT PyTorch's.  Shapes outside the kernels' coverage (D not a multiple of 64, or > 1024) take the same graph in PyTorch ops on
 the same device; host tensors are refused (``HyenaLibraryError``), as is a missing library.
 """
 import torch
@@ -22,15 +24,16 @@ __all__ = ["dropout_add_layer_norm", "AddLayerNormFunc"]
 
 class AddLayerNormFunc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, residual, weight, bias, eps, prenorm):
+    def forward(ctx, x0, residual, weight, bias, eps, prenorm, dropout_p=0.0, seed=None):
         shape = x0.shape
         D = shape[-1]
         x2 = x0.reshape(-1, D).contiguous()
         r2 = None if residual is None else residual.reshape(-1, D).to(torch.float32).contiguous()
         w = weight.detach().to(torch.float32).contiguous()
         b = bias.detach().to(torch.float32).contiguous()
-        out, res_out, mean, rstd = _lib.add_norm_fwd(x2, r2, w, b, eps, x0.dtype)
+        out, res_out, mean, rstd = _lib.add_norm_fwd(x2, r2, w, b, eps, x0.dtype, dropout_p=dropout_p, seed=seed)
         ctx.save_for_backward(res_out, w, mean, rstd)
+        ctx.drop = (float(dropout_p), seed)
         ctx.meta = (shape, x0.dtype, None if residual is None else residual.dtype, weight.dtype, bias.dtype, prenorm)
         ctx.mark_non_differentiable()
         if prenorm:
@@ -45,9 +48,10 @@ class AddLayerNormFunc(torch.autograd.Function):
         dres_out = rest[0] if prenorm and rest and rest[0] is not None else None
         d2 = dout.reshape(-1, D).contiguous()
         h2 = None if dres_out is None else dres_out.reshape(-1, D).to(torch.float32).contiguous()
-        dx, dres, dw, db = _lib.add_norm_bwd(d2, h2, res_out, w, mean, rstd, x_dtype, need_dres=r_dtype is not None)
+        dx, dres, dw, db = _lib.add_norm_bwd(d2, h2, res_out, w, mean, rstd, x_dtype, need_dres=r_dtype is not None,
+                                             dropout_p=ctx.drop[0], seed=ctx.drop[1])
         return (dx.view(shape), None if dres is None else dres.view(shape).to(r_dtype), dw.to(w_dtype), db.to(b_dtype),
-                None, None)
+                None, None, None, None)
 
 
 def _fused_ok(x0, residual, weight):
@@ -62,10 +66,15 @@ def dropout_add_layer_norm(x0, residual, weight, bias, dropout_p, epsilon, rowsc
     """Drop-in for ``flash_attn.ops.layer_norm.dropout_add_layer_norm`` as the reference calls it."""
     if rowscale is not None or layerscale is not None or return_dropout_mask:
         raise NotImplementedError("rowscale / layerscale / return_dropout_mask are not used by any HyenaDNA configuration")
-    if dropout_p > 0.0:
-        x0 = F.dropout(x0, dropout_p, training=True)      # the reference passes p = 0 in eval mode (long_conv_lm.py:392)
     if residual_in_fp32 and _fused_ok(x0, residual, weight):
+        if dropout_p > 0.0:                               # (the reference passes p = 0 in eval mode, long_conv_lm.py:392)
+            if not dropout_p < 1.0:
+                raise ValueError(f"dropout probability has to be in [0, 1), got {dropout_p}")
+            seed = torch.empty(1, dtype=torch.int64, device=x0.device).random_()      # from the device's generator, on the device
+            return AddLayerNormFunc.apply(x0, residual, weight, bias, epsilon, prenorm, float(dropout_p), seed)
         return AddLayerNormFunc.apply(x0, residual, weight, bias, epsilon, prenorm)
+    if dropout_p > 0.0:
+        x0 = F.dropout(x0, dropout_p, training=True)
     # generic graph (simple_lm.py:267-271)
     res = x0 + residual if residual is not None else x0
     if residual_in_fp32:

@@ -4,8 +4,11 @@
 // the reference takes when flash_attn is installed is flash_attn.ops.layer_norm.dropout_add_layer_norm):
 //     residual' = dropout(x0) + residual            (fp32 when residual_in_fp32)
 //     out       = LayerNorm(residual'; weight, bias, eps)
-// returning (out, residual') for prenorm blocks, out alone for the final norm.  HyenaDNA trains with residual dropout 0;
-// a non-zero dropout is applied by the caller before the kernel (hyena_dna_amd/block.py).
+// returning (out, residual') for prenorm blocks, out alone for the final norm.  HyenaDNA trains with residual dropout 0 and an
+// embedding dropout of 0.1, which the reference applies as the FIRST block's dropout (long_conv_lm.py: resid_dropout1 = embed_dropout
+// for layer 0).  Dropout (round 4) is part of the pass: the keep / drop decision of element i is a pure function of (seed, i) -- Philox
+// 4x32-10, four consecutive elements per call -- so the backward regenerates it and no mask tensor exists (PyTorch's unfused dropout
+// reads and writes the activation once more in each direction and keeps a byte per element: 0.86 ms per step at 2^20 x 256 fp32).
 //
 // One pass forward (read x0, residual; write out, residual'; + mean / rstd per row), one pass backward (read dout,
 // residual', d residual'; write dx0 = d residual; per-workgroup partial weight / bias gradients, summed in a fixed
@@ -33,7 +36,39 @@ struct AddNormArgs {
     long rows;
     int D;
     float eps;
+    const unsigned long long* seed;   // device pointer to the 64-bit dropout seed, or null: no dropout
+    unsigned drop_below;              // an element is dropped when its 32 random bits are < drop_below (= p * 2^32)
+    float keep_scale;                 // 1 / (1 - p)
 };
+
+// Philox 4x32-10 (Salmon et al., SC'11): counter (c0, c1, 0, 0), key (k0, k1) -> four 32-bit words
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+    unsigned x0 = c0, x1 = c1, x2 = 0u, x3 = 0u;
+    HY_UNROLL
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * x0, p1 = (unsigned long long)0xCD9E8D57u * x2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ x1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ x3 ^ k1, n3 = (unsigned)p0;
+        x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
+}
+// v[e] -> dropout(v[e]) for the E consecutive elements starting at linear index `off` (a multiple of E; E a multiple of 4 or E < 4)
+template <int E>
+__device__ __forceinline__ void blk_dropout(float (&v)[E], size_t off, unsigned long long seed, unsigned drop_below, float keep_scale) {
+    HY_UNROLL
+    for (int q = 0; q < (E + 3) / 4; ++q) {
+        const size_t idx = (off + 4 * q) >> 2;                  // one Philox call per aligned group of four elements
+        unsigned rnd[4];
+        philox4x32_10((unsigned)idx, (unsigned)(idx >> 32), (unsigned)seed, (unsigned)(seed >> 32), rnd);
+        HY_UNROLL
+        for (int i = 0; i < 4 && 4 * q + i < E; ++i) {
+            const unsigned word = rnd[(off + 4 * q + i) & 3];   // E < 4: the lane's elements are a part of an aligned group
+            v[4 * q + i] = word < drop_below ? 0.f : v[4 * q + i] * keep_scale;
+        }
+    }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
     HY_UNROLL
@@ -68,10 +103,12 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_fwd_kernel(AddNormArgs a
     HY_UNROLL
     for (int e = 0; e < E; ++e) { w[e] = a.weight[c0 + e]; b[e] = a.bias[c0 + e]; }
     const float inv_d = 1.f / (float)a.D;
+    const unsigned long long seed = a.seed != nullptr ? *a.seed : 0ull;
     for (long row = (long)blockIdx.x * BLK_WAVES + wave; row < a.rows; row += (long)gridDim.x * BLK_WAVES) {
         const size_t off = (size_t)row * a.D + c0;
         float r[E];
         blk_load<XDT, E>(a.x, off, r);
+        if (a.seed != nullptr) blk_dropout<E>(r, off, seed, a.drop_below, a.keep_scale);
         if (a.res_in != nullptr) {
             float q[E];
             blk_load<DT_F32, E>(a.res_in, off, q);
@@ -105,6 +142,7 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_bwd_kernel(AddNormArgs a
     HY_UNROLL
     for (int e = 0; e < E; ++e) { w[e] = a.weight[c0 + e]; dw[e] = 0.f; db[e] = 0.f; }
     const float inv_d = 1.f / (float)a.D;
+    const unsigned long long seed = a.seed != nullptr ? *a.seed : 0ull;
     for (long row = (long)blockIdx.x * BLK_WAVES + wave; row < a.rows; row += (long)gridDim.x * BLK_WAVES) {
         const size_t off = (size_t)row * a.D + c0;
         float g[E], r[E];
@@ -132,8 +170,9 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_bwd_kernel(AddNormArgs a
             HY_UNROLL
             for (int e = 0; e < E; ++e) dr[e] += h[e];
         }
-        blk_store<ODT, E>(a.out, off, dr);
         if (a.res_out != nullptr) blk_store<DT_F32, E>(a.res_out, off, dr);
+        if (a.seed != nullptr) blk_dropout<E>(dr, off, seed, a.drop_below, a.keep_scale);      // d x0 = d residual' through the same mask
+        blk_store<ODT, E>(a.out, off, dr);
     }
     // weight / bias gradient partials of this workgroup: the 4 wavefronts are added in order
     const int D = 64 * E;

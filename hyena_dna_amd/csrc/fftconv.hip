@@ -845,15 +845,36 @@ int hyena_add_norm_supported(int D, int x_dtype, int out_dtype) {
            blk_dtype_ok(out_dtype);
 }
 
-int hyena_add_norm_fwd(const void* x0, int x_dtype, const float* residual_in, const float* weight, const float* bias, float eps,
-                       void* out, int out_dtype, float* residual_out, float* mean, float* rstd, long rows, int D, void* stream) {
+namespace {
+// dropout parameters of a launch; false if (p, seed) are inconsistent
+bool blk_set_dropout(AddNormArgs& a, float p, const unsigned long long* seed) {
+    a.seed = nullptr; a.drop_below = 0u; a.keep_scale = 1.f;
+    if (p == 0.f) return true;
+    if (!(p > 0.f) || !(p < 1.f) || seed == nullptr) return false;
+    a.seed = seed;
+    a.drop_below = (unsigned)((double)p * 4294967296.0);
+    a.keep_scale = (float)(1.0 / (1.0 - (double)p));
+    return true;
+}
+}  // namespace
+
+int hyena_dropout_add_norm_fwd(const void* x0, int x_dtype, const float* residual_in, const float* weight, const float* bias, float eps,
+                               float dropout_p, const unsigned long long* seed, void* out, int out_dtype, float* residual_out,
+                               float* mean, float* rstd, long rows, int D, void* stream) {
     if (x0 == nullptr || weight == nullptr || bias == nullptr || out == nullptr || residual_out == nullptr || mean == nullptr ||
         rstd == nullptr || rows < 1 || !hyena_add_norm_supported(D, x_dtype, out_dtype))
         return HYENA_ERR_BAD_ARG;
     AddNormArgs a;
     a.x = x0; a.res_in = residual_in; a.weight = weight; a.bias = bias; a.out = out; a.res_out = residual_out; a.saved = nullptr;
     a.mean = mean; a.rstd = rstd; a.part = nullptr; a.rows = rows; a.D = D; a.eps = eps;
+    if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
     return blk_launch(true, x_dtype, out_dtype, a, stream);
+}
+
+int hyena_add_norm_fwd(const void* x0, int x_dtype, const float* residual_in, const float* weight, const float* bias, float eps,
+                       void* out, int out_dtype, float* residual_out, float* mean, float* rstd, long rows, int D, void* stream) {
+    return hyena_dropout_add_norm_fwd(x0, x_dtype, residual_in, weight, bias, eps, 0.f, nullptr, out, out_dtype, residual_out, mean, rstd,
+                                      rows, D, stream);
 }
 
 size_t hyena_add_norm_partial_floats(long rows, int D) {
@@ -864,6 +885,14 @@ size_t hyena_add_norm_partial_floats(long rows, int D) {
 int hyena_add_norm_bwd(const void* dout, int dout_dtype, const float* d_residual_out, const float* residual_out,
                        const float* weight, const float* mean, const float* rstd, void* dx0, int dx_dtype,
                        float* d_residual_in, float* dweight, float* dbias, float* partial, long rows, int D, void* stream) {
+    return hyena_dropout_add_norm_bwd(dout, dout_dtype, d_residual_out, residual_out, weight, mean, rstd, 0.f, nullptr, dx0, dx_dtype,
+                                      d_residual_in, dweight, dbias, partial, rows, D, stream);
+}
+
+int hyena_dropout_add_norm_bwd(const void* dout, int dout_dtype, const float* d_residual_out, const float* residual_out,
+                               const float* weight, const float* mean, const float* rstd, float dropout_p,
+                               const unsigned long long* seed, void* dx0, int dx_dtype, float* d_residual_in, float* dweight,
+                               float* dbias, float* partial, long rows, int D, void* stream) {
     if (dout == nullptr || residual_out == nullptr || weight == nullptr || mean == nullptr || rstd == nullptr || dx0 == nullptr ||
         dweight == nullptr || dbias == nullptr || partial == nullptr || rows < 1 || !hyena_add_norm_supported(D, dout_dtype, dx_dtype))
         return HYENA_ERR_BAD_ARG;
@@ -871,6 +900,7 @@ int hyena_add_norm_bwd(const void* dout, int dout_dtype, const float* d_residual
     a.x = dout; a.res_in = d_residual_out; a.weight = weight; a.bias = nullptr; a.out = dx0; a.res_out = d_residual_in;
     a.saved = residual_out; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.part = partial;
     a.rows = rows; a.D = D; a.eps = 0.f;
+    if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
     const int st = blk_launch(false, dout_dtype, dx_dtype, a, stream);
     if (st) return st;
     const int grid = blk_grid(rows);

@@ -74,14 +74,97 @@ def test_dropout_and_fallbacks(emu_backend):
     x0 = torch.randn(2, 3, 64)
     res = torch.randn(2, 3, 64)
     w, b = torch.ones(64), torch.zeros(64)
+    # D = 48 with dropout: PyTorch's dropout in front of the generic graph
+    x48, r48 = torch.randn(2, 3, 48), torch.randn(2, 3, 48)
     torch.manual_seed(0)
-    a = dropout_add_layer_norm(x0, res, w, b, 0.5, 1e-5, prenorm=True, residual_in_fp32=True)
+    a = dropout_add_layer_norm(x48, r48, torch.ones(48), torch.zeros(48), 0.5, 1e-5, prenorm=True, residual_in_fp32=True)
     torch.manual_seed(0)
-    dropped = F.dropout(x0, 0.5, training=True)
-    assert torch.allclose(a[1], dropped + res, atol=1e-6)
+    dropped = F.dropout(x48, 0.5, training=True)
+    assert torch.allclose(a[1], dropped + r48, atol=1e-6)
     # D = 48 is outside the kernels' coverage: same graph in PyTorch ops
     y = dropout_add_layer_norm(torch.randn(2, 3, 48), torch.randn(2, 3, 48), torch.ones(48), torch.zeros(48), 0.0, 1e-5,
                                prenorm=False, residual_in_fp32=True)
     assert y.shape == (2, 3, 48)
     with pytest.raises(NotImplementedError):
         dropout_add_layer_norm(x0, res, w, b, 0.0, 1e-5, rowscale=torch.ones(2, 3))
+
+
+def _philox4x32_10(c0, c1, k0, k1):
+    """Philox 4x32-10 as published (Salmon et al., SC'11), counter (c0, c1, 0, 0): the generator csrc/block_kernels.h restates"""
+    M = 0xFFFFFFFF
+    x = [c0, c1, 0, 0]
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * x[0], 0xCD9E8D57 * x[2]
+        x = [(p1 >> 32) ^ x[1] ^ k0, p1 & M, (p0 >> 32) ^ x[3] ^ k1, p0 & M]
+        k0, k1 = (k0 + 0x9E3779B9) & M, (k1 + 0xBB67AE85) & M
+    return x
+
+
+@pytest.mark.parametrize("shape,dtype,p", [((3, 70, 256), torch.float32, 0.1), ((2, 33, 128), torch.bfloat16, 0.5), ((1, 9, 64), torch.float32, 0.25),
+                                           ((2, 5, 512), torch.float16, 0.1)])
+def test_fused_dropout_is_a_function_of_seed_and_index(emu_backend, shape, dtype, p):
+    """dropout inside the add + LayerNorm pass: the mask is exactly Philox(seed, index) >= p 2^32 (checked against a Python restatement of the
+    published generator), kept elements are scaled by 1 / (1 - p), out is the LayerNorm of dropout(x0) + residual, and the backward sends
+    the gradient of residual' through the SAME mask to x0 and unmasked to the residual."""
+    from hyena_dna_amd import _lib
+    from hyena_dna_amd.block import AddLayerNormFunc
+    g = torch.Generator().manual_seed(sum(shape))
+    D = shape[-1]
+    x0 = (torch.randn(shape, generator=g) + 3.0).to(dtype).requires_grad_(True)              # (no zeros: a zero output means "dropped")
+    residual = (torch.randn(shape, generator=g) * 2).requires_grad_(True)
+    weight = (1 + 0.2 * torch.randn(D, generator=g)).requires_grad_(True)
+    bias = (0.1 * torch.randn(D, generator=g)).requires_grad_(True)
+    seed = torch.tensor([0x1234_5678_9ABC_DEF0 & 0x7FFF_FFFF_FFFF_FFFF], dtype=torch.int64)
+    out, res = AddLayerNormFunc.apply(x0, residual, weight, bias, 1e-5, True, p, seed)
+    kept = (res.detach() - residual.detach()) != 0
+    # the mask, element by element, from the published generator
+    sv = int(seed.item())
+    k0, k1 = sv & 0xFFFFFFFF, (sv >> 32) & 0xFFFFFFFF
+    thr = int(p * 4294967296.0)
+    n = x0.numel()
+    want = torch.empty(n, dtype=torch.bool)
+    for i4 in range((n + 3) // 4):
+        w = _philox4x32_10(i4 & 0xFFFFFFFF, i4 >> 32, k0, k1)
+        for j in range(4):
+            if 4 * i4 + j < n:
+                want[4 * i4 + j] = w[j] >= thr
+    assert torch.equal(kept.reshape(-1), want)
+    assert abs(kept.float().mean().item() - (1 - p)) < 0.08
+    scale = 1.0 / (1.0 - p)
+    ref_res = x0.detach().float() * kept * scale + residual.detach()
+    assert torch.allclose(res, ref_res, rtol=1e-6, atol=1e-6)
+    ref_out = F.layer_norm(ref_res, (D,), weight.detach(), bias.detach(), 1e-5)
+    assert _rel(out.float(), ref_out) < (1e-6 if dtype == torch.float32 else 6e-3)
+    dout, dres = torch.randn(shape, generator=g).to(dtype), torch.randn(shape, generator=g)
+    gx, gr, gw, gb = torch.autograd.grad([out, res], [x0, residual, weight, bias], [dout, dres])
+    # reference gradients through the explicit mask
+    x0r, rr = x0.detach().float().requires_grad_(True), residual.detach().requires_grad_(True)
+    wr, br = weight.detach().requires_grad_(True), bias.detach().requires_grad_(True)
+    res_r = x0r * kept * scale + rr
+    out_r = F.layer_norm(res_r, (D,), wr, br, 1e-5)
+    hx, hr, hw, hb = torch.autograd.grad([out_r, res_r], [x0r, rr, wr, br], [dout.float(), dres])
+    tol = 2e-5 if dtype == torch.float32 else 8e-3
+    assert _rel(gx.float(), hx) < tol and _rel(gr, hr) < 2e-5 and _rel(gw, hw) < 2e-5 and _rel(gb, hb) < 2e-5
+    assert torch.equal(gx.float() != 0, kept & (hx != 0))                                    # dropped elements get exactly no gradient
+    # another seed, another mask; the same seed, the same bits
+    out2, res2 = AddLayerNormFunc.apply(x0, residual, weight, bias, 1e-5, True, p, seed + 1)
+    assert not torch.equal((res2.detach() - residual.detach()) != 0, kept)
+    out3, res3 = AddLayerNormFunc.apply(x0, residual, weight, bias, 1e-5, True, p, seed)
+    assert torch.equal(out3, out) and torch.equal(res3, res)
+    assert _lib.add_norm_supported(D, dtype, dtype)
+
+
+def test_dropout_add_layer_norm_draws_its_seed_from_torchs_generator(emu_backend):
+    from hyena_dna_amd.block import dropout_add_layer_norm
+    x0, res = torch.randn(4, 16, 256) + 3.0, torch.randn(4, 16, 256)
+    w, b = torch.ones(256), torch.zeros(256)
+    torch.manual_seed(5)
+    a = dropout_add_layer_norm(x0, res, w, b, 0.1, 1e-5, prenorm=True, residual_in_fp32=True)
+    c = dropout_add_layer_norm(x0, res, w, b, 0.1, 1e-5, prenorm=True, residual_in_fp32=True)
+    torch.manual_seed(5)
+    a2 = dropout_add_layer_norm(x0, res, w, b, 0.1, 1e-5, prenorm=True, residual_in_fp32=True)
+    assert torch.equal(a[1], a2[1]) and not torch.equal(a[1], c[1])                          # reproducible under manual_seed, fresh per call
+    keep = ((a[1] - res) != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.02
+    with pytest.raises(ValueError):
+        dropout_add_layer_norm(x0, res, w, b, 1.0, 1e-5, prenorm=True, residual_in_fp32=True)

@@ -147,3 +147,43 @@ def test_graphed_train_step_matches_eager(gpu_lib):
     n_ws = len(_lib._workspace)
     step.release()
     assert len(_lib._workspace) == n_ws - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype,p", [((2, 4096, 256), torch.float32, 0.1), ((1, 65536, 256), torch.bfloat16, 0.1), ((3, 1000, 128), torch.float16, 0.5)])
+def test_fused_dropout_on_gpu(gpu_lib, shape, dtype, p):
+    """dropout inside the add + LayerNorm pass on the gfx950 binary: the mask is Philox4x32-10(seed, index) >= p 2^32 (first 4096 elements
+    against the Python restatement of the published generator in tests/test_block_emu.py, the keep rate over the whole tensor), the values
+    and every gradient are those of the explicit-mask graph, the backward uses the forward's mask."""
+    from hyena_dna_amd.block import AddLayerNormFunc
+    from tests.test_block_emu import _philox4x32_10
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    D = shape[-1]
+    x0 = (torch.randn(shape, generator=g, device=dev) + 3.0).to(dtype).requires_grad_(True)
+    residual = (torch.randn(shape, generator=g, device=dev) * 2).requires_grad_(True)
+    weight = (1 + 0.2 * torch.randn(D, generator=g, device=dev)).requires_grad_(True)
+    bias = (0.1 * torch.randn(D, generator=g, device=dev)).requires_grad_(True)
+    seed = torch.tensor([0x0BAD_5EED_1234_5678], dtype=torch.int64, device=dev)
+    out, res = AddLayerNormFunc.apply(x0, residual, weight, bias, 1e-5, True, p, seed)
+    kept = (res.detach() - residual.detach()) != 0
+    sv = int(seed.item())
+    k0, k1, thr = sv & 0xFFFFFFFF, (sv >> 32) & 0xFFFFFFFF, int(p * 4294967296.0)
+    want = [w >= thr for i4 in range(1024) for w in _philox4x32_10(i4, 0, k0, k1)]
+    assert kept.reshape(-1)[:4096].cpu().tolist() == want
+    assert abs(kept.float().mean().item() - (1 - p)) < 5e-3
+    scale = 1.0 / (1.0 - p)
+    x0r, rr = x0.detach().double().requires_grad_(True), residual.detach().double().requires_grad_(True)
+    wr, br = weight.detach().double().requires_grad_(True), bias.detach().double().requires_grad_(True)
+    res_r = x0r * kept * scale + rr
+    out_r = F.layer_norm(res_r, (D,), wr, br, 1e-5)
+    rel = lambda a, b: ((a.double() - b).norm() / b.norm()).item()        # noqa: E731
+    assert rel(res, res_r) < 1e-6 and rel(out, out_r) < (2e-6 if dtype == torch.float32 else 5e-3)
+    dout, dres = torch.randn(shape, generator=g, device=dev).to(dtype), torch.randn(shape, generator=g, device=dev)
+    gx, gr, gw, gb = torch.autograd.grad([out, res], [x0, residual, weight, bias], [dout, dres])
+    hx, hr, hw, hb = torch.autograd.grad([out_r, res_r], [x0r, rr, wr, br], [dout.double(), dres.double()])
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel(gx, hx) < tol and rel(gr, hr) < 1e-5 and rel(gw, hw) < 1e-4 and rel(gb, hb) < 1e-4
+    assert torch.equal(gx != 0, kept & (hx != 0))
+    out2, res2 = AddLayerNormFunc.apply(x0, residual, weight, bias, 1e-5, True, p, seed)
+    assert torch.equal(out2, out) and torch.equal(res2, res)
