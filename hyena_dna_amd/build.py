@@ -34,27 +34,40 @@ def up_to_date():
 
 
 def build(force=False, verbose=True):
+    """Safe under concurrent callers (several test processes in a fresh checkout): one builds, under a file lock, and the library is
+    linked under a temporary name and renamed into place -- nobody ever loads a half-written one."""
     if not force and up_to_date():
         return LIB
-    hipcc = find_hipcc()
-    objdir = os.path.join(CSRC, "_obj")
-    os.makedirs(objdir, exist_ok=True)
-    jobs = []
-    for src in SOURCES:          # one hipcc process per translation unit, side by side
-        obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and up_to_date():                # somebody else built it while this process waited
+            return LIB
+        hipcc = find_hipcc()
+        objdir = os.path.join(CSRC, "_obj")
+        os.makedirs(objdir, exist_ok=True)
+        jobs = []
+        for src in SOURCES:          # one hipcc process per translation unit, side by side
+            obj = os.path.join(objdir, os.path.basename(src) + ".o")
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print("[hyena_dna_amd.build]", " ".join(cmd), flush=True)
+            jobs.append((subprocess.Popen(cmd), cmd, obj))
+        objs = []
+        for proc, cmd, obj in jobs:
+            if proc.wait() != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+            objs.append(obj)
+        tmp = f"{LIB}.{os.getpid()}.tmp"
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", tmp]
         if verbose:
             print("[hyena_dna_amd.build]", " ".join(cmd), flush=True)
-        jobs.append((subprocess.Popen(cmd), cmd, obj))
-    objs = []
-    for proc, cmd, obj in jobs:
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
-        objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
-    if verbose:
-        print("[hyena_dna_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return LIB
 
 

@@ -18,12 +18,29 @@ DEPS = SRC + [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv_kernels.h"), 
               os.path.join(ROOT, "hyena_dna_amd", "csrc", "proj_kernels.h"), os.path.join(ROOT, "include", "hyena_proj.h")]
 
 
+def _fresh():
+    return os.path.exists(OUT) and all(os.path.getmtime(f) <= os.path.getmtime(OUT) for f in DEPS)
+
+
 def build(force=False):
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(f) <= os.path.getmtime(OUT) for f in DEPS):
+    """Several processes may ask at once (pytest -n in a fresh checkout): one builds, under a file lock, into a temporary name that is
+    renamed into place when complete -- nobody ever loads a half-written library."""
+    if not force and _fresh():
         return OUT
-    cmd = ["g++", "-x", "c++", "-DHIPEMU", "-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared",
-           "-Wno-unknown-pragmas", "-Wno-psabi", "-I", HERE] + SRC + ["-o", OUT]
-    subprocess.check_call(cmd)
+    import fcntl
+    with open(OUT + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and _fresh():                    # somebody else built it while this process waited
+            return OUT
+        tmp = f"{OUT}.{os.getpid()}.tmp"
+        cmd = ["g++", "-x", "c++", "-DHIPEMU", "-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared",
+               "-Wno-unknown-pragmas", "-Wno-psabi", "-I", HERE] + SRC + ["-o", tmp]
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, OUT)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return OUT
 
 
