@@ -15,6 +15,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _product_library_present():
+    """Some CPU tests read host-only entry points through the C ABI (workspace sizes, plan selection ...): in a fresh checkout the library
+    is built once per session before any of them runs -- under build.py's lock, so parallel workers do not trip over each other.  (Only when
+    it is MISSING: a prebuilt library, e.g. the one that travelled to the GPU box, is never rebuilt from here.)"""
+    from hyena_dna_amd import build
+    if not os.path.exists(build.LIB):
+        try:
+            build.build(verbose=False)
+        except Exception:          # no hipcc here: the tests that need the library say so themselves
+            pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_fftconv():
     import torch
