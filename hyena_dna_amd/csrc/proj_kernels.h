@@ -119,7 +119,7 @@ __device__ __forceinline__ void lds_st16(HY_LDS char* p, const Frag& f) { *reint
 
 #ifdef HIPEMU
 // The test double models the memory pipeline's queue the way the kernels' counted waits assume it: operations retire in issue order, an
-// LDS-direct or asynchronous register load delivers its 16 bytes only when it retires, `s_waitcnt vmcnt(n)` retires the oldest operations until
+// LDS-direct load delivers its 16 bytes only when it retires, `s_waitcnt vmcnt(n)` retires the oldest operations until
 // n are left.  A wait that names too many younger operations therefore leaves the data stale under the emulator as well -- on the hardware such
 // a mistake is a race that may or may not show.  (One queue per thread: the stack of its fibre.  Stores are performed at issue and only counted.)
 struct EmuVmq {
