@@ -720,11 +720,10 @@ void launch_filter_layer_bwd(FilterBwdArgs a, float* part, float* dw, float* db,
         HY_LAUNCH(filter_reduce_kernel, dim3((NO * NI + FLT_RED_J - 1) / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream, (const float*)a.part_w, tmp, slots, NO * NI, 0);
         HY_LAUNCH(filter_compact_kernel, dim3((nw + 255) / 256), dim3(256), 0, stream, (const float*)tmp, dw, NO, NI, a.ni);
     }
-    if (db != nullptr)
-        HY_LAUNCH(filter_reduce_kernel, dim3((NO + FLT_RED_J - 1) / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream, (const float*)a.part_b, db, 2 * slots, NO, 0);
-    if (MODE & FLT_ACT)
-        HY_LAUNCH(filter_reduce_kernel, dim3(FLT_O / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream, (const float*)a.part_f, dfreq, grid * FLT_WAVES, FLT_O,
-                  first_freq ? 0 : 1);
+    RedBatch red;
+    if (db != nullptr) red.add(a.part_b, db, 2 * slots, NO, NO, 0);
+    if (MODE & FLT_ACT) red.add(a.part_f, dfreq, grid * FLT_WAVES, FLT_O, FLT_O, first_freq ? 0 : 1);
+    if (red.jobs.njobs > 0) HY_LAUNCH(filter_reduce_multi_kernel, dim3(red.blocks()), dim3(256), FLT_RED_SMEM, stream, red.jobs);
 }
 }  // namespace
 
@@ -905,10 +904,10 @@ int hyena_dropout_add_norm_bwd(const void* dout, int dout_dtype, const float* d_
     if (st) return st;
     const int grid = blk_grid(rows);
     // partial rows are [dweight (D) | dbias (D)]: two reductions with a row stride of 2 D
-    HY_LAUNCH(filter_reduce_strided_kernel, dim3((D + FLT_RED_J - 1) / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream,
-              (const float*)partial, dweight, grid, D, 2 * D);
-    HY_LAUNCH(filter_reduce_strided_kernel, dim3((D + FLT_RED_J - 1) / FLT_RED_J), dim3(256), FLT_RED_SMEM, stream,
-              (const float*)(partial + D), dbias, grid, D, 2 * D);
+    RedBatch red;
+    red.add(partial, dweight, grid, D, 2 * D, 0);
+    red.add(partial + D, dbias, grid, D, 2 * D, 0);
+    HY_LAUNCH(filter_reduce_multi_kernel, dim3(red.blocks()), dim3(256), FLT_RED_SMEM, stream, red.jobs);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 

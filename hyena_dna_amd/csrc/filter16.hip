@@ -61,11 +61,11 @@ void launch_layer(F16BwdArgs a, float* part, float* dw, float* db, float* dfreq,
     hy_allow_lds(flt16_layer_bwd_kernel<NO, MOD, DT, OUTF32>, F16BwdLds<NO>::BYTES, &done);
     HY_LAUNCH((flt16_layer_bwd_kernel<NO, MOD, DT, OUTF32>), dim3(grid), dim3(FLT_THREADS), F16BwdLds<NO>::BYTES, stream, a);
     const int nw = NO * FLT_O;
-    HY_LAUNCH(filter_reduce_kernel, dim3((nw + FLT_RED_J - 1) / FLT_RED_J), dim3(256), F16_RED_SMEM, stream, (const float*)a.part_w, dw, slots, nw, 0);
-    if (db != nullptr)
-        HY_LAUNCH(filter_reduce_kernel, dim3((NO + FLT_RED_J - 1) / FLT_RED_J), dim3(256), F16_RED_SMEM, stream, (const float*)a.part_b, db, 2 * slots, NO, 0);
-    HY_LAUNCH(filter_reduce_kernel, dim3(FLT_O / FLT_RED_J), dim3(256), F16_RED_SMEM, stream, (const float*)a.part_f, dfreq, grid * FLT_WAVES, FLT_O,
-              first_freq ? 0 : 1);
+    RedBatch red;                                   // the layer's three fixed-order reductions in one launch
+    red.add(a.part_w, dw, slots, nw, nw, 0);
+    if (db != nullptr) red.add(a.part_b, db, 2 * slots, NO, NO, 0);
+    red.add(a.part_f, dfreq, grid * FLT_WAVES, FLT_O, FLT_O, first_freq ? 0 : 1);
+    HY_LAUNCH(filter_reduce_multi_kernel, dim3(red.blocks()), dim3(256), F16_RED_SMEM, stream, red.jobs);
 }
 
 // the first layer (contraction length E <= 8) on filter_kernels.h's fp32 kernel, operands rounded on load (FilterBwdArgs::rdt)
@@ -81,7 +81,11 @@ void launch_layer0(FilterBwdArgs a, float* part, float* dw, float* db, void* str
     HY_LAUNCH((filter_layer_bwd_kernel<FLT_O, FLT_E, 0>), dim3(grid), dim3(FLT_THREADS), Cfg::BYTES, stream, a);
     const int nw = FLT_O * a.ni;
     if (a.ni == FLT_E) {
-        HY_LAUNCH(filter_reduce_kernel, dim3((nw + FLT_RED_J - 1) / FLT_RED_J), dim3(256), F16_RED_SMEM, stream, (const float*)a.part_w, dw, slots, nw, 0);
+        RedBatch red;
+        red.add(a.part_w, dw, slots, nw, nw, 0);
+        red.add(a.part_b, db, 2 * slots, (int)FLT_O, (int)FLT_O, 0);
+        HY_LAUNCH(filter_reduce_multi_kernel, dim3(red.blocks()), dim3(256), F16_RED_SMEM, stream, red.jobs);
+        return;
     } else {
         float* tmp = a.part_f + (size_t)grid * FLT_WAVES * FLT_O;
         HY_LAUNCH(filter_reduce_kernel, dim3((FLT_O * FLT_E + FLT_RED_J - 1) / FLT_RED_J), dim3(256), F16_RED_SMEM, stream, (const float*)a.part_w, tmp, slots,

@@ -519,7 +519,13 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
 
 // (filter.hip defines FLT_DECLARE_ONLY: the non-template kernels below are defined once, in fftconv.hip's translation unit)
 enum { FLT_RED_J = 16, FLT_RED_S = 16 };
+// Several such reductions in ONE launch (round 4: a layer's weight, bias and frequency gradients, the weight and bias gradients of the add +
+// LayerNorm backward): each is a handful of workgroups and a dependent launch of its own cost ~7 us of an otherwise idle GPU -- ten per filter
+// backward, two per norm.  Job i owns blocks [first[i], first[i + 1]); the arithmetic and its order are filter_reduce_strided_kernel's.
+struct RedJob { const float* part; float* out; int count, n, stride, accumulate; };
+struct RedJobs { RedJob j[4]; int first[5]; int njobs; };
 #ifdef FLT_DECLARE_ONLY
+__global__ void filter_reduce_multi_kernel(RedJobs jobs);
 __global__ void filter_reduce_kernel(const float* part, float* out, int count, int n, int accumulate);
 __global__ void filter_reduce_strided_kernel(const float* part, float* out, int count, int n, int stride);
 __global__ void filter_compact_kernel(const float* src, float* dst, int rows, int cols, int used);
@@ -577,6 +583,38 @@ __global__ void __launch_bounds__(256) filter_reduce_strided_kernel(const float*
     }
 }
 
+__global__ void __launch_bounds__(256) filter_reduce_multi_kernel(RedJobs jobs) {
+    HY_SMEM(smem);
+    HY_LDS float* sm = HY_LDS_CAST(float, smem);
+    int ji = 0;
+    HY_UNROLL
+    for (int i = 1; i < 4; ++i)
+        if (i < jobs.njobs && (int)blockIdx.x >= jobs.first[i]) ji = i;
+    const RedJob job = jobs.j[ji];
+    const float* part = job.part;
+    const int count = job.count, n = job.n, stride = job.stride;
+    const int jj = threadIdx.x & (FLT_RED_J - 1), cs = threadIdx.x / FLT_RED_J;
+    const int j = ((int)blockIdx.x - jobs.first[ji]) * FLT_RED_J + jj;
+    const int jc = j < n ? j : n - 1;
+    float s = 0.f;
+    int c = cs;
+    for (; c + 7 * FLT_RED_S < count; c += 8 * FLT_RED_S) {          // eight independent loads in flight, added in the same order
+        float v[8];
+        HY_UNROLL
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u * FLT_RED_S) * stride + jc];
+        HY_UNROLL
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < count; c += FLT_RED_S) s += part[(size_t)c * stride + jc];
+    sm[cs * FLT_RED_J + jj] = s;
+    __syncthreads();
+    if (cs == 0 && j < n) {
+        float r = job.accumulate ? job.out[j] : 0.f;
+        for (int q = 0; q < FLT_RED_S; ++q) r += sm[q * FLT_RED_J + jj];
+        job.out[j] = r;
+    }
+}
+
 // dst (rows, used) <- first `used` columns of src (rows, cols)
 __global__ void __launch_bounds__(256) filter_compact_kernel(const float* src, float* dst, int rows, int cols, int used) {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -584,5 +622,18 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const float* src, f
 }
 
 #endif  // FLT_DECLARE_ONLY
+
+// host side: collect up to four reductions, then one launch
+struct RedBatch {
+    RedJobs jobs;
+    RedBatch() { jobs.njobs = 0; jobs.first[0] = 0; }
+    void add(const float* part, float* out, int count, int n, int stride, int accumulate) {
+        RedJob& j = jobs.j[jobs.njobs];
+        j.part = part; j.out = out; j.count = count; j.n = n; j.stride = stride; j.accumulate = accumulate;
+        jobs.first[jobs.njobs + 1] = jobs.first[jobs.njobs] + (n + FLT_RED_J - 1) / FLT_RED_J;
+        ++jobs.njobs;
+    }
+    int blocks() const { return jobs.first[jobs.njobs]; }
+};
 
 }  // namespace hyena
