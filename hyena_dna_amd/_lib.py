@@ -205,6 +205,16 @@ def lib():
         L.hyena_dropout_add_norm_bwd.restype = c_int
         L.hyena_dropout_add_norm_bwd.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]
+        L.hyena_embed_add_norm_supported.restype = c_int
+        L.hyena_embed_add_norm_supported.argtypes = [c_int, c_int, c_int]
+        L.hyena_embed_add_norm_fwd.restype = c_int
+        L.hyena_embed_add_norm_fwd.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int,
+                                               c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]
+        L.hyena_embed_add_norm_partial_floats.restype = c_size_t
+        L.hyena_embed_add_norm_partial_floats.argtypes = [c_long, c_int]
+        L.hyena_embed_add_norm_bwd.restype = c_int
+        L.hyena_embed_add_norm_bwd.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                               c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]
         L.hyena_add_norm_partial_floats.restype = c_size_t
         L.hyena_add_norm_partial_floats.argtypes = [c_long, c_int]
         L.hyena_add_norm_bwd.restype = c_int
@@ -676,6 +686,52 @@ def add_norm_fwd(x0, residual, weight, bias, eps, out_dtype, dropout_p=0.0, seed
                                                seed.data_ptr() if dropout_p > 0.0 else None, out.data_ptr(), dtype_code(out_dtype),
                                                res_out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, _backend.stream(x0.device)))
     return out, res_out, mean, rstd
+
+
+def embed_add_norm_supported(V, D, out_dtype):
+    try:
+        return bool(lib().hyena_embed_add_norm_supported(int(V), int(D), dtype_code(out_dtype)))
+    except TypeError:
+        return False
+
+
+def embed_add_norm_fwd(ids, table, weight, bias, eps, out_dtype, dropout_p=0.0, seed=None):
+    """ids (rows,) int64, table (V, D) fp32 -> out (rows, D) out_dtype = LayerNorm(dropout(table[ids])), residual' = dropout(table[ids]) fp32,
+    mean, rstd (rows,): the embedding gathered inside the first block's add + LayerNorm pass (include/hyena_block.h)."""
+    _require_gpu(table, "table")
+    rows, (V, D) = ids.numel(), table.shape
+    dev = table.device
+    out = torch.empty((rows, D), dtype=out_dtype, device=dev)
+    res_out = torch.empty((rows, D), dtype=torch.float32, device=dev)
+    mean = torch.empty(rows, dtype=torch.float32, device=dev)
+    rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+    if rows == 0:
+        return out, res_out, mean, rstd
+    with _backend.guard(dev):
+        check(lib().hyena_embed_add_norm_fwd(ids.data_ptr(), table.data_ptr(), V, weight.data_ptr(), bias.data_ptr(), float(eps),
+                                             float(dropout_p), seed.data_ptr() if dropout_p > 0.0 else None, out.data_ptr(),
+                                             dtype_code(out_dtype), res_out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D,
+                                             _backend.stream(dev)))
+    return out, res_out, mean, rstd
+
+
+def embed_add_norm_bwd(dout, d_res_out, res_out, ids, V, weight, mean, rstd, dropout_p=0.0, seed=None):
+    """-> d_table (V, D) fp32 (per-token-class sums of the gradient of the gathered rows, fixed order), dweight (D,), dbias (D,)."""
+    _require_gpu(dout, "dout")
+    rows, D = dout.shape
+    dev = dout.device
+    dt = torch.zeros((V, D), dtype=torch.float32, device=dev)
+    dw = torch.zeros(D, dtype=torch.float32, device=dev)
+    db = torch.zeros(D, dtype=torch.float32, device=dev)
+    if rows == 0:
+        return dt, dw, db
+    part = torch.empty(lib().hyena_embed_add_norm_partial_floats(rows, D), dtype=torch.float32, device=dev)
+    with _backend.guard(dev):
+        check(lib().hyena_embed_add_norm_bwd(dout.data_ptr(), dtype_code(dout.dtype), None if d_res_out is None else d_res_out.data_ptr(),
+                                             res_out.data_ptr(), ids.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             float(dropout_p), seed.data_ptr() if dropout_p > 0.0 else None, dt.data_ptr(), V,
+                                             dw.data_ptr(), db.data_ptr(), part.data_ptr(), rows, D, _backend.stream(dev)))
+    return dt, dw, db
 
 
 def add_norm_bwd(dout, d_res_out, res_out, weight, mean, rstd, dx_dtype, need_dres, dropout_p=0.0, seed=None):

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from . import _lib
 
-__all__ = ["dropout_add_layer_norm", "AddLayerNormFunc"]
+__all__ = ["dropout_add_layer_norm", "AddLayerNormFunc", "embedding_dropout_add_layer_norm", "embedding_fusable"]
 
 
 class AddLayerNormFunc(torch.autograd.Function):
@@ -52,6 +52,59 @@ class AddLayerNormFunc(torch.autograd.Function):
                                              dropout_p=ctx.drop[0], seed=ctx.drop[1])
         return (dx.view(shape), None if dres is None else dres.view(shape).to(r_dtype), dw.to(w_dtype), db.to(b_dtype),
                 None, None, None, None)
+
+
+class EmbedAddLayerNormFunc(torch.autograd.Function):
+    """(out, residual') of the FIRST block's norm with the token embedding gathered inside the pass: residual' = dropout(table[ids]),
+    out = LayerNorm(residual').  The (rows, D) embedding and its gradient are never materialised: the backward returns the table's
+    gradient as per-token-class sums (include/hyena_block.h, hyena_embed_add_norm_*)."""
+
+    @staticmethod
+    def forward(ctx, ids, table, weight, bias, eps, out_dtype, dropout_p=0.0, seed=None):
+        shape = tuple(ids.shape) + (table.shape[1],)
+        i2 = ids.reshape(-1).contiguous()
+        t = table.detach().to(torch.float32).contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        b = bias.detach().to(torch.float32).contiguous()
+        out, res_out, mean, rstd = _lib.embed_add_norm_fwd(i2, t, w, b, eps, out_dtype, dropout_p=dropout_p, seed=seed)
+        ctx.save_for_backward(res_out, w, mean, rstd, i2)
+        ctx.drop = (float(dropout_p), seed)
+        ctx.meta = (shape, table.shape[0], table.dtype, weight.dtype, bias.dtype)
+        return out.view(shape), res_out.view(shape)
+
+    @staticmethod
+    def backward(ctx, dout, dres_out):
+        res_out, w, mean, rstd, i2 = ctx.saved_tensors
+        shape, V, t_dtype, w_dtype, b_dtype = ctx.meta
+        D = shape[-1]
+        d2 = dout.reshape(-1, D).contiguous()
+        h2 = None if dres_out is None else dres_out.reshape(-1, D).to(torch.float32).contiguous()
+        dt, dw, db = _lib.embed_add_norm_bwd(d2, h2, res_out, i2, V, w, mean, rstd, dropout_p=ctx.drop[0], seed=ctx.drop[1])
+        return None, dt.to(t_dtype), dw.to(w_dtype), db.to(b_dtype), None, None, None, None
+
+
+def embedding_fusable(ids, embedding, norm_weight):
+    """the conditions under which the first block's norm can gather the token embedding itself: a plain nn.Embedding of at most 16 fp32
+    rows (the DNA vocabulary), d_model 64 / 128 / 256, ids on the kernels' device"""
+    w = embedding.weight
+    _lib._require_gpu(w, "embedding weight")
+    return (ids.dtype == torch.int64 and ids.device == w.device and w.dtype == torch.float32 and embedding.padding_idx is None
+            and embedding.max_norm is None and not embedding.sparse and norm_weight is not None
+            and _lib.embed_add_norm_supported(w.shape[0], w.shape[1], torch.float32))
+
+
+def embedding_dropout_add_layer_norm(ids, table, weight, bias, dropout_p, epsilon, out_dtype=None):
+    """``dropout_add_layer_norm(F.embedding(ids, table), None, weight, bias, dropout_p, epsilon, prenorm=True, residual_in_fp32=True)`` in one
+    pass (the caller checks ``embedding_fusable``).  ``out_dtype``: fp32 like the unfused call's, or the autocast type the next module would
+    round it to anyway (one rounding of the fp32 LayerNorm result either way)."""
+    if out_dtype is None:
+        out_dtype = torch.float32
+    if dropout_p > 0.0:
+        if not dropout_p < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {dropout_p}")
+        seed = torch.empty(1, dtype=torch.int64, device=table.device).random_()
+        return EmbedAddLayerNormFunc.apply(ids, table, weight, bias, epsilon, out_dtype, float(dropout_p), seed)
+    return EmbedAddLayerNormFunc.apply(ids, table, weight, bias, epsilon, out_dtype)
 
 
 def _fused_ok(x0, residual, weight):

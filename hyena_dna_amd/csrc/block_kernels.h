@@ -20,7 +20,7 @@
 
 namespace hyena {
 
-enum { BLK_WAVES = 4, BLK_THREADS = BLK_WAVES * 64, BLK_MAX_GRID = 2048 };
+enum { BLK_WAVES = 4, BLK_THREADS = BLK_WAVES * 64, BLK_MAX_GRID = 2048, BLK_VMAX = 16 /* token classes of the EMB kernels (the DNA vocabulary: 12 -> 16) */ };
 
 struct AddNormArgs {
     const void* x;          // (rows, D) elements of XDT        fwd: x0          bwd: dout
@@ -36,6 +36,9 @@ struct AddNormArgs {
     long rows;
     int D;
     float eps;
+    const long long* ids;   // EMB kernels: (rows,) token ids; x0[row] = table[ids[row]] with table = `x` (V_MAX rows at most, fp32) -- the embedding
+                            // is never materialised; the backward returns per-token-class sums of d x0 instead of d x0 (part_e)
+    float* part_e;          // EMB bwd: [gridDim.x][BLK_VMAX][D] partial sums of the embedding gradient
     const unsigned long long* seed;   // device pointer to the 64-bit dropout seed, or null: no dropout
     unsigned drop_below;              // an element is dropped when its 32 random bits are < drop_below (= p * 2^32)
     float keep_scale;                 // 1 / (1 - p)
@@ -95,7 +98,7 @@ __device__ __forceinline__ void blk_store(void* base, size_t off, const float (&
     *reinterpret_cast<Raw*>(reinterpret_cast<elem_t*>(base) + off) = raw;
 }
 
-template <int XDT, int ODT, int E>
+template <int XDT, int ODT, int E, bool EMB = false>
 __global__ void __launch_bounds__(BLK_THREADS) add_norm_fwd_kernel(AddNormArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = lane * E;
@@ -107,7 +110,7 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_fwd_kernel(AddNormArgs a
     for (long row = (long)blockIdx.x * BLK_WAVES + wave; row < a.rows; row += (long)gridDim.x * BLK_WAVES) {
         const size_t off = (size_t)row * a.D + c0;
         float r[E];
-        blk_load<XDT, E>(a.x, off, r);
+        blk_load<XDT, E>(a.x, EMB ? (size_t)a.ids[row] * a.D + c0 : off, r);          // EMB: the row of the embedding table
         if (a.seed != nullptr) blk_dropout<E>(r, off, seed, a.drop_below, a.keep_scale);
         if (a.res_in != nullptr) {
             float q[E];
@@ -132,15 +135,21 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_fwd_kernel(AddNormArgs a
     }
 }
 
-template <int GDT, int ODT, int E>
+template <int GDT, int ODT, int E, bool EMB = false>
 __global__ void __launch_bounds__(BLK_THREADS) add_norm_bwd_kernel(AddNormArgs a) {
     HY_SMEM(smem);
-    HY_LDS float* red = HY_LDS_CAST(float, smem);            // [BLK_WAVES][2][64 * E]
+    HY_LDS float* red = HY_LDS_CAST(float, smem);            // [BLK_WAVES][2][64 * E]  (EMB: also [BLK_VMAX][64 * E], whichever is larger)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = lane * E;
     float w[E], dw[E], db[E];
     HY_UNROLL
     for (int e = 0; e < E; ++e) { w[e] = a.weight[c0 + e]; dw[e] = 0.f; db[e] = 0.f; }
+    float eacc[EMB ? BLK_VMAX : 1][E];                       // EMB: this wavefront's sums of d x0 per token class (its rows, in order)
+    HY_UNROLL
+    for (int q = 0; q < (EMB ? BLK_VMAX : 1); ++q) {
+        HY_UNROLL
+        for (int e = 0; e < E; ++e) eacc[q][e] = 0.f;
+    }
     const float inv_d = 1.f / (float)a.D;
     const unsigned long long seed = a.seed != nullptr ? *a.seed : 0ull;
     for (long row = (long)blockIdx.x * BLK_WAVES + wave; row < a.rows; row += (long)gridDim.x * BLK_WAVES) {
@@ -172,10 +181,40 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_bwd_kernel(AddNormArgs a
         }
         if (a.res_out != nullptr) blk_store<DT_F32, E>(a.res_out, off, dr);
         if (a.seed != nullptr) blk_dropout<E>(dr, off, seed, a.drop_below, a.keep_scale);      // d x0 = d residual' through the same mask
-        blk_store<ODT, E>(a.out, off, dr);
+        if (EMB) {
+            const int v = HY_SGPR((int)a.ids[row]);          // the row's token class: wave-uniform
+            HY_UNROLL
+            for (int q = 0; q < BLK_VMAX; ++q) {
+                if (v == q) {
+                    HY_UNROLL
+                    for (int e = 0; e < E; ++e) eacc[EMB ? q : 0][e] += dr[e];
+                }
+            }
+        } else {
+            blk_store<ODT, E>(a.out, off, dr);
+        }
+    }
+    const int D = 64 * E;
+    if (EMB) {
+        // embedding-gradient partials of this workgroup: the 4 wavefronts add their sums into the LDS image one after the other
+        HY_UNROLL
+        for (int wv = 0; wv < BLK_WAVES; ++wv) {
+            if (wave == wv) {
+                HY_UNROLL
+                for (int q = 0; q < BLK_VMAX; ++q) {
+                    HY_UNROLL
+                    for (int e = 0; e < E; ++e) {
+                        HY_LDS float* slot = red + q * D + c0 + e;
+                        *slot = wv == 0 ? eacc[EMB ? q : 0][e] : *slot + eacc[EMB ? q : 0][e];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = threadIdx.x; i < BLK_VMAX * D; i += BLK_THREADS) a.part_e[(size_t)blockIdx.x * BLK_VMAX * D + i] = red[i];
+        __syncthreads();
     }
     // weight / bias gradient partials of this workgroup: the 4 wavefronts are added in order
-    const int D = 64 * E;
     HY_UNROLL
     for (int e = 0; e < E; ++e) {
         red[(wave * 2 + 0) * D + c0 + e] = dw[e];

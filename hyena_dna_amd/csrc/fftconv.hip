@@ -836,6 +836,33 @@ int blk_launch(bool fwd, int xdt, int odt, const AddNormArgs& a, void* stream) {
 }
 }  // namespace
 
+namespace {
+// the embedding-fused forms: x0 = table[ids] (fp32 table, d_model 64 / 128 / 256), see block_kernels.h
+template <int ODT>
+int blk_launch_emb_fwd(const AddNormArgs& a, void* stream) {
+    const int grid = blk_grid(a.rows);
+    switch (a.D / 64) {
+        case 1: HY_LAUNCH((add_norm_fwd_kernel<DT_F32, ODT, 1, true>), dim3(grid), dim3(BLK_THREADS), 0, stream, a); break;
+        case 2: HY_LAUNCH((add_norm_fwd_kernel<DT_F32, ODT, 2, true>), dim3(grid), dim3(BLK_THREADS), 0, stream, a); break;
+        case 4: HY_LAUNCH((add_norm_fwd_kernel<DT_F32, ODT, 4, true>), dim3(grid), dim3(BLK_THREADS), 0, stream, a); break;
+        default: return HYENA_ERR_BAD_ARG;
+    }
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+template <int GDT>
+int blk_launch_emb_bwd(const AddNormArgs& a, void* stream) {
+    const int grid = blk_grid(a.rows);
+    const size_t lds = (size_t)BLK_VMAX * a.D * sizeof(float);              // >= the [BLK_WAVES][2][D] of the weight / bias partials
+    switch (a.D / 64) {
+        case 1: HY_LAUNCH((add_norm_bwd_kernel<GDT, DT_F32, 1, true>), dim3(grid), dim3(BLK_THREADS), lds, stream, a); break;
+        case 2: HY_LAUNCH((add_norm_bwd_kernel<GDT, DT_F32, 2, true>), dim3(grid), dim3(BLK_THREADS), lds, stream, a); break;
+        case 4: HY_LAUNCH((add_norm_bwd_kernel<GDT, DT_F32, 4, true>), dim3(grid), dim3(BLK_THREADS), lds, stream, a); break;
+        default: return HYENA_ERR_BAD_ARG;
+    }
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int hyena_add_norm_supported(int D, int x_dtype, int out_dtype) {
@@ -865,7 +892,7 @@ int hyena_dropout_add_norm_fwd(const void* x0, int x_dtype, const float* residua
         return HYENA_ERR_BAD_ARG;
     AddNormArgs a;
     a.x = x0; a.res_in = residual_in; a.weight = weight; a.bias = bias; a.out = out; a.res_out = residual_out; a.saved = nullptr;
-    a.mean = mean; a.rstd = rstd; a.part = nullptr; a.rows = rows; a.D = D; a.eps = eps;
+    a.mean = mean; a.rstd = rstd; a.part = nullptr; a.rows = rows; a.D = D; a.eps = eps; a.ids = nullptr; a.part_e = nullptr;
     if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
     return blk_launch(true, x_dtype, out_dtype, a, stream);
 }
@@ -874,6 +901,61 @@ int hyena_add_norm_fwd(const void* x0, int x_dtype, const float* residual_in, co
                        void* out, int out_dtype, float* residual_out, float* mean, float* rstd, long rows, int D, void* stream) {
     return hyena_dropout_add_norm_fwd(x0, x_dtype, residual_in, weight, bias, eps, 0.f, nullptr, out, out_dtype, residual_out, mean, rstd,
                                       rows, D, stream);
+}
+
+int hyena_embed_add_norm_supported(int V, int D, int out_dtype) {
+    return V >= 1 && V <= BLK_VMAX && (D == 64 || D == 128 || D == 256) && blk_dtype_ok(out_dtype);
+}
+
+int hyena_embed_add_norm_fwd(const long long* ids, const float* table, int V, const float* weight, const float* bias, float eps,
+                             float dropout_p, const unsigned long long* seed, void* out, int out_dtype, float* residual_out,
+                             float* mean, float* rstd, long rows, int D, void* stream) {
+    if (ids == nullptr || table == nullptr || weight == nullptr || bias == nullptr || out == nullptr || residual_out == nullptr ||
+        mean == nullptr || rstd == nullptr || rows < 1 || !hyena_embed_add_norm_supported(V, D, out_dtype))
+        return HYENA_ERR_BAD_ARG;
+    AddNormArgs a;
+    a.x = table; a.res_in = nullptr; a.weight = weight; a.bias = bias; a.out = out; a.res_out = residual_out; a.saved = nullptr;
+    a.mean = mean; a.rstd = rstd; a.part = nullptr; a.rows = rows; a.D = D; a.eps = eps; a.ids = ids; a.part_e = nullptr;
+    if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
+    switch (out_dtype) {
+        case HYENA_F32: return blk_launch_emb_fwd<DT_F32>(a, stream);
+        case HYENA_BF16: return blk_launch_emb_fwd<DT_BF16>(a, stream);
+        default: return blk_launch_emb_fwd<DT_F16>(a, stream);
+    }
+}
+
+size_t hyena_embed_add_norm_partial_floats(long rows, int D) {
+    if (rows < 1 || D < 1) return 0;
+    return (size_t)blk_grid(rows) * (2 + BLK_VMAX) * D;
+}
+
+int hyena_embed_add_norm_bwd(const void* dout, int dout_dtype, const float* d_residual_out, const float* residual_out, const long long* ids,
+                             const float* weight, const float* mean, const float* rstd, float dropout_p,
+                             const unsigned long long* seed, float* d_table, int V, float* dweight, float* dbias, float* partial,
+                             long rows, int D, void* stream) {
+    if (dout == nullptr || residual_out == nullptr || ids == nullptr || weight == nullptr || mean == nullptr || rstd == nullptr ||
+        d_table == nullptr || dweight == nullptr || dbias == nullptr || partial == nullptr || rows < 1 ||
+        !hyena_embed_add_norm_supported(V, D, dout_dtype))
+        return HYENA_ERR_BAD_ARG;
+    const int grid = blk_grid(rows);
+    AddNormArgs a;
+    a.x = dout; a.res_in = d_residual_out; a.weight = weight; a.bias = nullptr; a.out = nullptr; a.res_out = nullptr;
+    a.saved = residual_out; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.part = partial;
+    a.rows = rows; a.D = D; a.eps = 0.f; a.ids = ids; a.part_e = partial + (size_t)grid * 2 * D;
+    if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
+    int st;
+    switch (dout_dtype) {
+        case HYENA_F32: st = blk_launch_emb_bwd<DT_F32>(a, stream); break;
+        case HYENA_BF16: st = blk_launch_emb_bwd<DT_BF16>(a, stream); break;
+        default: st = blk_launch_emb_bwd<DT_F16>(a, stream); break;
+    }
+    if (st) return st;
+    RedBatch red;                                   // LayerNorm weight / bias gradients and the V x D embedding gradient, fixed order
+    red.add(partial, dweight, grid, D, 2 * D, 0);
+    red.add(partial + D, dbias, grid, D, 2 * D, 0);
+    red.add(a.part_e, d_table, grid, V * D, BLK_VMAX * D, 0);
+    HY_LAUNCH(filter_reduce_multi_kernel, dim3(red.blocks()), dim3(256), FLT_RED_SMEM, stream, red.jobs);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
 size_t hyena_add_norm_partial_floats(long rows, int D) {
@@ -898,7 +980,7 @@ int hyena_dropout_add_norm_bwd(const void* dout, int dout_dtype, const float* d_
     AddNormArgs a;
     a.x = dout; a.res_in = d_residual_out; a.weight = weight; a.bias = nullptr; a.out = dx0; a.res_out = d_residual_in;
     a.saved = residual_out; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.part = partial;
-    a.rows = rows; a.D = D; a.eps = 0.f;
+    a.rows = rows; a.D = D; a.eps = 0.f; a.ids = nullptr; a.part_e = nullptr;
     if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
     const int st = blk_launch(false, dout_dtype, dx_dtype, a, stream);
     if (st) return st;

@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .block import dropout_add_layer_norm
+from .block import dropout_add_layer_norm, embedding_dropout_add_layer_norm, embedding_fusable
 from .projection import hyena_linear
 
 __all__ = ["Mlp", "Block", "GPT2Embeddings", "MHA", "GenerationMixin", "HyenaDNALM", "sync_shared_params", "all_gather_raw"]
@@ -283,9 +283,12 @@ class Block(nn.Module):
             residual = residual.to(torch.float32)
         return hidden_states, residual
 
-    def forward(self, hidden_states, residual=None, mixer_subset=None, mixer_kwargs=None):
+    def forward(self, hidden_states, residual=None, mixer_subset=None, mixer_kwargs=None, normed=False):
+        """``normed``: (hidden_states, residual) are already the outputs of this block's first dropout -> add -> LayerNorm (HyenaDNALM hands
+        them over when that pass also gathered the token embedding)"""
         if self.prenorm:
-            hidden_states, residual = self._add_norm(hidden_states, residual, self.dropout1, self.norm1)
+            if not normed:
+                hidden_states, residual = self._add_norm(hidden_states, residual, self.dropout1, self.norm1)
             mixer_kwargs = {} if mixer_kwargs is None else mixer_kwargs
             if mixer_subset is not None:
                 mixer_kwargs["mixer_subset"] = mixer_subset
@@ -432,8 +435,24 @@ class HyenaDNALM(nn.Module, GenerationMixin):
 
     def hidden(self, input_ids, position_ids=None):
         bb = self.backbone
-        hidden_states, residual = bb.embeddings(input_ids, position_ids=position_ids), None
-        for blk in bb.layers:
+        emb, blk0 = bb.embeddings, bb.layers[0]
+        if (self.fused_dropout_add_ln and self.residual_in_fp32 and isinstance(blk0, Block) and blk0.prenorm and blk0.fused_dropout_add_ln
+                and blk0.residual_in_fp32 and emb.project_in is None and emb.max_position_embeddings <= 0
+                and embedding_fusable(input_ids, emb.word_embeddings, blk0.norm1.weight)):
+            # the token embedding gathered inside the first block's dropout -> add -> LayerNorm pass (block.py): neither the (B, L, D) fp32
+            # embedding nor its gradient exists; the normed output leaves in the autocast type the mixer would round it to anyway
+            dev_type = input_ids.device.type
+            odt = torch.get_autocast_dtype(dev_type) if torch.is_autocast_enabled(dev_type) else torch.float32
+            if odt not in (torch.bfloat16, torch.float16):
+                odt = torch.float32
+            hidden_states, residual = embedding_dropout_add_layer_norm(input_ids, emb.word_embeddings.weight, blk0.norm1.weight, blk0.norm1.bias,
+                                                                       blk0.dropout1.p if self.training else 0.0, blk0.norm1.eps, out_dtype=odt)
+            hidden_states, residual = blk0(hidden_states, residual, normed=True)
+            rest = list(bb.layers)[1:]
+        else:
+            hidden_states, residual = emb(input_ids, position_ids=position_ids), None
+            rest = bb.layers
+        for blk in rest:
             hidden_states, residual = blk(hidden_states, residual)
         if self.fused_dropout_add_ln:
             return dropout_add_layer_norm(hidden_states, residual, bb.ln_f.weight, bb.ln_f.bias,

@@ -168,3 +168,53 @@ def test_dropout_add_layer_norm_draws_its_seed_from_torchs_generator(emu_backend
     assert abs(keep - 0.9) < 0.02
     with pytest.raises(ValueError):
         dropout_add_layer_norm(x0, res, w, b, 1.0, 1e-5, prenorm=True, residual_in_fp32=True)
+
+
+@pytest.mark.parametrize("shape,D,V,odt,p", [((3, 70), 256, 16, torch.float32, 0.0), ((2, 33), 128, 12, torch.bfloat16, 0.25), ((1, 200), 64, 16, torch.float16, 0.1),
+                                             ((4, 130), 256, 12, torch.bfloat16, 0.1)])
+def test_embedding_inside_the_first_add_norm_pass(emu_backend, shape, D, V, odt, p):
+    """EmbedAddLayerNormFunc == F.embedding + AddLayerNormFunc (same seed -> the same Philox mask, element for element): values bit for bit
+    (the out tensor up to its one rounding), the table's gradient == the one-hot product of the unfused path's d x0, LayerNorm gradients alike."""
+    from hyena_dna_amd.block import AddLayerNormFunc, EmbedAddLayerNormFunc
+    g = torch.Generator().manual_seed(sum(shape) + D)
+    ids = torch.randint(0, V, shape, generator=g)
+    table = torch.randn(V, D, generator=g).requires_grad_(True)
+    weight = (1 + 0.2 * torch.randn(D, generator=g)).requires_grad_(True)
+    bias = (0.1 * torch.randn(D, generator=g)).requires_grad_(True)
+    seed = torch.tensor([987654321987], dtype=torch.int64)
+    args = (p, seed) if p > 0 else ()
+    out, res = EmbedAddLayerNormFunc.apply(ids, table, weight, bias, 1e-5, odt, *args)
+    x0 = F.embedding(ids, table)
+    out_u, res_u = AddLayerNormFunc.apply(x0, None, weight, bias, 1e-5, True, *args)
+    assert out.dtype == odt and res.dtype == torch.float32 and out.shape == shape + (D,)
+    assert torch.equal(res, res_u)
+    assert torch.equal(out, out_u.to(odt))                              # one rounding of the same fp32 LayerNorm result
+    dout, dres = torch.randn(shape + (D,), generator=g).to(odt), torch.randn(shape + (D,), generator=g)
+    gt, gw, gb = torch.autograd.grad([out, res], [table, weight, bias], [dout, dres])
+    ht, hw, hb = torch.autograd.grad([out_u, res_u], [table, weight, bias], [dout.float(), dres])
+    assert _rel(gt, ht) < 2e-6 and _rel(gw, hw) < 2e-6 and _rel(gb, hb) < 2e-6
+    assert gt.shape == table.shape and (V == 16 or torch.equal(gt[V:], ht[V:]))
+
+
+def test_lm_first_block_gathers_its_embedding(emu_backend, monkeypatch):
+    """HyenaDNALM routes the first block through the embedding-fused pass and gets the loss and gradients of the unfused route"""
+    import hyena_dna_amd.lm as LM
+    L, D = 64, 64
+    layer = dict(l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10)
+    torch.manual_seed(0)
+    m = LM.HyenaDNALM(d_model=D, n_layer=2, d_inner=4 * D, vocab_size=12, layer=layer, resid_dropout=0.0, embed_dropout=0.0,
+                      pad_vocab_size_multiple=8, fused_dropout_add_ln=True, residual_in_fp32=True)
+    ids = torch.randint(7, 11, (2, L))
+    tgt = torch.roll(ids, -1, 1)
+    calls = []
+    real = LM.embedding_dropout_add_layer_norm
+    monkeypatch.setattr(LM, "embedding_dropout_add_layer_norm", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    loss = m.loss(ids, tgt)
+    grads = torch.autograd.grad(loss, [p for p in m.parameters() if p.requires_grad])
+    assert calls == [1]
+    monkeypatch.setattr(LM, "embedding_fusable", lambda *a, **k: False)
+    loss_u = m.loss(ids, tgt)
+    grads_u = torch.autograd.grad(loss_u, [p for p in m.parameters() if p.requires_grad])
+    assert calls == [1] and abs(loss.item() - loss_u.item()) < 1e-6
+    for a, b in zip(grads, grads_u):
+        assert _rel(a, b) < 1e-5

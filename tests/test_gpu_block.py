@@ -187,3 +187,36 @@ def test_fused_dropout_on_gpu(gpu_lib, shape, dtype, p):
     assert torch.equal(gx != 0, kept & (hx != 0))
     out2, res2 = AddLayerNormFunc.apply(x0, residual, weight, bias, 1e-5, True, p, seed)
     assert torch.equal(out2, out) and torch.equal(res2, res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,D,V,odt,p", [((2, 4096), 256, 16, torch.bfloat16, 0.1), ((1, 70001), 256, 12, torch.float32, 0.0), ((3, 999), 128, 16, torch.float16, 0.3)])
+def test_embedding_inside_the_first_add_norm_pass_on_gpu(gpu_lib, shape, D, V, odt, p):
+    """the embedding-fused first pass on the gfx950 binary == F.embedding + the (dropout ->) add -> LayerNorm pass with the same seed: residual'
+    bit for bit, out up to its one rounding, the table's gradient == the unfused route's (per-token-class sums in a fixed order)"""
+    from hyena_dna_amd.block import AddLayerNormFunc, EmbedAddLayerNormFunc
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(sum(shape) + D)
+    ids = torch.randint(0, V, shape, generator=g, device=dev)
+    table = torch.randn(V, D, generator=g, device=dev).requires_grad_(True)
+    weight = (1 + 0.2 * torch.randn(D, generator=g, device=dev)).requires_grad_(True)
+    bias = (0.1 * torch.randn(D, generator=g, device=dev)).requires_grad_(True)
+    seed = torch.tensor([424242424242], dtype=torch.int64, device=dev)
+    args = (p, seed) if p > 0 else ()
+    out, res = EmbedAddLayerNormFunc.apply(ids, table, weight, bias, 1e-5, odt, *args)
+    out_u, res_u = AddLayerNormFunc.apply(F.embedding(ids, table), None, weight, bias, 1e-5, True, *args)
+    assert torch.equal(res, res_u)
+    if odt == torch.float16:
+        # fp16 output: hipcc folds the last multiply-add and the conversion into v_fma_mixlo_f16 -- ONE rounding of the exact result, where the
+        # unfused route rounds to fp32 first: the neighbouring fp16 value in a few elements per million
+        ref16 = out_u.to(odt)
+        assert ((out.float() - out_u).abs() <= 2.0 ** -11 * out_u.abs() + 1e-7).all() and (out != ref16).float().mean().item() < 1e-3
+    else:
+        assert torch.equal(out, out_u.to(odt))
+    dout, dres = torch.randn(shape + (D,), generator=g, device=dev).to(odt), torch.randn(shape + (D,), generator=g, device=dev)
+    gt, gw, gb = torch.autograd.grad([out, res], [table, weight, bias], [dout, dres])
+    ht, hw, hb = torch.autograd.grad([out_u, res_u], [table, weight, bias], [dout.float(), dres])
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()      # noqa: E731
+    assert rel(gt, ht) < 1e-5 and rel(gw, hw) < 1e-5 and rel(gb, hb) < 1e-5
+    gt2, _, _ = torch.autograd.grad(EmbedAddLayerNormFunc.apply(ids, table, weight, bias, 1e-5, odt, *args), [table, weight, bias], [dout, dres])
+    assert torch.equal(gt2, gt)                                                                             # deterministic
