@@ -105,3 +105,22 @@ def test_python_binding_matches_header(product_lib):
     for s in declared_symbols():
         assert ("L." + s) in src, s
 
+
+
+def test_block_host_only_entry_points(product_lib):
+    """the host-side answers of include/hyena_block.h's round-4 additions (no device touched)"""
+    L = product_lib
+    L.hyena_embed_add_norm_partial_floats.restype = ctypes.c_size_t
+    L.hyena_embed_add_norm_partial_floats.argtypes = [ctypes.c_long, ctypes.c_int]
+    L.hyena_add_norm_partial_floats.restype = ctypes.c_size_t
+    L.hyena_add_norm_partial_floats.argtypes = [ctypes.c_long, ctypes.c_int]
+    BF16, F32 = 1, 0
+    assert L.hyena_embed_add_norm_supported(16, 256, BF16) == 1 and L.hyena_embed_add_norm_supported(12, 128, F32) == 1
+    assert L.hyena_embed_add_norm_supported(17, 256, BF16) == 0 and L.hyena_embed_add_norm_supported(16, 512, BF16) == 0
+    assert L.hyena_embed_add_norm_supported(0, 256, BF16) == 0
+    rows, D = 1 << 20, 256
+    grid = L.hyena_add_norm_partial_floats(rows, D) // (2 * D)
+    assert grid == 2048 and L.hyena_embed_add_norm_partial_floats(rows, D) == grid * (2 + 16) * D
+    # dropout: p outside [0, 1) or a missing seed is refused before anything is launched
+    assert L.hyena_dropout_add_norm_fwd(None, BF16, None, None, None, ctypes.c_float(1e-5), ctypes.c_float(0.1), None, None, BF16, None, None,
+                                        None, ctypes.c_long(4), 256, None) == 1
