@@ -65,10 +65,23 @@ def lds_exchange_bytes(B, D, M):
     return (5 * B + 2) * D * 2 * 2 * 8 * M
 
 
-# Which generation of the long-convolution kernels the tree holds; bumped BY HAND whenever a kernel of that plan changes in a way that can
-# change its HBM traffic.  A PMC record (profiles/pmc_traffic.json, `kernel_set`) taken on another generation is reported as stale (traffic
-# null) instead of being passed off as a measurement of the current kernels.
-KERNEL_SET = {"onchip": "r2", "twolevel": "r2"}
+# Which generation of the long-convolution kernels the tree holds: a hash of the plan's source files (round 5; until then a label bumped by
+# hand, and missed twice).  A PMC record (profiles/pmc_traffic.json, `kernel_set`) taken on other sources is reported as stale (traffic null)
+# instead of being passed off as a measurement of the current kernels.
+PLAN_SOURCES = {"onchip": ("onchip_kernels.h", "onchip.hip", "onchip_dk.hip", "onchip_host.h", "launch.h"),
+                "twolevel": ("fftconv_kernels.h", "fftconv.hip", "launch.h")}
+
+
+def _plan_hash(plan):
+    import hashlib
+    h = hashlib.sha1()
+    for name in PLAN_SOURCES[plan]:
+        with open(os.path.join(ROOT, "hyena_dna_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:12]
+
+
+KERNEL_SET = {plan: _plan_hash(plan) for plan in PLAN_SOURCES}
 
 
 def measured_traffic(L, D, B, io_dtype, save, plan):
@@ -94,6 +107,10 @@ def measured_traffic(L, D, B, io_dtype, save, plan):
 SWEEP = [(1024, 8, 128), (32768, 8, 256), (160000, 2, 256), (450560, 1, 256)]
 # ... and one length between the plans' home grounds (the former cliff above 32768: VERDICT r3 item 8), not a contract configuration
 SWEEP_EXTRA = [(65536, 4, 256)]
+# The lengths the reference's trainer really hands the operator: hg38_dataset.py:220-223 (`data = seq[:-1]`) makes L = max_length - 1, odd, so
+# every channel-major row starts 2 bytes off a 4- / 16-byte boundary.  (L, B per GPU, d, the aligned neighbour it is compared with)
+SWEEP_REAL = [(32767, 8, 256, 32768), (159999, 2, 256, 160000), (449999, 1, 256, 450000), (999999, 1, 256, 1000000),
+              (1048575, 1, 256, 1048576)]
 # What the part sustains for the mixed read + write streams of the two-level plan (profiles/cpol_bw_r2.txt: 5.0-5.3 TB/s typical, 5.8 TB/s
 # the single best case): the floor of ANY exact-fp32 two-pass transform is its real traffic / this rate
 MIXED_STREAM_TBS = 5.8
@@ -125,47 +142,90 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(L, D, dtype, budget_s=25.0):
-    """The oracle (reference torch.fft path) fwd+bwd on the host cores, on a bounded sample of the same workload:
-    the same L, a subset of the D channels (channels are independent), B = 1; best of 3 timed repetitions."""
+def cpu_baseline(L, D, dtype, budget_s=30.0):
+    """The oracle (reference torch.fft path) fwd+bwd on the host cores, on a bounded sample of the same workload: the same L, a
+    subset of the D channels (channels are independent), B = 1.  A 64-row FFT job does not fill a many-core host and
+    oversubscribing it is slower than using fewer threads, so the sample is timed at several thread counts --
+    {8, 32, all cores} -- best of 3 each after a warm-up, and the BEST (thread count, time) is what is reported; `cores` = the threads
+    of that best run.  The figure is the sample's own throughput scaled by the channel fraction: on a host with more cores than the best
+    thread count the remaining cores could run further channel groups side by side, which this figure does NOT claim."""
     from oracle import hyena_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    # ~50 ns per (channel, position) per core-ish for fwd+bwd; at most 64 channels, so that 1 warm-up + 3 timed repetitions fit the budget
-    Ds = max(1, min(D, 64, int(4.0e8 * max(cores, 8) / 8 / max(L, 1024) / 12)))
+    host = os.cpu_count() or 1
+    Ds = max(1, min(D, 64, int(4.0e8 / max(L, 1024) / 12 * 8)))
     g = torch.Generator().manual_seed(0)
     u = torch.randn(1, Ds, L, generator=g).to(dtype)
     k = torch.randn(Ds, L, generator=g) * torch.exp(-5.0 * torch.linspace(0, 1, L))[None] * 0.1
     bias = torch.randn(Ds, generator=g)
     dout = torch.randn(1, Ds, L, generator=g).to(dtype)
-    best, timed = None, 0
-    t_start = time.perf_counter()
-    for rep in range(4):                      # 1 warm-up + 3 timed repetitions (fewer only if one repetition alone overruns the budget)
+
+    def once():
         u_ = u.clone().requires_grad_(True)
         k_ = k.clone().requires_grad_(True)
         b_ = bias.clone().requires_grad_(True)
         t0 = time.perf_counter()
         out = O.fftconv_ref(u_, k_, b_, None, gelu=False)
         out.backward(dout)
-        dt = time.perf_counter() - t0
-        if rep > 0:
-            best = dt if best is None else min(best, dt)
-            timed += 1
-        if best is not None and time.perf_counter() - t_start + dt > 1.5 * budget_s:
+        return time.perf_counter() - t0
+
+    t_start = time.perf_counter()
+    tried = {}
+    saved_threads = torch.get_num_threads()
+    for t in sorted({min(8, host), min(32, host), host}):
+        if tried and time.perf_counter() - t_start > budget_s:
             break
+        torch.set_num_threads(t)
+        once()                                                    # warm-up at this thread count
+        best = None
+        for _ in range(3):
+            dt = once()
+            best = dt if best is None else min(best, dt)
+            if time.perf_counter() - t_start > 1.5 * budget_s:
+                break
+        tried[t] = best
+    torch.set_num_threads(saved_threads)
+    t_best = min(tried, key=tried.get)
+    best = tried[t_best]
     nt_per_s = L * (Ds / D) / best           # a nucleotide = one position through all D channels
-    return {"value": nt_per_s, "unit": "nt/s", "cores": cores, "kind": "port", "repetitions": timed,
-            "sample": f"oracle fftconv_ref fwd+bwd (torch.fft, fp32 math), B=1, L={L}, {Ds} of {D} channels, "
-                      f"best of {timed} timed repetition{'s' if timed != 1 else ''} after 1 warm-up, "
-                      f"{best * 1e3:.0f} ms; scaled by {Ds}/{D} channels"}
+    return {"value": nt_per_s, "unit": "nt/s", "cores": t_best, "host_cores": host, "kind": "port", "repetitions": 3,
+            "by_threads": {str(t): L * (Ds / D) / v for t, v in tried.items()},
+            "sample": f"oracle fftconv_ref fwd+bwd (torch.fft, fp32 math), B=1, L={L}, {Ds} of {D} channels, timed at "
+                      f"{sorted(tried)} threads (best of 3 after a warm-up each); best {best * 1e3:.0f} ms at {t_best} threads on a "
+                      f"{host}-core host; scaled by {Ds}/{D} channels"}
 
 
-def operator_layer(L, D, B, dtype, dev, steps=5, warmup=2):
+def operator_algorithmic_bytes(B, D, L, s):
+    """What ONE HyenaOperator layer has to move, forward + backward, if every tensor crossed HBM once (the roofline a whole layer is
+    judged against): SURVEY.md 8d's secondary boundary for the mixer core between the projections, 11 B L D s + 12 D L, plus the
+    projections' own I/O at the layer boundary -- forward: read u, write out (2 B L D s); backward: read dout, read u again for
+    in_proj's weight gradient, write du (3 B L D s) -- plus the layer's weights and their gradients (negligible: 4 D^2 * 2 s)."""
+    return 11 * B * L * D * s + 12 * D * L + 5 * B * L * D * s + 16 * D * D * s
+
+
+def _timed_steps(step, steps, dev):
+    """per-step HIP-event times (ms) of `steps` back-to-back calls: events between the steps, one synchronisation at the end"""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize(dev)
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+
+
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def operator_layer(L, D, B, dtype, dev, steps=20, warmup=3):
     """Secondary figure (not `value`): one whole HyenaOperator layer -- in_proj, short conv, gates, implicit filter, long
-    conv, out_proj -- forward + backward under autocast, HyenaDNA configuration (hg38_hyena.yaml:20-30), random init."""
+    conv, out_proj -- forward + backward under autocast, HyenaDNA configuration (hg38_hyena.yaml:20-30), random init.
+    `ms_per_step` is the mean of `steps` steps, with the minimum and the median beside it (box noise is +- 4 %: VERDICT r4 item 4),
+    and a roofline against operator_algorithmic_bytes."""
     from hyena_dna_amd.hyena import HyenaOperator
     torch.manual_seed(0)
-    op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
+    op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
                        lr=6e-4, wd=0.0, lr_pos_emb=0.0).to(dev)
     u = torch.randn(B, L, D, device=dev, dtype=dtype, requires_grad=True)
     dy = torch.randn(B, L, D, device=dev, dtype=dtype)
@@ -180,19 +240,21 @@ def operator_layer(L, D, B, dtype, dev, steps=5, warmup=2):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / steps
-    return {"ms_per_step": ms, "value": B * L / ms * 1e3, "unit": "nt/s", "steps": steps,
+    times = _timed_steps(step, steps, dev)
+    ms = sum(times) / steps
+    s = 4 if dtype == torch.float32 else 2
+    abytes = operator_algorithmic_bytes(B, D, L, s)
+    best = min(times)
+    return {"ms_per_step": ms, "min_ms": best, "median_ms": _median(times), "value": B * L / ms * 1e3, "unit": "nt/s", "steps": steps,
+            "roofline": {"bound": "hbm", "achieved": abytes / (best * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": abytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": abytes,
+                         "of": "min_ms", "boundary": "SURVEY 8d secondary (mixer core, 11 B L D s + 12 D L) + the projections' layer I/O "
+                                                     "(5 B L D s) + weights: every tensor of the layer boundary once"},
             "workload": f"one HyenaOperator layer fwd+bwd (projections + short conv + gates + implicit filter + long conv), "
                         f"L={L}, d={D}, B={B}, {str(dtype).split('.')[-1]} autocast; secondary figure, not `value`"}
 
 
-def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=3, warmup=2, emu=False, graphed_ok=True):
+def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=8, warmup=2, emu=False, graphed_ok=True):
     """Secondary figure (not `value`): the full hyenadna pre-training step of north_star configuration 5 on synthetic tokens --
     embedding -> n_layer x [add+LayerNorm -> HyenaOperator -> add+LayerNorm -> MLP (d -> 4d -> d, tanh-GELU)] -> LayerNorm ->
     tied LM head -> cross entropy, backward, AdamW step -- random init, autocast (hg38_hyena.yaml: d_model 256, n_layer 8,
@@ -236,11 +298,17 @@ def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=3, warmup=
     for _ in range(warmup):
         step()
     sync()
+    ev = None if emu else [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if ev:
+        ev[0].record()
+    for i in range(steps):
         loss = step()
+        if ev:
+            ev[i + 1].record()
     sync()
     wall = time.perf_counter() - t0
+    per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)] if ev else [wall * 1e3 / steps] * steps
     if world > 1:                                    # the step ends when the slowest rank's does
         tm = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -270,7 +338,8 @@ def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=3, warmup=
                        "how": "forward + loss + backward + AdamW captured into one hipGraph (hyena_dna_amd.lm.GraphedTrainStep)"}
         except Exception as e:                                     # never lose the eager figure over the capture
             graphed = {"error": repr(e)[:200]}
-    return {"ms_per_step": ms, "value": B * L * world / ms * 1e3, "unit": "nt/s", "n_gpus": world, "steps": steps, "loss": float(loss),
+    return {"ms_per_step": ms, "median_ms": _median(per_step), "min_ms": min(per_step),
+            "value": B * L * world / ms * 1e3, "unit": "nt/s", "n_gpus": world, "steps": steps, "loss": float(loss),
             "graphed": graphed, "params": sum(p.numel() for p in model.parameters()),
             "peak_mem_GB": None if emu else torch.cuda.max_memory_allocated(dev) / 2 ** 30,
             "parallelism": "single GPU" if world == 1 else
@@ -281,15 +350,26 @@ def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=3, warmup=
                         f"secondary figure, not `value`"}
 
 
-def make_conv_step(L, B, D, dtype, dev, seed, chunk=None, save=True, fwd_only=False):
+def make_conv_step(L, B, D, dtype, dev, seed, chunk=None, save=True, fwd_only=False, pitched=True):
     """Synthetic operands resident in HBM + the step closure: what hyena_dna_amd.fftconv.FFTConvFunc does per layer call -- forward
-    (keeping its spectra for the backward unless save is off), then the backward for a given upstream gradient."""
+    (keeping its spectra for the backward unless save is off), then the backward for a given upstream gradient.
+    pitched: the operands are laid out as the operator's fused path lays them out (hyena_dna_amd._lib.empty_rows: rows 64 elements apart
+    -- identical to the packed layout whenever L is a multiple of 64, i.e. at every aligned length); False: packed rows, what a caller of
+    the bare op seam (fftconv_func on its own contiguous tensors) gets."""
     from hyena_dna_amd import _lib
     g = torch.Generator(device=dev).manual_seed(seed)
-    u = torch.randn(B, D, L, generator=g, device=dev).to(dtype)
-    k = torch.randn(D, L, generator=g, device=dev) * torch.exp(-5.0 * torch.linspace(0, 1, L, device=dev))[None] * 0.1
+
+    def rows(t):
+        if not pitched:
+            return t
+        r = _lib.empty_rows(t.shape[:-1], t.shape[-1], t.dtype, t.device)
+        r.copy_(t)
+        return r
+
+    u = rows(torch.randn(B, D, L, generator=g, device=dev).to(dtype))
+    k = rows(torch.randn(D, L, generator=g, device=dev) * torch.exp(-5.0 * torch.linspace(0, 1, L, device=dev))[None] * 0.1)
     bias = torch.randn(D, generator=g, device=dev)
-    dout = torch.randn(B, D, L, generator=g, device=dev).to(dtype)
+    dout = rows(torch.randn(B, D, L, generator=g, device=dev).to(dtype))
 
     def step():
         if save:
@@ -365,13 +445,13 @@ def conv_rooflines(L, B, D, dtype_name, save, ev_ms_step):
     return roof, valu
 
 
-def sweep_configs(dtype, dtype_name, dev, steps, warmup, graph_ok, emu=False, configs=None):
+def sweep_configs(dtype, dtype_name, dev, steps, warmup, graph_ok, emu=False, configs=None, pitched=True):
     """The other BASELINE.json configurations through the same timed loop as the headline (HIP events around `steps` steps after
     `warmup`, operands resident): {ms_per_step, nt/s, both roofline fractions, floor, PMC traffic} each.  N = 1 only."""
     res = []
     for (L, B, D) in (configs or SWEEP):
         try:
-            step = make_conv_step(L, B, D, dtype, dev, seed=2222)
+            step = make_conv_step(L, B, D, dtype, dev, seed=2222, pitched=pitched)
             for _ in range(warmup):
                 step()
             run, graphed = (step, False) if emu else maybe_graph(step, L, B, D, dtype, dev, warmup, graph_ok)
@@ -399,6 +479,37 @@ def sweep_configs(dtype, dtype_name, dev, steps, warmup, graph_ok, emu=False, co
             if not emu:
                 torch.cuda.empty_cache()
         except Exception as e:                                       # a secondary figure never costs the contract line
+            res.append({"seq_len": L, "batch_per_gpu": B, "channels": D, "error": repr(e)[:200]})
+    return res
+
+
+def sweep_real_shapes(dtype, dtype_name, dev, steps, warmup, graph_ok):
+    """The sequence lengths the reference's trainer really produces (L = max_length - 1, hg38_dataset.py:220-223), each next to its aligned
+    neighbour through the same loop: {ms_per_step, value, frac} + `aligned` {seq_len, ms_per_step} + `vs_aligned` = real / aligned time.
+    `ms_per_step` is measured on PITCHED rows -- the layout the operator's fused path hands the convolution (rows 64 elements apart,
+    hyena_dna_amd._lib.row_pitch) --, `packed_ms` on packed (B, D, L) tensors, what a caller of the bare op seam passes.  Every leg is measured
+    twice, interleaved, and the better time is kept (the comparison is about a 2 % difference)."""
+    res = []
+    for (L, B, D, La) in SWEEP_REAL:
+        try:
+            best = {}
+            for rep in range(2):
+                for key, length, pitched in (("real", L, True), ("aligned", La, True), ("packed", L, False)):
+                    r = sweep_configs(dtype, dtype_name, dev, steps, warmup, graph_ok, configs=[(length, B, D)], pitched=pitched)[0]
+                    if "error" in r:
+                        raise RuntimeError(r["error"])
+                    if key not in best or r["ms_per_step"] < best[key]["ms_per_step"]:
+                        best[key] = r
+            r = {k: best["real"][k] for k in ("seq_len", "batch_per_gpu", "channels", "io_dtype", "steps", "warmup", "hipgraph_replay",
+                                              "ms_per_step", "value", "unit", "frac", "valu_frac", "algorithmic_bytes_per_step")}
+            from hyena_dna_amd import _lib
+            r["row_pitch"] = _lib.row_pitch(L)
+            r["aligned"] = {"seq_len": La, "ms_per_step": best["aligned"]["ms_per_step"]}
+            r["vs_aligned"] = best["real"]["ms_per_step"] / best["aligned"]["ms_per_step"]
+            r["packed_ms"] = best["packed"]["ms_per_step"]
+            r["packed_vs_aligned"] = best["packed"]["ms_per_step"] / best["aligned"]["ms_per_step"]
+            res.append(r)
+        except Exception as e:
             res.append({"seq_len": L, "batch_per_gpu": B, "channels": D, "error": repr(e)[:200]})
     return res
 
@@ -474,6 +585,10 @@ def main():
         if not args.emu:
             sweep_extra = sweep_configs(dtype, args.dtype, dev, max(args.steps, 20), args.warmup, not args.no_graph, configs=SWEEP_EXTRA)
 
+    sweep_real = None
+    if world == 1 and not args.no_sweep and not args.fwd_only and not args.emu:
+        sweep_real = sweep_real_shapes(dtype, args.dtype, dev, max(args.steps, 20), args.warmup, not args.no_graph)
+
     model_res = None
     if not args.no_model and not args.fwd_only and (world > 1 or not args.emu):
         # every rank takes part (DDP's collectives); a failure must not lose the contract line, nor leave the other ranks
@@ -507,6 +622,8 @@ def main():
             # the other four BASELINE.json configurations through the same loop (N = 1 runs; null otherwise)
             "sweep": sweep,
             "sweep_extra": sweep_extra,
+            # the lengths the reference's trainer really produces (L = max_length - 1), each next to its aligned neighbour
+            "sweep_real": sweep_real,
         }
         if world == 1 and not args.emu and not args.no_operator and not args.fwd_only:
             try:
@@ -514,6 +631,26 @@ def main():
             except Exception as e:                                   # secondary: never lose the contract line over it
                 line["operator_layer"] = {"error": repr(e)[:200]}
         line["model_step"] = model_res
+        if world == 1 and not args.emu and not args.no_sweep and not args.fwd_only and L % 2 == 0:
+            # the layer and the model at the length the reference's trainer feeds them for this max_length: L - 1
+            if not args.no_operator:
+                try:
+                    r = operator_layer(L - 1, D, B, dtype, dev)
+                    if "ms_per_step" in line.get("operator_layer", {}):
+                        r["vs_aligned"] = {"min": r["min_ms"] / line["operator_layer"]["min_ms"],
+                                           "median": r["median_ms"] / line["operator_layer"]["median_ms"]}
+                    line["operator_layer_real"] = r
+                except Exception as e:
+                    line["operator_layer_real"] = {"error": repr(e)[:200]}
+            if not args.no_model:
+                try:
+                    torch.cuda.empty_cache()
+                    r = model_step(L - 1, D, B, dtype, dev, n_layer=args.model_layers, graphed_ok=False)
+                    if model_res and "median_ms" in model_res:
+                        r["vs_aligned"] = {"min": r["min_ms"] / model_res["min_ms"], "median": r["median_ms"] / model_res["median_ms"]}
+                    line["model_step_real"] = r
+                except Exception as e:
+                    line["model_step_real"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline and not args.emu:
             line["cpu_baseline"] = cpu_baseline(L, D, dtype)          # rank 0 at N = 1 only (other ranks would idle at the barrier)
         else:

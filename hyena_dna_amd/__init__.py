@@ -31,7 +31,10 @@ import torch as _torch
 _K = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 # safe = the variable reads "0" AND the HIP runtime reads it after it was set: found "0" at import (exported before the process started,
 # or set by the caller ahead of its imports), or set by prepare_graph_runtime() while the runtime was still uninitialised
-GRAPH_SAFE = _os.environ.get(_K) == "0"
+# (a process that starts the HIP runtime, THEN puts "0" into os.environ, THEN imports this package must not pass -- the runtime
+# never saw the knob.  A variable exported before the process started is indistinguishable from that here only if the runtime is already
+# up at import, and then the conservative answer is "not safe": export HYENA_GRAPH_SAFE_OVERRIDE=1 to vouch for it.)
+GRAPH_SAFE = _os.environ.get(_K) == "0" and (not _torch.cuda.is_initialized() or _os.environ.get("HYENA_GRAPH_SAFE_OVERRIDE") == "1")
 
 
 def prepare_graph_runtime():

@@ -120,6 +120,13 @@ def lib():
         L.hyena_fftconv_bwd_saved.restype = c_int
         L.hyena_fftconv_bwd_saved.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                               c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]
+        L.hyena_fftconv_fwd_ld.restype = c_int
+        L.hyena_fftconv_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]
+        L.hyena_fftconv_bwd_ld.restype = c_int
+        L.hyena_fftconv_bwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int,
+                                           c_void_p, c_size_t, c_void_p]
         # fused mixer shell (include/hyena_mixer.h)
         L.hyena_mixer_pre_fwd.restype = c_int
         L.hyena_mixer_pre_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
@@ -148,7 +155,25 @@ def lib():
         L.hyena_cm_pre_bwd.restype = c_int
         L.hyena_cm_pre_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_cm_pre_fwd_ld.restype = c_int
+        L.hyena_cm_pre_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p]
+        L.hyena_cm_post_fwd_ld.restype = c_int
+        L.hyena_cm_post_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_void_p]
+        L.hyena_cm_post_bwd_ld.restype = c_int
+        L.hyena_cm_post_bwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_cm_pre_bwd_ld.restype = c_int
+        L.hyena_cm_pre_bwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
         # input projection on the matrix cores + front of the shell (include/hyena_proj.h)
+        L.hyena_inproj_pre_fwd_ld.restype = c_int
+        L.hyena_inproj_pre_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_outproj_gate_fwd_ld.restype = c_int
+        L.hyena_outproj_gate_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
         L.hyena_proj_supported.restype = c_int
         L.hyena_proj_supported.argtypes = [c_int, c_int, c_int, c_int]
         L.hyena_inproj_pre_fwd.restype = c_int
@@ -192,6 +217,18 @@ def lib():
         L.hyena_filter16_bwd.restype = c_int
         L.hyena_filter16_bwd.argtypes = [ctypes.POINTER(FilterParams), c_int, c_void_p, c_void_p, ctypes.POINTER(FilterGrads),
                                          c_void_p, c_size_t, c_void_p]
+        L.hyena_filter_row_pitch.restype = c_int
+        L.hyena_filter_row_pitch.argtypes = [c_int]
+        L.hyena_filter_fwd_ld.restype = c_int
+        L.hyena_filter_fwd_ld.argtypes = [ctypes.POINTER(FilterParams), c_void_p, c_int, c_void_p, c_void_p]
+        L.hyena_filter_bwd_ld.restype = c_int
+        L.hyena_filter_bwd_ld.argtypes = [ctypes.POINTER(FilterParams), c_void_p, c_int, c_void_p, ctypes.POINTER(FilterGrads),
+                                          c_void_p, c_size_t, c_void_p]
+        L.hyena_filter16_fwd_ld.restype = c_int
+        L.hyena_filter16_fwd_ld.argtypes = [ctypes.POINTER(FilterParams), c_int, c_void_p, c_int, c_void_p, c_void_p]
+        L.hyena_filter16_bwd_ld.restype = c_int
+        L.hyena_filter16_bwd_ld.argtypes = [ctypes.POINTER(FilterParams), c_int, c_void_p, c_int, c_void_p, ctypes.POINTER(FilterGrads),
+                                            c_void_p, c_size_t, c_void_p]
         # fused residual add + LayerNorm (include/hyena_block.h)
         c_long, c_float = ctypes.c_long, ctypes.c_float
         L.hyena_add_norm_supported.restype = c_int
@@ -242,6 +279,65 @@ def _require_gpu(t, name):
     _backend.require(t, name)
 
 
+# ---- pitched rows (round 5) ---------------------------------------------------------------------------------------------------------
+# The reference's trainer hands the operator L = max_length - 1 positions (hg38_dataset.py:220-223): odd.  In a packed channel-major tensor
+# every second row of 16-bit elements then starts 2 bytes off a 4-byte boundary and none but the first is 16-byte aligned, which the
+# kernels' 16-byte accesses, the library GEMMs' vector loads and the filter kernels' fast paths all pay for (21 % of a layer at 2^20 - 1,
+# profiles/r5a_*).  So every tensor this package allocates BETWEEN the two projections -- xT, vg, y, zT, their gradients, the filter k and
+# dk -- is a [..., :L] view of a buffer whose rows are ROW_ALIGN elements apart (L rounded up): rows start 128-byte (16-bit) / 256-byte
+# (fp32) aligned whatever L is, and the C ABI's *_ld entry points are told the pitch.  With L a multiple of ROW_ALIGN nothing changes.
+ROW_ALIGN = 64
+
+
+def row_pitch(L):
+    return (int(L) + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+
+
+def empty_rows(lead, L, dtype, device, pitch=None):
+    """An uninitialised tensor of shape (*lead, L) whose rows are `pitch` (default row_pitch(L)) elements apart: the [..., :L] view of a
+    packed (*lead, pitch) buffer."""
+    ld = row_pitch(L) if pitch is None else int(pitch)
+    buf = torch.empty(tuple(lead) + (ld,), dtype=dtype, device=device)
+    return buf if ld == L else buf[..., :L]
+
+
+def ld_of(t):
+    """Row pitch (elements) of a tensor whose last dimension is contiguous and whose leading dimensions are packed over equally pitched
+    rows -- what empty_rows hands out, and every contiguous tensor (pitch = L); None for any other layout."""
+    if t.dim() < 1:
+        return None
+    L = t.shape[-1]
+    if L > 1 and t.stride(-1) != 1:
+        return None
+    if t.dim() == 1:
+        return L
+    # the pitch is the stride of the innermost leading dimension with more than one entry; all others must be packed over it
+    ld, expect = None, None
+    for i in range(t.dim() - 2, -1, -1):
+        if t.shape[i] == 1:
+            continue
+        if ld is None:
+            ld = t.stride(i)
+            if ld < L:
+                return None
+            expect = ld * t.shape[i]
+        else:
+            if t.stride(i) != expect:
+                return None
+            expect *= t.shape[i]
+    return L if ld is None else ld
+
+
+def as_rows(t):
+    """t itself if its layout is pitched rows (ld_of), else a packed copy"""
+    return t if ld_of(t) is not None else t.contiguous()
+
+
+def empty_like_rows(t, dtype=None):
+    """A new tensor with t's shape and t's row pitch"""
+    return empty_rows(t.shape[:-1], t.shape[-1], t.dtype if dtype is None else dtype, t.device, pitch=ld_of(t))
+
+
 def tables_for(device, L):
     """Twiddle tables for sequence length L on `device` (cached per transform size)."""
     M = lib().hyena_fftconv_fft_size(int(L))
@@ -261,7 +357,7 @@ def tables_for(device, L):
     return t
 
 
-_retired = []     # outgrown workspaces a captured hipGraph may still replay on: kept alive
+_retired = []     # (key, buffer): outgrown workspaces a captured hipGraph of that (device, stream) may still replay on: kept alive
 _captured = set() # (device index, stream) keys whose workspace was handed out during a hipGraph capture
 
 
@@ -276,7 +372,7 @@ def workspace_for(device, nbytes):
     if w is None or w.numel() < nbytes:
         if w is not None:
             if key in _captured:
-                _retired.append(w)
+                _retired.append((key, w))
                 _captured.discard(key)
             nbytes = max(int(nbytes), int(1.5 * w.numel()))
         w = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -293,9 +389,9 @@ def release_stream_state(device, stream):
     key = (getattr(device, "index", None), stream)
     w = _workspace.pop(key, None)
     _captured.discard(key)
-    if w is not None:
-        _retired[:] = [r for r in _retired if r.data_ptr() != w.data_ptr()]
-    return w is not None
+    n = len(_retired)
+    _retired[:] = [(k, r) for (k, r) in _retired if k != key]          # the graphs that could replay on them are gone with the stream
+    return w is not None or len(_retired) != n
 
 
 def reset_save_decisions(device=None):
@@ -351,13 +447,15 @@ def save_spectra_default(B, D, L, device=None):
 
 
 def fftconv_fwd(u, k, bias, chunk=None, save=False, grad=None):
-    """u (B, D, L) contiguous, k (D, L) fp32, bias (D,) fp32 or None -> out like u.
+    """u (B, D, L), k (D, L) fp32, bias (D,) fp32 or None -> out like u.  u and k may be packed or pitched rows (ld_of); out gets u's pitch.
     save=True additionally returns the saved-spectrum buffer for fftconv_bwd(..., saved=).
     grad: a backward of the same shape will follow (default: save or autograd's grad mode) -- the workspace is then sized
     for it right away instead of being outgrown at the first backward."""
     _require_gpu(u, "u")
     B, D, L = u.shape
-    out = torch.empty_like(u)
+    u, k = as_rows(u), as_rows(k)
+    ldx, ldk = ld_of(u), ld_of(k)
+    out = empty_like_rows(u)
     if B == 0:                                   # empty batch: nothing to launch (torch.fft returns an empty tensor too)
         return (out, torch.empty(0, dtype=torch.uint8, device=u.device)) if save else out
     chunk = _chunk_override() if chunk is None else int(chunk)
@@ -369,25 +467,38 @@ def fftconv_fwd(u, k, bias, chunk=None, save=False, grad=None):
     ws, stream = workspace_for(u.device, nbytes)
     bp = bias.data_ptr() if bias is not None else None
     with _backend.guard(u.device):
-        if save:
-            saved = torch.empty(saved_bytes(B, D, L), dtype=torch.uint8, device=u.device)
-            check(lib().hyena_fftconv_fwd_save(u.data_ptr(), k.data_ptr(), bp, out.data_ptr(), B, D, L, dtype_code(u.dtype),
-                                               tables.data_ptr(), ws.data_ptr(), ws.numel(), chunk, saved.data_ptr(),
-                                               saved.numel(), stream))
-            return out, saved
-        check(lib().hyena_fftconv_fwd(u.data_ptr(), k.data_ptr(), bp, out.data_ptr(), B, D, L, dtype_code(u.dtype),
-                                      tables.data_ptr(), ws.data_ptr(), ws.numel(), chunk, stream))
-    return out
+        saved = torch.empty(saved_bytes(B, D, L), dtype=torch.uint8, device=u.device) if save else None
+        check(lib().hyena_fftconv_fwd_ld(u.data_ptr(), k.data_ptr(), bp, out.data_ptr(), B, D, L, ldx, ldk, dtype_code(u.dtype),
+                                         tables.data_ptr(), ws.data_ptr(), ws.numel(), chunk,
+                                         saved.data_ptr() if save else None, saved.numel() if save else 0, stream))
+    return (out, saved) if save else out
+
+
+def _same_pitch(t, ld):
+    """t with row pitch ld (a copy if it has another one)"""
+    if ld_of(t) == ld:
+        return t
+    r = empty_rows(t.shape[:-1], t.shape[-1], t.dtype, t.device, pitch=ld)
+    r.copy_(t)
+    return r
 
 
 def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None, saved=None):
-    """Returns (du like u | None, dk (D, L) fp32 | None, dbias (D,) fp32 | None).
+    """Returns (du like dout | None, dk (D, L) fp32 | None, dbias (D,) fp32 | None).  Packed or pitched rows as in fftconv_fwd: du gets
+    dout's pitch, dk gets k's (row_pitch(L) when k is not given).
     With saved= (from fftconv_fwd(save=True)) k is not read, and u only on the workspace-free path (L <= 32768, where
     the saved buffer holds the filter spectrum alone)."""
     _require_gpu(dout, "dout")
     B, D, L = dout.shape
-    du = torch.empty_like(dout) if need_du else None
-    dk = torch.empty((D, L), dtype=torch.float32, device=dout.device) if need_dk else None
+    dout = as_rows(dout)
+    ldx = ld_of(dout)
+    if u is not None:
+        u = _same_pitch(as_rows(u), ldx)
+    if k is not None:
+        k = as_rows(k)
+    ldk = ld_of(k) if k is not None else row_pitch(L)
+    du = empty_like_rows(dout) if need_du else None
+    dk = empty_rows((D,), L, torch.float32, dout.device, pitch=ldk) if need_dk else None
     dbias = torch.empty((D,), dtype=torch.float32, device=dout.device) if need_dk else None
     if B == 0:                                   # empty batch: the parameter gradients are sums over nothing
         return du, None if dk is None else dk.zero_(), None if dbias is None else dbias.zero_()
@@ -398,14 +509,10 @@ def fftconv_bwd(dout, u, k, bias, need_du=True, need_dk=True, chunk=None, saved=
     bp = bias.data_ptr() if bias is not None else None
     ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
     with _backend.guard(dout.device):
-        if saved is not None:
-            check(lib().hyena_fftconv_bwd_saved(dout.data_ptr(), ptr(u), bp, ptr(du), ptr(dk), ptr(dbias), B, D, L,
-                                                dtype_code(dout.dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(), chunk,
-                                                saved.data_ptr(), saved.numel(), stream))
-        else:
-            check(lib().hyena_fftconv_bwd(dout.data_ptr(), u.data_ptr(), k.data_ptr(), bp, ptr(du), ptr(dk), ptr(dbias),
-                                          B, D, L, dtype_code(dout.dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(),
-                                          chunk, stream))
+        # (with the forward's spectra the library reads neither k nor -- for L > 32768 -- u; k is passed only without them)
+        check(lib().hyena_fftconv_bwd_ld(dout.data_ptr(), ptr(u), None if saved is not None else ptr(k), bp, ptr(du), ptr(dk), ptr(dbias),
+                                         B, D, L, ldx, ldk, dtype_code(dout.dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         chunk, ptr(saved), saved.numel() if saved is not None else 0, stream))
     return du, dk, dbias
 
 
@@ -460,25 +567,38 @@ def mixer_pre_bwd(dvg, x, w, b, dx, part):
 
 
 # ---- the shell in channel-major layout (include/hyena_mixer.h, hyena_cm_*) ------------------------------------------------
+# Every tensor here is packed or pitched rows (ld_of): xT / dxT carry their own pitch, all L-long tensors of a call share one
+# (row_pitch(L) for everything these functions allocate; an operand that arrives with another pitch is re-pitched by a copy).
+def _cm_lda(L, *ts):
+    for t in ts:
+        if t is not None and ld_of(t) is not None and ld_of(t) != L:
+            return ld_of(t)
+    return row_pitch(L)
+
+
 def cm_pre_fwd(xT, bin_, w, b, L):
     """xT (3D, B, Lx) [in_proj output without bias], bin_ (3D,) fp32 or None -> vg (B, D, L)."""
     _require_gpu(xT, "xT")
     D3, B, Lx = xT.shape
     D = D3 // 3
-    vg = torch.empty((B, D, L), dtype=xT.dtype, device=xT.device)
+    xT = as_rows(xT)
+    vg = empty_rows((B, D), L, xT.dtype, xT.device)
     with _backend.guard(xT.device):
-        check(lib().hyena_cm_pre_fwd(xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(), vg.data_ptr(),
-                                     B, L, Lx, D, dtype_code(xT.dtype), _backend.stream(xT.device)))
+        check(lib().hyena_cm_pre_fwd_ld(xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(), vg.data_ptr(),
+                                        B, L, Lx, D, ld_of(xT), ld_of(vg), dtype_code(xT.dtype), _backend.stream(xT.device)))
     return vg
 
 
 def cm_post_fwd(y, xT, bin_, w, b):
-    """y (B, D, L), xT (3D, B, Lx) -> zT (D, B, L)."""
+    """y (B, D, L), xT (3D, B, Lx) -> zT (D, B, L) with y's row pitch."""
     B, D, L = y.shape
-    zT = torch.empty((D, B, L), dtype=xT.dtype, device=xT.device)
+    xT, y = as_rows(xT), as_rows(y)
+    lda = ld_of(y)
+    zT = empty_rows((D, B), L, xT.dtype, xT.device, pitch=lda)
     with _backend.guard(xT.device):
-        check(lib().hyena_cm_post_fwd(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                      zT.data_ptr(), B, L, xT.shape[2], D, dtype_code(xT.dtype), _backend.stream(xT.device)))
+        check(lib().hyena_cm_post_fwd_ld(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                         zT.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), lda, dtype_code(xT.dtype),
+                                         _backend.stream(xT.device)))
     return zT
 
 
@@ -489,42 +609,49 @@ def cm_partials(xT, L):
 
 
 def cm_post_bwd(dzT, y, xT, bin_, w, b, dxT, part):
-    """-> dy (B, D, L); fills dxT[0:D] (positions < L) and part[0:D]."""
+    """-> dy (B, D, L) with y's row pitch; fills dxT[0:D] (positions < L) and part[0:D].  dxT must have xT's row pitch."""
     B, D, L = y.shape
-    dy = torch.empty_like(y)
+    xT, y = as_rows(xT), as_rows(y)
+    lda = ld_of(y)
+    dzT = _same_pitch(as_rows(dzT), lda)
+    assert ld_of(dxT) == ld_of(xT)
+    dy = empty_like_rows(y)
     with _backend.guard(xT.device):
-        check(lib().hyena_cm_post_bwd(dzT.data_ptr(), y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(),
-                                      b.data_ptr(), dy.data_ptr(), dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D,
-                                      dtype_code(xT.dtype), _backend.stream(xT.device)))
+        check(lib().hyena_cm_post_bwd_ld(dzT.data_ptr(), y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(),
+                                         b.data_ptr(), dy.data_ptr(), dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D,
+                                         ld_of(xT), lda, dtype_code(xT.dtype), _backend.stream(xT.device)))
     return dy
 
 
 def cm_pre_bwd(dvg, xT, bin_, w, b, dxT, part):
-    """fills dxT[D:3D] (positions < L) and part[D:3D]."""
+    """fills dxT[D:3D] (positions < L) and part[D:3D].  dxT must have xT's row pitch."""
     B, D, L = dvg.shape
+    xT, dvg = as_rows(xT), as_rows(dvg)
+    assert ld_of(dxT) == ld_of(xT)
     with _backend.guard(xT.device):
-        check(lib().hyena_cm_pre_bwd(dvg.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                     dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D, dtype_code(xT.dtype),
-                                     _backend.stream(xT.device)))
+        check(lib().hyena_cm_pre_bwd_ld(dvg.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                        dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), ld_of(dvg), dtype_code(xT.dtype),
+                                        _backend.stream(xT.device)))
 
 
 # ---- input projection on the matrix cores with the front of the shell in its epilogue (include/hyena_proj.h) --------------------
 def proj_supported(B, Lx, D, dtype):
     code = _DTYPES.get(dtype)
-    return code is not None and bool(lib().hyena_proj_supported(int(B), int(Lx), int(D), code))
+    return code is not None and bool(lib().hyena_proj_supported(int(B), int(Lx), int(D), code)) and B * row_pitch(Lx) < 2 ** 31
 
 
 def inproj_pre_fwd(u, W, bin_, w, b, L):
     """u (B, Lx, D) 16-bit, W (3D, D) same type, bin_ (3D,) fp32 or None, w (3D, 3) fp32, b (3D,) fp32
-    -> xT (3D, B, Lx) = W u^T (no bias), vg (B, D, L) = short_conv(xT + bin_)[v] * short_conv(xT + bin_)[x1]."""
+    -> xT (3D, B, Lx) = W u^T (no bias), vg (B, D, L) = short_conv(xT + bin_)[v] * short_conv(xT + bin_)[x1]; both pitched rows."""
     _require_gpu(u, "u")
     B, Lx, D = u.shape
     assert W.shape == (3 * D, D) and W.dtype == u.dtype and u.is_contiguous() and W.is_contiguous()
-    xT = torch.empty((3 * D, B, Lx), dtype=u.dtype, device=u.device)
-    vg = torch.empty((B, D, L), dtype=u.dtype, device=u.device)
+    xT = empty_rows((3 * D, B), Lx, u.dtype, u.device)
+    vg = empty_rows((B, D), L, u.dtype, u.device)
     with _backend.guard(u.device):
-        check(lib().hyena_inproj_pre_fwd(u.data_ptr(), W.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                         xT.data_ptr(), vg.data_ptr(), B, Lx, int(L), D, dtype_code(u.dtype), _backend.stream(u.device)))
+        check(lib().hyena_inproj_pre_fwd_ld(u.data_ptr(), W.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                            xT.data_ptr(), vg.data_ptr(), B, Lx, int(L), D, ld_of(xT), ld_of(vg), dtype_code(u.dtype),
+                                            _backend.stream(u.device)))
     return xT, vg
 
 
@@ -535,18 +662,20 @@ def outproj_supported(B, L, Lx, D, dtype):
 
 def outproj_gate_fwd(y, xT, bin_, w, b, W, bias, want_z):
     """y (B, D, L) conv output, xT (3D, B, Lx), bin_ / w / b as cm_post_fwd, W (D, D) out_proj weight (element type of y), bias (D,) fp32
-    [values already rounded to the element type] or None -> out (B, L, D) = (y * x0)^T W^T + bias, zT (D, B, L) = y * x0 if want_z else
-    None (bit-identical to cm_post_fwd).  One launch: the gate rides on the operand load of the matrix-core product."""
+    [values already rounded to the element type] or None -> out (B, L, D) = (y * x0)^T W^T + bias (packed), zT (D, B, L) = y * x0 with y's row
+    pitch if want_z else None (bit-identical to cm_post_fwd).  One launch: the gate rides on the operand load of the matrix-core product."""
     _require_gpu(y, "y")
     B, D, L = y.shape
-    assert W.shape == (D, D) and W.dtype == y.dtype and xT.dtype == y.dtype and W.is_contiguous() and y.is_contiguous() and xT.is_contiguous()
+    y, xT = as_rows(y), as_rows(xT)
+    assert W.shape == (D, D) and W.dtype == y.dtype and xT.dtype == y.dtype and W.is_contiguous()
+    lda = ld_of(y)
     out = torch.empty((B, L, D), dtype=y.dtype, device=y.device)
-    zT = torch.empty((D, B, L), dtype=y.dtype, device=y.device) if want_z else None
+    zT = empty_rows((D, B), L, y.dtype, y.device, pitch=lda) if want_z else None
     with _backend.guard(y.device):
-        check(lib().hyena_outproj_gate_fwd(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                           W.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(),
-                                           None if zT is None else zT.data_ptr(), B, L, xT.shape[2], D, dtype_code(y.dtype),
-                                           _backend.stream(y.device)))
+        check(lib().hyena_outproj_gate_fwd_ld(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                              W.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(),
+                                              None if zT is None else zT.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), lda,
+                                              dtype_code(y.dtype), _backend.stream(y.device)))
     return out, zT
 
 
@@ -615,30 +744,33 @@ def _filter_params(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modula
 
 
 def filter_fwd(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate, save, compute_dtype=None):
-    """z (L, E), t (L,), weights as in include/hyena_filter.h -> k (D, L) [, saved pre-activations].  ``compute_dtype`` bfloat16 /
-    float16: the graph the reference computes under torch.autocast of that type (hyena_filter16_fwd; the pre-activations are kept as
-    (3, 32, L) 32-bit words holding 16-bit pairs); None: the fp32 graph ((3, 64, L) fp32)."""
+    """z (L, E), t (L,), weights as in include/hyena_filter.h -> k (D, L) fp32, pitched rows [, saved pre-activations].  ``compute_dtype``
+    bfloat16 / float16: the graph the reference computes under torch.autocast of that type (hyena_filter16_fwd; the pre-activations are
+    kept as (3, 32, P) 32-bit words holding 16-bit pairs, P = the library's row pitch for L); None: the fp32 graph ((3, 64, P) fp32)."""
     p = _filter_params(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate)
-    k = torch.empty((p.D, p.L), dtype=torch.float32, device=z.device)
+    k = empty_rows((p.D,), p.L, torch.float32, z.device)
+    P = int(lib().hyena_filter_row_pitch(p.L))
     if compute_dtype is None:
-        saved = torch.empty((3, 64, p.L), dtype=torch.float32, device=z.device) if save else None
+        saved = torch.empty((3, 64, P), dtype=torch.float32, device=z.device) if save else None
     else:
-        saved = torch.empty((3, 32, p.L), dtype=torch.int32, device=z.device) if save else None
+        saved = torch.empty((3, 32, P), dtype=torch.int32, device=z.device) if save else None
     with _backend.guard(z.device):
         sp = None if saved is None else saved.data_ptr()
         if compute_dtype is None:
-            check(lib().hyena_filter_fwd(ctypes.byref(p), k.data_ptr(), sp, _backend.stream(z.device)))
+            check(lib().hyena_filter_fwd_ld(ctypes.byref(p), k.data_ptr(), ld_of(k), sp, _backend.stream(z.device)))
         else:
-            check(lib().hyena_filter16_fwd(ctypes.byref(p), dtype_code(compute_dtype), k.data_ptr(), sp, _backend.stream(z.device)))
+            check(lib().hyena_filter16_fwd_ld(ctypes.byref(p), dtype_code(compute_dtype), k.data_ptr(), ld_of(k), sp,
+                                              _backend.stream(z.device)))
     return (k, saved) if save else k
 
 
 def filter_bwd(dk, saved, z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate, need_dz, compute_dtype=None):
-    """-> (dw0, db0, dw1, db1, dw2, db2, dw3, dfreq, dz or None); dz is (L, E).  ``compute_dtype`` as in filter_fwd (``saved`` must come
-    from the forward of the same type)."""
+    """-> (dw0, db0, dw1, db1, dw2, db2, dw3, dfreq, dz or None); dz is (L, E).  dk (D, L) fp32, packed or pitched rows.  ``compute_dtype`` as
+    in filter_fwd (``saved`` must come from the forward of the same type)."""
     p = _filter_params(z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift, modulate)
     _require_gpu(dk, "dk")
-    assert dk.dtype == torch.float32 and dk.is_contiguous() and dk.shape == (p.D, p.L)
+    assert dk.dtype == torch.float32 and dk.shape == (p.D, p.L)
+    dk = as_rows(dk)
     outs = [torch.empty_like(x) for x in (w0, b0, w1, b1, w2, b2, w3, freq)]
     dzt = torch.empty((p.E, p.L), dtype=torch.float32, device=z.device) if need_dz else None
     g = FilterGrads()
@@ -650,12 +782,12 @@ def filter_bwd(dk, saved, z, t, w0, b0, w1, b1, w2, b2, w3, freq, deltas, shift,
         ws, stream = workspace_for(z.device, nbytes)
         if compute_dtype is None:
             assert saved.dtype == torch.float32
-            check(lib().hyena_filter_bwd(ctypes.byref(p), dk.data_ptr(), saved.data_ptr(), ctypes.byref(g), ws.data_ptr(),
-                                         ws.numel(), stream))
+            check(lib().hyena_filter_bwd_ld(ctypes.byref(p), dk.data_ptr(), ld_of(dk), saved.data_ptr(), ctypes.byref(g), ws.data_ptr(),
+                                            ws.numel(), stream))
         else:
             assert saved.dtype == torch.int32
-            check(lib().hyena_filter16_bwd(ctypes.byref(p), dtype_code(compute_dtype), dk.data_ptr(), saved.data_ptr(), ctypes.byref(g),
-                                           ws.data_ptr(), ws.numel(), stream))
+            check(lib().hyena_filter16_bwd_ld(ctypes.byref(p), dtype_code(compute_dtype), dk.data_ptr(), ld_of(dk), saved.data_ptr(),
+                                              ctypes.byref(g), ws.data_ptr(), ws.numel(), stream))
     return tuple(outs) + (None if dzt is None else dzt.t().contiguous(),)
 
 

@@ -42,6 +42,9 @@ struct AddNormArgs {
     const unsigned long long* seed;   // device pointer to the 64-bit dropout seed, or null: no dropout
     unsigned drop_below;              // an element is dropped when its 32 random bits are < drop_below (= p * 2^32)
     float keep_scale;                 // 1 / (1 - p)
+    int V;                            // EMB kernels: rows of the embedding table.  An id outside [0, V) reads NO memory: the forward poisons that
+                                      // row of out / residual' with NaN (F.embedding, which this pass replaces, device-asserts there), the
+                                      // backward leaves it out of every sum
 };
 
 // Philox 4x32-10 (Salmon et al., SC'11): counter (c0, c1, 0, 0), key (k0, k1) -> four 32-bit words
@@ -110,7 +113,13 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_fwd_kernel(AddNormArgs a
     for (long row = (long)blockIdx.x * BLK_WAVES + wave; row < a.rows; row += (long)gridDim.x * BLK_WAVES) {
         const size_t off = (size_t)row * a.D + c0;
         float r[E];
-        blk_load<XDT, E>(a.x, EMB ? (size_t)a.ids[row] * a.D + c0 : off, r);          // EMB: the row of the embedding table
+        const long long id = EMB ? a.ids[row] : 0;
+        const bool bad_id = EMB && (unsigned long long)id >= (unsigned long long)a.V;   // never index the table with it
+        blk_load<XDT, E>(a.x, EMB ? (size_t)(bad_id ? 0 : id) * a.D + c0 : off, r);          // EMB: the row of the embedding table
+        if (bad_id) {
+            HY_UNROLL
+            for (int e = 0; e < E; ++e) r[e] = __builtin_nanf("");
+        }
         if (a.seed != nullptr) blk_dropout<E>(r, off, seed, a.drop_below, a.keep_scale);
         if (a.res_in != nullptr) {
             float q[E];
@@ -182,7 +191,8 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_bwd_kernel(AddNormArgs a
         if (a.res_out != nullptr) blk_store<DT_F32, E>(a.res_out, off, dr);
         if (a.seed != nullptr) blk_dropout<E>(dr, off, seed, a.drop_below, a.keep_scale);      // d x0 = d residual' through the same mask
         if (EMB) {
-            const int v = HY_SGPR((int)a.ids[row]);          // the row's token class: wave-uniform
+            const long long id = a.ids[row];
+            const int v = HY_SGPR((unsigned long long)id < (unsigned long long)a.V ? (int)id : -1);   // the row's token class: wave-uniform; -1: no class
             HY_UNROLL
             for (int q = 0; q < BLK_VMAX; ++q) {
                 if (v == q) {

@@ -7,8 +7,8 @@
 using namespace hyena;
 
 namespace {
-bool cm_ok(const void* xT, const float* w, const float* b, int B, int L, int Lx, int D, int dtype) {
-    return xT != nullptr && w != nullptr && b != nullptr && B >= 1 && L >= 1 && Lx >= L && D >= 1 &&
+bool cm_ok(const void* xT, const float* w, const float* b, int B, int L, int Lx, int D, int ldx, int lda, int dtype) {
+    return xT != nullptr && w != nullptr && b != nullptr && B >= 1 && L >= 1 && Lx >= L && D >= 1 && ldx >= Lx && lda >= L &&
            (dtype == HYENA_F32 || dtype == HYENA_BF16 || dtype == HYENA_F16);
 }
 int cm_tiles(int L) { return (L + CM_TILE - 1) / CM_TILE; }
@@ -32,45 +32,63 @@ size_t hyena_cm_partial_floats(int B, int L, int D) {
     return (size_t)3 * D * B * cm_tiles(L) * CM_NP;
 }
 
-int hyena_cm_pre_fwd(const void* xT, const float* bin, const float* w, const float* b, void* vg, int B, int L, int Lx, int D, int dtype,
-                     void* stream) {
-    if (!cm_ok(xT, w, b, B, L, Lx, D, dtype) || vg == nullptr) return HYENA_ERR_BAD_ARG;
+int hyena_cm_pre_fwd_ld(const void* xT, const float* bin, const float* w, const float* b, void* vg, int B, int L, int Lx, int D, int ldx,
+                        int lda, int dtype, void* stream) {
+    if (!cm_ok(xT, w, b, B, L, Lx, D, ldx, lda, dtype) || vg == nullptr) return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = nullptr; a.a1 = nullptr; a.o0 = vg; a.dxT = nullptr; a.part = nullptr;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.ldx = ldx; a.lda = lda;
     HY_CM_DISPATCH(cm_pre_fwd_kernel, 0);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
-int hyena_cm_post_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, void* zT, int B, int L, int Lx,
-                      int D, int dtype, void* stream) {
-    if (!cm_ok(xT, w, b, B, L, Lx, D, dtype) || y == nullptr || zT == nullptr) return HYENA_ERR_BAD_ARG;
+int hyena_cm_post_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, void* zT, int B, int L, int Lx,
+                         int D, int ldx, int lda, int dtype, void* stream) {
+    if (!cm_ok(xT, w, b, B, L, Lx, D, ldx, lda, dtype) || y == nullptr || zT == nullptr) return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = y; a.a1 = nullptr; a.o0 = zT; a.dxT = nullptr; a.part = nullptr;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.ldx = ldx; a.lda = lda;
     HY_CM_DISPATCH(cm_post_fwd_kernel, 0);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
-int hyena_cm_post_bwd(const void* dzT, const void* y, const void* xT, const float* bin, const float* w, const float* b, void* dy,
-                      void* dxT, float* part, int B, int L, int Lx, int D, int dtype, void* stream) {
-    if (!cm_ok(xT, w, b, B, L, Lx, D, dtype) || dzT == nullptr || y == nullptr || dy == nullptr || dxT == nullptr || part == nullptr)
+int hyena_cm_post_bwd_ld(const void* dzT, const void* y, const void* xT, const float* bin, const float* w, const float* b, void* dy,
+                         void* dxT, float* part, int B, int L, int Lx, int D, int ldx, int lda, int dtype, void* stream) {
+    if (!cm_ok(xT, w, b, B, L, Lx, D, ldx, lda, dtype) || dzT == nullptr || y == nullptr || dy == nullptr || dxT == nullptr || part == nullptr)
         return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = y; a.a1 = dzT; a.o0 = dy; a.dxT = dxT; a.part = part;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.ldx = ldx; a.lda = lda;
     HY_CM_DISPATCH(cm_post_bwd_kernel, CM_SMEM);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
-int hyena_cm_pre_bwd(const void* dvg, const void* xT, const float* bin, const float* w, const float* b, void* dxT, float* part, int B,
-                     int L, int Lx, int D, int dtype, void* stream) {
-    if (!cm_ok(xT, w, b, B, L, Lx, D, dtype) || dvg == nullptr || dxT == nullptr || part == nullptr) return HYENA_ERR_BAD_ARG;
+int hyena_cm_pre_bwd_ld(const void* dvg, const void* xT, const float* bin, const float* w, const float* b, void* dxT, float* part, int B,
+                        int L, int Lx, int D, int ldx, int lda, int dtype, void* stream) {
+    if (!cm_ok(xT, w, b, B, L, Lx, D, ldx, lda, dtype) || dvg == nullptr || dxT == nullptr || part == nullptr) return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = dvg; a.a1 = nullptr; a.o0 = nullptr; a.dxT = dxT; a.part = part;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.ldx = ldx; a.lda = lda;
     HY_CM_DISPATCH(cm_pre_bwd_kernel, CM_SMEM);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+
+// the packed layouts: ldx = Lx, lda = L
+int hyena_cm_pre_fwd(const void* xT, const float* bin, const float* w, const float* b, void* vg, int B, int L, int Lx, int D, int dtype,
+                     void* stream) {
+    return hyena_cm_pre_fwd_ld(xT, bin, w, b, vg, B, L, Lx, D, Lx, L, dtype, stream);
+}
+int hyena_cm_post_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, void* zT, int B, int L, int Lx,
+                      int D, int dtype, void* stream) {
+    return hyena_cm_post_fwd_ld(y, xT, bin, w, b, zT, B, L, Lx, D, Lx, L, dtype, stream);
+}
+int hyena_cm_post_bwd(const void* dzT, const void* y, const void* xT, const float* bin, const float* w, const float* b, void* dy,
+                      void* dxT, float* part, int B, int L, int Lx, int D, int dtype, void* stream) {
+    return hyena_cm_post_bwd_ld(dzT, y, xT, bin, w, b, dy, dxT, part, B, L, Lx, D, Lx, L, dtype, stream);
+}
+int hyena_cm_pre_bwd(const void* dvg, const void* xT, const float* bin, const float* w, const float* b, void* dxT, float* part, int B,
+                     int L, int Lx, int D, int dtype, void* stream) {
+    return hyena_cm_pre_bwd_ld(dvg, xT, bin, w, b, dxT, part, B, L, Lx, D, Lx, L, dtype, stream);
 }
 
 }  // extern "C"

@@ -370,24 +370,25 @@ size_t hyena_fftconv_saved_bytes(int B, int D, int L) {
     return (size_t)(B + 1) * D * p.M * sizeof(c32);
 }
 
-static int fwd_impl(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int dtype,
+static int fwd_impl(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int ldx, int ldk, int dtype,
                     const void* d_tables, void* workspace, size_t workspace_bytes, int chunk, void* saved,
                     size_t saved_bytes, void* stream) {
     Plan p;
     if (u == nullptr || k == nullptr || out == nullptr || d_tables == nullptr || workspace == nullptr || B < 1 ||
-        D < 1 || (dtype != HYENA_F32 && dtype != HYENA_BF16 && dtype != HYENA_F16))
+        D < 1 || ldx < L || ldk < L || (dtype != HYENA_F32 && dtype != HYENA_BF16 && dtype != HYENA_F16))
         return HYENA_ERR_BAD_ARG;
+    const oc::Pitch ld = {ldx, ldk};
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
     if (p.R) {
         if ((size_t)D * p.M * sizeof(c32) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;       // 32-bit buffer offsets into H
         if (workspace_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
         if (saved != nullptr && saved_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
-        if (oc::small_ok(p.R, B, D, L, dtype))          // one launch: the filter transform rides in the convolution kernel
-            return oc::launch_small_fwd(p.R, u, out, k, bias, saved, d_tables, B, D, L, dtype, stream);
+        if (oc::small_ok(p.R, B, D, L, ld, dtype))          // one launch: the filter transform rides in the convolution kernel
+            return oc::launch_small_fwd(p.R, u, out, k, bias, saved, d_tables, B, D, L, ld, dtype, stream);
         void* H = saved ? saved : workspace;
-        int st = oc::launch_spec(p.R, k, bias, H, d_tables, D, L, stream);
+        int st = oc::launch_spec(p.R, k, bias, H, d_tables, D, L, ld, stream);
         if (st) return st;
-        return oc::launch_conv(p.R, u, out, H, d_tables, B, D, L, dtype, 0, stream);
+        return oc::launch_conv(p.R, u, out, H, d_tables, B, D, L, ld, dtype, 0, stream);
     }
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, 0);
     if (chunk > D) chunk = D;
@@ -408,13 +409,13 @@ static int fwd_impl(const void* u, const float* k, const float* bias, void* out,
         c32* Wu = saved ? saved_wu(saved, D, p.M) + (size_t)d0 * p.M : wsW;
         const int ub = saved ? D : cd;
         ColArgs ck;
-        ck.x = k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd; ck.w_bstride = cd;
-        ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
+        ck.x = k + (size_t)d0 * ldk; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd; ck.w_bstride = cd;
+        ck.outer_stride = 0; ck.inner_stride = ldk; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
         if ((st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
         ColArgs cu;
-        cu.x = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cu.W = Wu; cu.tab = tab; cu.L = L; cu.inner = cd;
+        cu.x = reinterpret_cast<const char*>(u) + (size_t)d0 * ldx * es; cu.W = Wu; cu.tab = tab; cu.L = L; cu.inner = cd;
         cu.w_bstride = ub;
-        cu.outer_stride = (long)D * L; cu.inner_stride = L; cu.aux0 = nullptr; cu.x2 = nullptr; cu.W2 = nullptr;
+        cu.outer_stride = (long)D * ldx; cu.inner_stride = ldx; cu.aux0 = nullptr; cu.x2 = nullptr; cu.W2 = nullptr;
         if ((st = launch_col<false>(dtype, p.M1, cu, B * cd, stream))) return st;
         RowArgs rc;
         rc.X = Wu; rc.U = Wk; rc.S = nullptr; rc.S0 = nullptr; rc.bias = bias ? bias + d0 : nullptr; rc.K = nullptr; rc.Y = wsW;
@@ -422,54 +423,55 @@ static int fwd_impl(const void* u, const float* k, const float* bias, void* out,
         rc.M1 = p.M1; rc.inner = cd; rc.B = B; rc.scale = 1.0f / (float)p.M;
         if ((st = launch_row_prod2<MODE_CONV>(rc, stream))) return st;
         ColArgs co = cu;
-        co.x = reinterpret_cast<char*>(out) + (size_t)d0 * L * es; co.W = wsW; co.w_bstride = cd;
+        co.x = reinterpret_cast<char*>(out) + (size_t)d0 * ldx * es; co.W = wsW; co.w_bstride = cd;
         if ((st = launch_col<true>(dtype, p.M1, co, B * cd, stream))) return st;
     }
     return HYENA_OK;
 }
 
 static int bwd_impl(const void* dout, const void* u, const float* k, const float* bias, void* du, float* dk,
-                    float* dbias, int B, int D, int L, int dtype, const void* d_tables, void* workspace,
+                    float* dbias, int B, int D, int L, int ldx, int ldk, int dtype, const void* d_tables, void* workspace,
                     size_t workspace_bytes, int chunk, const void* saved_c, size_t saved_bytes, void* stream) {
     Plan p;
     void* saved = const_cast<void*>(saved_c);
+    const oc::Pitch ld = {ldx, ldk};
     if (dout == nullptr || (u == nullptr && saved == nullptr) || (k == nullptr && saved == nullptr) ||
-        d_tables == nullptr || workspace == nullptr || B < 1 || D < 1 ||
+        d_tables == nullptr || workspace == nullptr || B < 1 || D < 1 || ldx < L || ldk < L ||
         (dtype != HYENA_F32 && dtype != HYENA_BF16 && dtype != HYENA_F16))
         return HYENA_ERR_BAD_ARG;
     if (dbias != nullptr && dk == nullptr) return HYENA_ERR_BAD_ARG;
     if (!make_plan(L, &p)) return HYENA_ERR_UNSUPPORTED_L;
     if (p.R) {
         if (dk != nullptr && u == nullptr) return HYENA_ERR_BAD_ARG;        // this path keeps no spectrum of u: it re-reads u
-        if (p.R == 1 && (size_t)B * D * L * elem_size(dtype) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;   // 32-bit row offsets (dk, T = 32)
+        if (p.R == 1 && (size_t)B * D * ldx * elem_size(dtype) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;   // 32-bit row offsets (dk, T = 32)
         if ((size_t)D * p.M * sizeof(c32) >= ((size_t)1 << 32)) return HYENA_ERR_BAD_ARG;
         if (workspace_bytes < hyena_fftconv_workspace_bytes(B, D, L, 1, chunk)) return HYENA_ERR_WORKSPACE;
         if (saved != nullptr && saved_bytes < oc::spectrum_bytes(D, p.R)) return HYENA_ERR_WORKSPACE;
         void* partials = reinterpret_cast<char*>(workspace) + oc::spectrum_bytes(D, p.R);
         int st;
-        if ((du != nullptr || dk != nullptr) && oc::small_ok(p.R, B, D, L, dtype)) {
+        if ((du != nullptr || dk != nullptr) && oc::small_ok(p.R, B, D, L, ld, dtype)) {
             // du and dk from one launch.  Without the forward's spectrum the filter is transformed first by the forward kernel run
             // over an empty batch: the same code, hence the same bits, as the H the saved path reads.
             const void* H = saved;
             if (H == nullptr) {
-                if ((st = oc::launch_small_fwd(p.R, nullptr, nullptr, k, bias, workspace, d_tables, 0, D, L, dtype, stream))) return st;
+                if ((st = oc::launch_small_fwd(p.R, nullptr, nullptr, k, bias, workspace, d_tables, 0, D, L, ld, dtype, stream))) return st;
                 H = workspace;
             }
-            return oc::launch_small_bwd(p.R, dout, u, du, dk, dbias, H, d_tables, B, D, L, dtype, stream);
+            return oc::launch_small_bwd(p.R, dout, u, du, dk, dbias, H, d_tables, B, D, L, ld, dtype, stream);
         }
         if (du != nullptr) {
             const void* H = saved;
             if (H == nullptr) {
-                if ((st = oc::launch_spec(p.R, k, bias, workspace, d_tables, D, L, stream))) return st;
+                if ((st = oc::launch_spec(p.R, k, bias, workspace, d_tables, D, L, ld, stream))) return st;
                 H = workspace;
             }
-            if ((st = oc::launch_conv(p.R, dout, du, H, d_tables, B, D, L, dtype, 1, stream))) return st;
+            if ((st = oc::launch_conv(p.R, dout, du, H, d_tables, B, D, L, ld, dtype, 1, stream))) return st;
         }
         if (dk != nullptr && oc::dk1_ok(p.R, B)) {          // B = 1: the spectrum of u behind the partial rows, then conv with the conjugate
             void* uspec = reinterpret_cast<char*>(partials) + oc::dk_partial_bytes(p.R, B, D, L);
-            return oc::launch_dk1(p.R, dout, u, dk, dbias, uspec, d_tables, D, L, dtype, stream);
+            return oc::launch_dk1(p.R, dout, u, dk, dbias, uspec, d_tables, D, L, ld, dtype, stream);
         }
-        if (dk != nullptr && (st = oc::launch_dk(p.R, dout, u, dk, dbias, partials, d_tables, B, D, L, dtype, stream))) return st;
+        if (dk != nullptr && (st = oc::launch_dk(p.R, dout, u, dk, dbias, partials, d_tables, B, D, L, ld, dtype, stream))) return st;
         return HYENA_OK;
     }
     if (chunk <= 0) chunk = hyena_fftconv_default_chunk(B, D, L, 1);
@@ -492,15 +494,15 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
         c32* Wu = saved ? saved_wu(saved, D, p.M) + (size_t)d0 * p.M : wsWu;
         const int ub = saved ? D : cd;
         ColArgs cg;
-        cg.x = reinterpret_cast<const char*>(dout) + (size_t)d0 * L * es; cg.W = Wg; cg.tab = tab; cg.L = L; cg.inner = cd;
+        cg.x = reinterpret_cast<const char*>(dout) + (size_t)d0 * ldx * es; cg.W = Wg; cg.tab = tab; cg.L = L; cg.inner = cd;
         cg.w_bstride = cd;
-        cg.outer_stride = (long)D * L; cg.inner_stride = L; cg.aux0 = nullptr; cg.x2 = nullptr; cg.W2 = nullptr;
+        cg.outer_stride = (long)D * ldx; cg.inner_stride = ldx; cg.aux0 = nullptr; cg.x2 = nullptr; cg.W2 = nullptr;
         ColArgs cgu = cg;                                        // dout (and u, when dk is wanted) in ONE launch
-        if (dk != nullptr && !saved) { cgu.x2 = reinterpret_cast<const char*>(u) + (size_t)d0 * L * es; cgu.W2 = Wu; }
+        if (dk != nullptr && !saved) { cgu.x2 = reinterpret_cast<const char*>(u) + (size_t)d0 * ldx * es; cgu.W2 = Wu; }
         if ((st = launch_col<false>(dtype, p.M1, cgu, B * cd, stream))) return st;
         ColArgs ck;
-        ck.x = saved ? nullptr : k + (size_t)d0 * L; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd; ck.w_bstride = cd;
-        ck.outer_stride = 0; ck.inner_stride = L; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
+        ck.x = saved ? nullptr : k + (size_t)d0 * ldk; ck.W = Wk; ck.tab = tab; ck.L = L; ck.inner = cd; ck.w_bstride = cd;
+        ck.outer_stride = 0; ck.inner_stride = ldk; ck.aux0 = nullptr; ck.x2 = nullptr; ck.W2 = nullptr;
         if (du != nullptr && !saved && (st = launch_col<false>(HYENA_F32, p.M1, ck, cd, stream))) return st;
         RowArgs rb;
         rb.X = Wg; rb.U = Wu; rb.S = Sdk; rb.S0 = S0; rb.bias = bias ? bias + d0 : nullptr; rb.K = Wk; rb.Y = Wg;
@@ -511,8 +513,8 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
             else st = launch_row_bwd<false>(rb, stream);
             if (st) return st;
             ColArgs cdk;
-            cdk.x = dk + (size_t)d0 * L; cdk.W = Sdk; cdk.tab = tab; cdk.L = L; cdk.inner = cd; cdk.w_bstride = cd;
-            cdk.outer_stride = 0; cdk.inner_stride = L; cdk.aux0 = dbias ? dbias + d0 : nullptr; cdk.x2 = nullptr; cdk.W2 = nullptr;
+            cdk.x = dk + (size_t)d0 * ldk; cdk.W = Sdk; cdk.tab = tab; cdk.L = L; cdk.inner = cd; cdk.w_bstride = cd;
+            cdk.outer_stride = 0; cdk.inner_stride = ldk; cdk.aux0 = dbias ? dbias + d0 : nullptr; cdk.x2 = nullptr; cdk.W2 = nullptr;
             if ((st = launch_col<true>(HYENA_F32, p.M1, cdk, cd, stream))) return st;
         } else {
             RowArgs rc = rb;                                     // du only: X = dout rows, H = filter rows, corr
@@ -521,7 +523,7 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
         }
         if (du != nullptr) {
             ColArgs co = cg;
-            co.x = reinterpret_cast<char*>(du) + (size_t)d0 * L * es;
+            co.x = reinterpret_cast<char*>(du) + (size_t)d0 * ldx * es;
             if ((st = launch_col<true>(dtype, p.M1, co, B * cd, stream))) return st;
         }
     }
@@ -530,20 +532,33 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
 
 int hyena_fftconv_fwd(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int dtype,
                       const void* d_tables, void* workspace, size_t workspace_bytes, int chunk, void* stream) {
-    return fwd_impl(u, k, bias, out, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk, nullptr, 0, stream);
+    return fwd_impl(u, k, bias, out, B, D, L, L, L, dtype, d_tables, workspace, workspace_bytes, chunk, nullptr, 0, stream);
 }
 
 int hyena_fftconv_fwd_save(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int dtype,
                            const void* d_tables, void* workspace, size_t workspace_bytes, int chunk, void* saved,
                            size_t saved_bytes, void* stream) {
     if (saved == nullptr) return HYENA_ERR_BAD_ARG;
-    return fwd_impl(u, k, bias, out, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk, saved, saved_bytes, stream);
+    return fwd_impl(u, k, bias, out, B, D, L, L, L, dtype, d_tables, workspace, workspace_bytes, chunk, saved, saved_bytes, stream);
+}
+
+int hyena_fftconv_fwd_ld(const void* u, const float* k, const float* bias, void* out, int B, int D, int L, int ldx, int ldk, int dtype,
+                         const void* d_tables, void* workspace, size_t workspace_bytes, int chunk, void* saved, size_t saved_bytes,
+                         void* stream) {
+    return fwd_impl(u, k, bias, out, B, D, L, ldx, ldk, dtype, d_tables, workspace, workspace_bytes, chunk, saved, saved_bytes, stream);
+}
+
+int hyena_fftconv_bwd_ld(const void* dout, const void* u, const float* k, const float* bias, void* du, float* dk, float* dbias, int B,
+                         int D, int L, int ldx, int ldk, int dtype, const void* d_tables, void* workspace, size_t workspace_bytes,
+                         int chunk, const void* saved, size_t saved_bytes, void* stream) {
+    return bwd_impl(dout, u, k, bias, du, dk, dbias, B, D, L, ldx, ldk, dtype, d_tables, workspace, workspace_bytes, chunk, saved,
+                    saved_bytes, stream);
 }
 
 int hyena_fftconv_bwd(const void* dout, const void* u, const float* k, const float* bias, void* du, float* dk,
                       float* dbias, int B, int D, int L, int dtype, const void* d_tables, void* workspace,
                       size_t workspace_bytes, int chunk, void* stream) {
-    return bwd_impl(dout, u, k, bias, du, dk, dbias, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk, nullptr, 0,
+    return bwd_impl(dout, u, k, bias, du, dk, dbias, B, D, L, L, L, dtype, d_tables, workspace, workspace_bytes, chunk, nullptr, 0,
                     stream);
 }
 
@@ -551,7 +566,7 @@ int hyena_fftconv_bwd_saved(const void* dout, const void* u, const float* bias, 
                             int L, int dtype, const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
                             const void* saved, size_t saved_bytes, void* stream) {
     if (saved == nullptr) return HYENA_ERR_BAD_ARG;
-    return bwd_impl(dout, u, nullptr, bias, du, dk, dbias, B, D, L, dtype, d_tables, workspace, workspace_bytes, chunk,
+    return bwd_impl(dout, u, nullptr, bias, du, dk, dbias, B, D, L, L, L, dtype, d_tables, workspace, workspace_bytes, chunk,
                     saved, saved_bytes, stream);
 }
 
@@ -733,19 +748,32 @@ int hyena_filter_supported(int L, int E, int order, int D) {
     return L >= 1 && L <= HYENA_MAX_L && E >= 1 && E <= FLT_E && order == FLT_O && (D == 64 || D == 128 || D == 256);
 }
 
-size_t hyena_filter_saved_bytes(int L) { return L >= 1 ? (size_t)3 * FLT_O * L * sizeof(float) : 0; }
+// Rows of the library-owned buffers (saved pre-activations, the backward's two gradient buffers) are pitched to 64 words whatever L is:
+// the reference trainer's L = max_length - 1 is odd, and 16-byte accesses to packed rows of odd length are not aligned (round 5)
+int hyena_filter_row_pitch(int L) { return L >= 1 ? (L + 63) & ~63 : 0; }
+
+size_t hyena_filter_saved_bytes(int L) { return L >= 1 ? (size_t)3 * FLT_O * hyena_filter_row_pitch(L) * sizeof(float) : 0; }
 
 size_t hyena_filter_workspace_bytes(int L, int D) {
     if (L < 1 || D < 1) return 0;
-    return ((size_t)2 * FLT_O * L + flt_part_floats(D)) * sizeof(float);
+    return ((size_t)2 * FLT_O * hyena_filter_row_pitch(L) + flt_part_floats(D)) * sizeof(float);
 }
 
 int hyena_filter_fwd(const hyena_filter_params* p, float* k, float* saved, void* stream) {
-    if (!flt_params_ok(p) || k == nullptr) return HYENA_ERR_BAD_ARG;
+    return hyena_filter_fwd_ld(p, k, p != nullptr ? p->L : 0, saved, stream);
+}
+
+int hyena_filter_bwd(const hyena_filter_params* p, const float* dk, const float* saved, const hyena_filter_grads* g,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    return hyena_filter_bwd_ld(p, dk, p != nullptr ? p->L : 0, saved, g, workspace, workspace_bytes, stream);
+}
+
+int hyena_filter_fwd_ld(const hyena_filter_params* p, float* k, int ldk, float* saved, void* stream) {
+    if (!flt_params_ok(p) || k == nullptr || ldk < p->L) return HYENA_ERR_BAD_ARG;
     FilterArgs a;
     a.z = p->z; a.t = p->t; a.w0 = p->w0; a.b0 = p->b0; a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2; a.w3 = p->w3;
     a.freq = p->freq; a.deltas = p->deltas; a.k = k; a.acts = saved; a.shift = p->shift; a.modulate = p->modulate;
-    a.L = p->L; a.E = p->E; a.zs = p->z_stride; a.D = p->D;
+    a.L = p->L; a.E = p->E; a.zs = p->z_stride; a.D = p->D; a.ldk = ldk; a.lds = hyena_filter_row_pitch(p->L);
     switch (p->D) {
         case 64: launch_filter_fwd<64>(a, stream); break;
         case 128: launch_filter_fwd<128>(a, stream); break;
@@ -754,34 +782,34 @@ int hyena_filter_fwd(const hyena_filter_params* p, float* k, float* saved, void*
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
-int hyena_filter_bwd(const hyena_filter_params* p, const float* dk, const float* saved, const hyena_filter_grads* g,
-                     void* workspace, size_t workspace_bytes, void* stream) {
-    if (!flt_params_ok(p) || dk == nullptr || saved == nullptr || g == nullptr || workspace == nullptr) return HYENA_ERR_BAD_ARG;
+int hyena_filter_bwd_ld(const hyena_filter_params* p, const float* dk, int ldk, const float* saved, const hyena_filter_grads* g,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!flt_params_ok(p) || dk == nullptr || saved == nullptr || g == nullptr || workspace == nullptr || ldk < p->L) return HYENA_ERR_BAD_ARG;
     if (!g->dw0 || !g->db0 || !g->dw1 || !g->db1 || !g->dw2 || !g->db2 || !g->dw3 || !g->dfreq) return HYENA_ERR_BAD_ARG;
     if (workspace_bytes < hyena_filter_workspace_bytes(p->L, p->D)) return HYENA_ERR_WORKSPACE;
-    const int L = p->L;
+    const int L = p->L, P = hyena_filter_row_pitch(L);
     float* dA = static_cast<float*>(workspace);
-    float* dB = dA + (size_t)FLT_O * L;
-    float* part = dB + (size_t)FLT_O * L;
+    float* dB = dA + (size_t)FLT_O * P;
+    float* part = dB + (size_t)FLT_O * P;
     const float* a0 = saved;
-    const float* a1 = saved + (size_t)FLT_O * L;
-    const float* a2 = saved + (size_t)2 * FLT_O * L;
+    const float* a1 = saved + (size_t)FLT_O * P;
+    const float* a2 = saved + (size_t)2 * FLT_O * P;
 
     FilterBwdArgs a;
     a.freq = p->freq; a.t = p->t; a.deltas = p->deltas; a.shift = p->shift; a.modulate = p->modulate; a.L = L; a.zs = p->z_stride; a.rdt = 0;
     // last layer: delta_out = dk * modulation;  dW3, and delta_2 -> dA
-    a.dout = dk; a.w = p->w3; a.aprev = a2; a.dprev = dA; a.ni = FLT_O;
+    a.dout = dk; a.w = p->w3; a.aprev = a2; a.dprev = dA; a.ni = FLT_O; a.ldo = ldk; a.lda = P; a.ldp = P;
     switch (p->D) {
         case 64: launch_filter_layer_bwd<64, FLT_O, FLT_ACT | FLT_MOD>(a, part, g->dw3, nullptr, g->dfreq, true, stream); break;
         case 128: launch_filter_layer_bwd<128, FLT_O, FLT_ACT | FLT_MOD>(a, part, g->dw3, nullptr, g->dfreq, true, stream); break;
         default: launch_filter_layer_bwd<256, FLT_O, FLT_ACT | FLT_MOD>(a, part, g->dw3, nullptr, g->dfreq, true, stream); break;
     }
-    a.modulate = 0;
+    a.modulate = 0; a.ldo = P;
     a.dout = dA; a.w = p->w2; a.aprev = a1; a.dprev = dB;
     launch_filter_layer_bwd<FLT_O, FLT_O, FLT_ACT>(a, part, g->dw2, g->db2, g->dfreq, false, stream);
     a.dout = dB; a.w = p->w1; a.aprev = a0; a.dprev = dA;
     launch_filter_layer_bwd<FLT_O, FLT_O, FLT_ACT>(a, part, g->dw1, g->db1, g->dfreq, false, stream);
-    a.dout = dA; a.w = p->w0; a.aprev = p->z; a.dprev = g->dz; a.ni = p->E;
+    a.dout = dA; a.w = p->w0; a.aprev = p->z; a.dprev = g->dz; a.ni = p->E; a.ldp = L;        // dz (E, L) is the caller's: packed
     launch_filter_layer_bwd<FLT_O, FLT_E, 0>(a, part, g->dw0, g->db0, g->dfreq, false, stream);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
@@ -892,7 +920,7 @@ int hyena_dropout_add_norm_fwd(const void* x0, int x_dtype, const float* residua
         return HYENA_ERR_BAD_ARG;
     AddNormArgs a;
     a.x = x0; a.res_in = residual_in; a.weight = weight; a.bias = bias; a.out = out; a.res_out = residual_out; a.saved = nullptr;
-    a.mean = mean; a.rstd = rstd; a.part = nullptr; a.rows = rows; a.D = D; a.eps = eps; a.ids = nullptr; a.part_e = nullptr;
+    a.mean = mean; a.rstd = rstd; a.part = nullptr; a.rows = rows; a.D = D; a.eps = eps; a.ids = nullptr; a.part_e = nullptr; a.V = 0;
     if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
     return blk_launch(true, x_dtype, out_dtype, a, stream);
 }
@@ -915,7 +943,7 @@ int hyena_embed_add_norm_fwd(const long long* ids, const float* table, int V, co
         return HYENA_ERR_BAD_ARG;
     AddNormArgs a;
     a.x = table; a.res_in = nullptr; a.weight = weight; a.bias = bias; a.out = out; a.res_out = residual_out; a.saved = nullptr;
-    a.mean = mean; a.rstd = rstd; a.part = nullptr; a.rows = rows; a.D = D; a.eps = eps; a.ids = ids; a.part_e = nullptr;
+    a.mean = mean; a.rstd = rstd; a.part = nullptr; a.rows = rows; a.D = D; a.eps = eps; a.ids = ids; a.part_e = nullptr; a.V = V;
     if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
     switch (out_dtype) {
         case HYENA_F32: return blk_launch_emb_fwd<DT_F32>(a, stream);
@@ -941,7 +969,7 @@ int hyena_embed_add_norm_bwd(const void* dout, int dout_dtype, const float* d_re
     AddNormArgs a;
     a.x = dout; a.res_in = d_residual_out; a.weight = weight; a.bias = nullptr; a.out = nullptr; a.res_out = nullptr;
     a.saved = residual_out; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.part = partial;
-    a.rows = rows; a.D = D; a.eps = 0.f; a.ids = ids; a.part_e = partial + (size_t)grid * 2 * D;
+    a.rows = rows; a.D = D; a.eps = 0.f; a.ids = ids; a.part_e = partial + (size_t)grid * 2 * D; a.V = V;
     if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
     int st;
     switch (dout_dtype) {
@@ -980,7 +1008,7 @@ int hyena_dropout_add_norm_bwd(const void* dout, int dout_dtype, const float* d_
     AddNormArgs a;
     a.x = dout; a.res_in = d_residual_out; a.weight = weight; a.bias = nullptr; a.out = dx0; a.res_out = d_residual_in;
     a.saved = residual_out; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.part = partial;
-    a.rows = rows; a.D = D; a.eps = 0.f; a.ids = nullptr; a.part_e = nullptr;
+    a.rows = rows; a.D = D; a.eps = 0.f; a.ids = nullptr; a.part_e = nullptr; a.V = 0;
     if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
     const int st = blk_launch(false, dout_dtype, dx_dtype, a, stream);
     if (st) return st;

@@ -96,27 +96,27 @@ void launch_layer0(FilterBwdArgs a, float* part, float* dw, float* db, void* str
 }
 
 template <int DT>
-void bwd_all(const hyena_filter_params* p, const float* dk, const void* saved, const hyena_filter_grads* g, void* workspace, void* stream) {
-    const int L = p->L;
-    float* dA = static_cast<float*>(workspace);              // (64, L) floats each: pair words use the first half
-    float* dB = dA + (size_t)FLT_O * L;
-    float* part = dB + (size_t)FLT_O * L;
+void bwd_all(const hyena_filter_params* p, const float* dk, int ldk, const void* saved, const hyena_filter_grads* g, void* workspace, void* stream) {
+    const int L = p->L, P = hyena_filter_row_pitch(L);       // library-owned rows are pitched to 64 words (fftconv.hip)
+    float* dA = static_cast<float*>(workspace);              // (64, P) floats each: pair words use the first half
+    float* dB = dA + (size_t)FLT_O * P;
+    float* part = dB + (size_t)FLT_O * P;
     const uint32_t* sv = static_cast<const uint32_t*>(saved);
     const uint32_t* a0 = sv;
-    const uint32_t* a1 = sv + (size_t)(FLT_O / 2) * L;
-    const uint32_t* a2 = sv + (size_t)FLT_O * L;
+    const uint32_t* a1 = sv + (size_t)(FLT_O / 2) * P;
+    const uint32_t* a2 = sv + (size_t)FLT_O * P;
 
     F16BwdArgs a;
     a.freq = p->freq; a.t = p->t; a.deltas = p->deltas; a.shift = p->shift; a.modulate = p->modulate; a.L = L;
     a.part_w = nullptr; a.part_b = nullptr; a.part_f = nullptr;
     // last layer: delta_3 = R(dk * modulation);  dW3, delta_2 -> dA
-    a.dout = dk; a.w = p->w3; a.aprev = a2; a.dprev = dA;
+    a.dout = dk; a.w = p->w3; a.aprev = a2; a.dprev = dA; a.ldo = ldk; a.lda = P; a.ldp = P;
     switch (p->D) {
         case 64: launch_layer<64, true, DT, false>(a, part, g->dw3, nullptr, g->dfreq, true, stream); break;
         case 128: launch_layer<128, true, DT, false>(a, part, g->dw3, nullptr, g->dfreq, true, stream); break;
         default: launch_layer<256, true, DT, false>(a, part, g->dw3, nullptr, g->dfreq, true, stream); break;
     }
-    a.modulate = 0; a.t = nullptr; a.deltas = nullptr;
+    a.modulate = 0; a.t = nullptr; a.deltas = nullptr; a.ldo = P;
     a.dout = dA; a.w = p->w2; a.aprev = a1; a.dprev = dB;
     launch_layer<FLT_O, false, DT, false>(a, part, g->dw2, g->db2, g->dfreq, false, stream);
     a.dout = dB; a.w = p->w1; a.aprev = a0; a.dprev = dA;                     // delta_0 leaves as fp32 rows for the fp32 kernel below
@@ -124,33 +124,42 @@ void bwd_all(const hyena_filter_params* p, const float* dk, const void* saved, c
     FilterBwdArgs b;
     b.dout = dA; b.w = p->w0; b.aprev = p->z; b.freq = p->freq; b.t = p->t; b.deltas = p->deltas; b.dprev = g->dz;
     b.part_w = nullptr; b.part_b = nullptr; b.part_f = nullptr; b.shift = p->shift; b.modulate = 0; b.L = L; b.ni = p->E; b.zs = p->z_stride;
-    b.rdt = DT;
+    b.rdt = DT; b.ldo = P; b.lda = P; b.ldp = L;              // dz (E, L) is the caller's: packed
     launch_layer0(b, part, g->dw0, g->db0, stream);
 }
 }  // namespace
 
 extern "C" {
 
-size_t hyena_filter16_saved_bytes(int L) { return L >= 1 ? (size_t)3 * (FLT_O / 2) * L * sizeof(uint32_t) : 0; }
+size_t hyena_filter16_saved_bytes(int L) { return L >= 1 ? (size_t)3 * (FLT_O / 2) * hyena_filter_row_pitch(L) * sizeof(uint32_t) : 0; }
 
 int hyena_filter16_fwd(const hyena_filter_params* p, int dtype, float* k, void* saved, void* stream) {
-    if (!f16_params_ok(p, dtype) || k == nullptr) return HYENA_ERR_BAD_ARG;
+    return hyena_filter16_fwd_ld(p, dtype, k, p != nullptr ? p->L : 0, saved, stream);
+}
+
+int hyena_filter16_bwd(const hyena_filter_params* p, int dtype, const float* dk, const void* saved, const hyena_filter_grads* g,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    return hyena_filter16_bwd_ld(p, dtype, dk, p != nullptr ? p->L : 0, saved, g, workspace, workspace_bytes, stream);
+}
+
+int hyena_filter16_fwd_ld(const hyena_filter_params* p, int dtype, float* k, int ldk, void* saved, void* stream) {
+    if (!f16_params_ok(p, dtype) || k == nullptr || ldk < p->L) return HYENA_ERR_BAD_ARG;
     FilterArgs a;
     a.z = p->z; a.t = p->t; a.w0 = p->w0; a.b0 = p->b0; a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2; a.w3 = p->w3;
     a.freq = p->freq; a.deltas = p->deltas; a.k = k; a.acts = static_cast<float*>(saved); a.shift = p->shift; a.modulate = p->modulate;
-    a.L = p->L; a.E = p->E; a.zs = p->z_stride; a.D = p->D;
+    a.L = p->L; a.E = p->E; a.zs = p->z_stride; a.D = p->D; a.ldk = ldk; a.lds = hyena_filter_row_pitch(p->L);
     if (dtype == HYENA_BF16) launch_fwd_d<DT_BF16>(a, stream);
     else launch_fwd_d<DT_F16>(a, stream);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
-int hyena_filter16_bwd(const hyena_filter_params* p, int dtype, const float* dk, const void* saved, const hyena_filter_grads* g,
-                       void* workspace, size_t workspace_bytes, void* stream) {
-    if (!f16_params_ok(p, dtype) || dk == nullptr || saved == nullptr || g == nullptr || workspace == nullptr) return HYENA_ERR_BAD_ARG;
+int hyena_filter16_bwd_ld(const hyena_filter_params* p, int dtype, const float* dk, int ldk, const void* saved, const hyena_filter_grads* g,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!f16_params_ok(p, dtype) || dk == nullptr || saved == nullptr || g == nullptr || workspace == nullptr || ldk < p->L) return HYENA_ERR_BAD_ARG;
     if (!g->dw0 || !g->db0 || !g->dw1 || !g->db1 || !g->dw2 || !g->db2 || !g->dw3 || !g->dfreq) return HYENA_ERR_BAD_ARG;
     if (workspace_bytes < hyena_filter_workspace_bytes(p->L, p->D)) return HYENA_ERR_WORKSPACE;
-    if (dtype == HYENA_BF16) bwd_all<DT_BF16>(p, dk, saved, g, workspace, stream);
-    else bwd_all<DT_F16>(p, dk, saved, g, workspace, stream);
+    if (dtype == HYENA_BF16) bwd_all<DT_BF16>(p, dk, ldk, saved, g, workspace, stream);
+    else bwd_all<DT_F16>(p, dk, ldk, saved, g, workspace, stream);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 

@@ -177,9 +177,9 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) flt16_fwd_kernel(FilterArgs a)
     const HY_LDS float* freq = cst + 3 * FLT_O;
     const HY_LDS float* cdec = cst + 4 * FLT_O;                // zeros without modulation: exp2(-t 0) + 0 = 1, no branch per element
     const float shift = a.modulate ? a.shift : 0.f;
-    const unsigned L4 = (unsigned)a.L * 4u;
-    const FBuf Kb = make_fbuf(a.k, (size_t)D * L4);
-    const FBuf Ab = make_fbuf(a.acts, SAVE ? (size_t)3 * (FLT_O / 2) * L4 : 0);
+    const unsigned L4 = (unsigned)a.L * 4u, K4 = (unsigned)a.ldk * 4u, S4 = (unsigned)a.lds * 4u;      // bytes per row: t, k, saved
+    const FBuf Kb = make_fbuf(a.k, (size_t)D * K4);
+    const FBuf Ab = make_fbuf(a.acts, SAVE ? (size_t)3 * (FLT_O / 2) * S4 : 0);
     const FBuf Zb = make_fbuf(a.z, (size_t)a.L * a.zs * 4u);
     const FBuf Tb = make_fbuf(a.t, L4);
     const HY_LDS char* wrow = sm + n * F16_WROW + half * 16;            // + layer base + 32 ob F16_WROW + 32 s
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) flt16_fwd_kernel(FilterArgs a)
             x[ob] = mfma16<DT>(wa, zb, x[ob]);
         }
         HY_SCHED_FENCE();
-        f16_act<SAVE, DT>(x, hb, freq, Ab, vpos, L4, half);
+        f16_act<SAVE, DT>(x, hb, freq, Ab, vpos, S4, half);
         HY_SCHED_FENCE();
         HY_UNROLL
         for (int layer = 1; layer < 3; ++layer) {
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) flt16_fwd_kernel(FilterArgs a)
                 for (int s = 0; s < 4; ++s) x[ob] = mfma16<DT>(lds_ld16(wrow + wbase + 32 * ob * F16_WROW + 32 * s), hb[s], x[ob]);
             }
             HY_SCHED_FENCE();
-            f16_act<SAVE, DT>(x, hb, freq, Ab, vpos + (unsigned)layer * (FLT_O / 2) * L4, L4, half);
+            f16_act<SAVE, DT>(x, hb, freq, Ab, vpos + (unsigned)layer * (FLT_O / 2) * S4, S4, half);
             HY_SCHED_FENCE();
         }
         // last layer + modulation, 32 output channels at a time
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) flt16_fwd_kernel(FilterArgs a)
             HY_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int d = 32 * db + crow(r, half);
-                fb_stf(Kb, vpos + (unsigned)d * L4, rnd16<DT>(y[r]) * (hy_exp2(-tl * cdec[d]) + shift));
+                fb_stf(Kb, vpos + (unsigned)d * K4, rnd16<DT>(y[r]) * (hy_exp2(-tl * cdec[d]) + shift));
             }
         }
     }
@@ -258,6 +258,7 @@ struct F16BwdArgs {
     float shift;
     int modulate;
     int L;
+    int ldo, lda, ldp;       // row pitch (32-bit words, >= L) of dout, aprev, dprev (packed: L)
 };
 
 // wavefronts per SIMD the backward kernels are compiled for (4 = two workgroups per CU, at most 128 registers: measured slower,
@@ -326,10 +327,10 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
         for (int r = 0; r < 16; ++r) accf[q][r] = 0.f;
     }
 
-    const unsigned L4 = (unsigned)L * 4u;
-    const FBuf Db = make_fbuf(a.dout, MOD ? (size_t)NO * L4 : (size_t)(NO / 2) * L4);
-    const FBuf Ab = make_fbuf(a.aprev, (size_t)(FLT_O / 2) * L4);
-    const FBuf Pb = make_fbuf(a.dprev, OUTF32 ? (size_t)FLT_O * L4 : (size_t)(FLT_O / 2) * L4);
+    const unsigned L4 = (unsigned)L * 4u, O4 = (unsigned)a.ldo * 4u, A4 = (unsigned)a.lda * 4u, P4 = (unsigned)a.ldp * 4u;
+    const FBuf Db = make_fbuf(a.dout, MOD ? (size_t)NO * O4 : (size_t)(NO / 2) * O4);
+    const FBuf Ab = make_fbuf(a.aprev, (size_t)(FLT_O / 2) * A4);
+    const FBuf Pb = make_fbuf(a.dprev, OUTF32 ? (size_t)FLT_O * P4 : (size_t)(FLT_O / 2) * P4);
     const FBuf Tb = make_fbuf(a.t, MOD ? L4 : 0);
     const HY_LDS char* wtrow = sm + Lds::WT + n * Lds::WROW + half * 16;        // + 32 q WROW + 32 s
     const int niter = (L + FLT_WG_POS - 1) / FLT_WG_POS;
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
             for (int q = 0; q < 2; ++q) {
                 HY_UNROLL
                 for (int r = 0; r < 16; r += 2)
-                    apw[q][r >> 1] = fb_ldu(Ab, vpos + (unsigned)(2 * half) * L4, (unsigned)((32 * q + crow(r, 0)) >> 1) * L4);
+                    apw[q][r >> 1] = fb_ldu(Ab, vpos + (unsigned)(2 * half) * A4, (unsigned)((32 * q + crow(r, 0)) >> 1) * A4);
             }
             f32x16 dh[2];
             HY_UNROLL
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
                     float dv[8 * S1];
                     HY_UNROLL
                     for (int j = 0; j < 8 * S1; ++j)
-                        dv[j] = fb_ld(Db, vpos + (unsigned)(8 * half) * L4, (unsigned)(16 * (s0 + (j >> 3)) + (j & 7)) * L4);
+                        dv[j] = fb_ld(Db, vpos + (unsigned)(8 * half) * O4, (unsigned)(16 * (s0 + (j >> 3)) + (j & 7)) * O4);
                     HY_UNROLL
                     for (int j = 0; j < 8 * S1; ++j) {
                         const int o = 16 * (s0 + (j >> 3)) + 8 * half + (j & 7);
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
                 } else {
                     HY_UNROLL
                     for (int j = 0; j < 4 * S1; ++j)
-                        db[j >> 2].w[j & 3] = fb_ldu(Db, vpos + (unsigned)(4 * half) * L4, (unsigned)(8 * (s0 + (j >> 2)) + (j & 3)) * L4);
+                        db[j >> 2].w[j & 3] = fb_ldu(Db, vpos + (unsigned)(4 * half) * O4, (unsigned)(8 * (s0 + (j >> 2)) + (j & 3)) * O4);
                 }
                 HY_UNROLL
                 for (int u = 0; u < S1; ++u) {
@@ -399,10 +400,10 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
                     accf[q][r] += g0 * ap0;
                     accf[q][r + 1] += g1 * ap1;
                     if (OUTF32) {
-                        fb_stf(Pb, vpos + (unsigned)f * L4, rnd16<DT>(g0 * fr0));
-                        fb_stf(Pb, vpos + (unsigned)(f + 1) * L4, rnd16<DT>(g1 * fr1));
+                        fb_stf(Pb, vpos + (unsigned)f * P4, rnd16<DT>(g0 * fr0));
+                        fb_stf(Pb, vpos + (unsigned)(f + 1) * P4, rnd16<DT>(g1 * fr1));
                     } else {
-                        fb_stu(Pb, vpos + (unsigned)(f >> 1) * L4, pack16<DT>(g0 * fr0, g1 * fr1));
+                        fb_stu(Pb, vpos + (unsigned)(f >> 1) * P4, pack16<DT>(g0 * fr0, g1 * fr1));
                     }
                     HY_LDS char* hp = sm + Lds::HS + f * F16_HROW + (FLT_TP * wave + n) * 2;
                     *HY_LDS_CAST(uint16_t, hp) = cvt16<DT>(sn0);
@@ -415,13 +416,13 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
         {
             const int o = 32 * rb + n;
             constexpr int S2 = NKS < F16_S2 ? NKS : F16_S2;
-            const unsigned rowbase = (MOD ? (unsigned)o : (unsigned)(o >> 1)) * (unsigned)L;
+            const unsigned rowbase = (MOD ? (unsigned)o : (unsigned)(o >> 1)) * (unsigned)a.ldo;
             const bool odd = (o & 1) != 0;                           // inner layers: this row's half of the pair words
             const float cd = MOD ? cdec[o] : 0.f;
             for (int kk0 = ks * NKS; kk0 < (ks + 1) * NKS; kk0 += S2) {
                 // the raw operand words of S2 steps first (8 per step: fp32 values or pair words), then the arithmetic
                 uint32_t raw[S2][8];
-                const bool whole = (L & 3) == 0 && p0 + 16 * (kk0 + S2) <= L;
+                const bool whole = (a.ldo & 3) == 0 && p0 + 16 * (kk0 + S2) <= L;
                 if (whole) {
                     HY_UNROLL
                     for (int u = 0; u < S2; ++u) {

@@ -138,6 +138,7 @@ struct FilterArgs {
     float shift;
     int modulate;
     int L, E, zs, D;
+    int ldk, lds;         // row pitch (floats, >= L) of k and of the saved pre-activations (packed: L)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -219,9 +220,9 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_fwd_kernel(FilterArgs a
     const int ntiles = (a.L + FLT_TP - 1) / FLT_TP;
     const HY_LDS float* freq = sm + Lds::CST + 3 * FLT_O;
     const HY_LDS float* cdec = sm + Lds::CST + 4 * FLT_O;
-    const unsigned L4 = (unsigned)a.L * 4u;
-    const FBuf Kb = make_fbuf(a.k, (size_t)D * L4);
-    const FBuf Ab = make_fbuf(a.acts, SAVE ? (size_t)3 * FLT_O * L4 : 0);
+    const unsigned L4 = (unsigned)a.L * 4u, K4 = (unsigned)a.ldk * 4u, S4 = (unsigned)a.lds * 4u;   // bytes per row: t, k, saved
+    const FBuf Kb = make_fbuf(a.k, (size_t)D * K4);
+    const FBuf Ab = make_fbuf(a.acts, SAVE ? (size_t)3 * FLT_O * S4 : 0);
     const FBuf Zb = make_fbuf(a.z, (size_t)a.L * a.zs * 4u);
     const FBuf Tb = make_fbuf(a.t, L4);
     for (int tile = blockIdx.x * FLT_WAVES + wave; tile < ntiles; tile += gridDim.x * FLT_WAVES) {
@@ -243,15 +244,15 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_fwd_kernel(FilterArgs a
             for (int ob = 0; ob < 2; ++ob) h[ob] = HY_MFMA(sm[Lds::W0 + (32 * ob + n) * (FLT_E + 1) + e], zv, h[ob]);
         }
         HY_SCHED_FENCE();
-        flt_act<SAVE>(h, freq, Ab, vpos, L4, half);
+        flt_act<SAVE>(h, freq, Ab, vpos, S4, half);
         HY_SCHED_FENCE();
         flt_layer<2>(sm + Lds::W1, FLT_O + 1, sm + Lds::CST + FLT_O, h, g, n, half);
         HY_SCHED_FENCE();
-        flt_act<SAVE>(g, freq, Ab, vpos + FLT_O * L4, L4, half);
+        flt_act<SAVE>(g, freq, Ab, vpos + FLT_O * S4, S4, half);
         HY_SCHED_FENCE();
         flt_layer<2>(sm + Lds::W2, FLT_O + 1, sm + Lds::CST + 2 * FLT_O, g, h, n, half);
         HY_SCHED_FENCE();
-        flt_act<SAVE>(h, freq, Ab, vpos + 2 * FLT_O * L4, L4, half);
+        flt_act<SAVE>(h, freq, Ab, vpos + 2 * FLT_O * S4, S4, half);
         HY_SCHED_FENCE();
         // last layer + modulation, 32 output channels at a time
         const float tl = fb_ld(Tb, vpos, 0);
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_fwd_kernel(FilterArgs a
             for (int r = 0; r < 16; ++r) {
                 const int d = 32 * db + crow(r, half);
                 const float m = a.modulate ? hy_exp2(-tl * cdec[d]) + a.shift : 1.f;
-                fb_st(Kb, vpos + (unsigned)d * L4, y[r] * m);
+                fb_st(Kb, vpos + (unsigned)d * K4, y[r] * m);
             }
         }
     }
@@ -294,6 +295,7 @@ struct FilterBwdArgs {
     float shift;
     int modulate;
     int L, ni, zs;
+    int ldo, lda, ldp;     // row pitch (floats, >= L) of dout, of aprev (FLT_ACT) and of dprev (packed: L)
     int rdt;               // DT_BF16 / DT_F16: the 16-bit path's first layer (filter16_kernels.h) -- the weight and the embedding rows are
                            // rounded to that type on load, dz on store (what the reference's autocast Linear sees); 0 = plain fp32
 };
@@ -323,10 +325,10 @@ struct FltBwdCfg {
     static_assert(NI < 32 || FLT_WAVES * FLT_O * FLT_TP <= NI * FLT_HS, "H doubles as reduction scratch");
 };
 
-// 16 consecutive floats of row `row` of a (rows, L) buffer starting at pos0 (a multiple of 16); positions >= L read as 0
-__device__ __forceinline__ void flt_load16(FBuf b, int row, int pos0, int L, float (&v)[16]) {
-    const unsigned base = ((unsigned)row * (unsigned)L + (unsigned)pos0) * 4u;
-    if ((L & 3) == 0 && pos0 + 16 <= L) {
+// 16 consecutive floats of row `row` of a (rows, L) buffer with row pitch ld, starting at pos0 (a multiple of 16); positions >= L read as 0
+__device__ __forceinline__ void flt_load16(FBuf b, int row, int pos0, int L, int ld, float (&v)[16]) {
+    const unsigned base = ((unsigned)row * (unsigned)ld + (unsigned)pos0) * 4u;
+    if ((ld & 3) == 0 && pos0 + 16 <= L) {
         HY_UNROLL
         for (int j = 0; j < 4; ++j) fb_ld4(b, base + 16u * j, &v[4 * j]);
     } else {
@@ -380,10 +382,10 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
         for (int r = 0; r < 16; ++r) accf[q][r] = 0.f;
     }
 
-    const unsigned L4 = (unsigned)L * 4u;
-    const FBuf Db = make_fbuf(a.dout, (size_t)NO * L4);
-    const FBuf Ab = make_fbuf(a.aprev, ACT ? (size_t)FLT_O * L4 : (size_t)L * a.zs * 4u);
-    const FBuf Pb = make_fbuf(a.dprev, a.dprev == nullptr ? 0 : (ACT ? (size_t)FLT_O * L4 : (size_t)a.ni * L4));
+    const unsigned L4 = (unsigned)L * 4u, O4 = (unsigned)a.ldo * 4u, A4 = (unsigned)a.lda * 4u, P4 = (unsigned)a.ldp * 4u;
+    const FBuf Db = make_fbuf(a.dout, (size_t)NO * O4);
+    const FBuf Ab = make_fbuf(a.aprev, ACT ? (size_t)FLT_O * A4 : (size_t)L * a.zs * 4u);
+    const FBuf Pb = make_fbuf(a.dprev, a.dprev == nullptr ? 0 : (ACT ? (size_t)FLT_O * P4 : (size_t)a.ni * P4));
     const FBuf Tb = make_fbuf(a.t, MOD ? L4 : 0);
     const int niter = (L + FLT_WG_POS - 1) / FLT_WG_POS;
     for (int it = blockIdx.x; it < niter; it += gridDim.x) {
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
                 for (int q = 0; q < Cfg::NIB; ++q) {
                     HY_UNROLL
                     for (int r = 0; r < 16; ++r)
-                        apv[q][r] = fb_ld(Ab, vpos + (unsigned)(4 * half) * L4, (unsigned)(32 * q + crow(r, 0)) * L4);
+                        apv[q][r] = fb_ld(Ab, vpos + (unsigned)(4 * half) * A4, (unsigned)(32 * q + crow(r, 0)) * A4);
                 }
             }
             HY_SCHED_FENCE();
@@ -418,7 +420,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
                 HY_UNROLL
                 for (int j = 0; j < 16; ++j) {
                     const int o = s0 + j + (NO / 2) * half;
-                    float v = fb_ld(Db, vpos + (unsigned)((NO / 2) * half) * L4, (unsigned)(s0 + j) * L4);
+                    float v = fb_ld(Db, vpos + (unsigned)((NO / 2) * half) * O4, (unsigned)(s0 + j) * O4);
                     if (MOD) v *= modulate ? hy_exp2(-tl * cdec[o]) + shift : 1.f;
                     dv[j] = v;
                 }
@@ -444,7 +446,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
                         hy_sincos(fr * ap, &sn, &cs);
                         const float gg = dh[q][r] * cs;
                         accf[q][r] += gg * ap;
-                        fb_st(Pb, vpos + (unsigned)f * L4, gg * fr);
+                        fb_st(Pb, vpos + (unsigned)f * P4, gg * fr);
                         Hs[f * FLT_HS + FLT_TP * wave + n] = sn;
                     }
                 }
@@ -454,7 +456,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
                 for (int r = 0; r < 4; ++r) {
                     const int e = crow(r, half);        // 0 .. 7
                     const bool ev = e < a.ni;
-                    fb_st(Pb, ev ? vpos + (unsigned)e * L4 : FLT_OOB, flt_rnd(dh[0][r], a.rdt));
+                    fb_st(Pb, ev ? vpos + (unsigned)e * P4 : FLT_OOB, flt_rnd(dh[0][r], a.rdt));
                     Hs[e * FLT_HS + FLT_TP * wave + n] = flt_rnd(fb_ld(Ab, valid && ev ? (unsigned)(pos * a.zs + e) * 4u : FLT_OOB, 0), a.rdt);
                 }
             }
@@ -467,7 +469,7 @@ __global__ void __launch_bounds__(FLT_THREADS, 2) filter_layer_bwd_kernel(Filter
             for (int pt = ks * PT_PER; pt < (ks + 1) * PT_PER; ++pt) {
                 const int q0 = FLT_TP * pt + 16 * half;          // first of this lane's 16 positions within the tile
                 float av[16];
-                flt_load16(Db, o, p0 + q0, L, av);
+                flt_load16(Db, o, p0 + q0, L, a.ldo, av);
                 if (MOD) {
                     const float cd = cdec[o];
                     HY_UNROLL

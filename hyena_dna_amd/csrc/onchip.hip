@@ -137,14 +137,14 @@ static bool small_enabled() {
     const char* e = std::getenv("HYENA_FFTCONV_SMALL");
     return !(e != nullptr && e[0] == '0');
 }
-bool small_ok(int R, int B, int D, int L, int dtype) {
+bool small_ok(int R, int B, int D, int L, Pitch ld, int dtype) {
     if (R > 2 || !small_enabled()) return false;
     const int G = 256 / (32 * R);
     // every row group takes at most two rows: beyond that the general kernels (one row per workgroup, the batch of a channel
     // sharing an XCD's L2) fill the chip better than D workgroups would
     if (B > 2 * G) return false;
     const size_t es = dtype == DT_F32 ? 4 : 2;
-    return (size_t)B * D * L * es < ((size_t)1 << 32) && (size_t)D * L * 4 < ((size_t)1 << 32);       // 32-bit buffer offsets
+    return (size_t)B * D * ld.ldx * es < ((size_t)1 << 32) && (size_t)D * ld.ldk * 4 < ((size_t)1 << 32);       // 32-bit buffer offsets
 }
 #define HY_OC_SWITCH(R, call)                 \
     switch (R) {                              \
@@ -157,9 +157,10 @@ bool small_ok(int R, int B, int D, int L, int dtype) {
         default: return HYENA_ERR_UNSUPPORTED_L; \
     }
 
-int launch_spec(int R, const float* k, const float* bias, void* H, const void* tab, int D, int L, void* stream) {
+int launch_spec(int R, const float* k, const float* bias, void* H, const void* tab, int D, int L, Pitch ld, void* stream) {
     SpecArgs a;
     a.k = k; a.bias = bias; a.H = reinterpret_cast<c32*>(H); a.tab = reinterpret_cast<const c32*>(tab); a.D = D; a.L = L; a.dtype = DT_F32;
+    a.ld = ld.ldk;
 #define HY_CALL(r) spec_r<r>(a, stream)
     HY_OC_SWITCH(R, HY_CALL)
 #undef HY_CALL
@@ -182,26 +183,26 @@ static int dk1_conv(int R, const ConvArgs& a, void* stream) {
     HY_OC_SWITCH(R, HY_CALL)
 #undef HY_CALL
 }
-int launch_dk1(int R, const void* dout, const void* u, float* dk, float* dbias, void* Uspec, const void* tab, int D, int L, int dtype,
-               void* stream) {
+int launch_dk1(int R, const void* dout, const void* u, float* dk, float* dbias, void* Uspec, const void* tab, int D, int L, Pitch ld,
+               int dtype, void* stream) {
     SpecArgs sa;
     sa.k = u; sa.bias = nullptr; sa.H = reinterpret_cast<c32*>(Uspec); sa.tab = reinterpret_cast<const c32*>(tab); sa.D = D; sa.L = L;
-    sa.dtype = dtype;
+    sa.dtype = dtype; sa.ld = ld.ldx;
     int st = dk1_spec(R, sa, stream);
     if (st) return st;
     ConvArgs a;
     a.x = dout; a.out = dk; a.H = reinterpret_cast<const c32*>(Uspec); a.tab = reinterpret_cast<const c32*>(tab);
-    a.B = 1; a.D = D; a.L = L; a.dtype = dtype; a.conj_sign = -1.0f;
+    a.B = 1; a.D = D; a.L = L; a.dtype = dtype; a.conj_sign = -1.0f; a.ldx = ld.ldx; a.ldo = ld.ldk;
     if ((st = dk1_conv(R, a, stream))) return st;
-    if (dbias != nullptr) HY_LAUNCH((dk_bias_kernel<0>), dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)dk, dbias, D, L);
+    if (dbias != nullptr) HY_LAUNCH((dk_bias_kernel<0>), dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)dk, dbias, D, ld.ldk);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
-int launch_conv(int R, const void* x, void* out, const void* H, const void* tab, int B, int D, int L, int dtype, int conj,
+int launch_conv(int R, const void* x, void* out, const void* H, const void* tab, int B, int D, int L, Pitch ld, int dtype, int conj,
                 void* stream) {
     ConvArgs a;
     a.x = x; a.out = out; a.H = reinterpret_cast<const c32*>(H); a.tab = reinterpret_cast<const c32*>(tab);
-    a.B = B; a.D = D; a.L = L; a.dtype = dtype; a.conj_sign = conj ? -1.0f : 1.0f;
+    a.B = B; a.D = D; a.L = L; a.dtype = dtype; a.conj_sign = conj ? -1.0f : 1.0f; a.ldx = a.ldo = ld.ldx;
 #define HY_CALL(r) conv_r<r>(a, stream)
     HY_OC_SWITCH(R, HY_CALL)
 #undef HY_CALL

@@ -53,20 +53,20 @@ static int small_bwd_rh(const SmallBwdArgs& a, void* stream) {
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 int launch_small_fwd(int R, const void* x, void* out, const float* k, const float* bias, void* Hout, const void* tab, int B, int D, int L,
-                     int dtype, void* stream) {
+                     Pitch ld, int dtype, void* stream) {
     SmallFwdArgs a;
     a.x = x; a.out = out; a.k = k; a.bias = bias; a.Hout = reinterpret_cast<c32*>(Hout); a.tab = reinterpret_cast<const c32*>(tab);
-    a.B = B; a.D = D; a.L = L; a.dtype = dtype;
+    a.B = B; a.D = D; a.L = L; a.dtype = dtype; a.ldx = ld.ldx; a.ldk = ld.ldk;
     const bool half = dtype != DT_F32;
     if (R == 1) return half ? small_fwd_rh<1, true>(a, stream) : small_fwd_rh<1, false>(a, stream);
     if (R == 2) return half ? small_fwd_rh<2, true>(a, stream) : small_fwd_rh<2, false>(a, stream);
     return HYENA_ERR_UNSUPPORTED_L;
 }
 int launch_small_bwd(int R, const void* dout, const void* u, void* du, float* dk, float* dbias, const void* H, const void* tab, int B, int D,
-                     int L, int dtype, void* stream) {
+                     int L, Pitch ld, int dtype, void* stream) {
     SmallBwdArgs a;
     a.dout = dout; a.u = u; a.du = du; a.dk = dk; a.dbias = dbias; a.H = reinterpret_cast<const c32*>(H);
-    a.tab = reinterpret_cast<const c32*>(tab); a.B = B; a.D = D; a.L = L; a.dtype = dtype;
+    a.tab = reinterpret_cast<const c32*>(tab); a.B = B; a.D = D; a.L = L; a.dtype = dtype; a.ldx = ld.ldx; a.ldk = ld.ldk;
     const bool half = dtype != DT_F32;
     if (R == 1) return half ? small_bwd_rh<1, true>(a, stream) : small_bwd_rh<1, false>(a, stream);
     if (R == 2) return half ? small_bwd_rh<2, true>(a, stream) : small_bwd_rh<2, false>(a, stream);
@@ -74,10 +74,10 @@ int launch_small_bwd(int R, const void* dout, const void* u, void* du, float* dk
 }
 
 int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, void* partials, const void* tab, int B, int D, int L,
-              int dtype, void* stream) {
+              Pitch ld, int dtype, void* stream) {
     DkArgs a;
     a.dout = dout; a.u = u; a.dk = dk; a.dbias = dbias; a.tab = reinterpret_cast<const c32*>(tab);
-    a.B = B; a.D = D; a.L = L; a.dtype = dtype;
+    a.B = B; a.D = D; a.L = L; a.dtype = dtype; a.ldx = ld.ldx; a.ldk = ld.ldk;
     a.S = dk_slices(R, B, D, &a.nb);
     a.part = reinterpret_cast<float*>(partials);
     if (a.S > 1 && partials == nullptr) return HYENA_ERR_WORKSPACE;

@@ -552,11 +552,12 @@ __device__ __forceinline__ void store_row(GBuf ob, bool bf, int tid, unsigned ro
 // kernels
 // ---------------------------------------------------------------------------------------------
 struct SpecArgs {          // row spectrum: H[d] = (FFT(c_k) + bias) / M -- of the filter rows (fp32), or, for dk at B = 1, of the u rows
-    const void* k;         // (D, L) fp32 / 16-bit
+    const void* k;         // (D, L) fp32 / 16-bit, row pitch ld
     const float* bias;     // (D,) or null
     c32* H;                // [D][M], register order
     const c32* tab;
     int D, L, dtype;
+    int ld;                // elements between the starts of consecutive rows of k (>= L)
 };
 struct ConvArgs {          // out = IFFT(FFT(x) .* H) (conj_sign = +1) or .* conj(H) (conj_sign = -1)
     const void* x;         // (B, D, L)
@@ -565,6 +566,7 @@ struct ConvArgs {          // out = IFFT(FFT(x) .* H) (conj_sign = +1) or .* con
     const c32* tab;
     int B, D, L, dtype;
     float conj_sign;
+    int ldx, ldo;          // row pitch (elements, >= L) of x and of out: row (b, d) starts at element (b D + d) ld
 };
 struct DkArgs {            // dk[d] = sum_b corr(dout[b, d], u[b, d]);  dbias[d] = dk[d][0]
     const void* dout;
@@ -575,6 +577,7 @@ struct DkArgs {            // dk[d] = sum_b corr(dout[b, d], u[b, d]);  dbias[d]
     float* part;           // S > 1: [S][D][L] fp32, the slices' partial dk rows (summed in slice order by dk_sum_kernel)
     int B, D, L, dtype;
     int S, nb;             // batch slices per channel (grid.y) and batch items per slice: slice s owns b in [s nb, min(B, (s + 1) nb))
+    int ldx, ldk;          // row pitch (elements, >= L) of dout / u and of dk (`part` rows are packed: pitch L)
 };
 
 // Wavefronts per SIMD the conv / spectrum kernels are compiled for (-> at most 128 VGPRs): a wavefront issues one VALU
@@ -618,9 +621,9 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) spec_kernel(SpecArgs a
     const int d = valid ? d_raw : a.D - 1;
     const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
     const int nrows = (a.D - d0) < RPW ? (a.D - d0) : RPW;
-    const GBuf kb = make_gbuf(reinterpret_cast<const char*>(a.k) + (size_t)d0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
+    const GBuf kb = make_gbuf(reinterpret_cast<const char*>(a.k) + (size_t)d0 * a.ld * ES, ((unsigned)(nrows - 1) * (unsigned)a.ld + (unsigned)a.L) * ES);
     c32 v[32];
-    load_row<R, 2, HALF, (RPW > 1)>(v, kb, bf, tid, (unsigned)(d - d0) * (unsigned)a.L * ES, a.L);
+    load_row<R, 2, HALF, (RPW > 1)>(v, kb, bf, tid, (unsigned)(d - d0) * (unsigned)a.ld * ES, a.L);
     fft_fwd<R>(v, c);
     const float bias = (a.bias != nullptr) ? a.bias[d] : 0.f;
     const float sc = 1.0f / (float)C::M;
@@ -659,9 +662,9 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a
     const int d = RPW == 1 ? HY_SGPR(r % a.D) : r % a.D;
     const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
     const int nrows = (rows - r0) < RPW ? (rows - r0) : RPW;
-    const GBuf xb = make_gbuf(reinterpret_cast<const char*>(a.x) + (size_t)r0 * a.L * ES, (unsigned)nrows * (unsigned)a.L * ES);
-    const GBuf ob = make_gbuf(reinterpret_cast<char*>(a.out) + (size_t)r0 * a.L * EO, (unsigned)nrows * (unsigned)a.L * EO);
-    const unsigned row_off = (unsigned)(r - r0) * (unsigned)a.L * ES, orow_off = (unsigned)(r - r0) * (unsigned)a.L * EO;
+    const GBuf xb = make_gbuf(reinterpret_cast<const char*>(a.x) + (size_t)r0 * a.ldx * ES, ((unsigned)(nrows - 1) * (unsigned)a.ldx + (unsigned)a.L) * ES);
+    const GBuf ob = make_gbuf(reinterpret_cast<char*>(a.out) + (size_t)r0 * a.ldo * EO, ((unsigned)(nrows - 1) * (unsigned)a.ldo + (unsigned)a.L) * EO);
+    const unsigned row_off = (unsigned)(r - r0) * (unsigned)a.ldx * ES, orow_off = (unsigned)(r - r0) * (unsigned)a.ldo * EO;
     const GBuf hb = make_gbuf(a.H, (unsigned)a.D * (unsigned)C::M * 8u);
 #if defined(OC_PROFILE) && !defined(HIPEMU)
     Prof prof;
@@ -725,9 +728,9 @@ __global__ void __launch_bounds__(WgCfg<R>::WGT, OC_MINW) conv_kernel(ConvArgs a
 
 // dbias[d] = dk[d][0] (after a dk that came out of conv_kernel)
 template <int UNUSED = 0>
-__global__ void __launch_bounds__(256) dk_bias_kernel(const float* dk, float* dbias, int D, int L) {
+__global__ void __launch_bounds__(256) dk_bias_kernel(const float* dk, float* dbias, int D, int ld) {
     const int d = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (d < D) dbias[d] = dk[(size_t)d * L];
+    if (d < D) dbias[d] = dk[(size_t)d * ld];
 }
 
 // dk.  A workgroup owns a channel; its BP row groups (T threads each) take the batch items b = g, g + BP, ... and keep
@@ -795,7 +798,7 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
     Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), rg, tid, a.tab);
     const unsigned rowbytes = (unsigned)a.L * ES;
     const float sc = 1.0f / (float)(C::M * NP);
-    float* dkrow = sliced ? a.part + ((size_t)sl * a.D + d) * a.L : a.dk + (size_t)d * a.L;
+    float* dkrow = sliced ? a.part + ((size_t)sl * a.D + d) * a.L : a.dk + (size_t)d * a.ldk;
     float* dbias = sliced ? nullptr : a.dbias;
     {
         constexpr int e = E0;
@@ -812,12 +815,13 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
         for (int b0 = b_lo; b0 < b_hi; b0 += BP) {    // uniform trip count: the transforms contain workgroup barriers
             const bool live = b0 + rg < b_hi;
             const int b = live ? b0 + rg : b_hi - 1;
-            const size_t row = ((size_t)b * a.D + d) * a.L * ES;
+            const size_t row = ((size_t)b * a.D + d) * a.ldx * ES;
             // one descriptor per row (hardware bounds check clips n >= L) -- except at T = 32, where the two row groups of
             // a wavefront need a common one: the whole tensor (< 4 GB, checked by the host) + a per-lane row offset
             constexpr bool WHOLE = T < 64;
-            const GBuf gb = WHOLE ? make_gbuf(a.dout, (unsigned)((size_t)a.B * a.D * a.L * ES)) : make_gbuf(reinterpret_cast<const char*>(a.dout) + row, rowbytes);
-            const GBuf ub = WHOLE ? make_gbuf(a.u, (unsigned)((size_t)a.B * a.D * a.L * ES)) : make_gbuf(reinterpret_cast<const char*>(a.u) + row, rowbytes);
+            const unsigned whole = (unsigned)((((size_t)a.B * a.D - 1) * a.ldx + a.L) * ES);
+            const GBuf gb = WHOLE ? make_gbuf(a.dout, whole) : make_gbuf(reinterpret_cast<const char*>(a.dout) + row, rowbytes);
+            const GBuf ub = WHOLE ? make_gbuf(a.u, whole) : make_gbuf(reinterpret_cast<const char*>(a.u) + row, rowbytes);
             const unsigned row_off = WHOLE ? (unsigned)row : 0u;
             c32 u[32], v[32];
             if (e == 0) dk_load<R, NP, HALF, PHI_A>(u, ub, bf, tid, row_off, a.L, sigma);
@@ -904,7 +908,7 @@ __global__ void __launch_bounds__(256) dk_sum_kernel(DkArgs a) {
     if (n >= a.L) return;
     float acc = a.part[(size_t)d * a.L + n];
     for (int s = 1; s < a.S; ++s) acc += a.part[((size_t)s * a.D + d) * a.L + n];
-    a.dk[(size_t)d * a.L + n] = acc;
+    a.dk[(size_t)d * a.ldk + n] = acc;
     if (n == 0 && a.dbias != nullptr) a.dbias[d] = acc;
 }
 
@@ -936,6 +940,7 @@ struct SmallFwdArgs {
     c32* Hout;             // [D][M] or null: where the backward finds the filter spectrum
     const c32* tab;
     int B, D, L, dtype;
+    int ldx, ldk;          // row pitch (elements, >= L) of x / out and of k
 };
 struct SmallBwdArgs {
     const void* dout;      // (B, D, L)
@@ -946,6 +951,7 @@ struct SmallBwdArgs {
     const c32* H;          // [D][M] from the forward
     const c32* tab;
     int B, D, L, dtype;
+    int ldx, ldk;          // row pitch (elements, >= L) of dout / u / du and of dk
 };
 
 template <int R> struct SmallCfg {
@@ -976,8 +982,8 @@ __global__ void __launch_bounds__(SmallCfg<R>::WGT_FWD) small_fwd_kernel(SmallFw
     if (grp >= G) {
         // the filter wavefront: H = (FFT(c_k) + bias) / M -> LDS (and the saved-spectrum buffer)
         c32 h[32];
-        const GBuf kb = make_gbuf(a.k, (unsigned)a.D * (unsigned)a.L * 4u);
-        load_row<R, 2, false, true>(h, kb, false, tid, (unsigned)d * (unsigned)a.L * 4u, a.L);
+        const GBuf kb = make_gbuf(a.k, ((unsigned)(a.D - 1) * (unsigned)a.ldk + (unsigned)a.L) * 4u);
+        load_row<R, 2, false, true>(h, kb, false, tid, (unsigned)d * (unsigned)a.ldk * 4u, a.L);
         fft_fwd<R>(h, c);
         const float bias = (a.bias != nullptr) ? a.bias[d] : 0.f;
         const float sc = 1.0f / (float)C::M;
@@ -995,7 +1001,7 @@ __global__ void __launch_bounds__(SmallCfg<R>::WGT_FWD) small_fwd_kernel(SmallFw
         __syncthreads();
         return;
     }
-    const unsigned total = (unsigned)a.B * (unsigned)a.D * (unsigned)a.L * ES;
+    const unsigned total = a.B > 0 ? (((unsigned)a.B * (unsigned)a.D - 1u) * (unsigned)a.ldx + (unsigned)a.L) * ES : 0u;
     const GBuf xb = make_gbuf(a.x, total);
     const GBuf ob = make_gbuf(a.out, total);
     c32 h[32];
@@ -1003,7 +1009,7 @@ __global__ void __launch_bounds__(SmallCfg<R>::WGT_FWD) small_fwd_kernel(SmallFw
     for (int b0 = 0; b0 < a.B; b0 += G) {
         const bool live = b0 + grp < a.B;
         const int b = live ? b0 + grp : a.B - 1;
-        const unsigned row_off = ((unsigned)b * (unsigned)a.D + (unsigned)d) * (unsigned)a.L * ES;
+        const unsigned row_off = ((unsigned)b * (unsigned)a.D + (unsigned)d) * (unsigned)a.ldx * ES;
         c32 v[32];
         load_row<R, 2, HALF, true>(v, xb, bf, tid, row_off, a.L);
         fft_fwd<R>(v, c);
@@ -1041,7 +1047,7 @@ __global__ void __launch_bounds__(SmallCfg<R>::WGT_BWD) small_bwd_kernel(SmallBw
     const int rg = is_u ? grp - G : grp;
     const int d = blockIdx.x;
     const Ctx c = make_ctx<R>(HY_LDS_CAST(char, smem), grp, tid, a.tab);
-    const unsigned total = (unsigned)a.B * (unsigned)a.D * (unsigned)a.L * ES;
+    const unsigned total = a.B > 0 ? (((unsigned)a.B * (unsigned)a.D - 1u) * (unsigned)a.ldx + (unsigned)a.L) * ES : 0u;
     const GBuf gb = make_gbuf(a.dout, total);
     const GBuf ub = make_gbuf(a.u != nullptr ? a.u : a.dout, total);
     const GBuf ob = make_gbuf(a.du != nullptr ? a.du : const_cast<void*>(a.dout), total);
@@ -1059,7 +1065,7 @@ __global__ void __launch_bounds__(SmallCfg<R>::WGT_BWD) small_bwd_kernel(SmallBw
         const bool last = b0 + G >= a.B;
         const bool live = b0 + rg < a.B;
         const int b = live ? b0 + rg : a.B - 1;
-        const unsigned row_off = ((unsigned)b * (unsigned)a.D + (unsigned)d) * (unsigned)a.L * ES;
+        const unsigned row_off = ((unsigned)b * (unsigned)a.D + (unsigned)d) * (unsigned)a.ldx * ES;
         if (is_u) {
             if (want_dk) {
                 c32 u[32];
@@ -1083,7 +1089,7 @@ __global__ void __launch_bounds__(SmallCfg<R>::WGT_BWD) small_bwd_kernel(SmallBw
                 fft_inv<R>(sum, c);
                 if (rg == 0) {
                     const float sc = 1.0f / (float)C::M;
-                    float* dkrow = a.dk + (size_t)d * a.L;
+                    float* dkrow = a.dk + (size_t)d * a.ldk;
                     HY_UNROLL
                     for (int s = 0; s < 32; ++s) {
                         const c32 w = twist_const<2>(s);

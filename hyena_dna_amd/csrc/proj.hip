@@ -126,12 +126,18 @@ int hyena_outproj_supported(int B, int L, int D, int dtype) {
 
 int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
                            const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int dtype, void* stream) {
-    if (y == nullptr || xT == nullptr || w == nullptr || b == nullptr || W == nullptr || out == nullptr || L > Lx ||
+    return hyena_outproj_gate_fwd_ld(y, xT, bin, w, b, W, bias, out, zT, B, L, Lx, D, Lx, L, dtype, stream);
+}
+
+int hyena_outproj_gate_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
+                              const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int ldx, int lda, int dtype,
+                              void* stream) {
+    if (y == nullptr || xT == nullptr || w == nullptr || b == nullptr || W == nullptr || out == nullptr || L > Lx || ldx < Lx || lda < L ||
         !hyena_outproj_supported(B, L, D, dtype))
         return HYENA_ERR_BAD_ARG;
     pj::OutProjArgs a;
     a.y = y; a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.W = W; a.bias = bias; a.out = out; a.zT = zT;
-    a.B = B; a.L = L; a.Lx = Lx; a.D = D;
+    a.B = B; a.L = L; a.Lx = Lx; a.D = D; a.ldx = ldx; a.lda = lda;
     a.tiles_per_seq = (L + pj::PJ_NT - 1) / pj::PJ_NT;
     a.tiles = B * a.tiles_per_seq;
     // two workgroups per CU are resident; a few runs per slot balance the tail, runs of >= 8 tiles amortise the weight load
@@ -152,11 +158,16 @@ int hyena_proj_supported(int B, int Lx, int D, int dtype) {
 
 int hyena_inproj_pre_fwd(const void* u, const void* W, const float* bin, const float* w, const float* b, void* xT, void* vg,
                          int B, int Lx, int Lc, int D, int dtype, void* stream) {
-    if (u == nullptr || W == nullptr || w == nullptr || b == nullptr || xT == nullptr || vg == nullptr || Lc < 1 || Lc > Lx ||
-        !hyena_proj_supported(B, Lx, D, dtype))
+    return hyena_inproj_pre_fwd_ld(u, W, bin, w, b, xT, vg, B, Lx, Lc, D, Lx, Lc, dtype, stream);
+}
+
+int hyena_inproj_pre_fwd_ld(const void* u, const void* W, const float* bin, const float* w, const float* b, void* xT, void* vg,
+                            int B, int Lx, int Lc, int D, int ldx, int ldv, int dtype, void* stream) {
+    if (u == nullptr || W == nullptr || w == nullptr || b == nullptr || xT == nullptr || vg == nullptr || Lc < 1 || Lc > Lx || ldx < Lx ||
+        ldv < Lc || !hyena_proj_supported(B, Lx, D, dtype) || (size_t)B * (size_t)ldx >= ((size_t)1 << 31))
         return HYENA_ERR_BAD_ARG;
     pj::InProjArgs a;
-    a.u = u; a.W = W; a.bin = bin; a.w = w; a.b = b; a.xT = xT; a.vg = vg; a.B = B; a.Lx = Lx; a.Lc = Lc; a.D = D;
+    a.u = u; a.W = W; a.bin = bin; a.w = w; a.b = b; a.xT = xT; a.vg = vg; a.B = B; a.Lx = Lx; a.Lc = Lc; a.D = D; a.ldx = ldx; a.ldv = ldv;
     const size_t P = (size_t)B * Lx;
     a.tiles = (int)((P + pj::PJ_NT - 1) / pj::PJ_NT);
     // One workgroup per CU is resident (its wavefronts hold the weights in ~350 registers): a few runs per CU balance the tail,

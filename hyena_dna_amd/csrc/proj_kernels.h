@@ -201,9 +201,10 @@ struct InProjArgs {
     const float* bin;    // (3D,) in_proj bias or null
     const float* w;      // (3D, 3) short-filter taps
     const float* b;      // (3D,) short-filter bias
-    void* xT;            // (3D, B, Lx)
-    void* vg;            // (B, D, Lc)
+    void* xT;            // (3D, B, Lx), row pitch ldx: row (c, b) starts at element (c B + b) ldx
+    void* vg;            // (B, D, Lc), row pitch ldv: row (b, d) starts at element (b D + d) ldv
     int B, Lx, Lc, D;
+    int ldx, ldv;        // >= Lx, >= Lc (packed tensors: ldx = Lx, ldv = Lc)
     int tiles;           // ceil(B Lx / 64)
     int tiles_per_wg;
 };
@@ -296,8 +297,9 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
     }
     // Piece m of a lane: id = lane + 64 m -> group m >> 1, channel (lane >> 3) + 8 (m & 1), piece lane & 7: the m-dependent part
     // of every address is wave-uniform (scalar registers), only piece 0's offset is held per lane.
-    const size_t xoff0 = (size_t)(d0 + (lane >> 3)) * P + 8u * (unsigned)(lane & 7);
-    const unsigned voff0 = (unsigned)(d0 + (lane >> 3)) * (unsigned)a.Lc + 8u * (unsigned)(lane & 7);
+    const size_t CS = (size_t)a.B * (size_t)a.ldx;                           // elements between the same position of consecutive xT channels
+    const size_t xoff0 = (size_t)(d0 + (lane >> 3)) * CS + 8u * (unsigned)(lane & 7);
+    const unsigned voff0 = (unsigned)(d0 + (lane >> 3)) * (unsigned)a.ldv + 8u * (unsigned)(lane & 7);
     const char* const ubase = reinterpret_cast<const char*>(a.u);
 
     const int t_first = t_begin > 0 ? t_begin - 1 : t_begin;                // warm-up tile: provides the halo of tile t_begin
@@ -370,22 +372,23 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
         };
         if (fast) {
             counted = t + 1 < t_whole;                                       // eight stores, no branch around any of them; the next tile's loads whole
+            const size_t xpos = (size_t)sb * (size_t)a.ldx + (size_t)sl0;   // the tile's first position inside an xT row (the tile lies in ONE sequence)
             // (3) xT: 3 x 16 rows x 8 pieces of 8 positions; piece m of a lane: group m >> 1, channel (lane >> 3) + 8 (m & 1), piece lane & 7
             Frag ra, rb;
             HY_UNROLL
             for (int g = 0; g < 3; ++g) {
                 park(g);
                 if (g > 0) {
-                    const size_t rowm = (size_t)((g - 1) * D) * P + p0;                               // wave-uniform
+                    const size_t rowm = (size_t)((g - 1) * D) * CS + xpos;                            // wave-uniform
                     PJ_ST16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), ra);
-                    PJ_ST16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm + (size_t)8 * P), rb);
+                    PJ_ST16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm + (size_t)8 * CS), rb);
                 }
                 HY_WAVE_SYNC_PJ();
                 ra = lds_ld16(ebuf + (g * IP_CB + (lane >> 3)) * C::EROW + 16 + (lane & 7) * 16);
                 rb = lds_ld16(ebuf + (g * IP_CB + (lane >> 3) + 8) * C::EROW + 16 + (lane & 7) * 16);
             }
             // (4) vg = shortconv(v) * shortconv(x1): 16 channels x 8 pieces
-            const size_t vbase = (size_t)sb * D * a.Lc + (size_t)sl0;
+            const size_t vbase = (size_t)sb * D * a.ldv + (size_t)sl0;
             Frag vf[IP_CB * 8 / 64];
             HY_UNROLL
             for (int m = 0; m < IP_CB * 8 / 64; ++m) {
@@ -415,14 +418,14 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                 for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
                 __builtin_memcpy(vf[m].w, out, 16);
                 if (m == 0) {                                       // the v rows of xT, behind the first half of the window arithmetic
-                    const size_t rowm = (size_t)(2 * D) * P + p0;
+                    const size_t rowm = (size_t)(2 * D) * CS + xpos;
                     PJ_ST16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm), ra);
-                    PJ_ST16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm + (size_t)8 * P), rb);
+                    PJ_ST16(reinterpret_cast<elem_t*>(a.xT) + (xoff0 + rowm + (size_t)8 * CS), rb);
                 } else {
-                    PJ_ST16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * (m - 1)) * (unsigned)a.Lc), vf[m - 1]);
+                    PJ_ST16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * (m - 1)) * (unsigned)a.ldv), vf[m - 1]);
                 }
             }
-            PJ_ST16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * (IP_CB * 8 / 64 - 1)) * (unsigned)a.Lc), vf[IP_CB * 8 / 64 - 1]);
+            PJ_ST16(reinterpret_cast<elem_t*>(a.vg) + (vbase + voff0 + (unsigned)(8 * (IP_CB * 8 / 64 - 1)) * (unsigned)a.ldv), vf[IP_CB * 8 / 64 - 1]);
         } else {
             HY_UNROLL
             for (int g = 0; g < 3; ++g) park(g);
@@ -437,13 +440,20 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                     const int g = m >> 1, ch = (lane >> 3) + 8 * (m & 1), pc = lane & 7;
                     const unsigned p = p0 + 8u * (unsigned)pc;
                     const Frag v = lds_ld16(ebuf + (g * IP_CB + ch) * C::EROW + 16 + pc * 16);
-                    elem_t* dst = reinterpret_cast<elem_t*>(a.xT) + (size_t)(g * D + d0 + ch) * P + p;
-                    if (p + 8 <= P) PJ_ST16(dst, v);
-                    else {
+                    if (p >= P) continue;
+                    const unsigned xb_ = p / (unsigned)a.Lx;                     // the piece's first position: sequence, position within it
+                    const int xl = (int)(p - xb_ * (unsigned)a.Lx);
+                    elem_t* const crow = reinterpret_cast<elem_t*>(a.xT) + (size_t)(g * D + d0 + ch) * CS;
+                    if (xl + 8 <= a.Lx) PJ_ST16(crow + (size_t)xb_ * a.ldx + xl, v);
+                    else {                                                       // the piece runs into the next sequence's row (or past the last one)
                         elem_t sv[8];
                         __builtin_memcpy(sv, v.w, 16);
-                        for (int i = 0; i < 8; ++i)
-                            if (p + i < P) dst[i] = sv[i];
+                        for (int i = 0; i < 8; ++i) {
+                            int li = xl + i;
+                            unsigned bi = xb_;
+                            if (li >= a.Lx) { li -= a.Lx; ++bi; }
+                            if (p + i < P) crow[(size_t)bi * a.ldx + li] = sv[i];
+                        }
                     }
                 }
                 HY_UNROLL
@@ -479,7 +489,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                     elem_t out[8];
                     HY_UNROLL
                     for (int i = 0; i < 8; ++i) out[i] = Elem<DT>::cvt(prod[i]);
-                    elem_t* vrow = reinterpret_cast<elem_t*>(a.vg) + ((size_t)b * D + d0 + ch) * a.Lc;
+                    elem_t* vrow = reinterpret_cast<elem_t*>(a.vg) + ((size_t)b * D + d0 + ch) * a.ldv;
                     if (l + 8 <= a.Lc) {
                         Frag f;
                         __builtin_memcpy(f.w, out, 16);
@@ -489,7 +499,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                             int li = l + i;
                             unsigned bi = b;
                             if (li >= a.Lx) { li -= a.Lx; ++bi; }
-                            if (p + i < P && li < a.Lc) reinterpret_cast<elem_t*>(a.vg)[((size_t)bi * D + d0 + ch) * a.Lc + li] = out[i];
+                            if (p + i < P && li < a.Lc) reinterpret_cast<elem_t*>(a.vg)[((size_t)bi * D + d0 + ch) * a.ldv + li] = out[i];
                         }
                     }
                 }
@@ -955,6 +965,7 @@ struct OutProjArgs {
     void* out;            // (B, L, N)
     void* zT;             // (D, B, L) or null
     int B, L, Lx, D;
+    int ldx, lda;         // row pitch (elements) of xT (row (c, b) at (c B + b) ldx, >= Lx) and of y / zT (rows (b, d) at (b D + d) lda, (d, b) at (d B + b) lda, >= L)
     int tiles_per_seq, tiles, tiles_per_wg;
 };
 
@@ -1020,8 +1031,8 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
             for (int ii = 0; ii < HR; ++ii) {
                 const int i = half * HR + ii;
                 const int k = 32 * i + 8 * wave + r;
-                const elem_t* yrow = yb + ((size_t)b * a.D + k) * a.L;
-                const elem_t* xrow = xb + ((size_t)k * a.B + b) * a.Lx;
+                const elem_t* yrow = yb + ((size_t)b * a.D + k) * a.lda;
+                const elem_t* xrow = xb + ((size_t)k * a.B + b) * a.ldx;
                 yr[ii] = ld16(yrow + lp);                           // (every tile is whole; gfx950 global memory takes under-aligned 16-byte accesses)
                 xr[ii] = ld16(xrow + lp);
                 uint32_t h2 = 0u;
@@ -1053,7 +1064,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
                 }
                 Frag zp;
                 __builtin_memcpy(zp.w, ze, 16);
-                if (zb != nullptr) st16(zb + ((size_t)k * a.B + b) * a.L + lp, zp);
+                if (zb != nullptr) st16(zb + ((size_t)k * a.B + b) * a.lda + lp, zp);
                 // lanes r (even) and r + 1 (= lane ^ 8) hold channels k, k + 1 for the same 8 positions: the even one takes positions
                 // 0..3 of both, the odd one positions 4..7
                 const bool odd = (r & 1) != 0;

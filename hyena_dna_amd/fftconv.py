@@ -170,13 +170,6 @@ def _conv_long(u, k, D):
     return torch.cat([lo, hi], dim=-1)[..., :L].to(u.dtype)
 
 
-def _bcast_D(D, ref):
-    """D as the reference broadcasts it against a (..., H, L) tensor: (H,) -> (H, 1); (1, H, 1) as HyenaOperator passes it stays"""
-    if D is None:
-        return None
-    return D.unsqueeze(-1) if D.dim() == 1 else D
-
-
 def fftconv_func(u, k, D, dropout_mask=None, gelu=True, force_fp16_output=False, output_hbl_layout=False, v=None,
                  head_dim=1, q=None, fftfp16=False, k_rev=None):
     """Same signature as the reference's ``fftconv_func`` (src/ops/fftconv.py:105-108).
@@ -193,8 +186,11 @@ def fftconv_func(u, k, D, dropout_mask=None, gelu=True, force_fp16_output=False,
     plain = (dropout_mask is None and not gelu and not output_hbl_layout and v is None and q is None and head_dim == 1 and not fftfp16)
     if plain and k_rev is None:
         return _conv(u, k, D, None, False, force_fp16_output, False, None, 1, None, False)
-    if (v is None) != (q is None):
-        raise ValueError("fftconv_func: the H3 form needs both v and q (src/ops/fftconv.py:37)")
+    if v is None and q is not None:
+        raise ValueError("fftconv_func: q without v (the reference kernel selects the H3 form on v alone, fftconv_cuda.cu:806, and would "
+                         "silently ignore q)")
+    # v WITHOUT q: the reference op accepts the call (src/ops/fftconv.py:58-84 checks nothing; its kernel then reads q through
+    # a null pointer).  Served with the only meaning the formula leaves: no q-multiply -- q = 1 -- so the head sum is a plain sum over d1.
     if v is None and head_dim != 1:
         raise ValueError("fftconv_func: head_dim > 1 without v / q")
     if v is not None and dropout_mask is not None:
@@ -220,8 +216,9 @@ def fftconv_func(u, k, D, dropout_mask=None, gelu=True, force_fp16_output=False,
         out = out * dropout_mask.to(out.dtype).unsqueeze(-1)                               # (b, H) -> rows
     if v is not None:
         from einops import rearrange
-        qr = rearrange(q, "b (h d1) l -> b d1 1 h l", d1=head_dim).float()
-        out = rearrange((out * qr).sum(dim=1), "b d2 h l -> b (h d2) l")                   # fftconv.py:50-55
+        if q is not None:
+            out = out * rearrange(q, "b (h d1) l -> b d1 1 h l", d1=head_dim).float()
+        out = rearrange(out.sum(dim=1), "b d2 h l -> b (h d2) l")                          # fftconv.py:50-55
     odt = torch.float16 if (force_fp16_output and u.dtype == torch.float32) else u.dtype
     out = out.to(odt)
     if output_hbl_layout:                                                                  # (b, h, l) values, (h, b, l) memory order

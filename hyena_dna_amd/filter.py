@@ -57,7 +57,7 @@ class HyenaFilterFunc(torch.autograd.Function):
     def backward(ctx, dk):
         saved, *args = ctx.saved_tensors
         shift, modulate, dtypes, compute_dtype = ctx.meta
-        g = _lib.filter_bwd(dk.to(torch.float32).contiguous(), saved, *args, shift, modulate, need_dz=ctx.needs_input_grad[0],
+        g = _lib.filter_bwd(_lib.as_rows(dk.to(torch.float32)), saved, *args, shift, modulate, need_dz=ctx.needs_input_grad[0],
                             compute_dtype=compute_dtype)
         dw0, db0, dw1, db1, dw2, db2, dw3, dfreq, dz = g
         outs = [dz, dw0, db0, dw1, db1, dw2, db2, dw3, dfreq]

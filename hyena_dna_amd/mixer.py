@@ -87,11 +87,11 @@ class HyenaMixerCMFunc(torch.autograd.Function):
         # cm_pre_fwd on this xT) -- a cached value, not a differentiable input
         D3, B, Lx = xT.shape
         D = D3 // 3
-        xc = xT.contiguous()
+        xc = _lib.as_rows(xT)
         bi = b_in.detach().to(torch.float32).contiguous()
         w = sf_weight.detach().to(torch.float32).reshape(D3, 3).contiguous()
         b = sf_bias.detach().to(torch.float32).contiguous()
-        kf = k.detach().to(torch.float32).contiguous()
+        kf = _lib.as_rows(k.detach().to(torch.float32))
         bf = bias.detach().to(torch.float32).reshape(D).contiguous()
         if vg is None:
             vg = _lib.cm_pre_fwd(xc, bi, w, b, L)
@@ -112,8 +112,10 @@ class HyenaMixerCMFunc(torch.autograd.Function):
         xc, bi, w, b, kf, bf, y = ctx.saved_tensors
         bin_dtype, w_shape, w_dtype, b_dtype, k_dtype, bias_shape, bias_dtype, L = ctx.meta
         D3, B, Lx = xc.shape
-        dzT = dzT.to(xc.dtype).contiguous()
-        dxT = torch.zeros_like(xc) if Lx > L else torch.empty_like(xc)
+        dzT = _lib.as_rows(dzT.to(xc.dtype))
+        dxT = _lib.empty_like_rows(xc)
+        if Lx > L:
+            dxT.zero_()
         part = _lib.cm_partials(xc, L)
         dy = _lib.cm_post_bwd(dzT, y, xc, bi, w, b, dxT, part)
         need_vg = ctx.spectra is None or _lib.lib().hyena_fftconv_plan(int(L)) == _lib.PLAN_ONCHIP
@@ -149,14 +151,11 @@ OUTPROJ_MFMA = _os.environ.get("HYENA_OUTPROJ_MFMA", "1") != "0"      # A/B knob
 
 
 def mixer_out_supported(xT, L, out_weight):
-    """16-bit channel-major tensors, d_model 128 / 256, sequences of at least one 64-position tile"""
+    """16-bit channel-major tensors, d_model 128 / 256, sequences of at least one 64-position tile.  (Round 4 switched the kernel off for
+    training calls at L % 8 != 0 -- the reference trainer's own lengths -- because zT's rows then started at odd element offsets; with
+    pitched rows, _lib.row_pitch, they do not, and the choice no longer depends on L or on the grad mode: ADVICE r4.)"""
     D3, B, Lx = xT.shape
     D = D3 // 3
-    if L % 8 != 0 and out_weight.requires_grad and torch.is_grad_enabled():
-        # out_proj's weight gradient wants zT in HBM, whose rows then start at odd element offsets: the kernel's 16-byte stores to them are
-        # split and cost more than the fusion saves (872 vs 564 us at L = 2^20 - 1, profiles/r4i_outproj_ragged.txt) -- such training calls keep
-        # cm_post_fwd + the library GEMM; inference, and any L that is a multiple of 8, take the kernel
-        return False
     return (OUTPROJ_MFMA and xT.dtype in (torch.bfloat16, torch.float16) and tuple(out_weight.shape) == (D, D)
             and (xT.is_cuda or _lib._backend.name != "hip") and _lib.outproj_supported(B, L, Lx, D, xT.dtype))
 
@@ -170,11 +169,11 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
     def forward(ctx, xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out):
         D3, B, Lx = xT.shape
         D = D3 // 3
-        xc = xT.contiguous()
+        xc = _lib.as_rows(xT)
         bi = b_in.detach().to(torch.float32).contiguous()
         w = sf_weight.detach().to(torch.float32).reshape(D3, 3).contiguous()
         b = sf_bias.detach().to(torch.float32).contiguous()
-        kf = k.detach().to(torch.float32).contiguous()
+        kf = _lib.as_rows(k.detach().to(torch.float32))
         bf = bias.detach().to(torch.float32).reshape(D).contiguous()
         if vg is None:
             vg = _lib.cm_pre_fwd(xc, bi, w, b, L)
@@ -197,7 +196,7 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        from .projection import _bmm_f32, split_count
+        from .projection import cm_from_pm, wgrad_pm_cm
         xc, bi, w, b, kf, bf, y, wo, zT = ctx.saved_tensors
         bin_dtype, w_shape, w_dtype, b_dtype, k_dtype, bias_shape, bias_dtype, L, wo_dtype, bo_dtype = ctx.meta
         D3, B, Lx = xc.shape
@@ -207,22 +206,18 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
         # ---- out_proj's backward (projection.OutProjCMFunc.backward) ----
         dW = dbo = None
         if ctx.needs_input_grad[8]:
-            z2 = (zT if ctx.has_z else _lib.cm_post_fwd(y, xc, bi, w, b)).reshape(D, rows)
-            s = split_count(rows)
-            body = (rows // s) * s
-            dW = _bmm_f32(dy2[:body].view(s, rows // s, D).transpose(1, 2), z2[:, :body].reshape(D, s, rows // s).permute(1, 2, 0)).sum(0)
-            if body < rows:
-                dW = dW + torch.mm(dy2[body:].t().float(), z2[:, body:].t().float())
-            dW = dW.to(wo_dtype)
+            dW = wgrad_pm_cm(dy2, zT if ctx.has_z else _lib.cm_post_fwd(y, xc, bi, w, b)).to(wo_dtype)
         if bo_dtype is not None and ctx.needs_input_grad[9]:
             dbo = _lib.colsum(dy2).to(bo_dtype)
         if not any(ctx.needs_input_grad[:6]):
             return None, None, None, None, None, None, None, None, dW, dbo
-        dzT = torch.mm(wo.t(), dy2.t()).view(D, B, L)                      # channel-major, straight from the GEMM
+        dzT = cm_from_pm(wo.t(), dy2, B, L)                                # channel-major (pitched rows), straight from the GEMM
         # ---- the core's backward (HyenaMixerCMFunc.backward) ----
-        dxT = torch.zeros_like(xc) if Lx > L else torch.empty_like(xc)
+        dxT = _lib.empty_like_rows(xc)
+        if Lx > L:
+            dxT.zero_()
         part = _lib.cm_partials(xc, L)
-        dy = _lib.cm_post_bwd(dzT.contiguous(), y, xc, bi, w, b, dxT, part)
+        dy = _lib.cm_post_bwd(dzT, y, xc, bi, w, b, dxT, part)
         need_vg = ctx.spectra is None or _lib.lib().hyena_fftconv_plan(int(L)) == _lib.PLAN_ONCHIP
         vg = _lib.cm_pre_fwd(xc, bi, w, b, L) if need_vg else None
         need_dk = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]

@@ -99,6 +99,77 @@ def _bmm_f32(a, b):
     return torch.bmm(a.float(), b.float())
 
 
+# Channel-major tensors are PITCHED rows since round 5 (hyena_dna_amd._lib.row_pitch: the reference trainer's L = max_length - 1 is odd, and a
+# packed (C, B, L) tensor then has no aligned row but the first).  A library GEMM takes a pitched operand as a matrix with a leading dimension
+# -- for B = 1 the whole tensor is one (C, L) matrix with ld = pitch; for B > 1 the B sequences are B such matrices, one product each (the
+# packed (C, B L) matrix exists only when the pitch is L itself).  The helpers below hide that; every product and its summation order are the
+# ones of rounds 2 - 4 when the pitch equals L.
+def _pieces(t, L):
+    """t (C, B, L) packed or pitched rows -> [(C, n) matrix view, first flattened position, n]: one piece if packed, else one per sequence"""
+    C, B, _ = t.shape
+    if t.is_contiguous():
+        return [(t.view(C, B * L), 0, B * L)]
+    return [(t[:, b, :], b * L, L) for b in range(B)]
+
+
+def cm_from_pm(w, x2, B, L):
+    """(C, B, L) pitched rows = w (C, K) x2^T for position-major x2 (B L, K)"""
+    from . import _lib
+    out = _lib.empty_rows((w.shape[0], B), L, x2.dtype, x2.device)
+    for m, p0, n in _pieces(out, L):
+        torch.mm(w, x2[p0:p0 + n].t(), out=m)
+    return out
+
+
+def pm_from_cm(t, w, bias=None):
+    """(B L, N) position-major = t^T w (+ bias) for t (C, B, L) packed or pitched rows, w (C, N)"""
+    C, B, L = t.shape
+    pieces = _pieces(t, L)
+    if len(pieces) == 1:
+        m = pieces[0][0]
+        return torch.mm(m.t(), w) if bias is None else torch.addmm(bias, m.t(), w)
+    out = torch.empty((B * L, w.shape[1]), dtype=t.dtype, device=t.device)
+    for m, p0, n in pieces:
+        if bias is None:
+            torch.mm(m.t(), w, out=out[p0:p0 + n])
+        else:
+            torch.addmm(bias, m.t(), w, out=out[p0:p0 + n])
+    return out
+
+
+def wgrad_cm_pm(d, x2):
+    """sum over the positions of d[c, p] x2[p, k] -> (C, K) fp32 for d (C, B, L) packed or pitched rows and position-major x2 (B L, K): S batched
+    position slices + a tail per piece, partial sums added in a fixed order (deterministic)"""
+    C, B, L = d.shape
+    k = x2.shape[1]
+    total = None
+    for m, p0, n in _pieces(d, L):
+        xs = x2[p0:p0 + n]
+        s = split_count(n)
+        body = (n // s) * s
+        g = _bmm_f32(m[:, :body].reshape(C, s, n // s).permute(1, 0, 2), xs[:body].view(s, n // s, k)).sum(0)
+        if body < n:
+            g = g + torch.mm(m[:, body:].float(), xs[body:].float())
+        total = g if total is None else total + g
+    return total
+
+
+def wgrad_pm_cm(dy2, z):
+    """sum over the positions of dy2[p, n] z[k, p] -> (N, K) fp32 for position-major dy2 (B L, N) and z (K, B, L) packed or pitched rows"""
+    K, B, L = z.shape
+    N = dy2.shape[1]
+    total = None
+    for m, p0, n in _pieces(z, L):
+        ds = dy2[p0:p0 + n]
+        s = split_count(n)
+        body = (n // s) * s
+        g = _bmm_f32(ds[:body].view(s, n // s, N).transpose(1, 2), m[:, :body].reshape(K, s, n // s).permute(1, 2, 0)).sum(0)
+        if body < n:
+            g = g + torch.mm(ds[body:].t().float(), m[:, body:].t().float())
+        total = g if total is None else total + g
+    return total
+
+
 class InProjCMFunc(torch.autograd.Function):
     """xT (N, B, L) = W (N, K) u^T, WITHOUT the bias (the shell kernels add it on load and return its gradient)."""
 
@@ -108,24 +179,18 @@ class InProjCMFunc(torch.autograd.Function):
         u2 = u.reshape(B * L, K)
         ctx.save_for_backward(u2, weight)
         ctx.ushape = u.shape
-        return torch.mm(weight, u2.t()).view(weight.shape[0], B, L)
+        return cm_from_pm(weight, u2, B, L)
 
     @staticmethod
     def backward(ctx, dxT):
+        from . import _lib
         u2, weight = ctx.saved_tensors
-        n, k = weight.shape
-        rows = u2.shape[0]
-        d2 = dxT.reshape(n, rows)
+        dxT = _lib.as_rows(dxT)
         du = dw = None
         if ctx.needs_input_grad[0]:
-            du = torch.mm(d2.t(), weight).view(ctx.ushape)
+            du = pm_from_cm(dxT, weight).view(ctx.ushape)
         if ctx.needs_input_grad[1]:
-            s = split_count(rows)
-            body = (rows // s) * s
-            dw = _bmm_f32(d2[:, :body].reshape(n, s, rows // s).permute(1, 0, 2), u2[:body].view(s, rows // s, k)).sum(0)
-            if body < rows:
-                dw = dw + torch.mm(d2[:, body:].float(), u2[body:].float())
-            dw = dw.to(weight.dtype)
+            dw = wgrad_cm_pm(dxT, u2).to(weight.dtype)
         return du, dw
 
 
@@ -180,30 +245,25 @@ class OutProjCMFunc(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, zT, weight, bias):
+        from . import _lib
         K, B, L = zT.shape
-        z2 = zT.reshape(K, B * L)
-        ctx.save_for_backward(z2, weight)
+        zT = _lib.as_rows(zT)
+        ctx.save_for_backward(zT, weight)
         ctx.has_bias = bias is not None
-        ctx.zshape = zT.shape
-        y = torch.mm(z2.t(), weight.t()) if bias is None else torch.addmm(bias, z2.t(), weight.t())
-        return y.view(B, L, weight.shape[0])
+        return pm_from_cm(zT, weight.t(), bias).view(B, L, weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        z2, weight = ctx.saved_tensors
+        zT, weight = ctx.saved_tensors
         n, k = weight.shape
-        rows = z2.shape[1]
+        K, B, L = zT.shape
+        rows = B * L
         dy2 = dy.reshape(rows, n)
         dz = dw = db = None
         if ctx.needs_input_grad[0]:
-            dz = torch.mm(weight.t(), dy2.t()).view(ctx.zshape)               # (K, B L): channel-major, straight from the GEMM
+            dz = cm_from_pm(weight.t(), dy2, B, L)                            # (K, B, L): channel-major, straight from the GEMM
         if ctx.needs_input_grad[1]:
-            s = split_count(rows)
-            body = (rows // s) * s
-            dw = _bmm_f32(dy2[:body].view(s, rows // s, n).transpose(1, 2), z2[:, :body].reshape(k, s, rows // s).permute(1, 2, 0)).sum(0)
-            if body < rows:
-                dw = dw + torch.mm(dy2[body:].t().float(), z2[:, body:].t().float())
-            dw = dw.to(weight.dtype)
+            dw = wgrad_pm_cm(dy2, zT).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             from . import _lib
             db = _lib.colsum(dy2.contiguous()).to(dy.dtype)
@@ -232,5 +292,5 @@ def out_proj_cm(zT, weight, bias):
     dt = _autocast_dtype(zT)
     if dt is not None:
         with torch.autocast("cuda" if zT.is_cuda else "cpu", enabled=False):
-            return OutProjCMFunc.apply(zT.to(dt).contiguous(), weight.to(dt), None if bias is None else bias.to(dt))
-    return OutProjCMFunc.apply(zT.contiguous(), weight.to(zT.dtype), None if bias is None else bias.to(zT.dtype))
+            return OutProjCMFunc.apply(zT.to(dt), weight.to(dt), None if bias is None else bias.to(dt))
+    return OutProjCMFunc.apply(zT, weight.to(zT.dtype), None if bias is None else bias.to(zT.dtype))

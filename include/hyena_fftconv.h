@@ -142,6 +142,27 @@ int hyena_fftconv_bwd_saved(const void* dout, const void* u, const float* bias, 
                             const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
                             const void* saved, size_t saved_bytes, void* stream);
 
+/* The same two operations on PITCHED rows (round 5).  The reference's trainer feeds the operator L = max_length - 1 positions
+ * (src/dataloaders/datasets/hg38_dataset.py:220-223: `data = seq[:-1]`) -- 32 767, 159 999, 449 999, 999 999, 1 048 575: odd, so in a packed
+ * (B, D, L) tensor every second row starts 2 bytes off a 4-byte boundary and no row but the first is 16-byte aligned.  Here the caller
+ * states where rows start instead:
+ *     ldx : elements between the starts of consecutive rows of u / out / dout / du -- row (b, d) starts at element (b D + d) ldx
+ *     ldk : the same for k / dk (fp32 elements) -- row d starts at element d ldk
+ * ldx, ldk >= L; elements [L, ld) of a row are never read or written.  ldx = ldk = L is the packed layout of the entry points above (which
+ * are these with that default).  hyena_dna_amd/_lib.py allocates the operator's channel-major tensors with ld = L rounded up to 64 elements
+ * and hands PyTorch the [..., :L] views.
+ * `saved` / `saved_bytes`: the optional spectrum buffer of hyena_fftconv_fwd_save / _bwd_saved, or NULL / 0.  With `saved` the backward does
+ * not read k (and, for L > 32768, not u): they may be NULL then. */
+int hyena_fftconv_fwd_ld(const void* u, const float* k, const float* bias, void* out,
+                         int B, int D, int L, int ldx, int ldk, int dtype,
+                         const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
+                         void* saved, size_t saved_bytes, void* stream);
+int hyena_fftconv_bwd_ld(const void* dout, const void* u, const float* k, const float* bias,
+                         void* du, float* dk, float* dbias,
+                         int B, int D, int L, int ldx, int ldk, int dtype,
+                         const void* d_tables, void* workspace, size_t workspace_bytes, int chunk,
+                         const void* saved, size_t saved_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,7 @@ typedef struct {           /* gradients, same shapes as the parameters; every po
 /* 1 if the fused kernels cover this configuration. */
 int hyena_filter_supported(int L, int E, int order, int D);
 
-/* Bytes of the pre-activation buffer the forward fills for the backward (3 x 64 x L floats). */
+/* Bytes of the pre-activation buffer the forward fills for the backward (3 x 64 rows of hyena_filter_row_pitch(L) floats). */
 size_t hyena_filter_saved_bytes(int L);
 
 /* Bytes of scratch the backward needs (two (64, L) gradient buffers + per-workgroup partial sums). */
@@ -78,7 +78,7 @@ int hyena_filter_bwd(const hyena_filter_params* p, const float* dk, const float*
  * Parameters are passed in fp32 exactly as above (autocast casts them per call: hyena.py:199-215 run under the trainer's autocast
  * context); k is fp32 (the modulation promotes to fp32, hyena.py:152-155).  `saved` holds the three pre-activations as 16-bit pairs. */
 
-/* Bytes of the pre-activation buffer hyena_filter16_fwd fills for the backward (3 x 64 x L 16-bit values). */
+/* Bytes of the pre-activation buffer hyena_filter16_fwd fills for the backward (3 x 32 rows of hyena_filter_row_pitch(L) 16-bit pairs). */
 size_t hyena_filter16_saved_bytes(int L);
 
 /* k (D, L) fp32 <- filter.  `saved` may be NULL (inference). */
@@ -88,6 +88,20 @@ int hyena_filter16_fwd(const hyena_filter_params* p, int dtype, float* k, void* 
  * (hyena_filter_workspace_bytes). */
 int hyena_filter16_bwd(const hyena_filter_params* p, int dtype, const float* dk, const void* saved, const hyena_filter_grads* g,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- pitched filter rows (round 5) -------------------------------------------------------------------------------------------------
+ * The reference's trainer asks for L = max_length - 1 taps (hg38_dataset.py:220-223 -> hyena.py:389-394: l_filter = min(L, l_max)): odd, so the
+ * rows of a packed (D, L) fp32 tensor are 4-byte but not 16-byte aligned.  `ldk` = floats between the starts of consecutive rows of k / dk
+ * (ldk >= L; elements [L, ldk) of a row are never read or written) -- the same pitch hyena_fftconv_fwd_ld / _bwd_ld take for them.  The entry
+ * points above are these with ldk = L.  The library-owned buffers (`saved`, the backward's workspace) are pitched internally to
+ * hyena_filter_row_pitch(L) = L rounded up to 64 words: their sizes are what hyena_filter*_saved_bytes / _workspace_bytes return. */
+int hyena_filter_row_pitch(int L);
+int hyena_filter_fwd_ld(const hyena_filter_params* p, float* k, int ldk, float* saved, void* stream);
+int hyena_filter_bwd_ld(const hyena_filter_params* p, const float* dk, int ldk, const float* saved, const hyena_filter_grads* g,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int hyena_filter16_fwd_ld(const hyena_filter_params* p, int dtype, float* k, int ldk, void* saved, void* stream);
+int hyena_filter16_bwd_ld(const hyena_filter_params* p, int dtype, const float* dk, int ldk, const void* saved, const hyena_filter_grads* g,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

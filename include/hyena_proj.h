@@ -29,6 +29,11 @@ extern "C" {
 int hyena_proj_supported(int B, int Lx, int D, int dtype);
 int hyena_inproj_pre_fwd(const void* u, const void* W, const float* bin, const float* w, const float* b, void* xT, void* vg,
                          int B, int Lx, int Lc, int D, int dtype, void* stream);
+/* ... on PITCHED outputs (round 5; hyena_fftconv.h, hyena_fftconv_fwd_ld, says why): ldx = elements between the starts of consecutive xT rows
+ * (row (c, b) at (c B + b) ldx, ldx >= Lx, B ldx < 2^31), ldv = the same for vg (row (b, d) at (b D + d) ldv, ldv >= Lc).  With both a
+ * multiple of 8 and -- for B > 1 -- Lx too, every 16-byte store of the kernel is aligned.  The entry point above = ldx Lx, ldv Lc. */
+int hyena_inproj_pre_fwd_ld(const void* u, const void* W, const float* bin, const float* w, const float* b, void* xT, void* vg,
+                            int B, int Lx, int Lc, int D, int ldx, int ldv, int dtype, void* stream);
 
 
 /* ---- out_proj with the second gate on its operand load (round 4) -----------------------------------------------------------------
@@ -46,6 +51,11 @@ int hyena_inproj_pre_fwd(const void* u, const void* W, const float* bin, const f
 int hyena_outproj_supported(int B, int L, int D, int dtype);
 int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
                            const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int dtype, void* stream);
+/* ... on PITCHED operands: ldx = row pitch of xT (>= Lx), lda = row pitch of y AND of zT (row (b, d) of y at (b D + d) lda, row (d, b) of zT at
+ * (d B + b) lda; >= L).  The entry point above = ldx Lx, lda L. */
+int hyena_outproj_gate_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
+                              const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int ldx, int lda, int dtype,
+                              void* stream);
 
 
 /* ---- the block's MLP (flash_attn.modules.mlp.Mlp = simple_lm.py:191-211; long_conv_lm.py:117-123: fc1 -> tanh-GELU -> fc2) ---------

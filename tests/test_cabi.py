@@ -51,8 +51,13 @@ def test_filter_host_only_entry_points(product_lib):
     assert L.hyena_filter_supported(1 << 20, 5, 64, 256) == 1 and L.hyena_filter_supported(1024, 5, 64, 128) == 1
     assert L.hyena_filter_supported(1024, 5, 16, 128) == 0 and L.hyena_filter_supported(1024, 9, 64, 128) == 0
     assert L.hyena_filter_supported(1024, 5, 64, 96) == 0 and L.hyena_filter_supported((1 << 20) + 1, 5, 64, 256) == 0
-    assert L.hyena_filter_saved_bytes(1000) == 3 * 64 * 1000 * 4
-    assert L.hyena_filter_workspace_bytes(1000, 256) == (2 * 64 * 1000 + 256 * (256 * 64 + 1024)) * 4
+    # library-owned rows are pitched to 64 words (round 5: the reference trainer's L = max_length - 1 is odd)
+    assert L.hyena_filter_row_pitch(1000) == 1024 and L.hyena_filter_row_pitch(1024) == 1024 and L.hyena_filter_row_pitch(1048575) == 1 << 20
+    assert L.hyena_filter_saved_bytes(1000) == 3 * 64 * 1024 * 4
+    assert L.hyena_filter_workspace_bytes(1000, 256) == (2 * 64 * 1024 + 256 * (256 * 64 + 1024)) * 4
+    L.hyena_filter16_saved_bytes.restype = ctypes.c_size_t
+    assert L.hyena_filter16_saved_bytes(999) == 3 * 32 * 1024 * 4
+    assert L.hyena_filter_fwd_ld(None, None, 0, None, None) == 1 and L.hyena_filter16_bwd_ld(None, 1, None, 0, None, None, None, 0, None) == 1
     assert L.hyena_filter_fwd(None, None, None, None) == 1          # HYENA_ERR_BAD_ARG, no device touched
 
 
@@ -61,7 +66,7 @@ def test_header_declares_the_expected_entry_points():
     for s in ("hyena_fftconv_fwd", "hyena_fftconv_bwd", "hyena_fftconv_workspace_bytes", "hyena_fftconv_init_tables",
               "hyena_fftconv_table_bytes", "hyena_fftconv_fft_size", "hyena_fftconv_abi_version",
               "hyena_fftconv_error_string", "hyena_fftconv_default_chunk", "hyena_fftconv_saved_bytes",
-              "hyena_fftconv_fwd_save", "hyena_fftconv_bwd_saved", "hyena_fftconv_plan"):
+              "hyena_fftconv_fwd_save", "hyena_fftconv_bwd_saved", "hyena_fftconv_plan", "hyena_fftconv_fwd_ld", "hyena_fftconv_bwd_ld"):
         assert s in syms
 
 

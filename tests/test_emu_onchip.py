@@ -199,3 +199,62 @@ def test_dk_at_batch_one_is_spectrum_plus_conjugate_conv(emu_backend, monkeypatc
     assert torch.equal(dbias, dk[:, 0]) and (dbias - r_db).abs().max() < 1e-5 * L ** 0.5 + 1e-5
     du1, dk1, db1 = emu_backend.fftconv_bwd(dout, u, k, bias, need_du=False, need_dk=True)
     assert du1 is None and torch.equal(dk1, dk) and torch.equal(db1, dbias)
+
+
+# (B, D, L, dtype): odd lengths of every kernel family -- one-launch pair (R <= 2, small batch), general conv / dk (with and without batch
+# slices, T = 32 with its whole-tensor descriptor), dk at B = 1 as spectrum + conjugate conv, the two parity launches at M = 32768,
+# and the two-level plan
+PITCHED_CASES = [
+    (2, 3, 999, torch.float32), (3, 2, 2047, torch.bfloat16), (17, 3, 701, torch.float32), (40, 3, 703, torch.bfloat16),
+    (9, 2, 1025, torch.float16), (3, 2, 4095, torch.bfloat16), (1, 2, 8191, torch.float32), (2, 1, 16383, torch.bfloat16),
+    (2, 2, 32767, torch.bfloat16), (1, 2, 32767, torch.bfloat16), (1, 1, 32767, torch.float32), (2, 2, 40001, torch.bfloat16),
+    (1, 3, 33333, torch.float32),
+]
+
+
+@pytest.mark.parametrize("B,D,L,dtype", PITCHED_CASES)
+def test_pitched_rows_give_the_packed_bits(emu_backend, B, D, L, dtype):
+    """Round 5: hyena_fftconv_fwd_ld / _bwd_ld on rows that are row_pitch(L) elements apart (what the operator's fused path hands the
+    convolution at the reference trainer's odd lengths) -- the same arithmetic on the same values, so the packed call's bits; what lies
+    between the rows is poisoned with NaN on the input side and must come back untouched on the output side."""
+    _lib = emu_backend
+    u, k, bias, dout = _inputs(B, D, L, dtype, seed=L + B)
+    ld = _lib.row_pitch(L)
+    assert ld % 64 == 0 and 0 < ld - L < 64
+
+    def pitched(t, fill):
+        buf = torch.full(t.shape[:-1] + (ld,), fill, dtype=t.dtype)
+        buf[..., :L] = t
+        return buf[..., :L], buf
+
+    ref_out, ref_saved = _lib.fftconv_fwd(u, k, bias, save=True)
+    ref = [ref_out] + list(_lib.fftconv_bwd(dout, u, k, bias, saved=ref_saved))
+    (up, _), (kp, _), (gp, _) = pitched(u, float("nan")), pitched(k, float("nan")), pitched(dout, float("nan"))
+    one = lambda t: t.numel() == t.shape[-1]                                  # a single row has no pitch to speak of: ld_of says L
+    assert _lib.ld_of(up) == (L if one(up) else ld) and _lib.ld_of(kp) == (L if one(kp) else ld)
+    out, saved = _lib.fftconv_fwd(up, kp, bias, save=True)
+    du, dk, dbias = _lib.fftconv_bwd(gp, up, kp, bias, saved=saved)
+    du2, dk2, dbias2 = _lib.fftconv_bwd(gp, up, kp, bias)                     # the recomputing backward reads u and k again
+    assert _lib.ld_of(out) == _lib.ld_of(up) and _lib.ld_of(du) == _lib.ld_of(up) and _lib.ld_of(dk) == _lib.ld_of(kp)
+    for a, b in zip(ref, (out, du, dk, dbias)):
+        assert torch.equal(a, b)
+    for a, b in zip(ref[1:], (du2, dk2, dbias2)):
+        assert torch.equal(a, b)
+    # nothing is written between the rows: outputs handed in with a sentinel there (through the C ABI directly)
+    sent = 12345.0
+    outp, outbuf = pitched(torch.zeros_like(u), sent)
+    tables = _lib.tables_for(u.device, L)
+    ws, stream = _lib.workspace_for(u.device, _lib.lib().hyena_fftconv_workspace_bytes(B, D, L, 1, 0))
+    _lib.check(_lib.lib().hyena_fftconv_fwd_ld(up.data_ptr(), kp.data_ptr(), bias.data_ptr(), outp.data_ptr(), B, D, L, ld, ld,
+                                               _lib.dtype_code(dtype), tables.data_ptr(), ws.data_ptr(), ws.numel(), 0, None, 0, stream))
+    assert torch.equal(outp, ref_out) and (outbuf[..., L:] == sent).all()
+    dup, dubuf = pitched(torch.zeros_like(u), sent)
+    dkp, dkbuf = pitched(torch.zeros_like(k), sent)
+    db = torch.zeros(D)
+    _lib.check(_lib.lib().hyena_fftconv_bwd_ld(gp.data_ptr(), up.data_ptr(), kp.data_ptr(), bias.data_ptr(), dup.data_ptr(), dkp.data_ptr(),
+                                               db.data_ptr(), B, D, L, ld, ld, _lib.dtype_code(dtype), tables.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), 0, None, 0, stream))
+    assert torch.equal(dup, ref[1]) and torch.equal(dkp, ref[2]) and (dubuf[..., L:] == sent).all() and (dkbuf[..., L:] == sent).all()
+    # a pitch below L is refused
+    assert _lib.lib().hyena_fftconv_fwd_ld(up.data_ptr(), kp.data_ptr(), None, outp.data_ptr(), B, D, L, L - 1, ld, _lib.dtype_code(dtype),
+                                           tables.data_ptr(), ws.data_ptr(), ws.numel(), 0, None, 0, stream) == 1

@@ -86,7 +86,10 @@ def test_output_layout_and_fp16_output_flags(emu_backend):
     assert fftconv_func(ub, k, D, gelu=False, force_fp16_output=True).dtype == torch.bfloat16        # fftconv.cpp:110: bf16 input wins
     assert _rel(fftconv_func(u, k, D, gelu=False, fftfp16=True), ref) < 3e-6                           # the transform stays fp32 here
     with pytest.raises(ValueError):
-        fftconv_func(u, k, D, gelu=False, v=u)                                                        # the H3 form needs both v and q
+        fftconv_func(u, k, D, gelu=False, q=u)                                                        # q without v: the reference kernel would ignore q
+    # v without q (the reference op accepts the call): no q-multiply, i.e. the H3 form with q = 1
+    got = fftconv_func(u, k, D, gelu=False, v=u)
+    assert _rel(got, O.fftconv_h3_ref(u, k, D, torch.ones_like(u), u, head_dim=1)) < 1e-5
 
 
 @pytest.mark.parametrize("L,dtype", [(2000, torch.float32), (2501, torch.float32), (1001, torch.float32), (3000, torch.bfloat16)])

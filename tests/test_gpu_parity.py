@@ -419,3 +419,49 @@ def test_randomised_shapes_workspace_free_plan(gpu_lib):
         assert _rel(dk, r_dk) < REL_FP32, tag
         db64 = (dout.double() * u.double()).sum(dim=(0, 2))
         assert (dbias.double().cpu() - db64).abs().max() < 3e-6 * (B * L) ** 0.5 + 1e-5, tag
+
+
+@pytest.mark.parametrize("B,D,L,dtype", [
+    (3, 8, 32767, torch.bfloat16), (2, 8, 159999, torch.bfloat16), (1, 8, 449999, torch.bfloat16), (1, 8, 999999, torch.bfloat16),
+    (1, 8, 1048575, torch.bfloat16), (2, 3, 32767, torch.float32), (1, 2, 1048575, torch.float32), (2, 5, 1023, torch.float16),
+])
+def test_real_training_lengths_on_pitched_rows(gpu_lib, B, D, L, dtype):
+    """L = max_length - 1, the only lengths the reference's trainer produces (hg38_dataset.py:220-223: 32 767, 159 999, 449 999, 999 999,
+    1 048 575): the operator hands the convolution PITCHED rows there (_lib.empty_rows: rows 64 elements apart, hyena_fftconv_fwd_ld /
+    _bwd_ld).  Same arithmetic as on packed rows, so the results must be the packed call's BITS -- and both the oracle's values."""
+    dev = torch.device("cuda", 0)
+    u, k, bias, dout = _inputs(B, D, L, dtype, seed=L)
+
+    def pitched(t):
+        r = gpu_lib.empty_rows(t.shape[:-1], t.shape[-1], t.dtype, dev)
+        r.copy_(t)
+        return r
+
+    assert gpu_lib.row_pitch(L) % 64 == 0 and gpu_lib.row_pitch(L) - L < 64
+    res = {}
+    for name, lay in (("packed", lambda t: t.to(dev)), ("pitched", pitched)):
+        ud, kd, gd = lay(u), lay(k), lay(dout)
+        bd = bias.to(dev)
+        if name == "pitched":
+            assert gpu_lib.ld_of(ud) == gpu_lib.row_pitch(L) and not ud.is_contiguous() and ud.data_ptr() % 128 == 0       # (B D > 1 in every case)
+            # poison what lies between the rows: nothing may read it, and nothing may write it
+            for t in (ud, kd, gd):
+                buf = torch.as_strided(t, t.shape[:-1] + (gpu_lib.ld_of(t),), t.stride())
+                buf[..., L:] = float("nan")
+        out, saved = gpu_lib.fftconv_fwd(ud, kd, bd, save=True)
+        du, dk, dbias = gpu_lib.fftconv_bwd(gd, ud, kd, bd, saved=saved)
+        du2, dk2, dbias2 = gpu_lib.fftconv_bwd(gd, ud, kd, bd)                  # the recomputing backward reads u and k again
+        assert torch.equal(du, du2) and torch.equal(dk, dk2) and torch.equal(dbias, dbias2)
+        if name == "pitched":
+            assert gpu_lib.ld_of(out) == gpu_lib.ld_of(ud) and gpu_lib.ld_of(du) == gpu_lib.ld_of(ud) and gpu_lib.ld_of(dk) == gpu_lib.ld_of(kd)
+        res[name] = [t.cpu() for t in (out, du, dk, dbias)]
+        assert all(torch.isfinite(t).all() for t in res[name])
+    for a, b in zip(res["packed"], res["pitched"]):
+        assert torch.equal(a, b)
+    out, du, dk, dbias = res["pitched"]
+    r_out, r_du, r_dk, r_db = _oracle(u.float(), k, bias, dout.float())
+    tol = REL_FP32 if dtype == torch.float32 else (6e-3 if dtype == torch.bfloat16 else 8e-4)
+    assert _rel(out.float(), r_out) < tol and _rel(du.float(), r_du) < tol
+    assert _rel(dk, r_dk) < REL_FP32
+    db64 = (dout.double() * u.double()).sum(dim=(0, 2))
+    assert (dbias.double() - db64).abs().max() < 3e-6 * (B * L) ** 0.5 + 1e-5

@@ -256,7 +256,7 @@ def test_workspace_growth_frees_unless_captured_and_save_decision_is_cached(emu_
     assert w3 is w2
     monkeypatch.setattr(_lib._backend, "capturing", lambda: False, raising=False)
     w4, _ = _lib.workspace_for(dev, 50000)
-    assert _lib._retired == [w2] and w4.numel() >= 50000
+    assert [r for _, r in _lib._retired] == [w2] and _lib._retired[0][0][1] == _lib._backend.stream(dev) and w4.numel() >= 50000
     # (b)
     B, D, L = 2, 4, 40000                                       # two-level plan
     u, k = torch.randn(B, D, L), torch.randn(D, L) * 0.01
@@ -361,8 +361,10 @@ def test_advice_r3_host_side_fixes(tmp_path, monkeypatch):
     w = torch.empty(16, dtype=torch.uint8)
     monkeypatch.setattr(_lib, "_workspace", {(0, 77): w})
     monkeypatch.setattr(_lib, "_captured", {(0, 77)})
-    monkeypatch.setattr(_lib, "_retired", [w])
-    assert _lib.release_stream_state(torch.device("cuda", 0), 77) and not _lib._workspace and not _lib._captured and not _lib._retired
+    other = torch.empty(8, dtype=torch.uint8)
+    monkeypatch.setattr(_lib, "_retired", [((0, 77), torch.empty(4, dtype=torch.uint8)), ((0, 78), other)])     # outgrown buffers, by owner
+    assert _lib.release_stream_state(torch.device("cuda", 0), 77) and not _lib._workspace and not _lib._captured
+    assert len(_lib._retired) == 1 and _lib._retired[0][0] == (0, 78) and _lib._retired[0][1] is other             # this stream's outgrown buffers go, another stream's stay
     assert not _lib.release_stream_state(torch.device("cuda", 0), 77)
 
 

@@ -239,23 +239,38 @@ def test_operator_with_and_without_the_fused_out_proj(emu_backend, monkeypatch, 
 
 
 def test_ragged_length_policy_of_the_fused_out_proj(emu_backend, monkeypatch):
-    """L not a multiple of 8: inference (and a frozen out_proj weight) takes the kernel -- its pulled-back last tile -- and gives the library
-    path's bits; a training call, whose zT rows would start at odd offsets, keeps cm_post_fwd + the library GEMM (mixer.mixer_out_supported)."""
+    """L not a multiple of 8 -- the reference trainer's own lengths (max_length - 1): since round 5 the channel-major tensors are pitched rows, so
+    the kernel serves training calls there as well (round 4 routed them to cm_post_fwd + the library GEMM), its choice no longer depends on the
+    grad mode, zT's rows start aligned, and outputs and every gradient are the library path's bits."""
     import hyena_dna_amd.mixer as MX
     from hyena_dna_amd.hyena import HyenaOperator
     torch.manual_seed(5)
     B, L, D = 2, 127, 128
     op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10).to(torch.bfloat16)
     u = torch.randn(B, L, D).to(torch.bfloat16)
-    calls, real = [], emu_backend.outproj_gate_fwd
-    monkeypatch.setattr(emu_backend, "outproj_gate_fwd", lambda *a, **k: (calls.append(k.get("want_z")), real(*a, **k))[1])
+    calls, zts, real = [], [], emu_backend.outproj_gate_fwd
+
+    def spy(*a, **k):
+        calls.append(k.get("want_z"))
+        out, zT = real(*a, **k)
+        zts.append(zT)
+        return out, zT
+
+    monkeypatch.setattr(emu_backend, "outproj_gate_fwd", spy)
     monkeypatch.setattr(MX, "OUTPROJ_MFMA", True)
-    op(u).float().sum().backward()
-    assert calls == []                                    # training, ragged: library path
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(MX, "OUTPROJ_MFMA", fused)
+        op.zero_grad(set_to_none=True)
+        y = op(u)
+        y.float().sum().backward()
+        res.append([y.detach()] + [p.grad.clone() for p in op.parameters() if p.grad is not None])
+    assert calls == [True]                                # training, ragged: the kernel, zT kept for the weight gradient
+    assert zts[0].shape == (D, B, L) and zts[0].stride() == (B * 128, 128, 1)      # rows 128 elements apart: aligned whatever L is
+    for a_, b_ in zip(*res):
+        assert torch.equal(a_, b_)
+    monkeypatch.setattr(MX, "OUTPROJ_MFMA", True)
     with torch.no_grad():
         y_k = op(u)
-    assert calls == [False]                               # inference: the kernel, no zT
-    monkeypatch.setattr(MX, "OUTPROJ_MFMA", False)
-    with torch.no_grad():
-        y_l = op(u)
-    assert torch.equal(y_k, y_l)
+    assert calls == [True, False]                         # inference: the same kernel, no zT
+    assert torch.equal(y_k, res[0][0])
