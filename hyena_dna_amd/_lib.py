@@ -171,6 +171,10 @@ def lib():
         L.hyena_inproj_pre_fwd_ld.restype = c_int
         L.hyena_inproj_pre_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_outproj_gate_addnorm_fwd_ld.restype = c_int
+        L.hyena_outproj_gate_addnorm_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                        c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
         L.hyena_outproj_gate_fwd_ld.restype = c_int
         L.hyena_outproj_gate_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
@@ -677,6 +681,32 @@ def outproj_gate_fwd(y, xT, bin_, w, b, W, bias, want_z):
                                               None if zT is None else zT.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), lda,
                                               dtype_code(y.dtype), _backend.stream(y.device)))
     return out, zT
+
+
+def outproj_gate_addnorm_fwd(y, xT, bin_, w, b, W, bias, want_z, residual, ln_w, ln_b, eps):
+    """outproj_gate_fwd with the block's residual add + LayerNorm in the kernel's epilogue (include/hyena_proj.h,
+    hyena_outproj_gate_addnorm_fwd_ld): residual (B L, D) fp32 or None, ln_w / ln_b (D,) fp32
+    -> normed (B, L, D) of y's type, residual' (B L, D) fp32, mean, rstd (B L,), zT or None.  The out_proj output itself is never written."""
+    _require_gpu(y, "y")
+    B, D, L = y.shape
+    y, xT = as_rows(y), as_rows(xT)
+    assert W.shape == (D, D) and W.dtype == y.dtype and xT.dtype == y.dtype and W.is_contiguous()
+    assert residual is None or (residual.dtype == torch.float32 and residual.is_contiguous() and residual.numel() == B * L * D)
+    lda = ld_of(y)
+    dev = y.device
+    out = torch.empty((B, L, D), dtype=y.dtype, device=dev)
+    res_out = torch.empty((B * L, D), dtype=torch.float32, device=dev)
+    mean = torch.empty(B * L, dtype=torch.float32, device=dev)
+    rstd = torch.empty(B * L, dtype=torch.float32, device=dev)
+    zT = empty_rows((D, B), L, y.dtype, dev, pitch=lda) if want_z else None
+    with _backend.guard(dev):
+        check(lib().hyena_outproj_gate_addnorm_fwd_ld(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(),
+                                                      b.data_ptr(), W.data_ptr(), None if bias is None else bias.data_ptr(),
+                                                      None if residual is None else residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+                                                      float(eps), out.data_ptr(), res_out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                      None if zT is None else zT.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), lda,
+                                                      dtype_code(y.dtype), _backend.stream(dev)))
+    return out, res_out, mean, rstd, zT
 
 
 def colsum(x2):

@@ -37,6 +37,12 @@ void mlp_schedule(size_t P, int ncg, pj::MlpArgs* a, int* runs_out, int* grid_ou
 template <int K, int DT>
 int launch_outproj(const pj::OutProjArgs& a, int grid, void* stream) {
     typedef pj::OpCfg<K> C;
+    if (a.ln_w != nullptr) {                       // the residual add + LayerNorm in the epilogue
+        static thread_local int done_ln = -1;
+        hy_allow_lds(pj::outproj_gate_fwd_kernel<K, DT, true>, C::LDS_LN, &done_ln);
+        HY_LAUNCH((pj::outproj_gate_fwd_kernel<K, DT, true>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS_LN, stream, a);
+        return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+    }
     static thread_local int done = -1;
     hy_allow_lds(pj::outproj_gate_fwd_kernel<K, DT>, C::LDS, &done);
     HY_LAUNCH((pj::outproj_gate_fwd_kernel<K, DT>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS, stream, a);
@@ -132,11 +138,23 @@ int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, cons
 int hyena_outproj_gate_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
                               const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int ldx, int lda, int dtype,
                               void* stream) {
+    return hyena_outproj_gate_addnorm_fwd_ld(y, xT, bin, w, b, W, bias, nullptr, nullptr, nullptr, 0.f, out, nullptr, nullptr, nullptr, zT, B, L,
+                                             Lx, D, ldx, lda, dtype, stream);
+}
+
+int hyena_outproj_gate_addnorm_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
+                                      const float* bias, const float* residual_in, const float* ln_weight, const float* ln_bias, float eps,
+                                      void* out, float* residual_out, float* mean, float* rstd, void* zT, int B, int L, int Lx, int D,
+                                      int ldx, int lda, int dtype, void* stream) {
     if (y == nullptr || xT == nullptr || w == nullptr || b == nullptr || W == nullptr || out == nullptr || L > Lx || ldx < Lx || lda < L ||
         !hyena_outproj_supported(B, L, D, dtype))
         return HYENA_ERR_BAD_ARG;
+    if (ln_weight != nullptr && (ln_bias == nullptr || residual_out == nullptr || mean == nullptr || rstd == nullptr ||
+                                 residual_out == residual_in))       // (a sequence's pulled-back last tile re-reads residual_in: not in place)
+        return HYENA_ERR_BAD_ARG;
     pj::OutProjArgs a;
     a.y = y; a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.W = W; a.bias = bias; a.out = out; a.zT = zT;
+    a.res_in = residual_in; a.ln_w = ln_weight; a.ln_b = ln_bias; a.res_out = residual_out; a.mean = mean; a.rstd = rstd; a.eps = eps;
     a.B = B; a.L = L; a.Lx = Lx; a.D = D; a.ldx = ldx; a.lda = lda;
     a.tiles_per_seq = (L + pj::PJ_NT - 1) / pj::PJ_NT;
     a.tiles = B * a.tiles_per_seq;

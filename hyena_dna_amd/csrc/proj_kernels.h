@@ -28,6 +28,7 @@
 #pragma once
 #define HY_HELPERS_ONLY
 #include "fftconv_kernels.h"
+#include "block_kernels.h"            // blk_load / blk_store / wave_sum: the add + LayerNorm arithmetic of the LN-fused out_proj epilogue
 
 namespace hyena {
 namespace pj {
@@ -952,6 +953,12 @@ template <int K> struct OpCfg {
     static constexpr int EBUF = 32 * EROW;                    // 32 positions at a time
     static constexpr int PCS = UW / 8;                        // 16-byte pieces per position and wavefront
     static constexpr size_t LDS = (size_t)ZBUF + TAPB + PJ_WAVES * (size_t)EBUF;
+    // LN = true (the residual add + LayerNorm in the epilogue): the four wavefronts park their 32 x UW blocks in ONE [32 positions][K] tile per
+    // half tile (rows padded by 16 B: the halves of a wavefront land 16 banks apart), double-buffered so that one workgroup barrier per half
+    // tile suffices; a wavefront then owns 8 whole rows of it
+    static constexpr int SROW = (K + 8) * 2;
+    static constexpr int SBUF = 32 * SROW;
+    static constexpr size_t LDS_LN = (size_t)ZBUF + TAPB + 2 * (size_t)SBUF;
 };
 
 struct OutProjArgs {
@@ -964,6 +971,14 @@ struct OutProjArgs {
     const float* bias;    // (N,) fp32 (values already rounded to the element type) or null
     void* out;            // (B, L, N)
     void* zT;             // (D, B, L) or null
+    // LN = true: out (B, L, N) = LayerNorm(residual'), residual' = round(z W^T + bias) + residual_in  (block_kernels.h's add_norm_fwd_kernel, bit for bit)
+    const float* res_in;  // (B L, N) fp32 or null
+    const float* ln_w;    // (N,)
+    const float* ln_b;    // (N,)
+    float* res_out;       // (B L, N) fp32: residual'
+    float* mean;          // (B L,)
+    float* rstd;          // (B L,)
+    float eps;
     int B, L, Lx, D;
     int ldx, lda;         // row pitch (elements) of xT (row (c, b) at (c B + b) ldx, >= Lx) and of y / zT (rows (b, d) at (b D + d) lda, (d, b) at (d B + b) lda, >= L)
     int tiles_per_seq, tiles, tiles_per_wg;
@@ -971,7 +986,7 @@ struct OutProjArgs {
 
 __device__ __forceinline__ int op_slot(int pos) { return pos ^ (pos >> 3); }
 
-template <int K, int DT>
+template <int K, int DT, bool LN = false>
 __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProjArgs a) {
     typedef OpCfg<K> C;
     typedef typename Elem<DT>::type elem_t;
@@ -994,6 +1009,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
         taps[k * 8 + 0] = a.w[k * 3]; taps[k * 8 + 1] = a.w[k * 3 + 1]; taps[k * 8 + 2] = a.w[k * 3 + 2];
         taps[k * 8 + 3] = a.b[k];
         taps[k * 8 + 4] = a.bin != nullptr ? a.bin[k] : 0.f;
+        if constexpr (LN) { taps[k * 8 + 5] = a.ln_w[k]; taps[k * 8 + 6] = a.ln_b[k]; }      // (N = K: the LayerNorm's weight / bias ride in the spare slots)
     }
     // stationary operand: UW weight rows as B fragments (column = output channel j of tile ut, k = 16 ks + 8 hb ...)
     Frag wf[C::UT][C::KS];
@@ -1099,6 +1115,68 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
                 HY_UNROLL
                 for (int ut = 0; ut < C::UT; ++ut) acc[ut] = mfma<DT>(af, wf[ut][ks], acc[ut]);
             }
+            if constexpr (LN) {
+                // ---- the residual add + LayerNorm of the block, on whole rows (round 5): the out_proj output never reaches memory.  The four
+                //      wavefronts' rounded blocks meet in ONE [32][K] tile (buffer pt: the other buffer may still be read by a slower wavefront);
+                //      after the barrier a wavefront owns positions 8 wave .. 8 wave + 7, lane l channels E l .. E l + E - 1 -- the layout and,
+                //      operation for operation, the arithmetic of add_norm_fwd_kernel (block_kernels.h): residual', out, mean and rstd are its bits.
+                constexpr int E = K / 64;
+                HY_LDS char* const sh = HY_LDS_CAST(char, smem) + C::ZBUF + C::TAPB + pt * C::SBUF;
+                HY_UNROLL
+                for (int ut = 0; ut < C::UT; ++ut) {
+                    HY_UNROLL
+                    for (int q = 0; q < 16; ++q) {
+                        const int pos = pj_row(q, hb), un = n0 + ut * 32 + j;
+                        *(reinterpret_cast<HY_LDS elem_t*>(sh + pos * C::SROW) + un) = Elem<DT>::cvt(acc[ut][q] + bias[ut]);
+                    }
+                }
+                __syncthreads();
+                const int c0 = lane * E;
+                const float inv_d = 1.f / (float)K;
+                constexpr int RB = 2;                            // rows per batch: their residual loads in flight together (four: 49 spilled registers)
+                for (int g4 = 0; g4 < 8 / RB; ++g4) {
+                    float r[RB][E];
+                    HY_UNROLL
+                    for (int i = 0; i < RB; ++i) {
+                        const int pos = 8 * wave + RB * g4 + i;
+                        const size_t off = ((size_t)b * a.L + l0 + pt * 32 + pos) * N + c0;
+                        if (a.res_in != nullptr) blk_load<DT_F32, E>(a.res_in, off, r[i]);
+                        else {
+                            HY_UNROLL
+                            for (int e = 0; e < E; ++e) r[i][e] = 0.f;
+                        }
+                    }
+                    HY_UNROLL
+                    for (int i = 0; i < RB; ++i) {
+                        const int pos = 8 * wave + RB * g4 + i;
+                        const size_t row = (size_t)b * a.L + l0 + pt * 32 + pos, off = row * N + c0;
+                        elem_t xe[E];
+                        __builtin_memcpy(xe, sh + pos * C::SROW + c0 * 2, sizeof(xe));
+                        float v[E];
+                        HY_UNROLL
+                        for (int e = 0; e < E; ++e) v[e] = Elem<DT>::dec(xe[e]);
+                        if (a.res_in != nullptr) {
+                            HY_UNROLL
+                            for (int e = 0; e < E; ++e) v[e] += r[i][e];
+                        }
+                        float sm = 0.f;
+                        HY_UNROLL
+                        for (int e = 0; e < E; ++e) sm += v[e];
+                        const float mean = wave_sum(sm) * inv_d;
+                        float vs = 0.f;
+                        HY_UNROLL
+                        for (int e = 0; e < E; ++e) vs += (v[e] - mean) * (v[e] - mean);
+                        const float rstd = 1.f / sqrtf(wave_sum(vs) * inv_d + a.eps);
+                        float o[E];
+                        HY_UNROLL
+                        for (int e = 0; e < E; ++e) o[e] = (v[e] - mean) * rstd * taps[(c0 + e) * 8 + 5] + taps[(c0 + e) * 8 + 6];
+                        blk_store<DT, E>(a.out, off, o);
+                        blk_store<DT_F32, E>(a.res_out, off, v);
+                        if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+                    }
+                }
+                HY_SCHED_FENCE();
+            } else {
             // epilogue, wavefront-private: register q of lane (j, hb) = position pt 32 + pj_row(q, hb), channel ut 32 + j
             HY_WAVE_SYNC_PJ();
             HY_UNROLL
@@ -1116,6 +1194,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
                 st16(ob + (((size_t)b * a.L + l0 + pt * 32 + pos) * N + n0 + 8 * pc), lds_ld16(et + pos * C::EROW + pc * 16));
             }
             HY_SCHED_FENCE();
+            }
         }
         HY_WAVE_SYNC_PJ();
     }

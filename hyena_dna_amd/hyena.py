@@ -27,6 +27,7 @@ from .projection import hyena_linear, in_proj_cm, in_proj_pre_cm, out_proj_cm
 # the out_proj GEMM, no transposes anywhere: csrc/cm_kernels.h) or the reference's position-major (B, L, 3D) with the
 # transposes fused into the shell kernels (csrc/mixer_kernels.h).  HYENA_MIXER_LAYOUT=position selects the latter (A/B).
 CHANNEL_MAJOR = os.environ.get("HYENA_MIXER_LAYOUT", "channel").lower() != "position"
+ADD_NORM_FUSED = os.environ.get("HYENA_ADD_NORM_FUSED", "1") != "0"      # A/B knob: 0 = out_proj writes its output, the block's add + LayerNorm reads it back
 
 __all__ = ["HyenaOperator", "HyenaFilter", "PositionalEmbedding", "ExponentialModulation", "Sin"]
 
@@ -267,6 +268,32 @@ class HyenaOperator(nn.Module):
         return (self.order == 2 and self.num_heads == 1 and self.num_blocks == 1 and self.inner_factor == 1
                 and not self.outer_mixing and not self.post_order_ffn and self.short_filter_order == 3
                 and (self.dropout.p == 0.0 or not self.training) and not getattr(self.filter_fn, "bidirectional", False))
+
+    def forward_add_norm(self, u, residual, norm_weight, norm_bias, eps):
+        """``forward(u)`` followed by the prenorm block's ``residual' = out + residual; hidden = LayerNorm(residual')`` (flash_attn Block with
+        fused_dropout_add_ln and dropout 0: simple_lm.py:280-284, long_conv_lm.py:381-396) in ONE pass: out_proj's matrix-core kernel forms both
+        from its accumulators and the out_proj output is never written (csrc/proj_kernels.h, round 5).  Returns (hidden, residual' fp32), or None
+        when the call is not served this way (the caller then runs ``forward`` and its own add + LayerNorm -- same values, bit for bit)."""
+        l = u.size(-2)
+        l_filter = min(l, self.l_max)
+        if not (CHANNEL_MAJOR and ADD_NORM_FUSED and self._fused_ok() and 0 < l_filter <= _lib_max_l() and l_filter == l and u.shape[0] > 0
+                and not self.return_state and norm_weight is not None and norm_bias is not None
+                and (residual is None or residual.shape == u.shape)):
+            return None
+        dt = torch.get_autocast_dtype("cuda" if u.is_cuda else "cpu") if torch.is_autocast_enabled() else u.dtype
+        if dt not in (torch.bfloat16, torch.float16):
+            return None
+        k = self.filter_fn.filter_dl(l_filter)
+        fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
+        xT, vg = in_proj_pre_cm(u, self.in_proj.weight, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, l_filter)
+        if not mixer_out_supported(xT, l_filter, self.out_proj.weight):
+            # (xT is already made: finish on the unfused route so that nothing is computed twice)
+            zT = hyena_mixer_core_cm(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter, vg=vg)
+            y = out_proj_cm(zT, self.out_proj.weight, self.out_proj.bias)
+            from .block import dropout_add_layer_norm
+            return dropout_add_layer_norm(y, residual, norm_weight, norm_bias, 0.0, eps, prenorm=True, residual_in_fp32=True)
+        return hyena_mixer_out_cm(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter, vg,
+                                  self.out_proj.weight, self.out_proj.bias, add_norm=(residual, norm_weight, norm_bias, eps))
 
     def forward(self, u, *args, **kwargs):
         l = u.size(-2)

@@ -292,6 +292,15 @@ class Block(nn.Module):
             mixer_kwargs = {} if mixer_kwargs is None else mixer_kwargs
             if mixer_subset is not None:
                 mixer_kwargs["mixer_subset"] = mixer_subset
+            fused = None
+            if (not mixer_kwargs and not isinstance(self.mlp, nn.Identity) and self.fused_dropout_add_ln and self.residual_in_fp32
+                    and (self.dropout2.p == 0.0 or not self.training) and hasattr(self.mixer, "forward_add_norm")
+                    and isinstance(self.norm2, nn.LayerNorm) and self.norm2.weight is not None):
+                # the mixer's last kernel carries this block's second add + LayerNorm in its epilogue (hyena.HyenaOperator.forward_add_norm)
+                fused = self.mixer.forward_add_norm(hidden_states, residual, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            if fused is not None:
+                hidden_states, residual = fused
+                return self.mlp(hidden_states), residual
             hidden_states = self.mixer(hidden_states, **mixer_kwargs)
             if mixer_subset is not None:
                 residual = residual[:, mixer_subset]

@@ -163,10 +163,14 @@ def mixer_out_supported(xT, L, out_weight):
 class HyenaMixerOutCMFunc(torch.autograd.Function):
     """out (B, L, D) = out_proj(fftconv(v * x1, k, bias) * x0): HyenaMixerCMFunc followed by projection.OutProjCMFunc, with the forward's
     ``zT = y * x0`` formed inside the projection kernel (and written out only when out_proj's weight gradient will need it).  The backward
-    is the two functions' backward unchanged: dzT and the weight gradient are library GEMMs (contractions over d_model / the positions)."""
+    is the two functions' backward unchanged: dzT and the weight gradient are library GEMMs (contractions over d_model / the positions).
+
+    With ``ln_w`` (round 5): the prenorm block's residual add + LayerNorm behind the mixer (simple_lm.py:280-284; flash_attn's
+    dropout_add_layer_norm with p = 0) runs in the same kernel's epilogue -- returns (LayerNorm(residual'), residual') with
+    residual' = out_proj(...) + residual in fp32, bit for bit what block.AddLayerNormFunc makes of the unfused output, which is never written."""
 
     @staticmethod
-    def forward(ctx, xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out):
+    def forward(ctx, xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out, residual=None, ln_w=None, ln_b=None, eps=0.0):
         D3, B, Lx = xT.shape
         D = D3 // 3
         xc = _lib.as_rows(xT)
@@ -177,8 +181,8 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
         bf = bias.detach().to(torch.float32).reshape(D).contiguous()
         if vg is None:
             vg = _lib.cm_pre_fwd(xc, bi, w, b, L)
-        need = _gradmode.needs(ctx)
-        want_grad = any(need[:6]) or need[8] or need[9]
+        need = list(_gradmode.needs(ctx)) + [False] * 4
+        want_grad = any(need[:6]) or any(need[8:13])
         spectra = None
         if want_grad and _lib.save_spectra_default(B, D, L, device=vg.device):
             y, spectra = _lib.fftconv_fwd(vg, kf, bf, save=True)
@@ -186,23 +190,48 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
             y = _lib.fftconv_fwd(vg, kf, bf, grad=want_grad)
         wo = w_out.detach().to(xc.dtype).contiguous()
         bo = None if b_out is None else b_out.detach().to(xc.dtype).to(torch.float32).contiguous()      # rounded as autocast rounds it
-        out, zT = _lib.outproj_gate_fwd(y, xc, bi, w, b, wo, bo, want_z=bool(need[8]))
-        ctx.save_for_backward(xc, bi, w, b, kf, bf, y, wo, zT if zT is not None else torch.empty(0, device=xc.device))
+        none = torch.empty(0, device=xc.device)
+        ctx.norm = ln_w is not None
+        if ctx.norm:
+            lw = ln_w.detach().to(torch.float32).contiguous()
+            lb = ln_b.detach().to(torch.float32).contiguous()
+            r2 = None if residual is None else residual.detach().reshape(B * L, D).to(torch.float32).contiguous()
+            out, res_out, mean, rstd, zT = _lib.outproj_gate_addnorm_fwd(y, xc, bi, w, b, wo, bo, bool(need[8]), r2, lw, lb, eps)
+            ctx.save_for_backward(xc, bi, w, b, kf, bf, y, wo, zT if zT is not None else none, res_out, lw, mean, rstd)
+            ctx.norm_meta = (None if residual is None else residual.dtype, ln_w.dtype, ln_b.dtype)
+        else:
+            out, zT = _lib.outproj_gate_fwd(y, xc, bi, w, b, wo, bo, want_z=bool(need[8]))
+            ctx.save_for_backward(xc, bi, w, b, kf, bf, y, wo, zT if zT is not None else none)
         ctx.has_z = zT is not None
         ctx.spectra = spectra
         ctx.meta = (b_in.dtype, sf_weight.shape, sf_weight.dtype, sf_bias.dtype, k.dtype, bias.shape, bias.dtype, L, w_out.dtype,
                     None if b_out is None else b_out.dtype)
+        if ctx.norm:
+            return out, res_out.view(B, L, D)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dres_out=None):
         from .projection import cm_from_pm, wgrad_pm_cm
-        xc, bi, w, b, kf, bf, y, wo, zT = ctx.saved_tensors
         bin_dtype, w_shape, w_dtype, b_dtype, k_dtype, bias_shape, bias_dtype, L, wo_dtype, bo_dtype = ctx.meta
-        D3, B, Lx = xc.shape
-        D = D3 // 3
-        rows = B * L
-        dy2 = dout.to(xc.dtype).reshape(rows, D).contiguous()
+        norm_grads = (None, None, None, None)
+        if ctx.norm:
+            xc, bi, w, b, kf, bf, y, wo, zT, res_out, lw, mean, rstd = ctx.saved_tensors
+            D3, B, Lx = xc.shape
+            D = D3 // 3
+            rows = B * L
+            r_dtype, lw_dtype, lb_dtype = ctx.norm_meta
+            # the block's add + LayerNorm backward (block.AddLayerNormFunc.backward): d out_proj output (= dx0) and d residual
+            h2 = None if dres_out is None else dres_out.reshape(rows, D).to(torch.float32).contiguous()
+            dy2, dres, dlw, dlb = _lib.add_norm_bwd(dout.reshape(rows, D).contiguous(), h2, res_out, lw, mean, rstd, xc.dtype,
+                                                    need_dres=r_dtype is not None)
+            norm_grads = (None if dres is None else dres.view(B, L, D).to(r_dtype), dlw.to(lw_dtype), dlb.to(lb_dtype), None)
+        else:
+            xc, bi, w, b, kf, bf, y, wo, zT = ctx.saved_tensors
+            D3, B, Lx = xc.shape
+            D = D3 // 3
+            rows = B * L
+            dy2 = dout.to(xc.dtype).reshape(rows, D).contiguous()
         # ---- out_proj's backward (projection.OutProjCMFunc.backward) ----
         dW = dbo = None
         if ctx.needs_input_grad[8]:
@@ -210,7 +239,7 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
         if bo_dtype is not None and ctx.needs_input_grad[9]:
             dbo = _lib.colsum(dy2).to(bo_dtype)
         if not any(ctx.needs_input_grad[:6]):
-            return None, None, None, None, None, None, None, None, dW, dbo
+            return (None, None, None, None, None, None, None, None, dW, dbo) + norm_grads
         dzT = cm_from_pm(wo.t(), dy2, B, L)                                # channel-major (pitched rows), straight from the GEMM
         # ---- the core's backward (HyenaMixerCMFunc.backward) ----
         dxT = _lib.empty_like_rows(xc)
@@ -229,11 +258,17 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
         db = red[:, 3].to(b_dtype)
         dbin = red[:, 4].to(bin_dtype)
         return (dxT, dbin, dw, db, dk.to(k_dtype) if dk is not None else None,
-                dbias.reshape(bias_shape).to(bias_dtype) if dbias is not None else None, None, None, dW, dbo)
+                dbias.reshape(bias_shape).to(bias_dtype) if dbias is not None else None, None, None, dW, dbo) + norm_grads
 
 
-def hyena_mixer_out_cm(xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out):
+def hyena_mixer_out_cm(xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out, add_norm=None):
     """(3D, B, Lx) -> (B, L, D): the channel-major core and out_proj in one autograd function (see HyenaMixerOutCMFunc); the caller
-    checks mixer_out_supported first.  Runs with autocast disabled on tensors already in the compute type, like projection.out_proj_cm."""
+    checks mixer_out_supported first.  Runs with autocast disabled on tensors already in the compute type, like projection.out_proj_cm.
+    add_norm = (residual or None, ln_weight, ln_bias, eps): the prenorm block's residual add + LayerNorm in the same kernel
+    -> (LayerNorm(residual'), residual' fp32)."""
     with torch.autocast("cuda" if xT.is_cuda else "cpu", enabled=False):
+        if add_norm is not None:
+            residual, ln_w, ln_b, eps = add_norm
+            return _gradmode.apply(HyenaMixerOutCMFunc, xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out, residual, ln_w, ln_b,
+                                   float(eps))
         return _gradmode.apply(HyenaMixerOutCMFunc, xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out)

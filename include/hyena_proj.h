@@ -56,6 +56,19 @@ int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, cons
 int hyena_outproj_gate_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
                               const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int ldx, int lda, int dtype,
                               void* stream);
+/* ... with the block's residual add + LayerNorm in its epilogue (round 5).  In a prenorm block (flash_attn Block =
+ * src/models/sequence/simple_lm.py:262-284, long_conv_lm.py:381-396) the mixer's output goes straight into
+ *     residual' = dropout(mixer_out) + residual;   hidden = LayerNorm(residual')          (dropout p = 0 in every HyenaDNA configuration)
+ * A 64 x d_model output tile holds whole rows, so the kernel forms both from its accumulators and the out_proj output itself is never
+ * written (nor read back by hyena_add_norm_fwd: 1 GB of traffic and one launch per layer at L = 2^20, d_model 256):
+ *     out (B, L, D) 16-bit = LayerNorm(residual'; ln_weight, ln_bias, eps);  residual_out (B L, D) fp32 = round16(z W^T + bias) + residual_in;
+ *     mean, rstd (B L,) fp32 for the backward (hyena_add_norm_bwd).
+ * Values: exactly those of hyena_outproj_gate_fwd_ld followed by hyena_add_norm_fwd (same roundings, same summation order) -- bit for bit.
+ * residual_in: (B L, D) fp32 or NULL (no residual yet); must not alias residual_out.  ln_weight == NULL: plain hyena_outproj_gate_fwd_ld. */
+int hyena_outproj_gate_addnorm_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
+                                      const float* bias, const float* residual_in, const float* ln_weight, const float* ln_bias, float eps,
+                                      void* out, float* residual_out, float* mean, float* rstd, void* zT, int B, int L, int Lx, int D,
+                                      int ldx, int lda, int dtype, void* stream);
 
 
 /* ---- the block's MLP (flash_attn.modules.mlp.Mlp = simple_lm.py:191-211; long_conv_lm.py:117-123: fc1 -> tanh-GELU -> fc2) ---------

@@ -274,3 +274,41 @@ def test_ragged_length_policy_of_the_fused_out_proj(emu_backend, monkeypatch):
         y_k = op(u)
     assert calls == [True, False]                         # inference: the same kernel, no zT
     assert torch.equal(y_k, res[0][0])
+
+
+@pytest.mark.parametrize("B,L,D,dtype,with_res", [(2, 127, 128, torch.bfloat16, True), (1, 200, 256, torch.float16, True),
+                                                  (3, 64, 128, torch.bfloat16, False), (1, 321, 256, torch.bfloat16, True)])
+def test_out_proj_with_the_blocks_add_norm_in_its_epilogue(emu_backend, B, L, D, dtype, with_res):
+    """Round 5: the prenorm block's second residual add + LayerNorm (simple_lm.py:280-284) inside out_proj's matrix-core kernel
+    (hyena_outproj_gate_addnorm_fwd_ld).  The epilogue repeats add_norm_fwd_kernel's arithmetic operation for operation on the rounded
+    out_proj output, so hidden, residual' and EVERY gradient are the unfused route's bits (out_proj kernel -> AddLayerNormFunc)."""
+    from hyena_dna_amd.block import dropout_add_layer_norm
+    from hyena_dna_amd.hyena import HyenaOperator
+    torch.manual_seed(11)
+    op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10).to(dtype)
+    lw = (1.0 + 0.1 * torch.randn(D)).requires_grad_(True)
+    lb = (0.1 * torch.randn(D)).requires_grad_(True)
+    u0 = torch.randn(B, L, D).to(dtype)
+    r0 = torch.randn(B, L, D) * 3 if with_res else None
+    gh, gr = torch.randn(B, L, D).to(dtype), torch.randn(B, L, D)
+    res = []
+    for fused in (True, False):
+        op.zero_grad(set_to_none=True)
+        lw.grad = lb.grad = None
+        u = u0.clone().requires_grad_(True)
+        r = None if r0 is None else r0.clone().requires_grad_(True)
+        if fused:
+            out = op.forward_add_norm(u, r, lw, lb, 1e-5)
+            assert out is not None
+            h, rr = out
+        else:
+            h, rr = dropout_add_layer_norm(op(u), r, lw, lb, 0.0, 1e-5, prenorm=True, residual_in_fp32=True)
+        assert h.dtype == dtype and rr.dtype == torch.float32 and h.shape == (B, L, D) and rr.shape == (B, L, D)
+        ((h.float() * gh.float()).sum() + (rr * gr).sum()).backward()
+        res.append([h.detach(), rr.detach(), u.grad, lw.grad.clone(), lb.grad.clone()] + ([] if r is None else [r.grad]) +
+                   [p.grad.clone() for p in op.parameters() if p.grad is not None])
+    assert len(res[0]) == len(res[1]) and len(res[0]) > 12
+    for a_, b_ in zip(*res):
+        assert torch.equal(a_, b_)
+    # fp32 operands are not served: the caller falls back to forward + its own add + LayerNorm
+    assert op.float().forward_add_norm(u0.float(), r0, lw, lb, 1e-5) is None
