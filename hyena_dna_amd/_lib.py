@@ -175,6 +175,13 @@ def lib():
         L.hyena_outproj_gate_addnorm_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                         c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L.hyena_outproj_dgrad_supported.restype = c_int
+        L.hyena_outproj_dgrad_supported.argtypes = [c_int, c_int, c_int, c_int]
+        L.hyena_outproj_dgrad_partial_floats.restype = c_size_t
+        L.hyena_outproj_dgrad_partial_floats.argtypes = [c_int, c_int, c_int]
+        L.hyena_outproj_dgrad_gate_bwd_ld.restype = c_int
+        L.hyena_outproj_dgrad_gate_bwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                      c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
         L.hyena_outproj_gate_fwd_ld.restype = c_int
         L.hyena_outproj_gate_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
@@ -707,6 +714,30 @@ def outproj_gate_addnorm_fwd(y, xT, bin_, w, b, W, bias, want_z, residual, ln_w,
                                                       None if zT is None else zT.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), lda,
                                                       dtype_code(y.dtype), _backend.stream(dev)))
     return out, res_out, mean, rstd, zT
+
+
+def outproj_dgrad_supported(B, L, D, dtype):
+    code = _DTYPES.get(dtype)
+    return code is not None and code != 0 and bool(lib().hyena_outproj_dgrad_supported(int(B), int(L), int(D), code))
+
+
+def outproj_dgrad_gate_bwd(dy2, WoT, y, xT, bin_, w, b, dxT):
+    """out_proj's input gradient with cm_post_bwd's work in the kernel's epilogue (include/hyena_proj.h, hyena_outproj_dgrad_gate_bwd_ld):
+    dy2 (B L, D) 16-bit, WoT (D, D) = out_proj.weight^T contiguous, y (B, D, L), xT (3D, B, Lx); fills dxT[0:D] (positions < L)
+    -> dyc (B, D, L) with y's row pitch, part0 (D, runs, 8) whose [:, :, :5].sum(1) are (dw0, dw1, dw2, db_sc, db_in) of channels [0, D)."""
+    _require_gpu(y, "y")
+    B, D, L = y.shape
+    y, xT = as_rows(y), as_rows(xT)
+    assert dy2.shape == (B * L, D) and dy2.is_contiguous() and dy2.dtype == y.dtype and WoT.shape == (D, D) and WoT.is_contiguous()
+    assert ld_of(dxT) == ld_of(xT)
+    dyc = empty_like_rows(y)
+    part = torch.empty(lib().hyena_outproj_dgrad_partial_floats(B, L, D), dtype=torch.float32, device=y.device).view(D, -1, 8)
+    with _backend.guard(y.device):
+        check(lib().hyena_outproj_dgrad_gate_bwd_ld(dy2.data_ptr(), WoT.data_ptr(), y.data_ptr(), xT.data_ptr(),
+                                                    None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(), dyc.data_ptr(),
+                                                    dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), ld_of(y),
+                                                    dtype_code(y.dtype), _backend.stream(y.device)))
+    return dyc, part
 
 
 def colsum(x2):

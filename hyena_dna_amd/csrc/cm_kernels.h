@@ -178,7 +178,8 @@ __device__ __forceinline__ CmPart cm_sc_bwd(const float (&da)[CM_V + 2], const f
     for (int i = 0; i < CM_V; ++i) {
         const int m = l0 + i;
         // x[m] feeds outputs m (tap 2), m + 1 (tap 1), m + 2 (tap 0); da is already zero beyond L
-        dx[i] = t.w2 * da[i] + t.w1 * da[i + 1] + t.w0 * da[i + 2];
+        // (explicit fused multiply-adds in a fixed order: outproj_dgrad_gate_bwd_kernel, proj_kernels.h, evaluates the same expression and must give the same bits)
+        dx[i] = __builtin_fmaf(t.w0, da[i + 2], __builtin_fmaf(t.w1, da[i + 1], t.w2 * da[i]));
         if (m < L) p.dbin += dx[i];
         // the outputs this thread owns (l = m): dw[j] += da[l] x_true[l - 2 + j]
         const float x0 = m >= 2 ? xs[i] + t.bin : 0.f, x1 = m >= 1 ? xs[i + 1] + t.bin : 0.f, x2 = xs[i + 2] + t.bin;

@@ -48,6 +48,28 @@ int launch_outproj(const pj::OutProjArgs& a, int grid, void* stream) {
     HY_LAUNCH((pj::outproj_gate_fwd_kernel<K, DT>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
+template <int K, int DT>
+int launch_dgrad(const pj::DgArgs& a, int grid, void* stream) {
+    typedef pj::DgCfg<K> C;
+    static thread_local int done = -1;
+    hy_allow_lds(pj::outproj_dgrad_gate_bwd_kernel<K, DT>, C::LDS, &done);
+    HY_LAUNCH((pj::outproj_dgrad_gate_bwd_kernel<K, DT>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+// runs of tiles per channel group of the dgrad kernel: a few per workgroup slot, at least 16 tiles long (weight load + the warm-up tile amortised)
+void dgrad_schedule(int B, int L, int D, pj::DgArgs* a, int* runs_out, int* grid_out) {
+    const int ncg = D / (pj::PJ_WAVES * pj::DG_CB);
+    a->tiles_per_seq = (L + pj::PJ_NT - 1) / pj::PJ_NT;
+    a->tiles = B * a->tiles_per_seq;
+    int runs = 256 * 4 / ncg;
+    if (runs > a->tiles) runs = a->tiles;
+    a->tiles_per_wg = (a->tiles + runs - 1) / runs;
+    if (a->tiles_per_wg < 16 && a->tiles >= 16) a->tiles_per_wg = 16;
+    runs = (a->tiles + a->tiles_per_wg - 1) / a->tiles_per_wg;
+    a->nrec = runs;
+    *runs_out = runs;
+    *grid_out = ((runs + 7) / 8) * 8 * ncg;
+}
 template <int MODE>
 int dispatch_mlp(const pj::MlpArgs& a, int K, int dtype, int grid, void* stream) {
     if (K == 256) return dtype == HYENA_BF16 ? launch_mlp<256, DT_BF16, MODE>(a, grid, stream) : launch_mlp<256, DT_F16, MODE>(a, grid, stream);
@@ -166,6 +188,35 @@ int hyena_outproj_gate_addnorm_fwd_ld(const void* y, const void* xT, const float
     runs = (a.tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     if (D == 256) return dtype == HYENA_BF16 ? launch_outproj<256, DT_BF16>(a, runs, stream) : launch_outproj<256, DT_F16>(a, runs, stream);
     return dtype == HYENA_BF16 ? launch_outproj<128, DT_BF16>(a, runs, stream) : launch_outproj<128, DT_F16>(a, runs, stream);
+}
+
+int hyena_outproj_dgrad_supported(int B, int L, int D, int dtype) {
+    if (!(D == 128 || D == 256) || !(dtype == HYENA_BF16 || dtype == HYENA_F16)) return 0;
+    if (B < 1 || L < 1) return 0;
+    return (size_t)B * (size_t)L < ((size_t)1 << 31) - 64 ? 1 : 0;
+}
+
+size_t hyena_outproj_dgrad_partial_floats(int B, int L, int D) {
+    if (B < 1 || L < 1 || !(D == 128 || D == 256)) return 0;
+    pj::DgArgs a;
+    int runs, grid;
+    dgrad_schedule(B, L, D, &a, &runs, &grid);
+    return (size_t)D * runs * 8;
+}
+
+int hyena_outproj_dgrad_gate_bwd_ld(const void* dy, const void* Wt, const void* y, const void* xT, const float* bin, const float* w,
+                                    const float* b, void* dyc, void* dxT, float* part, int B, int L, int Lx, int D, int ldx, int lda,
+                                    int dtype, void* stream) {
+    if (dy == nullptr || Wt == nullptr || y == nullptr || xT == nullptr || w == nullptr || b == nullptr || dyc == nullptr || dxT == nullptr ||
+        part == nullptr || L > Lx || ldx < Lx || lda < L || !hyena_outproj_dgrad_supported(B, L, D, dtype))
+        return HYENA_ERR_BAD_ARG;
+    pj::DgArgs a;
+    a.dy = dy; a.Wt = Wt; a.y = y; a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.dyc = dyc; a.dxT = dxT; a.part = part;
+    a.B = B; a.L = L; a.Lx = Lx; a.D = D; a.ldx = ldx; a.lda = lda;
+    int runs, grid;
+    dgrad_schedule(B, L, D, &a, &runs, &grid);
+    if (D == 256) return dtype == HYENA_BF16 ? launch_dgrad<256, DT_BF16>(a, grid, stream) : launch_dgrad<256, DT_F16>(a, grid, stream);
+    return dtype == HYENA_BF16 ? launch_dgrad<128, DT_BF16>(a, grid, stream) : launch_dgrad<128, DT_F16>(a, grid, stream);
 }
 
 int hyena_proj_supported(int B, int Lx, int D, int dtype) {

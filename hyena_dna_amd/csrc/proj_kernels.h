@@ -1200,5 +1200,263 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
     }
 }
 
+
+// =============================================================================================================================
+// out_proj's input gradient with the second gate's backward in its epilogue (round 5).  hyena.py:432-440, backwards:
+//     dz^T = W_out^T dy^T                                                   (D, B, L)   the gradient of z = y * x0 (transposed GEMM)
+//     d y_conv = dz * x0c;   g = dz * y  ->  through the short filter of the x0 channels:
+//     d xT[d, m] = w2 g[m] + w1 g[m + 1] + w0 g[m + 2]   (+ the partial sums of d w, d b_sc, d b_in)
+// Until round 5: a library GEMM wrote dz^T (560 us for 1 GB at L = 2^20, d = 256 -- the one product of the layer the library runs far below
+// the memory rate) and cm_post_bwd (cm_kernels.h) read it back with y and xT.  Here the in_proj kernel's scheme runs the other way round:
+// weights-stationary v_mfma_f32_16x16x32 (A = 32 rows of W_out^T per wavefront, B = the staged dy tile, positions on the lanes), accumulators
+// rounded to the storage type (dz^T is a 16-bit tensor in the unfused graph: same rounding) and parked as [channel][position] rows in a
+// wavefront-private LDS tile; each lane then takes 8 positions of a channel, loads the matching 16-byte pieces of y and of the x0 row of xT,
+// and forms everything cm_post_bwd forms -- expression for expression (cm_sc, cm_sc_bwd) -- so dz^T never exists in memory.
+// The transposed short convolution needs g at the two positions AFTER a piece: from the neighbouring lane, and across tiles from the tile
+// above -- so a workgroup walks its run of tiles DOWNWARDS (a warm-up tile above the run supplies the first two values, its results are
+// dropped), the mirror image of the in_proj kernel's halo.  Tiles never cross a sequence (tiles_per_seq per sequence, the last one ragged):
+// with pitched rows (ldx, lda multiples of 8) every 16-byte access of the epilogue is aligned whatever L and B are.
+// Partial sums (d w0..2, d b_sc, d b_in per channel) stay in registers over the run, are reduced over the 8 lanes of a channel by shuffles
+// and leave as one record per (channel, run): part[c][run][8], summed over the runs by the host in a fixed order -- deterministic.
+// =============================================================================================================================
+enum { DG_CB = 32 /* channels per wavefront: two 16-row MFMA groups */, DG_G = DG_CB / 16, DG_M = DG_CB * 8 / 64 /* (channel, piece) pairs per lane */ };
+template <int K> struct DgCfg {
+    static_assert(K == 128 || K == 256, "d_model of the HyenaDNA models");
+    static constexpr int KS = K / 32;
+    static constexpr int PCS = K / 8;
+    static constexpr int UROWB = K * 2, UBUF = PJ_NT * UROWB;   // the dy tile [64 positions][K], filled by LDS-direct loads (issue_operand_tile)
+    static constexpr int EROW = PJ_EW * 2;                      // [channel][64 positions] + 16 B: conflict-free 16-byte reads
+    static constexpr int EBUF = DG_CB * EROW;
+    static constexpr size_t LDS = (size_t)UBUF + PJ_WAVES * (size_t)EBUF;
+};
+
+struct DgArgs {
+    const void* dy;       // (B L, N) 16-bit: gradient of out_proj's output, N = K = D
+    const void* Wt;       // (D, N) 16-bit: out_proj.weight TRANSPOSED (row d = the weights that multiply dy[:, n] into channel d)
+    const void* y;        // (B, D, L) long-convolution output, row pitch lda
+    const void* xT;       // (3D, B, Lx) in_proj output without its bias, row pitch ldx; rows [0, D) are read
+    const float* bin;     // (3D,) or null
+    const float* w;       // (3D, 3)
+    const float* b;       // (3D,)
+    void* dyc;            // (B, D, L) out: gradient of the long convolution's output, row pitch lda
+    void* dxT;            // (3D, B, Lx) out: rows [0, D), positions < L, row pitch ldx
+    float* part;          // out: [D][nrec][8] (dw0, dw1, dw2, db_sc, db_in, -, -, -), record = run
+    int B, L, Lx, D;
+    int ldx, lda;
+    int tiles_per_seq, tiles, tiles_per_wg, nrec;
+};
+
+template <int K, int DT>
+__global__ void __launch_bounds__(PJ_THREADS, 2) outproj_dgrad_gate_bwd_kernel(DgArgs a) {
+    typedef DgCfg<K> C;
+    typedef typename Elem<DT>::type elem_t;
+    static_assert(sizeof(elem_t) == 2, "16-bit element types only");
+    HY_SMEM(smem);
+    PJ_VMQ_DECL;
+    const int tid = (int)threadIdx.x, wave = HY_SGPR(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
+    const int D = a.D;
+    const unsigned P = (unsigned)a.B * (unsigned)a.L;
+    const int ncg = D / (PJ_WAVES * DG_CB);
+    int cg, run;
+    {
+        const int wg = blockIdx.x, xcd = wg & 7, seq = wg >> 3;       // the channel groups of one run of positions share an XCD's L2 (the dy tiles)
+        cg = seq % ncg;
+        run = (seq / ncg) * 8 + xcd;
+    }
+    const int t_begin = run * a.tiles_per_wg;
+    if (t_begin >= a.tiles) return;
+    const int t_end = (t_begin + a.tiles_per_wg < a.tiles) ? t_begin + a.tiles_per_wg : a.tiles;
+    const int d0 = cg * PJ_WAVES * DG_CB + wave * DG_CB;             // first channel of this wavefront
+
+    HY_LDS char* const ubuf = HY_LDS_CAST(char, smem);
+    HY_LDS char* const ebuf = HY_LDS_CAST(char, smem) + C::UBUF + wave * C::EBUF;
+
+    // stationary operand: 32 rows of W_out^T as A fragments (row = channel 16 g + j, k = 32 ks + 8 kq ...)
+    Frag wf[DG_G][C::KS];
+    HY_UNROLL
+    for (int g = 0; g < DG_G; ++g) {
+        const char* row = reinterpret_cast<const char*>(a.Wt) + ((size_t)(d0 + 16 * g + j) * K + 8 * kq) * 2;
+        HY_UNROLL
+        for (int ks = 0; ks < C::KS; ++ks) wf[g][ks] = ld16(row + ks * 64);
+    }
+    // this lane's DG_M (channel, piece) pairs: channel (lane >> 3) + 8 m, positions 8 (lane & 7) .. + 7 of the tile
+    const int pc = lane & 7;
+    float tw0[DG_M], tw1[DG_M], tw2[DG_M], tbs[DG_M], tbi[DG_M];
+    HY_UNROLL
+    for (int m = 0; m < DG_M; ++m) {
+        const int c = d0 + (lane >> 3) + 8 * m;
+        tw0[m] = a.w[c * 3]; tw1[m] = a.w[c * 3 + 1]; tw2[m] = a.w[c * 3 + 2]; tbs[m] = a.b[c];
+        tbi[m] = a.bin != nullptr ? a.bin[c] : 0.f;
+    }
+    float sdw0[DG_M], sdw1[DG_M], sdw2[DG_M], sdbs[DG_M], sdbi[DG_M];      // partial sums of the run
+    float cr0[DG_M], cr1[DG_M];                                             // g at the first two positions of the tile above (held by the piece-0 lanes)
+    HY_UNROLL
+    for (int m = 0; m < DG_M; ++m) { sdw0[m] = sdw1[m] = sdw2[m] = sdbs[m] = sdbi[m] = 0.f; cr0[m] = cr1[m] = 0.f; }
+
+    const char* const dbase = reinterpret_cast<const char*>(a.dy);
+    const elem_t* const yb = reinterpret_cast<const elem_t*>(a.y);
+    const elem_t* const xb = reinterpret_cast<const elem_t*>(a.xT);
+    elem_t* const ob = reinterpret_cast<elem_t*>(a.dyc);
+    elem_t* const gb = reinterpret_cast<elem_t*>(a.dxT);
+
+    // the walk goes DOWN: tile t_end (if it belongs to the sequence of tile t_end - 1) is the warm-up tile
+    const bool warm = t_end < a.tiles && (t_end % a.tiles_per_seq) != 0;
+    const int t_first = warm ? t_end : t_end - 1;
+    auto tile_p0 = [&](int t) -> unsigned { const int sb = t / a.tiles_per_seq; return (unsigned)sb * (unsigned)a.L + (unsigned)(t - sb * a.tiles_per_seq) * PJ_NT; };
+    {
+        const unsigned p0 = tile_p0(t_first);
+        if (p0 + PJ_NT <= P) issue_operand_tile<K, true>(dbase, p0, P, ubuf, wave, lane PJ_VMQ_ARG);
+        else issue_operand_tile<K, false>(dbase, p0, P, ubuf, wave, lane PJ_VMQ_ARG);
+    }
+    for (int t = t_first; t >= t_begin; --t) {
+        const int sb = t / a.tiles_per_seq, ti = t - sb * a.tiles_per_seq, l0 = ti * PJ_NT;
+        PJ_VMWAIT(0);
+        PJ_BARRIER();                                                        // everybody's share of the tile has landed
+        acc4_t acc[DG_G][IP_NT4];
+        HY_UNROLL
+        for (int g = 0; g < DG_G; ++g) {
+            HY_UNROLL
+            for (int nt = 0; nt < IP_NT4; ++nt) {
+                HY_UNROLL
+                for (int r = 0; r < 4; ++r) acc[g][nt][r] = 0.f;
+            }
+        }
+        const int ua = j * C::UROWB, ux = (kq ^ j) * 16;
+        HY_UNROLL
+        for (int ks = 0; ks < C::KS; ++ks) {
+            HY_UNROLL
+            for (int nt = 0; nt < IP_NT4; ++nt) {
+                const Frag bf = lds_ld16(ubuf + nt * 16 * C::UROWB + ua + (ux ^ (((4 * ks) ^ ((16 * nt) % C::PCS)) * 16)));
+                HY_UNROLL
+                for (int g = 0; g < DG_G; ++g) acc[g][nt] = mfma16<DT>(wf[g][ks], bf, acc[g][nt]);
+            }
+        }
+        PJ_BARRIER();                                                        // every wavefront has read its last fragment
+        if (t - 1 >= t_begin) {
+            const unsigned p0 = tile_p0(t - 1);
+            if (p0 + PJ_NT <= P) issue_operand_tile<K, true>(dbase, p0, P, ubuf, wave, lane PJ_VMQ_ARG);
+            else issue_operand_tile<K, false>(dbase, p0, P, ubuf, wave, lane PJ_VMQ_ARG);
+        }
+        // ---- epilogue, wavefront-private -------------------------------------------------------------------------------------
+        // (1) dz, rounded to the storage type, as [channel][position] rows; positions beyond the sequence are zero (a ragged last tile
+        //     multiplied rows of the next sequence, or stale ones)
+        HY_UNROLL
+        for (int g = 0; g < DG_G; ++g) {
+            HY_UNROLL
+            for (int nt = 0; nt < IP_NT4; ++nt) {
+                HY_UNROLL
+                for (int r = 0; r < 4; ++r) {
+                    HY_LDS elem_t* e = reinterpret_cast<HY_LDS elem_t*>(ebuf + (g * 16 + 4 * kq + r) * C::EROW);
+                    e[nt * 16 + j] = l0 + nt * 16 + j < a.L ? Elem<DT>::cvt(acc[g][nt][r]) : (elem_t)0;
+                }
+            }
+        }
+        HY_WAVE_SYNC_PJ();
+        if (ti == a.tiles_per_seq - 1) {                                     // a sequence's last tile: nothing above it
+            HY_UNROLL
+            for (int m = 0; m < DG_M; ++m) { cr0[m] = 0.f; cr1[m] = 0.f; }
+        }
+        const bool keep = t < t_end;                                         // (the warm-up tile only supplies cr0 / cr1)
+        const int l = l0 + 8 * pc;                                           // this lane's first position in the sequence
+        const bool whole = l + 8 <= a.L;
+        HY_UNROLL
+        for (int m = 0; m < DG_M; ++m) {
+            const int ch = (lane >> 3) + 8 * m, c = d0 + ch;
+            elem_t dze[8], ye[8], xe[10];
+            {
+                const Frag f = lds_ld16(ebuf + ch * C::EROW + pc * 16);
+                __builtin_memcpy(dze, f.w, 16);
+            }
+            const elem_t* yrow = yb + ((size_t)sb * D + c) * a.lda;
+            const elem_t* xrow = xb + ((size_t)c * a.B + sb) * a.ldx;
+            if (whole) {
+                const Frag fy = ld16(yrow + l), fx = ld16(xrow + l);
+                __builtin_memcpy(ye, fy.w, 16);
+                __builtin_memcpy(xe + 2, fx.w, 16);
+            } else {
+                HY_UNROLL
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = l + i < a.L;
+                    ye[i] = ok ? yrow[ok ? l + i : 0] : (elem_t)0;
+                    xe[2 + i] = ok ? xrow[ok ? l + i : 0] : (elem_t)0;
+                }
+            }
+            // the two raw x values before the piece: the previous lane's last pair, or (piece 0) straight from the row
+            {
+                uint32_t own;
+                __builtin_memcpy(&own, xe + 8, 4);
+                uint32_t hw = HY_SHFL_U32(own, lane - 1);
+                if (pc == 0) {
+                    hw = 0u;
+                    if (l0 >= 2) __builtin_memcpy(&hw, xrow + (l0 - 2), 4);
+                }
+                __builtin_memcpy(xe, &hw, 4);
+            }
+            float dz[8], g8[10], c0[8];
+            HY_UNROLL
+            for (int i = 0; i < 8; ++i) dz[i] = Elem<DT>::dec(dze[i]);
+            HY_UNROLL
+            for (int i = 0; i < 8; ++i) {
+                const int li = l + i;
+                const float x0 = li >= 2 ? Elem<DT>::dec(xe[i]) + tbi[m] : 0.f, x1 = li >= 1 ? Elem<DT>::dec(xe[i + 1]) + tbi[m] : 0.f,
+                            x2 = Elem<DT>::dec(xe[i + 2]) + tbi[m];
+                c0[i] = __builtin_fmaf(tw2[m], x2, __builtin_fmaf(tw1[m], x1, __builtin_fmaf(tw0[m], x0, tbs[m])));       // = cm_sc
+                g8[i] = dz[i] * Elem<DT>::dec(ye[i]);                                                                  // zero beyond L: dz is
+                if (keep) {
+                    sdw0[m] += g8[i] * x0; sdw1[m] += g8[i] * x1; sdw2[m] += g8[i] * x2; sdbs[m] += g8[i];            // = cm_sc_bwd
+                }
+            }
+            // g at the two positions after the piece: the next lane's first two, or (piece 7) the tile above's
+            {
+                const float n0 = u2f(HY_SHFL_U32(f2u(g8[0]), lane + 1)), n1 = u2f(HY_SHFL_U32(f2u(g8[1]), lane + 1));
+                const float u0 = u2f(HY_SHFL_U32(f2u(cr0[m]), lane - 7)), u1 = u2f(HY_SHFL_U32(f2u(cr1[m]), lane - 7));
+                g8[8] = pc == 7 ? u0 : n0;
+                g8[9] = pc == 7 ? u1 : n1;
+                cr0[m] = g8[0]; cr1[m] = g8[1];                               // (meaningful in the piece-0 lanes: the tile below reads them there)
+            }
+            if (keep) {
+                elem_t oe[8], de[8];
+                HY_UNROLL
+                for (int i = 0; i < 8; ++i) {
+                    oe[i] = Elem<DT>::cvt(dz[i] * c0[i]);                                                                              // = cm_post_bwd's dy
+                    const float dx = __builtin_fmaf(tw0[m], g8[i + 2], __builtin_fmaf(tw1[m], g8[i + 1], tw2[m] * g8[i]));         // = cm_sc_bwd's dx
+                    if (l + i < a.L) sdbi[m] += dx;
+                    de[i] = Elem<DT>::cvt(dx);
+                }
+                elem_t* orow = ob + ((size_t)sb * D + c) * a.lda;
+                elem_t* drow = gb + ((size_t)c * a.B + sb) * a.ldx;
+                if (whole) {
+                    Frag fo, fd;
+                    __builtin_memcpy(fo.w, oe, 16);
+                    __builtin_memcpy(fd.w, de, 16);
+                    st16(orow + l, fo);
+                    st16(drow + l, fd);
+                } else {
+                    HY_UNROLL
+                    for (int i = 0; i < 8; ++i) {
+                        if (l + i < a.L) { orow[l + i] = oe[i]; drow[l + i] = de[i]; }
+                    }
+                }
+            }
+        }
+        HY_WAVE_SYNC_PJ();                        // the tile is re-written in the next round
+    }
+    // ---- the run's partial sums: over the 8 lanes (pieces) of a channel, fixed order; one record per (channel, run) ----
+    HY_UNROLL
+    for (int m = 0; m < DG_M; ++m) {
+        float v[5] = {sdw0[m], sdw1[m], sdw2[m], sdbs[m], sdbi[m]};
+        HY_UNROLL
+        for (int f = 0; f < 5; ++f) {
+            HY_UNROLL
+            for (int o = 1; o < 8; o <<= 1) v[f] += u2f(HY_SHFL_U32(f2u(v[f]), lane ^ o));
+        }
+        if (pc == 0) {
+            float* rec = a.part + ((size_t)(d0 + (lane >> 3) + 8 * m) * a.nrec + run) * 8;
+            HY_UNROLL
+            for (int f = 0; f < 5; ++f) rec[f] = v[f];
+        }
+    }
+}
+
 }  // namespace pj
 }  // namespace hyena

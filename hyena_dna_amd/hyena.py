@@ -27,7 +27,12 @@ from .projection import hyena_linear, in_proj_cm, in_proj_pre_cm, out_proj_cm
 # the out_proj GEMM, no transposes anywhere: csrc/cm_kernels.h) or the reference's position-major (B, L, 3D) with the
 # transposes fused into the shell kernels (csrc/mixer_kernels.h).  HYENA_MIXER_LAYOUT=position selects the latter (A/B).
 CHANNEL_MAJOR = os.environ.get("HYENA_MIXER_LAYOUT", "channel").lower() != "position"
-ADD_NORM_FUSED = os.environ.get("HYENA_ADD_NORM_FUSED", "1") != "0"      # A/B knob: 0 = out_proj writes its output, the block's add + LayerNorm reads it back
+# Round 5: out_proj's kernel can carry the block's residual add + LayerNorm in its epilogue (HyenaOperator.forward_add_norm; bit-identical
+# results).  MEASURED SLOWER and therefore OFF by default (profiles/r5c_outproj_addnorm_not_kept.txt: 1 576 us against 594 + 658 us for the two
+# launches at L = 2^20, model step 161.3 against 157.4 ms): the matrix-core kernel runs two wavefronts per SIMD with 128 weight registers each, so
+# the row phase -- eight rows per wavefront, two six-step wavefront reductions per row behind a residual load -- has nothing to hide its latency
+# behind, while the stand-alone pass streams the same bytes at 5 TB/s with sixteen wavefronts per SIMD.  HYENA_ADD_NORM_FUSED=1 turns it on.
+ADD_NORM_FUSED = os.environ.get("HYENA_ADD_NORM_FUSED", "0") == "1"
 
 __all__ = ["HyenaOperator", "HyenaFilter", "PositionalEmbedding", "ExponentialModulation", "Sin"]
 

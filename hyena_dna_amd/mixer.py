@@ -148,6 +148,7 @@ def hyena_mixer_core_cm(xT, b_in, sf_weight, sf_bias, k, bias, L, vg=None):
 import os as _os
 
 OUTPROJ_MFMA = _os.environ.get("HYENA_OUTPROJ_MFMA", "1") != "0"      # A/B knob: 0 = cm_post_fwd + library GEMM
+DGRAD_MFMA = _os.environ.get("HYENA_OUTPROJ_DGRAD_MFMA", "1") != "0"   # A/B knob: 0 = library GEMM (dz^T) + cm_post_bwd
 
 
 def mixer_out_supported(xT, L, out_weight):
@@ -240,20 +241,28 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
             dbo = _lib.colsum(dy2).to(bo_dtype)
         if not any(ctx.needs_input_grad[:6]):
             return (None, None, None, None, None, None, None, None, dW, dbo) + norm_grads
-        dzT = cm_from_pm(wo.t(), dy2, B, L)                                # channel-major (pitched rows), straight from the GEMM
         # ---- the core's backward (HyenaMixerCMFunc.backward) ----
         dxT = _lib.empty_like_rows(xc)
         if Lx > L:
             dxT.zero_()
         part = _lib.cm_partials(xc, L)
-        dy = _lib.cm_post_bwd(dzT, y, xc, bi, w, b, dxT, part)
+        part0 = None
+        if DGRAD_MFMA and _lib.outproj_dgrad_supported(B, L, D, xc.dtype):
+            # dz^T = W_out^T dy^T and the gate's backward in ONE matrix-core kernel: dz^T is never written (csrc/proj_kernels.h, round 5)
+            dy, part0 = _lib.outproj_dgrad_gate_bwd(dy2, wo.t().contiguous(), y, xc, bi, w, b, dxT)
+        else:
+            dzT = cm_from_pm(wo.t(), dy2, B, L)                            # channel-major (pitched rows), straight from the GEMM
+            dy = _lib.cm_post_bwd(dzT, y, xc, bi, w, b, dxT, part)
         need_vg = ctx.spectra is None or _lib.lib().hyena_fftconv_plan(int(L)) == _lib.PLAN_ONCHIP
         vg = _lib.cm_pre_fwd(xc, bi, w, b, L) if need_vg else None
         need_dk = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
         dvg, dk, dbias = _lib.fftconv_bwd(dy, vg, kf, bf, need_du=True, need_dk=need_dk, saved=ctx.spectra)
         ctx.spectra = None
         _lib.cm_pre_bwd(dvg, xc, bi, w, b, dxT, part)
-        red = part[:, :, :5].sum(dim=1)
+        if part0 is None:
+            red = part[:, :, :5].sum(dim=1)
+        else:                                                              # channels [0, D): the dgrad kernel's per-run records
+            red = torch.cat([part0[:, :, :5].sum(dim=1), part[D:, :, :5].sum(dim=1)], dim=0)
         dw = red[:, :3].reshape(w_shape).to(w_dtype)
         db = red[:, 3].to(b_dtype)
         dbin = red[:, 4].to(bin_dtype)

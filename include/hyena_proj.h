@@ -71,6 +71,24 @@ int hyena_outproj_gate_addnorm_fwd_ld(const void* y, const void* xT, const float
                                       int ldx, int lda, int dtype, void* stream);
 
 
+/* ---- out_proj's input gradient with the second gate's backward in its epilogue (round 5) ---------------------------------------------
+ * The backward of the lines hyena_outproj_gate_fwd replaces (hyena.py:432-440) up to the long convolution, in ONE launch (until round 5: a
+ * library GEMM writing dz^T = W_out^T dy^T, then hyena_cm_post_bwd reading it back):
+ *     dz^T = round16(W_out^T dy^T)                     (never written)
+ *     dyc[b, d, l] = dz * x0c                          gradient of the long convolution's output          (B, D, L), row pitch lda
+ *     dxT[d, b, m] = w2 g[m] + w1 g[m + 1] + w0 g[m + 2],  g = dz * y      rows [0, D) of (3D, B, Lx), positions < L, row pitch ldx
+ *     part[d][run][8] = per-run partial sums of (dw0, dw1, dw2, db_sc, db_in) of the x0 channels' short filter / in_proj bias;
+ *                       hyena_outproj_dgrad_partial_floats(B, L, D) floats = D x runs x 8; summing axis 1 gives the gradients (fixed order).
+ * dy (B L, D) 16-bit; Wt (D, D) = out_proj.weight TRANSPOSED, contiguous; y, xT, bin, w, b as for hyena_outproj_gate_fwd_ld.
+ * Values: those of the unfused pair up to the summation order inside the product (dz^T within one 16-bit ulp of the library GEMM's, identical
+ * almost everywhere); given the same dz^T, dyc and dxT are hyena_cm_post_bwd's bits.  D in {128, 256}, 16-bit types, any L >= 1. */
+int hyena_outproj_dgrad_supported(int B, int L, int D, int dtype);
+size_t hyena_outproj_dgrad_partial_floats(int B, int L, int D);
+int hyena_outproj_dgrad_gate_bwd_ld(const void* dy, const void* Wt, const void* y, const void* xT, const float* bin, const float* w,
+                                    const float* b, void* dyc, void* dxT, float* part, int B, int L, int Lx, int D, int ldx, int lda,
+                                    int dtype, void* stream);
+
+
 /* ---- the block's MLP (flash_attn.modules.mlp.Mlp = simple_lm.py:191-211; long_conv_lm.py:117-123: fc1 -> tanh-GELU -> fc2) ---------
  * The two products contracting over d_model, position-major, with the reference's element-wise passes in their epilogues:
  *   forward   a = x W1^T + b1,  h = gelu_tanh(a)          x (P, K), W1 (N, K), b1 (N,) fp32 or NULL [values already rounded to the

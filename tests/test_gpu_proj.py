@@ -198,3 +198,63 @@ def test_operator_uses_the_fused_out_proj_and_matches_the_library_path(gpu_lib, 
     assert len(calls) == 1 and len(res[0]) == len(res[1])
     for a, b_ in zip(*res):
         assert ((a - b_).norm() / b_.norm().clamp_min(1e-20)).item() < 1.5e-2
+
+
+@pytest.mark.parametrize("B,L,D,dtype", [(8, 32767, 256, torch.bfloat16), (2, 159999, 256, torch.bfloat16), (1, 1048575, 256, torch.bfloat16),
+                                         (1, 1048576, 256, torch.bfloat16), (3, 4099, 128, torch.float16), (2, 65, 128, torch.bfloat16)])
+def test_out_proj_dgrad_with_the_gate_backward_on_gpu(gpu_lib, B, L, D, dtype):
+    """hyena_outproj_dgrad_gate_bwd_ld (round 5) against the pair it replaces -- library GEMM dz^T = W_out^T dy^T, then cm_post_bwd -- on the
+    gfx950 binary at the contract shapes incl. the reference trainer's odd lengths: with operands whose dz^T is exact in any summation
+    order d y_conv and d xT are the pair's bits; with random operands they agree to the rounding flips of dz^T; determinism."""
+    from hyena_dna_amd.projection import cm_from_pm
+    dev = torch.device("cuda", 0)
+    for exact in (True, False):
+        g = torch.Generator(device=dev).manual_seed(L + D + exact)
+        rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
+        if exact:
+            dy2 = torch.randint(-1, 2, (B * L, D), generator=g, device=dev).to(dtype)
+            Wo = torch.randint(-1, 2, (D, D), generator=g, device=dev).to(dtype)
+        else:
+            dy2, Wo = rn(B * L, D).to(dtype), (rn(D, D) / D ** 0.5).to(dtype)
+        y = gpu_lib.empty_rows((B, D), L, dtype, dev).copy_(rn(B, D, L).to(dtype))
+        xT = gpu_lib.empty_rows((3 * D, B), L, dtype, dev).copy_(rn(3 * D, B, L).to(dtype))
+        bin_, w, b = rn(3 * D) * 0.1, rn(3 * D, 3) * 0.5, rn(3 * D) * 0.1
+        dx_f, dx_u = gpu_lib.empty_like_rows(xT).fill_(7.0), gpu_lib.empty_like_rows(xT).fill_(7.0)
+        dyc, part0 = gpu_lib.outproj_dgrad_gate_bwd(dy2, Wo.t().contiguous(), y, xT, bin_, w, b, dx_f)
+        dzT = cm_from_pm(Wo.t(), dy2, B, L)
+        part = gpu_lib.cm_partials(xT, L)
+        dy_u = gpu_lib.cm_post_bwd(dzT, y, xT, bin_, w, b, dx_u, part)
+        assert (dx_f[D:] == 7.0).all()
+        red_f, red_u = part0[:, :, :5].sum(1), part[:D, :, :5].sum(1)
+        if exact:
+            assert torch.equal(dyc, dy_u) and torch.equal(dx_f[:D], dx_u[:D])
+            assert (red_f - red_u).abs().max() <= 1e-4 * red_u.abs().max() + 1e-3
+            dx_2 = gpu_lib.empty_like_rows(xT).fill_(7.0)
+            dyc2, part2 = gpu_lib.outproj_dgrad_gate_bwd(dy2, Wo.t().contiguous(), y, xT, bin_, w, b, dx_2)
+            assert torch.equal(dyc, dyc2) and torch.equal(dx_f[:D], dx_2[:D]) and torch.equal(part0, part2)
+        else:
+            eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+            for got, ref in ((dyc, dy_u), (dx_f[:D], dx_u[:D])):
+                assert (got != ref).float().mean().item() < 0.03
+                assert ((got.float() - ref.float()).abs() <= eps * ref.float().abs() + 2e-2).all()
+            assert (red_f - red_u).abs().max() <= 2e-2 * red_u.abs().max()
+
+
+@pytest.mark.parametrize("B,L,D,dtype", [(8, 32767, 256, torch.bfloat16), (1, 1048575, 256, torch.bfloat16), (2, 4099, 128, torch.float16)])
+def test_out_proj_with_add_norm_epilogue_on_gpu(gpu_lib, B, L, D, dtype):
+    """hyena_outproj_gate_addnorm_fwd_ld (round 5; off by default -- measured slower, profiles/r5c_outproj_addnorm_not_kept.txt): all five outputs
+    are the bits of hyena_outproj_gate_fwd_ld followed by hyena_add_norm_fwd"""
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(L + D)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
+    y = gpu_lib.empty_rows((B, D), L, dtype, dev).copy_(rn(B, D, L).to(dtype))
+    xT = gpu_lib.empty_rows((3 * D, B), L, dtype, dev).copy_(rn(3 * D, B, L).to(dtype))
+    bin_, w, b = rn(3 * D) * 0.1, rn(3 * D, 3) * 0.5, rn(3 * D) * 0.1
+    W = (rn(D, D) / D ** 0.5).to(dtype)
+    bias = (rn(D) * 0.1).to(dtype).float()
+    res, lw, lb = rn(B * L, D) * 3, 1.0 + 0.1 * rn(D), 0.1 * rn(D)
+    o, z = gpu_lib.outproj_gate_fwd(y, xT, bin_, w, b, W, bias, want_z=True)
+    two = gpu_lib.add_norm_fwd(o.view(B * L, D), res, lw, lb, 1e-5, dtype) + (z,)
+    one = gpu_lib.outproj_gate_addnorm_fwd(y, xT, bin_, w, b, W, bias, True, res, lw, lb, 1e-5)
+    for p, q in zip(two, one):
+        assert torch.equal(p.reshape(-1), q.reshape(-1))

@@ -278,12 +278,14 @@ def test_ragged_length_policy_of_the_fused_out_proj(emu_backend, monkeypatch):
 
 @pytest.mark.parametrize("B,L,D,dtype,with_res", [(2, 127, 128, torch.bfloat16, True), (1, 200, 256, torch.float16, True),
                                                   (3, 64, 128, torch.bfloat16, False), (1, 321, 256, torch.bfloat16, True)])
-def test_out_proj_with_the_blocks_add_norm_in_its_epilogue(emu_backend, B, L, D, dtype, with_res):
+def test_out_proj_with_the_blocks_add_norm_in_its_epilogue(emu_backend, monkeypatch, B, L, D, dtype, with_res):
     """Round 5: the prenorm block's second residual add + LayerNorm (simple_lm.py:280-284) inside out_proj's matrix-core kernel
     (hyena_outproj_gate_addnorm_fwd_ld).  The epilogue repeats add_norm_fwd_kernel's arithmetic operation for operation on the rounded
     out_proj output, so hidden, residual' and EVERY gradient are the unfused route's bits (out_proj kernel -> AddLayerNormFunc)."""
+    import hyena_dna_amd.hyena as HY
     from hyena_dna_amd.block import dropout_add_layer_norm
     from hyena_dna_amd.hyena import HyenaOperator
+    monkeypatch.setattr(HY, "ADD_NORM_FUSED", True)           # (off by default: measured slower on the MI355X, profiles/r5c_outproj_addnorm_not_kept.txt)
     torch.manual_seed(11)
     op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10).to(dtype)
     lw = (1.0 + 0.1 * torch.randn(D)).requires_grad_(True)
@@ -312,3 +314,77 @@ def test_out_proj_with_the_blocks_add_norm_in_its_epilogue(emu_backend, B, L, D,
         assert torch.equal(a_, b_)
     # fp32 operands are not served: the caller falls back to forward + its own add + LayerNorm
     assert op.float().forward_add_norm(u0.float(), r0, lw, lb, 1e-5) is None
+
+
+def _dgrad_operands(B, L, Lx, D, dtype, seed, exact):
+    g = torch.Generator().manual_seed(seed)
+    if exact:      # values whose products and 256-term sums are exact in fp32 AND in the 16-bit type: dz^T is then the same in any summation order
+        dy2 = torch.randint(-1, 2, (B * L, D), generator=g).to(dtype)
+        Wo = torch.randint(-1, 2, (D, D), generator=g).to(dtype)
+    else:
+        dy2 = torch.randn(B * L, D, generator=g).to(dtype)
+        Wo = (torch.randn(D, D, generator=g) / D ** 0.5).to(dtype)
+    y = torch.randn(B, D, L, generator=g).to(dtype)
+    xT = torch.randn(3 * D, B, Lx, generator=g).to(dtype)
+    bin_ = torch.randn(3 * D, generator=g) * 0.1
+    w = torch.randn(3 * D, 3, generator=g) * 0.5
+    b = torch.randn(3 * D, generator=g) * 0.1
+    return dy2, Wo, y, xT, bin_, w, b
+
+
+@pytest.mark.parametrize("B,L,Lx,D,dtype", [(2, 127, 127, 128, torch.bfloat16), (1, 200, 203, 256, torch.float16), (3, 64, 64, 128, torch.bfloat16),
+                                            (1, 2500, 2500, 128, torch.bfloat16), (2, 1100, 1100, 256, torch.bfloat16), (2, 1, 3, 128, torch.float16),
+                                            (1, 65, 65, 256, torch.bfloat16)])
+def test_out_proj_dgrad_with_the_gate_backward_in_its_epilogue(emu_backend, B, L, Lx, D, dtype):
+    """Round 5: dz^T = W_out^T dy^T on the matrix cores with cm_post_bwd's work in the epilogue (hyena_outproj_dgrad_gate_bwd_ld): dz^T is
+    never written.  (a) operands whose dz^T is exact in any summation order: d y_conv and d xT are the unfused pair's BITS (library GEMM ->
+    cm_post_bwd), the short filter's partial sums agree to summation order; (b) random operands: dz^T differs from the library's by rounding
+    flips only -- the outputs agree to a 16-bit ulp almost everywhere.  Runs of several tiles walk DOWN through their sequence with a warm-up
+    tile above (L = 2500: three runs), sequences end inside tiles, pieces end inside pieces, rows are pitched."""
+    _lib = emu_backend
+    from hyena_dna_amd.projection import cm_from_pm
+    for exact in (True, False):
+        dy2, Wo, y, xT, bin_, w, b = _dgrad_operands(B, L, Lx, D, dtype, seed=L + D + exact, exact=exact)
+        yp, xp = _lib.empty_rows((B, D), L, dtype, y.device), _lib.empty_rows((3 * D, B), Lx, dtype, y.device)
+        yp.copy_(y)
+        xp.copy_(xT)
+        assert _lib.outproj_dgrad_supported(B, L, D, dtype)
+        dx_f, dx_u = _lib.empty_like_rows(xp).fill_(7.0), _lib.empty_like_rows(xp).fill_(7.0)
+        dyc, part0 = _lib.outproj_dgrad_gate_bwd(dy2, Wo.t().contiguous(), yp, xp, bin_, w, b, dx_f)
+        dzT = cm_from_pm(Wo.t(), dy2, B, L)
+        part = _lib.cm_partials(xp, L)
+        dy_u = _lib.cm_post_bwd(dzT, yp, xp, bin_, w, b, dx_u, part)
+        assert _lib.ld_of(dyc) == _lib.ld_of(yp)
+        assert (dx_f[D:] == 7.0).all() and (dx_f[:D, :, L:] == 7.0).all()              # only rows [0, D), positions < L are written
+        red_f, red_u = part0[:, :, :5].sum(1), part[:D, :, :5].sum(1)
+        if exact:
+            assert torch.equal(dyc, dy_u) and torch.equal(dx_f[:D, :, :L], dx_u[:D, :, :L])
+            assert (red_f - red_u).abs().max() <= 2e-5 * red_u.abs().max() + 1e-5
+        else:
+            for got, ref in ((dyc, dy_u), (dx_f[:D, :, :L], dx_u[:D, :, :L])):
+                diff = (got.float() - ref.float()).abs()
+                assert (got != ref).float().mean() < 0.03
+                assert (diff <= 2.0 ** (-7 if dtype == torch.bfloat16 else -10) * ref.float().abs() + 2e-2).all()
+            assert (red_f - red_u).abs().max() <= 2e-2 * red_u.abs().max()
+
+
+def test_operator_gradients_with_and_without_the_fused_dgrad(emu_backend, monkeypatch):
+    """the whole operator, training step: HYENA_OUTPROJ_DGRAD_MFMA on / off give the same gradients (to the rounding flips of dz^T)"""
+    import hyena_dna_amd.mixer as MX
+    from hyena_dna_amd.hyena import HyenaOperator
+    torch.manual_seed(9)
+    B, L, D = 2, 191, 128
+    op = HyenaOperator(d_model=D, l_max=L, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10).to(torch.bfloat16)
+    u0 = torch.randn(B, L, D).to(torch.bfloat16)
+    dy = torch.randn(B, L, D).to(torch.bfloat16)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(MX, "DGRAD_MFMA", on)
+        op.zero_grad(set_to_none=True)
+        u = u0.clone().requires_grad_(True)
+        op(u).backward(dy)
+        res.append({"du": u.grad.float(), **{n: p.grad.float() for n, p in op.named_parameters() if p.grad is not None}})
+    assert res[0].keys() == res[1].keys() and len(res[0]) > 10
+    for n in res[0]:
+        a_, b_ = res[0][n], res[1][n]
+        assert ((a_ - b_).norm() / b_.norm().clamp_min(1e-20)).item() < 2e-2, n
