@@ -61,7 +61,9 @@ void dgrad_schedule(int B, int L, int D, pj::DgArgs* a, int* runs_out, int* grid
     const int ncg = D / (pj::PJ_WAVES * pj::DG_CB);
     a->tiles_per_seq = (L + pj::PJ_NT - 1) / pj::PJ_NT;
     a->tiles = B * a->tiles_per_seq;
-    int runs = 256 * 4 / ncg;
+    // ONE round of resident workgroups (DG_WGS per CU): a second, partly filled round costs up to half the launch (160 000 x 2: 640 workgroups
+    // on 512 slots ran at 2.6 TB/s); runs of at least 16 tiles amortise the weight load and the warm-up tile
+    int runs = 256 * DG_WGS / ncg;
     if (runs > a->tiles) runs = a->tiles;
     a->tiles_per_wg = (a->tiles + runs - 1) / runs;
     if (a->tiles_per_wg < 16 && a->tiles >= 16) a->tiles_per_wg = 16;

@@ -1246,8 +1246,12 @@ struct DgArgs {
     int tiles_per_seq, tiles, tiles_per_wg, nrec;
 };
 
+#ifndef DG_WGS
+#define DG_WGS 2                 // workgroups per CU the kernel is compiled for.  3 (<= 168 registers, 16 of them spilled) measured 756 vs 800 us at
+                                 // L = 2^20 but 250 vs 190 us at 32768 x 8 and 266 vs 224 us at 160000 x 2 (profiles/r5e_outproj_dgrad.txt)
+#endif
 template <int K, int DT>
-__global__ void __launch_bounds__(PJ_THREADS, 2) outproj_dgrad_gate_bwd_kernel(DgArgs a) {
+__global__ void __launch_bounds__(PJ_THREADS, DG_WGS) outproj_dgrad_gate_bwd_kernel(DgArgs a) {
     typedef DgCfg<K> C;
     typedef typename Elem<DT>::type elem_t;
     static_assert(sizeof(elem_t) == 2, "16-bit element types only");
@@ -1281,13 +1285,19 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_dgrad_gate_bwd_kernel(D
     }
     // this lane's DG_M (channel, piece) pairs: channel (lane >> 3) + 8 m, positions 8 (lane & 7) .. + 7 of the tile
     const int pc = lane & 7;
-    float tw0[DG_M], tw1[DG_M], tw2[DG_M], tbs[DG_M], tbi[DG_M];
+    // the channels' short-filter taps live in the 16 spare bytes behind each row of the epilogue tile (w0, w1, w2, b_sc), the in_proj bias in a register
+    float tbi[DG_M];
     HY_UNROLL
     for (int m = 0; m < DG_M; ++m) {
         const int c = d0 + (lane >> 3) + 8 * m;
-        tw0[m] = a.w[c * 3]; tw1[m] = a.w[c * 3 + 1]; tw2[m] = a.w[c * 3 + 2]; tbs[m] = a.b[c];
         tbi[m] = a.bin != nullptr ? a.bin[c] : 0.f;
     }
+    if (lane < DG_CB) {
+        HY_LDS float* tp = reinterpret_cast<HY_LDS float*>(ebuf + lane * C::EROW + PJ_NT * 2);
+        const int c = d0 + lane;
+        tp[0] = a.w[c * 3]; tp[1] = a.w[c * 3 + 1]; tp[2] = a.w[c * 3 + 2]; tp[3] = a.b[c];
+    }
+    HY_WAVE_SYNC_PJ();
     float sdw0[DG_M], sdw1[DG_M], sdw2[DG_M], sdbs[DG_M], sdbi[DG_M];      // partial sums of the run
     float cr0[DG_M], cr1[DG_M];                                             // g at the first two positions of the tile above (held by the piece-0 lanes)
     HY_UNROLL
@@ -1395,12 +1405,14 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_dgrad_gate_bwd_kernel(D
             float dz[8], g8[10], c0[8];
             HY_UNROLL
             for (int i = 0; i < 8; ++i) dz[i] = Elem<DT>::dec(dze[i]);
+            const HY_LDS float* tp = reinterpret_cast<const HY_LDS float*>(ebuf + ch * C::EROW + PJ_NT * 2);
+            const float tw0 = tp[0], tw1 = tp[1], tw2 = tp[2], tbs = tp[3];
             HY_UNROLL
             for (int i = 0; i < 8; ++i) {
                 const int li = l + i;
                 const float x0 = li >= 2 ? Elem<DT>::dec(xe[i]) + tbi[m] : 0.f, x1 = li >= 1 ? Elem<DT>::dec(xe[i + 1]) + tbi[m] : 0.f,
                             x2 = Elem<DT>::dec(xe[i + 2]) + tbi[m];
-                c0[i] = __builtin_fmaf(tw2[m], x2, __builtin_fmaf(tw1[m], x1, __builtin_fmaf(tw0[m], x0, tbs[m])));       // = cm_sc
+                c0[i] = __builtin_fmaf(tw2, x2, __builtin_fmaf(tw1, x1, __builtin_fmaf(tw0, x0, tbs)));       // = cm_sc
                 g8[i] = dz[i] * Elem<DT>::dec(ye[i]);                                                                  // zero beyond L: dz is
                 if (keep) {
                     sdw0[m] += g8[i] * x0; sdw1[m] += g8[i] * x1; sdw2[m] += g8[i] * x2; sdbs[m] += g8[i];            // = cm_sc_bwd
@@ -1419,7 +1431,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_dgrad_gate_bwd_kernel(D
                 HY_UNROLL
                 for (int i = 0; i < 8; ++i) {
                     oe[i] = Elem<DT>::cvt(dz[i] * c0[i]);                                                                              // = cm_post_bwd's dy
-                    const float dx = __builtin_fmaf(tw0[m], g8[i + 2], __builtin_fmaf(tw1[m], g8[i + 1], tw2[m] * g8[i]));         // = cm_sc_bwd's dx
+                    const float dx = __builtin_fmaf(tw0, g8[i + 2], __builtin_fmaf(tw1, g8[i + 1], tw2 * g8[i]));         // = cm_sc_bwd's dx
                     if (l + i < a.L) sdbi[m] += dx;
                     de[i] = Elem<DT>::cvt(dx);
                 }

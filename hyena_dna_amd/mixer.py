@@ -148,7 +148,20 @@ def hyena_mixer_core_cm(xT, b_in, sf_weight, sf_bias, k, bias, L, vg=None):
 import os as _os
 
 OUTPROJ_MFMA = _os.environ.get("HYENA_OUTPROJ_MFMA", "1") != "0"      # A/B knob: 0 = cm_post_fwd + library GEMM
-DGRAD_MFMA = _os.environ.get("HYENA_OUTPROJ_DGRAD_MFMA", "1") != "0"   # A/B knob: 0 = library GEMM (dz^T) + cm_post_bwd
+# out_proj's input gradient with the gate backward in its epilogue (csrc/proj_kernels.h::outproj_dgrad_gate_bwd_kernel, round 5) against the pair
+# it can replace, library GEMM (dz^T) + cm_post_bwd, measured on the MI355X (profiles/r5e_outproj_dgrad.txt): the kernel wins where the library
+# needs one product per sequence -- several sequences on pitched rows: 32767 x 8 190 vs 292 us, 159999 x 2 224 vs 281 us -- and at 32768 x 8
+# (190 vs 205 us); it loses at B = 1 (L = 2^20: 756 - 800 vs 719 us; the pair streams its bytes at 4.9 TB/s, the matrix-core kernel at 3.4 - 3.6).
+# "auto" (default) takes it exactly where it wins; HYENA_OUTPROJ_DGRAD_MFMA=1 / 0 forces it on / off.
+DGRAD_MFMA = {"1": True, "0": False}.get(_os.environ.get("HYENA_OUTPROJ_DGRAD_MFMA", "auto"), "auto")
+
+
+def _dgrad_fused(B, L, D, y, dtype):
+    if DGRAD_MFMA is False or not _lib.outproj_dgrad_supported(B, L, D, dtype):
+        return False
+    if DGRAD_MFMA is True:
+        return True
+    return B >= 2 and (_lib.ld_of(y) != L or B >= 8)
 
 
 def mixer_out_supported(xT, L, out_weight):
@@ -247,7 +260,7 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
             dxT.zero_()
         part = _lib.cm_partials(xc, L)
         part0 = None
-        if DGRAD_MFMA and _lib.outproj_dgrad_supported(B, L, D, xc.dtype):
+        if _dgrad_fused(B, L, D, y, xc.dtype):
             # dz^T = W_out^T dy^T and the gate's backward in ONE matrix-core kernel: dz^T is never written (csrc/proj_kernels.h, round 5)
             dy, part0 = _lib.outproj_dgrad_gate_bwd(dy2, wo.t().contiguous(), y, xc, bi, w, b, dxT)
         else:

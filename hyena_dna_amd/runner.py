@@ -397,6 +397,19 @@ def build_dataset(cfg, split="train"):
                        replace_N_token=d.get("replace_N_token", False), pad_interval=d.get("pad_interval", False))
 
 
+def precision_dtype(precision):
+    """trainer.precision -> the autocast type (None: no autocast).  Lightning 1.8.6 spellings: 16 / "16" / "16-mixed" -> float16 (with a loss
+    scaler, see train), "bf16" / "bf16-mixed" -> bfloat16, 32 / "32" / "32-true" -> None."""
+    p = str(precision)
+    if p in ("16", "16-mixed"):
+        return torch.float16
+    if p in ("bf16", "bf16-mixed"):
+        return torch.bfloat16
+    if p in ("32", "32-true"):
+        return None
+    raise ValueError(f"trainer.precision={precision!r}: expected 16, bf16 or 32")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the loop
 # ---------------------------------------------------------------------------------------------------------------------
@@ -424,10 +437,14 @@ def train(cfg, max_steps, device, graphed=False, log_every=10, log=print):
     tr = cfg.get("trainer", {})
     accum = max(1, int(tr.get("accumulate_grad_batches", 1) or 1))
     clip = float(tr.get("gradient_clip_val", 0.0) or 0.0)
-    # trainer.precision 16 is fp16 AMP with a loss scaler on the reference's GPUs ("bf16 only a100", hg38_hyena.yaml:39); the
-    # MI355X path trains in bf16 autocast, which needs no scaler
-    amp = str(tr.get("precision", 32)) in ("16", "bf16", "16-mixed", "bf16-mixed")
+    # trainer.precision (hg38_hyena.yaml:41 `precision: 16`; PyTorch Lightning 1.8.6's native AMP plugin): 16 = float16 autocast WITH a
+    # dynamic loss scaler (torch.amp.GradScaler, PyTorch's defaults: 65536, x2 every 2000 clean steps, / 2 and the update skipped on an inf / nan
+    # gradient; gradients are unscaled before clipping, as Lightning does); bf16 = bfloat16 autocast, no scaler (the yaml's own comment:
+    # "bf16 only a100" -- what the MI355X benchmarks of this repository run); 32 = no autocast.  Round 5: until then 16 was mapped to bf16.
+    amp_dtype = precision_dtype(tr.get("precision", 32))
+    amp = amp_dtype is not None
     dev_type = device.type
+    scaler = torch.amp.GradScaler(dev_type, enabled=True) if (amp_dtype == torch.float16 and dev_type == "cuda") else None
     log(f"[runner] params {sum(p.numel() for p in model.parameters())}, groups "
         f"{[(len(g['params']), g['lr'] if not torch.is_tensor(g['lr']) else float(g['lr']), g['weight_decay']) for g in opt.param_groups]}, "
         f"accumulate {accum}, clip {clip}, gpu_mem {cfg.get('train', {}).get('gpu_mem')}")
@@ -446,11 +463,14 @@ def train(cfg, max_steps, device, graphed=False, log_every=10, log=print):
     if graphed:
         if accum != 1 or world != 1:
             raise NotImplementedError("graphed=True captures one micro-batch per update on one GPU")
+        if scaler is not None:
+            raise NotImplementedError("graphed=True with trainer.precision=16: the loss scaler's skipped updates are decided on the host; "
+                                      "capture bf16 (trainer.precision=bf16) or fp32 steps")
         from .lm import GraphedTrainStep
         x, y = next(it)
         # the capture's warm-up updates are undone (parameters, moments, step counters: lm.GraphedTrainStep), and the batch it warmed up on
         # is the first counted step's batch: a graphed and an eager run of the same config + seed follow the same trajectory
-        step = GraphedTrainStep(model, opt, x, y, autocast_dtype=torch.bfloat16 if amp else None, warmup=2, clip_grad_norm=clip)
+        step = GraphedTrainStep(model, opt, x, y, autocast_dtype=amp_dtype, warmup=2, clip_grad_norm=clip)
         for i in range(max_steps):
             if i > 0:
                 x, y = next(it)
@@ -470,18 +490,26 @@ def train(cfg, max_steps, device, graphed=False, log_every=10, log=print):
             # hg38_hyena resolves it to >= 64, so all-reducing every micro-batch would multiply the collective traffic by that)
             hold = net.no_sync() if (world > 1 and a + 1 < accum) else contextlib.nullcontext()
             with hold:
-                with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=amp and dev_type == "cuda"):
+                with torch.autocast(dev_type, dtype=amp_dtype or torch.bfloat16, enabled=amp and dev_type == "cuda"):
                     logits = net(x)[0].logits
                     loss = _token_cross_entropy()(logits, y)
-                (loss / accum).backward()
+                micro = loss / accum
+                (scaler.scale(micro) if scaler is not None else micro).backward()
             total += float(loss.detach()) / accum
-        if clip > 0:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
-        opt.step()
+        if scaler is not None:
+            if clip > 0:
+                scaler.unscale_(opt)                              # clip the TRUE gradients (Lightning: precision_plugin.pre_optimizer_step -> unscale, then clip)
+                torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+            scaler.step(opt)                                      # skipped when a gradient overflowed in fp16
+            scaler.update()
+        else:
+            if clip > 0:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+            opt.step()
         if sched is not None:
             sched.step()
         losses.append(total)
         if (i + 1) % log_every == 0:
             log(f"[runner] step {i + 1} loss {total:.4f} lr {opt.param_groups[0]['lr']:.3e} "
-                f"({(time.perf_counter() - t0) / (i + 1) * 1e3:.1f} ms/step)")
+                f"({(time.perf_counter() - t0) / (i + 1) * 1e3:.1f} ms/step)" + (f" loss scale {scaler.get_scale():.0f}" if scaler is not None else ""))
     return losses

@@ -220,3 +220,30 @@ def test_embedding_inside_the_first_add_norm_pass_on_gpu(gpu_lib, shape, D, V, o
     assert rel(gt, ht) < 1e-5 and rel(gw, hw) < 1e-5 and rel(gb, hb) < 1e-5
     gt2, _, _ = torch.autograd.grad(EmbedAddLayerNormFunc.apply(ids, table, weight, bias, 1e-5, odt, *args), [table, weight, bias], [dout, dres])
     assert torch.equal(gt2, gt)                                                                             # deterministic
+    # ... and DIRECTLY against the graph it replaces, in float64 (not only against this package's own unfused pass):
+    #     F.embedding -> dropout mask -> (no residual yet) -> layer_norm, the mask being Philox4x32-10(seed, element index) >= p 2^32
+    from tests.test_block_emu import _philox4x32_10
+    kept = torch.ones(shape + (D,), dtype=torch.bool, device=dev)
+    if p > 0:
+        kept = res.detach() != 0                            # (N(0, 1) table entries: a kept element is never exactly zero)
+        sv = int(seed.item())
+        k0, k1, thr = sv & 0xFFFFFFFF, (sv >> 32) & 0xFFFFFFFF, int(p * 4294967296.0)
+        want = [w_ >= thr for i4 in range(256) for w_ in _philox4x32_10(i4, 0, k0, k1)]
+        assert kept.reshape(-1)[:1024].cpu().tolist() == want
+        assert abs(kept.float().mean().item() - (1 - p)) < 2e-2
+    t64 = table.detach().double().requires_grad_(True)
+    w64, b64 = weight.detach().double().requires_grad_(True), bias.detach().double().requires_grad_(True)
+    res_r = F.embedding(ids, t64) * kept * (1.0 / (1.0 - p))
+    out_r = F.layer_norm(res_r, (D,), w64, b64, 1e-5)
+    assert rel(res, res_r) < 1e-7 and rel(out, out_r) < (2e-6 if odt == torch.float32 else (5e-3 if odt == torch.bfloat16 else 6e-4))
+    ft, fw, fb = torch.autograd.grad([out_r, res_r], [t64, w64, b64], [dout.double(), dres.double()])
+    assert rel(gt, ft) < 1e-5 and rel(gw, fw) < 1e-4 and rel(gb, fb) < 1e-4
+    # an id outside [0, V) reads no memory: its row comes back as NaN (F.embedding device-asserts there), every other row untouched
+    bad = ids.clone()
+    bad.view(-1)[5] = V
+    bad.view(-1)[11] = -1
+    out_b, res_b = EmbedAddLayerNormFunc.apply(bad, table.detach(), weight.detach(), bias.detach(), 1e-5, odt, *args)
+    rows = torch.ones(ids.numel(), dtype=torch.bool, device=dev)
+    rows[5] = rows[11] = False
+    assert torch.isnan(res_b.reshape(-1, D)[~rows]).all() and torch.isnan(out_b.reshape(-1, D)[~rows].float()).all()
+    assert torch.equal(res_b.reshape(-1, D)[rows], res.detach().reshape(-1, D)[rows])

@@ -63,3 +63,23 @@ def test_graphed_runner_follows_the_eager_runner(gpu_lib, genome):
     eager = runner.train(cfg, 6, dev, graphed=False, log=lambda *_: None)
     graphed = runner.train(cfg, 6, dev, graphed=True, log=lambda *_: None)
     assert all(abs(a - b) <= 5e-3 * abs(a) for a, b in zip(eager, graphed)), (eager, graphed)
+
+
+def test_runner_precision_16_is_fp16_with_a_loss_scaler(gpu_lib, genome):
+    """hg38_hyena.yaml:41 `precision: 16` under PyTorch Lightning 1.8.6 = float16 autocast + a dynamic loss scaler (the
+    runner used to train bf16 there).  12 updates through the fp16 kernels (filter16, matrix-core projections / MLP, long conv with fp16
+    rows): finite, falling loss; the scaler is live (its scale is logged and stays a power of two); the trajectory stays near the bf16 one."""
+    from hyena_dna_amd import runner
+    dev = torch.device("cuda", 0)
+    assert runner.precision_dtype(16) == torch.float16 and runner.precision_dtype("bf16") == torch.bfloat16 and runner.precision_dtype(32) is None
+    base = [o for o in OVERRIDES if not o.startswith("trainer.precision")] + genome
+    logs = []
+    fp16 = runner.train(runner.compose(COMPOSED, overrides=base + ["trainer.precision=16"]), 12, dev, log_every=4, log=logs.append)
+    bf16 = runner.train(runner.compose(COMPOSED, overrides=base + ["trainer.precision=bf16"]), 12, dev, log=lambda *_: None)
+    assert len(fp16) == 12 and all(l == l and l < 3.0 for l in fp16)
+    assert sum(fp16[-3:]) / 3 < 0.97 * sum(fp16[:3]) / 3, fp16
+    scales = [float(l.split("loss scale")[1]) for l in logs if "loss scale" in l]
+    assert scales and all(s_ >= 1.0 and (s_ == 2.0 ** round(__import__("math").log2(s_))) for s_ in scales), logs
+    assert abs(fp16[0] - bf16[0]) < 2e-2 and abs(sum(fp16[-3:]) - sum(bf16[-3:])) / 3 < 0.15, (fp16, bf16)
+    with pytest.raises(NotImplementedError):
+        runner.train(runner.compose(COMPOSED, overrides=base + ["trainer.precision=16"]), 2, dev, graphed=True, log=lambda *_: None)

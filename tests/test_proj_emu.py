@@ -378,6 +378,8 @@ def test_operator_gradients_with_and_without_the_fused_dgrad(emu_backend, monkey
     u0 = torch.randn(B, L, D).to(torch.bfloat16)
     dy = torch.randn(B, L, D).to(torch.bfloat16)
     res = []
+    assert MX._dgrad_fused(2, 191, 128, emu_backend.empty_rows((2, 128), 191, torch.bfloat16, "cpu"), torch.bfloat16)          # "auto": pitched, B >= 2
+    assert not MX._dgrad_fused(1, 191, 128, emu_backend.empty_rows((1, 128), 191, torch.bfloat16, "cpu"), torch.bfloat16)      # B = 1: the library pair
     for on in (True, False):
         monkeypatch.setattr(MX, "DGRAD_MFMA", on)
         op.zero_grad(set_to_none=True)
