@@ -156,35 +156,36 @@ def lib():
         L.hyena_cm_pre_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int, c_int, c_int, c_int, c_int, c_void_p]
         L.hyena_cm_pre_fwd_ld.restype = c_int
-        L.hyena_cm_pre_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                          c_void_p]
+        L.hyena_cm_pre_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_long, c_int, c_int,
+                                          c_int, c_void_p]
         L.hyena_cm_post_fwd_ld.restype = c_int
-        L.hyena_cm_post_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                           c_int, c_void_p]
+        L.hyena_cm_post_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_long, c_int,
+                                           ctypes.c_long, c_int, c_int, c_int, c_void_p]
         L.hyena_cm_post_bwd_ld.restype = c_int
         L.hyena_cm_post_bwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+                                           c_int, c_int, c_int, c_int, ctypes.c_long, c_int, ctypes.c_long, c_int, c_int, c_int, c_void_p]
         L.hyena_cm_pre_bwd_ld.restype = c_int
         L.hyena_cm_pre_bwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+                                          c_int, c_int, c_int, c_int, ctypes.c_long, c_int, c_int, c_int, c_void_p]
         # input projection on the matrix cores + front of the shell (include/hyena_proj.h)
         L.hyena_inproj_pre_fwd_ld.restype = c_int
         L.hyena_inproj_pre_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+                                              c_int, c_int, c_int, c_int, ctypes.c_long, c_int, c_int, c_int, c_void_p]
         L.hyena_outproj_gate_addnorm_fwd_ld.restype = c_int
         L.hyena_outproj_gate_addnorm_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                         c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+                                                        c_int, c_int, c_int, c_int, ctypes.c_long, c_int, ctypes.c_long, c_int, c_int, c_int,
+                                                        c_void_p]
         L.hyena_outproj_dgrad_supported.restype = c_int
         L.hyena_outproj_dgrad_supported.argtypes = [c_int, c_int, c_int, c_int]
         L.hyena_outproj_dgrad_partial_floats.restype = c_size_t
         L.hyena_outproj_dgrad_partial_floats.argtypes = [c_int, c_int, c_int]
         L.hyena_outproj_dgrad_gate_bwd_ld.restype = c_int
         L.hyena_outproj_dgrad_gate_bwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                      c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+                                                      c_void_p, c_int, c_int, c_int, c_int, ctypes.c_long, c_int, c_int, c_int, c_void_p]
         L.hyena_outproj_gate_fwd_ld.restype = c_int
         L.hyena_outproj_gate_fwd_ld.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+                                                c_int, c_int, c_int, c_int, ctypes.c_long, c_int, ctypes.c_long, c_int, c_int, c_int, c_void_p]
         L.hyena_proj_supported.restype = c_int
         L.hyena_proj_supported.argtypes = [c_int, c_int, c_int, c_int]
         L.hyena_inproj_pre_fwd.restype = c_int
@@ -347,6 +348,53 @@ def as_rows(t):
 def empty_like_rows(t, dtype=None):
     """A new tensor with t's shape and t's row pitch"""
     return empty_rows(t.shape[:-1], t.shape[-1], t.dtype if dtype is None else dtype, t.device, pitch=ld_of(t))
+
+
+# Channel-major (C, B, L) tensors that a library GEMM touches as well -- xT, dxT, zT, dzT -- come in a second layout when B > 1: the CHANNEL rows
+# are pitched over the flattened positions (row (c, b) at c cs + b L with cs = B L rounded up), so that the GEMM still sees ONE (C, B L) matrix
+# with a leading dimension (per-sequence pitched rows would need one product per sequence: 32767 x 8 ran 64 % slower that way,
+# profiles/r5h_*) and the in_proj kernel's 64-position tiles over the flattened positions store aligned.  For B = 1 the two layouts coincide.
+def empty_cm(C, B, L, dtype, device):
+    """uninitialised (C, B, L), channel rows row_pitch(B L) elements apart: strides (cs, L, 1)"""
+    cs = row_pitch(B * L)
+    buf = torch.empty((C, cs), dtype=dtype, device=device)
+    return buf[:, :B * L].view(C, B, L) if B * L > 0 else buf[:, :0].view(C, B, L)
+
+
+def cm_strides(t):
+    """(cs, bs) of a channel-major (C, B, L) tensor -- row (c, b) at element c cs + b bs, rows not overlapping -- or None"""
+    if t.dim() != 3:
+        return None
+    C, B, L = t.shape
+    if L > 1 and t.stride(2) != 1:
+        return None
+    bs = t.stride(1) if B > 1 else L
+    if bs < L:
+        return None
+    need = (B - 1) * bs + L
+    cs = t.stride(0) if C > 1 else need
+    return (cs, bs) if cs >= need else None
+
+
+def as_cm(t):
+    return t if cm_strides(t) is not None else t.contiguous()
+
+
+def empty_like_cm(t):
+    """a new tensor with t's shape and t's (cs, bs) layout"""
+    C, B, L = t.shape
+    cs, bs = cm_strides(t)
+    buf = torch.empty(max(C * cs, 1), dtype=t.dtype, device=t.device)
+    return torch.as_strided(buf, (C, B, L), (cs, bs, 1))
+
+
+def cm_matrix(t):
+    """the (C, B L) matrix view of a channel-major tensor whose sequences follow one another inside a channel row (bs = L), else None"""
+    C, B, L = t.shape
+    cs, bs = cm_strides(t)
+    if B > 1 and bs != L:
+        return None
+    return torch.as_strided(t, (C, B * L), (cs, 1))
 
 
 def tables_for(device, L):
@@ -578,37 +626,32 @@ def mixer_pre_bwd(dvg, x, w, b, dx, part):
 
 
 # ---- the shell in channel-major layout (include/hyena_mixer.h, hyena_cm_*) ------------------------------------------------
-# Every tensor here is packed or pitched rows (ld_of): xT / dxT carry their own pitch, all L-long tensors of a call share one
-# (row_pitch(L) for everything these functions allocate; an operand that arrives with another pitch is re-pitched by a copy).
-def _cm_lda(L, *ts):
-    for t in ts:
-        if t is not None and ld_of(t) is not None and ld_of(t) != L:
-            return ld_of(t)
-    return row_pitch(L)
-
-
+# xT / dxT / zT / dzT: any (cs, bs) layout (cm_strides); vg / y / dy / dvg: packed or pitched rows (ld_of).  What these functions allocate:
+# empty_cm for the first kind, empty_rows for the second.
 def cm_pre_fwd(xT, bin_, w, b, L):
     """xT (3D, B, Lx) [in_proj output without bias], bin_ (3D,) fp32 or None -> vg (B, D, L)."""
     _require_gpu(xT, "xT")
     D3, B, Lx = xT.shape
     D = D3 // 3
-    xT = as_rows(xT)
+    xT = as_cm(xT)
+    csx, bsx = cm_strides(xT)
     vg = empty_rows((B, D), L, xT.dtype, xT.device)
     with _backend.guard(xT.device):
         check(lib().hyena_cm_pre_fwd_ld(xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(), vg.data_ptr(),
-                                        B, L, Lx, D, ld_of(xT), ld_of(vg), dtype_code(xT.dtype), _backend.stream(xT.device)))
+                                        B, L, Lx, D, csx, bsx, ld_of(vg), dtype_code(xT.dtype), _backend.stream(xT.device)))
     return vg
 
 
 def cm_post_fwd(y, xT, bin_, w, b):
-    """y (B, D, L), xT (3D, B, Lx) -> zT (D, B, L) with y's row pitch."""
+    """y (B, D, L), xT (3D, B, Lx) -> zT (D, B, L)."""
     B, D, L = y.shape
-    xT, y = as_rows(xT), as_rows(y)
-    lda = ld_of(y)
-    zT = empty_rows((D, B), L, xT.dtype, xT.device, pitch=lda)
+    xT, y = as_cm(xT), as_rows(y)
+    csx, bsx = cm_strides(xT)
+    zT = empty_cm(D, B, L, xT.dtype, xT.device)
+    csz, bsz = cm_strides(zT)
     with _backend.guard(xT.device):
         check(lib().hyena_cm_post_fwd_ld(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                         zT.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), lda, dtype_code(xT.dtype),
+                                         zT.data_ptr(), B, L, xT.shape[2], D, csx, bsx, csz, bsz, ld_of(y), dtype_code(xT.dtype),
                                          _backend.stream(xT.device)))
     return zT
 
@@ -620,48 +663,50 @@ def cm_partials(xT, L):
 
 
 def cm_post_bwd(dzT, y, xT, bin_, w, b, dxT, part):
-    """-> dy (B, D, L) with y's row pitch; fills dxT[0:D] (positions < L) and part[0:D].  dxT must have xT's row pitch."""
+    """-> dy (B, D, L) with y's row pitch; fills dxT[0:D] (positions < L) and part[0:D].  dxT must have xT's layout."""
     B, D, L = y.shape
-    xT, y = as_rows(xT), as_rows(y)
-    lda = ld_of(y)
-    dzT = _same_pitch(as_rows(dzT), lda)
-    assert ld_of(dxT) == ld_of(xT)
+    xT, y, dzT = as_cm(xT), as_rows(y), as_cm(dzT)
+    csx, bsx = cm_strides(xT)
+    csz, bsz = cm_strides(dzT)
+    assert cm_strides(dxT) == (csx, bsx)
     dy = empty_like_rows(y)
     with _backend.guard(xT.device):
         check(lib().hyena_cm_post_bwd_ld(dzT.data_ptr(), y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(),
                                          b.data_ptr(), dy.data_ptr(), dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D,
-                                         ld_of(xT), lda, dtype_code(xT.dtype), _backend.stream(xT.device)))
+                                         csx, bsx, csz, bsz, ld_of(y), dtype_code(xT.dtype), _backend.stream(xT.device)))
     return dy
 
 
 def cm_pre_bwd(dvg, xT, bin_, w, b, dxT, part):
-    """fills dxT[D:3D] (positions < L) and part[D:3D].  dxT must have xT's row pitch."""
+    """fills dxT[D:3D] (positions < L) and part[D:3D].  dxT must have xT's layout."""
     B, D, L = dvg.shape
-    xT, dvg = as_rows(xT), as_rows(dvg)
-    assert ld_of(dxT) == ld_of(xT)
+    xT, dvg = as_cm(xT), as_rows(dvg)
+    csx, bsx = cm_strides(xT)
+    assert cm_strides(dxT) == (csx, bsx)
     with _backend.guard(xT.device):
         check(lib().hyena_cm_pre_bwd_ld(dvg.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                        dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), ld_of(dvg), dtype_code(xT.dtype),
+                                        dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D, csx, bsx, ld_of(dvg), dtype_code(xT.dtype),
                                         _backend.stream(xT.device)))
 
 
 # ---- input projection on the matrix cores with the front of the shell in its epilogue (include/hyena_proj.h) --------------------
 def proj_supported(B, Lx, D, dtype):
     code = _DTYPES.get(dtype)
-    return code is not None and bool(lib().hyena_proj_supported(int(B), int(Lx), int(D), code)) and B * row_pitch(Lx) < 2 ** 31
+    return code is not None and bool(lib().hyena_proj_supported(int(B), int(Lx), int(D), code)) and row_pitch(B * Lx) < 2 ** 31
 
 
 def inproj_pre_fwd(u, W, bin_, w, b, L):
     """u (B, Lx, D) 16-bit, W (3D, D) same type, bin_ (3D,) fp32 or None, w (3D, 3) fp32, b (3D,) fp32
-    -> xT (3D, B, Lx) = W u^T (no bias), vg (B, D, L) = short_conv(xT + bin_)[v] * short_conv(xT + bin_)[x1]; both pitched rows."""
+    -> xT (3D, B, Lx) = W u^T (no bias; empty_cm layout), vg (B, D, L) = short_conv(xT + bin_)[v] * short_conv(xT + bin_)[x1] (pitched rows)."""
     _require_gpu(u, "u")
     B, Lx, D = u.shape
     assert W.shape == (3 * D, D) and W.dtype == u.dtype and u.is_contiguous() and W.is_contiguous()
-    xT = empty_rows((3 * D, B), Lx, u.dtype, u.device)
+    xT = empty_cm(3 * D, B, Lx, u.dtype, u.device)
+    csx, bsx = cm_strides(xT)
     vg = empty_rows((B, D), L, u.dtype, u.device)
     with _backend.guard(u.device):
         check(lib().hyena_inproj_pre_fwd_ld(u.data_ptr(), W.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                            xT.data_ptr(), vg.data_ptr(), B, Lx, int(L), D, ld_of(xT), ld_of(vg), dtype_code(u.dtype),
+                                            xT.data_ptr(), vg.data_ptr(), B, Lx, int(L), D, csx, bsx, ld_of(vg), dtype_code(u.dtype),
                                             _backend.stream(u.device)))
     return xT, vg
 
@@ -673,20 +718,9 @@ def outproj_supported(B, L, Lx, D, dtype):
 
 def outproj_gate_fwd(y, xT, bin_, w, b, W, bias, want_z):
     """y (B, D, L) conv output, xT (3D, B, Lx), bin_ / w / b as cm_post_fwd, W (D, D) out_proj weight (element type of y), bias (D,) fp32
-    [values already rounded to the element type] or None -> out (B, L, D) = (y * x0)^T W^T + bias (packed), zT (D, B, L) = y * x0 with y's row
-    pitch if want_z else None (bit-identical to cm_post_fwd).  One launch: the gate rides on the operand load of the matrix-core product."""
-    _require_gpu(y, "y")
-    B, D, L = y.shape
-    y, xT = as_rows(y), as_rows(xT)
-    assert W.shape == (D, D) and W.dtype == y.dtype and xT.dtype == y.dtype and W.is_contiguous()
-    lda = ld_of(y)
-    out = torch.empty((B, L, D), dtype=y.dtype, device=y.device)
-    zT = empty_rows((D, B), L, y.dtype, y.device, pitch=lda) if want_z else None
-    with _backend.guard(y.device):
-        check(lib().hyena_outproj_gate_fwd_ld(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                              W.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(),
-                                              None if zT is None else zT.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), lda,
-                                              dtype_code(y.dtype), _backend.stream(y.device)))
+    [values already rounded to the element type] or None -> out (B, L, D) = (y * x0)^T W^T + bias (packed), zT (D, B, L) = y * x0 (empty_cm
+    layout) if want_z else None (bit-identical to cm_post_fwd).  One launch: the gate rides on the operand load of the matrix-core product."""
+    out, _, _, _, zT = _outproj(y, xT, bin_, w, b, W, bias, want_z, None)
     return out, zT
 
 
@@ -694,24 +728,32 @@ def outproj_gate_addnorm_fwd(y, xT, bin_, w, b, W, bias, want_z, residual, ln_w,
     """outproj_gate_fwd with the block's residual add + LayerNorm in the kernel's epilogue (include/hyena_proj.h,
     hyena_outproj_gate_addnorm_fwd_ld): residual (B L, D) fp32 or None, ln_w / ln_b (D,) fp32
     -> normed (B, L, D) of y's type, residual' (B L, D) fp32, mean, rstd (B L,), zT or None.  The out_proj output itself is never written."""
+    return _outproj(y, xT, bin_, w, b, W, bias, want_z, (residual, ln_w, ln_b, eps))
+
+
+def _outproj(y, xT, bin_, w, b, W, bias, want_z, norm):
     _require_gpu(y, "y")
     B, D, L = y.shape
-    y, xT = as_rows(y), as_rows(xT)
+    y, xT = as_rows(y), as_cm(xT)
     assert W.shape == (D, D) and W.dtype == y.dtype and xT.dtype == y.dtype and W.is_contiguous()
-    assert residual is None or (residual.dtype == torch.float32 and residual.is_contiguous() and residual.numel() == B * L * D)
-    lda = ld_of(y)
     dev = y.device
+    csx, bsx = cm_strides(xT)
     out = torch.empty((B, L, D), dtype=y.dtype, device=dev)
-    res_out = torch.empty((B * L, D), dtype=torch.float32, device=dev)
-    mean = torch.empty(B * L, dtype=torch.float32, device=dev)
-    rstd = torch.empty(B * L, dtype=torch.float32, device=dev)
-    zT = empty_rows((D, B), L, y.dtype, dev, pitch=lda) if want_z else None
+    zT = empty_cm(D, B, L, y.dtype, dev) if want_z else None
+    csz, bsz = cm_strides(zT) if want_z else (0, 0)
+    res_out = mean = rstd = residual = ln_w = ln_b = None
+    eps = 0.0
+    if norm is not None:
+        residual, ln_w, ln_b, eps = norm
+        assert residual is None or (residual.dtype == torch.float32 and residual.is_contiguous() and residual.numel() == B * L * D)
+        res_out = torch.empty((B * L, D), dtype=torch.float32, device=dev)
+        mean = torch.empty(B * L, dtype=torch.float32, device=dev)
+        rstd = torch.empty(B * L, dtype=torch.float32, device=dev)
+    ptr = lambda t: None if t is None else t.data_ptr()      # noqa: E731
     with _backend.guard(dev):
-        check(lib().hyena_outproj_gate_addnorm_fwd_ld(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(),
-                                                      b.data_ptr(), W.data_ptr(), None if bias is None else bias.data_ptr(),
-                                                      None if residual is None else residual.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
-                                                      float(eps), out.data_ptr(), res_out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                      None if zT is None else zT.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), lda,
+        check(lib().hyena_outproj_gate_addnorm_fwd_ld(y.data_ptr(), xT.data_ptr(), ptr(bin_), w.data_ptr(), b.data_ptr(), W.data_ptr(), ptr(bias),
+                                                      ptr(residual), ptr(ln_w), ptr(ln_b), float(eps), out.data_ptr(), ptr(res_out), ptr(mean),
+                                                      ptr(rstd), ptr(zT), B, L, xT.shape[2], D, csx, bsx, csz, bsz, ld_of(y),
                                                       dtype_code(y.dtype), _backend.stream(dev)))
     return out, res_out, mean, rstd, zT
 
@@ -727,15 +769,16 @@ def outproj_dgrad_gate_bwd(dy2, WoT, y, xT, bin_, w, b, dxT):
     -> dyc (B, D, L) with y's row pitch, part0 (D, runs, 8) whose [:, :, :5].sum(1) are (dw0, dw1, dw2, db_sc, db_in) of channels [0, D)."""
     _require_gpu(y, "y")
     B, D, L = y.shape
-    y, xT = as_rows(y), as_rows(xT)
+    y, xT = as_rows(y), as_cm(xT)
     assert dy2.shape == (B * L, D) and dy2.is_contiguous() and dy2.dtype == y.dtype and WoT.shape == (D, D) and WoT.is_contiguous()
-    assert ld_of(dxT) == ld_of(xT)
+    csx, bsx = cm_strides(xT)
+    assert cm_strides(dxT) == (csx, bsx)
     dyc = empty_like_rows(y)
     part = torch.empty(lib().hyena_outproj_dgrad_partial_floats(B, L, D), dtype=torch.float32, device=y.device).view(D, -1, 8)
     with _backend.guard(y.device):
         check(lib().hyena_outproj_dgrad_gate_bwd_ld(dy2.data_ptr(), WoT.data_ptr(), y.data_ptr(), xT.data_ptr(),
                                                     None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(), dyc.data_ptr(),
-                                                    dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D, ld_of(xT), ld_of(y),
+                                                    dxT.data_ptr(), part.data_ptr(), B, L, xT.shape[2], D, csx, bsx, ld_of(y),
                                                     dtype_code(y.dtype), _backend.stream(y.device)))
     return dyc, part
 

@@ -7,8 +7,10 @@
 using namespace hyena;
 
 namespace {
-bool cm_ok(const void* xT, const float* w, const float* b, int B, int L, int Lx, int D, int ldx, int lda, int dtype) {
-    return xT != nullptr && w != nullptr && b != nullptr && B >= 1 && L >= 1 && Lx >= L && D >= 1 && ldx >= Lx && lda >= L &&
+// a (C, B, len) layout: row (c, b) at c cs + b bs; rows must not overlap
+bool cm_layout_ok(long cs, int bs, int B, int len) { return bs >= len && cs >= (long)(B - 1) * bs + len; }
+bool cm_ok(const void* xT, const float* w, const float* b, int B, int L, int Lx, int D, long csx, int bsx, int lda, int dtype) {
+    return xT != nullptr && w != nullptr && b != nullptr && B >= 1 && L >= 1 && Lx >= L && D >= 1 && cm_layout_ok(csx, bsx, B, Lx) && lda >= L &&
            (dtype == HYENA_F32 || dtype == HYENA_BF16 || dtype == HYENA_F16);
 }
 int cm_tiles(int L) { return (L + CM_TILE - 1) / CM_TILE; }
@@ -32,43 +34,46 @@ size_t hyena_cm_partial_floats(int B, int L, int D) {
     return (size_t)3 * D * B * cm_tiles(L) * CM_NP;
 }
 
-int hyena_cm_pre_fwd_ld(const void* xT, const float* bin, const float* w, const float* b, void* vg, int B, int L, int Lx, int D, int ldx,
-                        int lda, int dtype, void* stream) {
-    if (!cm_ok(xT, w, b, B, L, Lx, D, ldx, lda, dtype) || vg == nullptr) return HYENA_ERR_BAD_ARG;
+int hyena_cm_pre_fwd_ld(const void* xT, const float* bin, const float* w, const float* b, void* vg, int B, int L, int Lx, int D, long csx,
+                        int bsx, int lda, int dtype, void* stream) {
+    const long csz = 0; const int bsz = 0;
+    if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || vg == nullptr) return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = nullptr; a.a1 = nullptr; a.o0 = vg; a.dxT = nullptr; a.part = nullptr;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.ldx = ldx; a.lda = lda;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda;
     HY_CM_DISPATCH(cm_pre_fwd_kernel, 0);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
 int hyena_cm_post_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, void* zT, int B, int L, int Lx,
-                         int D, int ldx, int lda, int dtype, void* stream) {
-    if (!cm_ok(xT, w, b, B, L, Lx, D, ldx, lda, dtype) || y == nullptr || zT == nullptr) return HYENA_ERR_BAD_ARG;
+                         int D, long csx, int bsx, long csz, int bsz, int lda, int dtype, void* stream) {
+    if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || y == nullptr || zT == nullptr || !cm_layout_ok(csz, bsz, B, L)) return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = y; a.a1 = nullptr; a.o0 = zT; a.dxT = nullptr; a.part = nullptr;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.ldx = ldx; a.lda = lda;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda;
     HY_CM_DISPATCH(cm_post_fwd_kernel, 0);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
 int hyena_cm_post_bwd_ld(const void* dzT, const void* y, const void* xT, const float* bin, const float* w, const float* b, void* dy,
-                         void* dxT, float* part, int B, int L, int Lx, int D, int ldx, int lda, int dtype, void* stream) {
-    if (!cm_ok(xT, w, b, B, L, Lx, D, ldx, lda, dtype) || dzT == nullptr || y == nullptr || dy == nullptr || dxT == nullptr || part == nullptr)
+                         void* dxT, float* part, int B, int L, int Lx, int D, long csx, int bsx, long csz, int bsz, int lda, int dtype,
+                         void* stream) {
+    if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || !cm_layout_ok(csz, bsz, B, L) || dzT == nullptr || y == nullptr || dy == nullptr || dxT == nullptr || part == nullptr)
         return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = y; a.a1 = dzT; a.o0 = dy; a.dxT = dxT; a.part = part;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.ldx = ldx; a.lda = lda;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda;
     HY_CM_DISPATCH(cm_post_bwd_kernel, CM_SMEM);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
 
 int hyena_cm_pre_bwd_ld(const void* dvg, const void* xT, const float* bin, const float* w, const float* b, void* dxT, float* part, int B,
-                        int L, int Lx, int D, int ldx, int lda, int dtype, void* stream) {
-    if (!cm_ok(xT, w, b, B, L, Lx, D, ldx, lda, dtype) || dvg == nullptr || dxT == nullptr || part == nullptr) return HYENA_ERR_BAD_ARG;
+                        int L, int Lx, int D, long csx, int bsx, int lda, int dtype, void* stream) {
+    const long csz = 0; const int bsz = 0;
+    if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || dvg == nullptr || dxT == nullptr || part == nullptr) return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = dvg; a.a1 = nullptr; a.o0 = nullptr; a.dxT = dxT; a.part = part;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.ldx = ldx; a.lda = lda;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda;
     HY_CM_DISPATCH(cm_pre_bwd_kernel, CM_SMEM);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
@@ -76,19 +81,19 @@ int hyena_cm_pre_bwd_ld(const void* dvg, const void* xT, const float* bin, const
 // the packed layouts: ldx = Lx, lda = L
 int hyena_cm_pre_fwd(const void* xT, const float* bin, const float* w, const float* b, void* vg, int B, int L, int Lx, int D, int dtype,
                      void* stream) {
-    return hyena_cm_pre_fwd_ld(xT, bin, w, b, vg, B, L, Lx, D, Lx, L, dtype, stream);
+    return hyena_cm_pre_fwd_ld(xT, bin, w, b, vg, B, L, Lx, D, (long)B * Lx, Lx, L, dtype, stream);
 }
 int hyena_cm_post_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, void* zT, int B, int L, int Lx,
                       int D, int dtype, void* stream) {
-    return hyena_cm_post_fwd_ld(y, xT, bin, w, b, zT, B, L, Lx, D, Lx, L, dtype, stream);
+    return hyena_cm_post_fwd_ld(y, xT, bin, w, b, zT, B, L, Lx, D, (long)B * Lx, Lx, (long)B * L, L, L, dtype, stream);
 }
 int hyena_cm_post_bwd(const void* dzT, const void* y, const void* xT, const float* bin, const float* w, const float* b, void* dy,
                       void* dxT, float* part, int B, int L, int Lx, int D, int dtype, void* stream) {
-    return hyena_cm_post_bwd_ld(dzT, y, xT, bin, w, b, dy, dxT, part, B, L, Lx, D, Lx, L, dtype, stream);
+    return hyena_cm_post_bwd_ld(dzT, y, xT, bin, w, b, dy, dxT, part, B, L, Lx, D, (long)B * Lx, Lx, (long)B * L, L, L, dtype, stream);
 }
 int hyena_cm_pre_bwd(const void* dvg, const void* xT, const float* bin, const float* w, const float* b, void* dxT, float* part, int B,
                      int L, int Lx, int D, int dtype, void* stream) {
-    return hyena_cm_pre_bwd_ld(dvg, xT, bin, w, b, dxT, part, B, L, Lx, D, Lx, L, dtype, stream);
+    return hyena_cm_pre_bwd_ld(dvg, xT, bin, w, b, dxT, part, B, L, Lx, D, (long)B * Lx, Lx, L, dtype, stream);
 }
 
 }  // extern "C"

@@ -40,8 +40,10 @@ struct CmArgs {
     void* dxT;          // bwd: (3D, B, Lx) gradient of xT (post_bwd writes rows [0, D), pre_bwd rows [D, 3D)); positions >= L untouched
     float* part;        // bwd: [3D][B * tiles][CM_NP] partial sums (dw0, dw1, dw2, db_sc, db_in, -, -, -): the host reads [:5]
     int B, L, D, Lx;
-    int ldx;            // row pitch (elements, >= Lx) of xT and dxT: row (c, b) starts at element (c B + b) ldx
-    int lda;            // row pitch (elements, >= L) of every L-long tensor: vg / y / dy / dvg (b, d) at (b D + d) lda, zT / dzT (d, b) at (d B + b) lda
+    long csx; int bsx;  // xT and dxT: row (c, b) starts at element c csx + b bsx (packed: csx = B Lx, bsx = Lx; per-sequence pitch ld: csx = B ld, bsx = ld;
+                        // channel rows pitched over the FLATTENED positions -- what a library GEMM takes as one matrix -- csx >= B Lx, bsx = Lx)
+    long csz; int bsz;  // zT / dzT (d, b) likewise
+    int lda;            // row pitch (elements, >= L) of the (B, D, L) tensors vg / y / dy / dvg: row (b, d) at (b D + d) lda
 };
 
 // v[i] = row[l0 + i] for i in [LO, HI), zero outside [0, L).  Interior vectors move as 16-byte (8 x 16-bit) or 2 x 16-byte
@@ -122,6 +124,10 @@ __device__ __forceinline__ void cm_sc(const float (&xs)[N + 2], int l0, const Cm
 __device__ __forceinline__ const char* cm_row(const void* base, size_t row, int len, size_t es) {
     return reinterpret_cast<const char*>(base) + row * (size_t)len * es;
 }
+// row (c, b) of a channel-major (C, B, .) tensor with channel stride cs and sequence stride bs (elements)
+__device__ __forceinline__ const char* cm_cb(const void* base, int c, int b, long cs, int bs, size_t es) {
+    return reinterpret_cast<const char*>(base) + ((size_t)c * (size_t)cs + (size_t)b * (size_t)bs) * es;
+}
 template <int DT> struct CmEs { static constexpr size_t V = (DT == DT_F32) ? 4 : 2; };
 
 // vg[b, d, :] = xc[2D + d, b, :] * xc[D + d, b, :]                grid (tiles, D, B)
@@ -133,8 +139,8 @@ __global__ void __launch_bounds__(CM_THREADS) cm_pre_fwd_kernel(CmArgs a) {
     if (l0 >= a.L) return;
     const CmTap t1 = cm_tap(a, a.D + d), tv = cm_tap(a, 2 * a.D + d);
     float x1[CM_V + 2], xv[CM_V + 2], c1[CM_V], cv[CM_V], o[CM_V];
-    cm_ld<DT, CM_V + 2>(cm_row(a.xT, (size_t)(a.D + d) * a.B + b, a.ldx, ES), l0 - 2, a.Lx, x1);
-    cm_ld<DT, CM_V + 2>(cm_row(a.xT, (size_t)(2 * a.D + d) * a.B + b, a.ldx, ES), l0 - 2, a.Lx, xv);
+    cm_ld<DT, CM_V + 2>(cm_cb(a.xT, a.D + d, b, a.csx, a.bsx, ES), l0 - 2, a.Lx, x1);
+    cm_ld<DT, CM_V + 2>(cm_cb(a.xT, 2 * a.D + d, b, a.csx, a.bsx, ES), l0 - 2, a.Lx, xv);
     cm_sc<CM_V>(x1, l0, t1, c1);
     cm_sc<CM_V>(xv, l0, tv, cv);
     HY_UNROLL
@@ -151,12 +157,12 @@ __global__ void __launch_bounds__(CM_THREADS) cm_post_fwd_kernel(CmArgs a) {
     if (l0 >= a.L) return;
     const CmTap t0 = cm_tap(a, d);
     float x0[CM_V + 2], c0[CM_V], y[CM_V], o[CM_V];
-    cm_ld<DT, CM_V + 2>(cm_row(a.xT, (size_t)d * a.B + b, a.ldx, ES), l0 - 2, a.Lx, x0);
+    cm_ld<DT, CM_V + 2>(cm_cb(a.xT, d, b, a.csx, a.bsx, ES), l0 - 2, a.Lx, x0);
     cm_ld<DT, CM_V>(cm_row(a.a0, (size_t)b * a.D + d, a.lda, ES), l0, a.L, y);
     cm_sc<CM_V>(x0, l0, t0, c0);
     HY_UNROLL
     for (int i = 0; i < CM_V; ++i) o[i] = y[i] * c0[i];
-    cm_st<DT, CM_V>(const_cast<char*>(cm_row(a.o0, (size_t)d * a.B + b, a.lda, ES)), l0, a.L, o);
+    cm_st<DT, CM_V>(const_cast<char*>(cm_cb(a.o0, d, b, a.csz, a.bsz, ES)), l0, a.L, o);
 }
 
 // wavefront sum (xor butterfly: every lane ends with the total, fixed order)
@@ -224,8 +230,8 @@ __global__ void __launch_bounds__(CM_THREADS) cm_post_bwd_kernel(CmArgs a) {
     const int l0 = (blockIdx.x * CM_THREADS + threadIdx.x) * CM_V;      // (threads beyond L still take part in the sums)
     const CmTap t0 = cm_tap(a, d);
     float x0[CM_V + 2], dz[CM_V + 2], y[CM_V + 2], c0[CM_V], dy[CM_V], da[CM_V + 2];
-    cm_ld<DT, CM_V + 2>(cm_row(a.xT, (size_t)d * a.B + b, a.ldx, ES), l0 - 2, a.Lx, x0);
-    cm_ld<DT, CM_V + 2>(cm_row(a.a1, (size_t)d * a.B + b, a.lda, ES), l0, a.L, dz);
+    cm_ld<DT, CM_V + 2>(cm_cb(a.xT, d, b, a.csx, a.bsx, ES), l0 - 2, a.Lx, x0);
+    cm_ld<DT, CM_V + 2>(cm_cb(a.a1, d, b, a.csz, a.bsz, ES), l0, a.L, dz);
     cm_ld<DT, CM_V + 2>(cm_row(a.a0, (size_t)b * a.D + d, a.lda, ES), l0, a.L, y);
     cm_sc<CM_V>(x0, l0, t0, c0);
     HY_UNROLL
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(CM_THREADS) cm_post_bwd_kernel(CmArgs a) {
     if (l0 < a.L) cm_st<DT, CM_V>(const_cast<char*>(cm_row(a.o0, (size_t)b * a.D + d, a.lda, ES)), l0, a.L, dy);
     CmPart p = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (l0 < a.L)
-        p = cm_sc_bwd<DT>(da, x0, l0, a.L, t0, const_cast<char*>(cm_row(a.dxT, (size_t)d * a.B + b, a.ldx, ES)), a.Lx);
+        p = cm_sc_bwd<DT>(da, x0, l0, a.L, t0, const_cast<char*>(cm_cb(a.dxT, d, b, a.csx, a.bsx, ES)), a.Lx);
     const int cs[1] = {d};
     const CmPart ps[1] = {p};
     cm_store_parts<1>(a, cs, b * gridDim.x + blockIdx.x, a.B * gridDim.x, ps, red);
@@ -252,8 +258,8 @@ __global__ void __launch_bounds__(CM_THREADS) cm_pre_bwd_kernel(CmArgs a) {
     const CmTap t1 = cm_tap(a, a.D + d), tv = cm_tap(a, 2 * a.D + d);
     // conv outputs are needed at l0 .. l0 + V + 1, hence raw inputs at l0 - 2 .. l0 + V + 1
     float x1[CM_V + 4], xv[CM_V + 4], g[CM_V + 2], c1[CM_V + 2], cv[CM_V + 2], da1[CM_V + 2], dav[CM_V + 2];
-    cm_ld<DT, CM_V + 4>(cm_row(a.xT, (size_t)(a.D + d) * a.B + b, a.ldx, ES), l0 - 2, a.Lx, x1);
-    cm_ld<DT, CM_V + 4>(cm_row(a.xT, (size_t)(2 * a.D + d) * a.B + b, a.ldx, ES), l0 - 2, a.Lx, xv);
+    cm_ld<DT, CM_V + 4>(cm_cb(a.xT, a.D + d, b, a.csx, a.bsx, ES), l0 - 2, a.Lx, x1);
+    cm_ld<DT, CM_V + 4>(cm_cb(a.xT, 2 * a.D + d, b, a.csx, a.bsx, ES), l0 - 2, a.Lx, xv);
     cm_ld<DT, CM_V + 2>(cm_row(a.a0, (size_t)b * a.D + d, a.lda, ES), l0, a.L, g);
     cm_sc<CM_V + 2>(x1, l0, t1, c1);
     cm_sc<CM_V + 2>(xv, l0, tv, cv);
@@ -264,8 +270,8 @@ __global__ void __launch_bounds__(CM_THREADS) cm_pre_bwd_kernel(CmArgs a) {
     for (int i = 0; i < CM_V + 2; ++i) { xs1[i] = x1[i]; xsv[i] = xv[i]; }
     CmPart p1 = {0.f, 0.f, 0.f, 0.f, 0.f}, pv = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (l0 < a.L) {
-        p1 = cm_sc_bwd<DT>(da1, xs1, l0, a.L, t1, const_cast<char*>(cm_row(a.dxT, (size_t)(a.D + d) * a.B + b, a.ldx, ES)), a.Lx);
-        pv = cm_sc_bwd<DT>(dav, xsv, l0, a.L, tv, const_cast<char*>(cm_row(a.dxT, (size_t)(2 * a.D + d) * a.B + b, a.ldx, ES)), a.Lx);
+        p1 = cm_sc_bwd<DT>(da1, xs1, l0, a.L, t1, const_cast<char*>(cm_cb(a.dxT, a.D + d, b, a.csx, a.bsx, ES)), a.Lx);
+        pv = cm_sc_bwd<DT>(dav, xsv, l0, a.L, tv, const_cast<char*>(cm_cb(a.dxT, 2 * a.D + d, b, a.csx, a.bsx, ES)), a.Lx);
     }
     const int cs[2] = {a.D + d, 2 * a.D + d};
     const CmPart ps[2] = {p1, pv};

@@ -156,22 +156,24 @@ int hyena_outproj_supported(int B, int L, int D, int dtype) {
 
 int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
                            const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int dtype, void* stream) {
-    return hyena_outproj_gate_fwd_ld(y, xT, bin, w, b, W, bias, out, zT, B, L, Lx, D, Lx, L, dtype, stream);
+    return hyena_outproj_gate_fwd_ld(y, xT, bin, w, b, W, bias, out, zT, B, L, Lx, D, (long)B * Lx, Lx, (long)B * L, L, L, dtype, stream);
 }
 
 int hyena_outproj_gate_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
-                              const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int ldx, int lda, int dtype,
-                              void* stream) {
+                              const float* bias, void* out, void* zT, int B, int L, int Lx, int D, long csx, int bsx, long csz, int bsz,
+                              int lda, int dtype, void* stream) {
     return hyena_outproj_gate_addnorm_fwd_ld(y, xT, bin, w, b, W, bias, nullptr, nullptr, nullptr, 0.f, out, nullptr, nullptr, nullptr, zT, B, L,
-                                             Lx, D, ldx, lda, dtype, stream);
+                                             Lx, D, csx, bsx, csz, bsz, lda, dtype, stream);
 }
+
+static bool pj_layout_ok(long cs, int bs, int B, int len) { return bs >= len && cs >= (long)(B - 1) * bs + len; }
 
 int hyena_outproj_gate_addnorm_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
                                       const float* bias, const float* residual_in, const float* ln_weight, const float* ln_bias, float eps,
                                       void* out, float* residual_out, float* mean, float* rstd, void* zT, int B, int L, int Lx, int D,
-                                      int ldx, int lda, int dtype, void* stream) {
-    if (y == nullptr || xT == nullptr || w == nullptr || b == nullptr || W == nullptr || out == nullptr || L > Lx || ldx < Lx || lda < L ||
-        !hyena_outproj_supported(B, L, D, dtype))
+                                      long csx, int bsx, long csz, int bsz, int lda, int dtype, void* stream) {
+    if (y == nullptr || xT == nullptr || w == nullptr || b == nullptr || W == nullptr || out == nullptr || L > Lx || lda < L ||
+        !hyena_outproj_supported(B, L, D, dtype) || !pj_layout_ok(csx, bsx, B, Lx) || (zT != nullptr && !pj_layout_ok(csz, bsz, B, L)))
         return HYENA_ERR_BAD_ARG;
     if (ln_weight != nullptr && (ln_bias == nullptr || residual_out == nullptr || mean == nullptr || rstd == nullptr ||
                                  residual_out == residual_in))       // (a sequence's pulled-back last tile re-reads residual_in: not in place)
@@ -179,7 +181,7 @@ int hyena_outproj_gate_addnorm_fwd_ld(const void* y, const void* xT, const float
     pj::OutProjArgs a;
     a.y = y; a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.W = W; a.bias = bias; a.out = out; a.zT = zT;
     a.res_in = residual_in; a.ln_w = ln_weight; a.ln_b = ln_bias; a.res_out = residual_out; a.mean = mean; a.rstd = rstd; a.eps = eps;
-    a.B = B; a.L = L; a.Lx = Lx; a.D = D; a.ldx = ldx; a.lda = lda;
+    a.B = B; a.L = L; a.Lx = Lx; a.D = D; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda;
     a.tiles_per_seq = (L + pj::PJ_NT - 1) / pj::PJ_NT;
     a.tiles = B * a.tiles_per_seq;
     // two workgroups per CU are resident; a few runs per slot balance the tail, runs of >= 8 tiles amortise the weight load
@@ -207,14 +209,14 @@ size_t hyena_outproj_dgrad_partial_floats(int B, int L, int D) {
 }
 
 int hyena_outproj_dgrad_gate_bwd_ld(const void* dy, const void* Wt, const void* y, const void* xT, const float* bin, const float* w,
-                                    const float* b, void* dyc, void* dxT, float* part, int B, int L, int Lx, int D, int ldx, int lda,
-                                    int dtype, void* stream) {
+                                    const float* b, void* dyc, void* dxT, float* part, int B, int L, int Lx, int D, long csx, int bsx,
+                                    int lda, int dtype, void* stream) {
     if (dy == nullptr || Wt == nullptr || y == nullptr || xT == nullptr || w == nullptr || b == nullptr || dyc == nullptr || dxT == nullptr ||
-        part == nullptr || L > Lx || ldx < Lx || lda < L || !hyena_outproj_dgrad_supported(B, L, D, dtype))
+        part == nullptr || L > Lx || !pj_layout_ok(csx, bsx, B, Lx) || lda < L || !hyena_outproj_dgrad_supported(B, L, D, dtype))
         return HYENA_ERR_BAD_ARG;
     pj::DgArgs a;
     a.dy = dy; a.Wt = Wt; a.y = y; a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.dyc = dyc; a.dxT = dxT; a.part = part;
-    a.B = B; a.L = L; a.Lx = Lx; a.D = D; a.ldx = ldx; a.lda = lda;
+    a.B = B; a.L = L; a.Lx = Lx; a.D = D; a.csx = csx; a.bsx = bsx; a.lda = lda;
     int runs, grid;
     dgrad_schedule(B, L, D, &a, &runs, &grid);
     if (D == 256) return dtype == HYENA_BF16 ? launch_dgrad<256, DT_BF16>(a, grid, stream) : launch_dgrad<256, DT_F16>(a, grid, stream);
@@ -229,16 +231,16 @@ int hyena_proj_supported(int B, int Lx, int D, int dtype) {
 
 int hyena_inproj_pre_fwd(const void* u, const void* W, const float* bin, const float* w, const float* b, void* xT, void* vg,
                          int B, int Lx, int Lc, int D, int dtype, void* stream) {
-    return hyena_inproj_pre_fwd_ld(u, W, bin, w, b, xT, vg, B, Lx, Lc, D, Lx, Lc, dtype, stream);
+    return hyena_inproj_pre_fwd_ld(u, W, bin, w, b, xT, vg, B, Lx, Lc, D, (long)B * Lx, Lx, Lc, dtype, stream);
 }
 
 int hyena_inproj_pre_fwd_ld(const void* u, const void* W, const float* bin, const float* w, const float* b, void* xT, void* vg,
-                            int B, int Lx, int Lc, int D, int ldx, int ldv, int dtype, void* stream) {
-    if (u == nullptr || W == nullptr || w == nullptr || b == nullptr || xT == nullptr || vg == nullptr || Lc < 1 || Lc > Lx || ldx < Lx ||
-        ldv < Lc || !hyena_proj_supported(B, Lx, D, dtype) || (size_t)B * (size_t)ldx >= ((size_t)1 << 31))
+                            int B, int Lx, int Lc, int D, long csx, int bsx, int ldv, int dtype, void* stream) {
+    if (u == nullptr || W == nullptr || w == nullptr || b == nullptr || xT == nullptr || vg == nullptr || Lc < 1 || Lc > Lx ||
+        ldv < Lc || !hyena_proj_supported(B, Lx, D, dtype) || bsx < Lx || csx < (long)(B - 1) * bsx + Lx || csx >= ((long)1 << 31))
         return HYENA_ERR_BAD_ARG;
     pj::InProjArgs a;
-    a.u = u; a.W = W; a.bin = bin; a.w = w; a.b = b; a.xT = xT; a.vg = vg; a.B = B; a.Lx = Lx; a.Lc = Lc; a.D = D; a.ldx = ldx; a.ldv = ldv;
+    a.u = u; a.W = W; a.bin = bin; a.w = w; a.b = b; a.xT = xT; a.vg = vg; a.B = B; a.Lx = Lx; a.Lc = Lc; a.D = D; a.csx = csx; a.bsx = bsx; a.ldv = ldv;
     const size_t P = (size_t)B * Lx;
     a.tiles = (int)((P + pj::PJ_NT - 1) / pj::PJ_NT);
     // One workgroup per CU is resident (its wavefronts hold the weights in ~350 registers): a few runs per CU balance the tail,

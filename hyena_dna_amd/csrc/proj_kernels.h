@@ -202,10 +202,11 @@ struct InProjArgs {
     const float* bin;    // (3D,) in_proj bias or null
     const float* w;      // (3D, 3) short-filter taps
     const float* b;      // (3D,) short-filter bias
-    void* xT;            // (3D, B, Lx), row pitch ldx: row (c, b) starts at element (c B + b) ldx
+    void* xT;            // (3D, B, Lx): row (c, b) starts at element c csx + b bsx
     void* vg;            // (B, D, Lc), row pitch ldv: row (b, d) starts at element (b D + d) ldv
     int B, Lx, Lc, D;
-    int ldx, ldv;        // >= Lx, >= Lc (packed tensors: ldx = Lx, ldv = Lc)
+    long csx; int bsx;   // bsx >= Lx, csx >= (B - 1) bsx + Lx (packed: B Lx, Lx)
+    int ldv;             // >= Lc (packed: Lc)
     int tiles;           // ceil(B Lx / 64)
     int tiles_per_wg;
 };
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
     }
     // Piece m of a lane: id = lane + 64 m -> group m >> 1, channel (lane >> 3) + 8 (m & 1), piece lane & 7: the m-dependent part
     // of every address is wave-uniform (scalar registers), only piece 0's offset is held per lane.
-    const size_t CS = (size_t)a.B * (size_t)a.ldx;                           // elements between the same position of consecutive xT channels
+    const size_t CS = (size_t)a.csx;                                         // elements between the same position of consecutive xT channels
     const size_t xoff0 = (size_t)(d0 + (lane >> 3)) * CS + 8u * (unsigned)(lane & 7);
     const unsigned voff0 = (unsigned)(d0 + (lane >> 3)) * (unsigned)a.ldv + 8u * (unsigned)(lane & 7);
     const char* const ubase = reinterpret_cast<const char*>(a.u);
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
         };
         if (fast) {
             counted = t + 1 < t_whole;                                       // eight stores, no branch around any of them; the next tile's loads whole
-            const size_t xpos = (size_t)sb * (size_t)a.ldx + (size_t)sl0;   // the tile's first position inside an xT row (the tile lies in ONE sequence)
+            const size_t xpos = (size_t)sb * (size_t)a.bsx + (size_t)sl0;   // the tile's first position inside an xT row (the tile lies in ONE sequence)
             // (3) xT: 3 x 16 rows x 8 pieces of 8 positions; piece m of a lane: group m >> 1, channel (lane >> 3) + 8 (m & 1), piece lane & 7
             Frag ra, rb;
             HY_UNROLL
@@ -445,7 +446,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                     const unsigned xb_ = p / (unsigned)a.Lx;                     // the piece's first position: sequence, position within it
                     const int xl = (int)(p - xb_ * (unsigned)a.Lx);
                     elem_t* const crow = reinterpret_cast<elem_t*>(a.xT) + (size_t)(g * D + d0 + ch) * CS;
-                    if (xl + 8 <= a.Lx) PJ_ST16(crow + (size_t)xb_ * a.ldx + xl, v);
+                    if (xl + 8 <= a.Lx) PJ_ST16(crow + (size_t)xb_ * a.bsx + xl, v);
                     else {                                                       // the piece runs into the next sequence's row (or past the last one)
                         elem_t sv[8];
                         __builtin_memcpy(sv, v.w, 16);
@@ -453,7 +454,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) inproj_pre_fwd_kernel(InProjArg
                             int li = xl + i;
                             unsigned bi = xb_;
                             if (li >= a.Lx) { li -= a.Lx; ++bi; }
-                            if (p + i < P) crow[(size_t)bi * a.ldx + li] = sv[i];
+                            if (p + i < P) crow[(size_t)bi * a.bsx + li] = sv[i];
                         }
                     }
                 }
@@ -980,7 +981,9 @@ struct OutProjArgs {
     float* rstd;          // (B L,)
     float eps;
     int B, L, Lx, D;
-    int ldx, lda;         // row pitch (elements) of xT (row (c, b) at (c B + b) ldx, >= Lx) and of y / zT (rows (b, d) at (b D + d) lda, (d, b) at (d B + b) lda, >= L)
+    long csx; int bsx;    // xT: row (c, b) at c csx + b bsx
+    long csz; int bsz;    // zT: row (d, b) at d csz + b bsz
+    int lda;              // y: row (b, d) at (b D + d) lda
     int tiles_per_seq, tiles, tiles_per_wg;
 };
 
@@ -1048,7 +1051,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
                 const int i = half * HR + ii;
                 const int k = 32 * i + 8 * wave + r;
                 const elem_t* yrow = yb + ((size_t)b * a.D + k) * a.lda;
-                const elem_t* xrow = xb + ((size_t)k * a.B + b) * a.ldx;
+                const elem_t* xrow = xb + ((size_t)k * (size_t)a.csx + (size_t)b * a.bsx);
                 yr[ii] = ld16(yrow + lp);                           // (every tile is whole; gfx950 global memory takes under-aligned 16-byte accesses)
                 xr[ii] = ld16(xrow + lp);
                 uint32_t h2 = 0u;
@@ -1080,7 +1083,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
                 }
                 Frag zp;
                 __builtin_memcpy(zp.w, ze, 16);
-                if (zb != nullptr) st16(zb + ((size_t)k * a.B + b) * a.lda + lp, zp);
+                if (zb != nullptr) st16(zb + ((size_t)k * (size_t)a.csz + (size_t)b * a.bsz) + lp, zp);
                 // lanes r (even) and r + 1 (= lane ^ 8) hold channels k, k + 1 for the same 8 positions: the even one takes positions
                 // 0..3 of both, the odd one positions 4..7
                 const bool odd = (r & 1) != 0;
@@ -1215,7 +1218,7 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) outproj_gate_fwd_kernel(OutProj
 // The transposed short convolution needs g at the two positions AFTER a piece: from the neighbouring lane, and across tiles from the tile
 // above -- so a workgroup walks its run of tiles DOWNWARDS (a warm-up tile above the run supplies the first two values, its results are
 // dropped), the mirror image of the in_proj kernel's halo.  Tiles never cross a sequence (tiles_per_seq per sequence, the last one ragged):
-// with pitched rows (ldx, lda multiples of 8) every 16-byte access of the epilogue is aligned whatever L and B are.
+// with per-sequence pitched rows every 16-byte access of the epilogue is aligned whatever L and B are.
 // Partial sums (d w0..2, d b_sc, d b_in per channel) stay in registers over the run, are reduced over the 8 lanes of a channel by shuffles
 // and leave as one record per (channel, run): part[c][run][8], summed over the runs by the host in a fixed order -- deterministic.
 // =============================================================================================================================
@@ -1234,15 +1237,16 @@ struct DgArgs {
     const void* dy;       // (B L, N) 16-bit: gradient of out_proj's output, N = K = D
     const void* Wt;       // (D, N) 16-bit: out_proj.weight TRANSPOSED (row d = the weights that multiply dy[:, n] into channel d)
     const void* y;        // (B, D, L) long-convolution output, row pitch lda
-    const void* xT;       // (3D, B, Lx) in_proj output without its bias, row pitch ldx; rows [0, D) are read
+    const void* xT;       // (3D, B, Lx) in_proj output without its bias, row (c, b) at c csx + b bsx; rows [0, D) are read
     const float* bin;     // (3D,) or null
     const float* w;       // (3D, 3)
     const float* b;       // (3D,)
     void* dyc;            // (B, D, L) out: gradient of the long convolution's output, row pitch lda
-    void* dxT;            // (3D, B, Lx) out: rows [0, D), positions < L, row pitch ldx
+    void* dxT;            // (3D, B, Lx) out: rows [0, D), positions < L, xT's layout
     float* part;          // out: [D][nrec][8] (dw0, dw1, dw2, db_sc, db_in, -, -, -), record = run
     int B, L, Lx, D;
-    int ldx, lda;
+    long csx; int bsx;    // xT / dxT: row (c, b) at c csx + b bsx
+    int lda;              // y / dyc: row (b, d) at (b D + d) lda
     int tiles_per_seq, tiles, tiles_per_wg, nrec;
 };
 
@@ -1378,7 +1382,7 @@ __global__ void __launch_bounds__(PJ_THREADS, DG_WGS) outproj_dgrad_gate_bwd_ker
                 __builtin_memcpy(dze, f.w, 16);
             }
             const elem_t* yrow = yb + ((size_t)sb * D + c) * a.lda;
-            const elem_t* xrow = xb + ((size_t)c * a.B + sb) * a.ldx;
+            const elem_t* xrow = xb + ((size_t)c * (size_t)a.csx + (size_t)sb * a.bsx);
             if (whole) {
                 const Frag fy = ld16(yrow + l), fx = ld16(xrow + l);
                 __builtin_memcpy(ye, fy.w, 16);
@@ -1436,7 +1440,7 @@ __global__ void __launch_bounds__(PJ_THREADS, DG_WGS) outproj_dgrad_gate_bwd_ker
                     de[i] = Elem<DT>::cvt(dx);
                 }
                 elem_t* orow = ob + ((size_t)sb * D + c) * a.lda;
-                elem_t* drow = gb + ((size_t)c * a.B + sb) * a.ldx;
+                elem_t* drow = gb + ((size_t)c * (size_t)a.csx + (size_t)sb * a.bsx);
                 if (whole) {
                     Frag fo, fd;
                     __builtin_memcpy(fo.w, oe, 16);

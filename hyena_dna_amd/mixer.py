@@ -87,7 +87,7 @@ class HyenaMixerCMFunc(torch.autograd.Function):
         # cm_pre_fwd on this xT) -- a cached value, not a differentiable input
         D3, B, Lx = xT.shape
         D = D3 // 3
-        xc = _lib.as_rows(xT)
+        xc = _lib.as_cm(xT)
         bi = b_in.detach().to(torch.float32).contiguous()
         w = sf_weight.detach().to(torch.float32).reshape(D3, 3).contiguous()
         b = sf_bias.detach().to(torch.float32).contiguous()
@@ -112,8 +112,8 @@ class HyenaMixerCMFunc(torch.autograd.Function):
         xc, bi, w, b, kf, bf, y = ctx.saved_tensors
         bin_dtype, w_shape, w_dtype, b_dtype, k_dtype, bias_shape, bias_dtype, L = ctx.meta
         D3, B, Lx = xc.shape
-        dzT = _lib.as_rows(dzT.to(xc.dtype))
-        dxT = _lib.empty_like_rows(xc)
+        dzT = _lib.as_cm(dzT.to(xc.dtype))
+        dxT = _lib.empty_like_cm(xc)
         if Lx > L:
             dxT.zero_()
         part = _lib.cm_partials(xc, L)
@@ -149,19 +149,18 @@ import os as _os
 
 OUTPROJ_MFMA = _os.environ.get("HYENA_OUTPROJ_MFMA", "1") != "0"      # A/B knob: 0 = cm_post_fwd + library GEMM
 # out_proj's input gradient with the gate backward in its epilogue (csrc/proj_kernels.h::outproj_dgrad_gate_bwd_kernel, round 5) against the pair
-# it can replace, library GEMM (dz^T) + cm_post_bwd, measured on the MI355X (profiles/r5e_outproj_dgrad.txt): the kernel wins where the library
-# needs one product per sequence -- several sequences on pitched rows: 32767 x 8 190 vs 292 us, 159999 x 2 224 vs 281 us -- and at 32768 x 8
-# (190 vs 205 us); it loses at B = 1 (L = 2^20: 756 - 800 vs 719 us; the pair streams its bytes at 4.9 TB/s, the matrix-core kernel at 3.4 - 3.6).
-# "auto" (default) takes it exactly where it wins; HYENA_OUTPROJ_DGRAD_MFMA=1 / 0 forces it on / off.
+# it can replace, library GEMM (dz^T) + cm_post_bwd, measured on the MI355X (profiles/r5e_outproj_dgrad.txt): the kernel wins at many short
+# sequences (32768 x 8: 190 vs 205 us), ties at 160000 x 2 (224 vs 226) and loses at B = 1 (L = 2^20: 756 - 800 vs 719 us; the pair streams its
+# bytes at 4.9 TB/s, the matrix-core kernel at 3.4 - 3.6).  "auto" (default) takes it where it wins; HYENA_OUTPROJ_DGRAD_MFMA=1 / 0 forces it.
 DGRAD_MFMA = {"1": True, "0": False}.get(_os.environ.get("HYENA_OUTPROJ_DGRAD_MFMA", "auto"), "auto")
 
 
-def _dgrad_fused(B, L, D, y, dtype):
+def _dgrad_fused(B, L, D, dtype):
     if DGRAD_MFMA is False or not _lib.outproj_dgrad_supported(B, L, D, dtype):
         return False
     if DGRAD_MFMA is True:
         return True
-    return B >= 2 and (_lib.ld_of(y) != L or B >= 8)
+    return B >= 8
 
 
 def mixer_out_supported(xT, L, out_weight):
@@ -187,7 +186,7 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
     def forward(ctx, xT, b_in, sf_weight, sf_bias, k, bias, L, vg, w_out, b_out, residual=None, ln_w=None, ln_b=None, eps=0.0):
         D3, B, Lx = xT.shape
         D = D3 // 3
-        xc = _lib.as_rows(xT)
+        xc = _lib.as_cm(xT)
         bi = b_in.detach().to(torch.float32).contiguous()
         w = sf_weight.detach().to(torch.float32).reshape(D3, 3).contiguous()
         b = sf_bias.detach().to(torch.float32).contiguous()
@@ -255,12 +254,12 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
         if not any(ctx.needs_input_grad[:6]):
             return (None, None, None, None, None, None, None, None, dW, dbo) + norm_grads
         # ---- the core's backward (HyenaMixerCMFunc.backward) ----
-        dxT = _lib.empty_like_rows(xc)
+        dxT = _lib.empty_like_cm(xc)
         if Lx > L:
             dxT.zero_()
         part = _lib.cm_partials(xc, L)
         part0 = None
-        if _dgrad_fused(B, L, D, y, xc.dtype):
+        if _dgrad_fused(B, L, D, xc.dtype):
             # dz^T = W_out^T dy^T and the gate's backward in ONE matrix-core kernel: dz^T is never written (csrc/proj_kernels.h, round 5)
             dy, part0 = _lib.outproj_dgrad_gate_bwd(dy2, wo.t().contiguous(), y, xc, bi, w, b, dxT)
         else:

@@ -99,23 +99,24 @@ def _bmm_f32(a, b):
     return torch.bmm(a.float(), b.float())
 
 
-# Channel-major tensors are PITCHED rows since round 5 (hyena_dna_amd._lib.row_pitch: the reference trainer's L = max_length - 1 is odd, and a
-# packed (C, B, L) tensor then has no aligned row but the first).  A library GEMM takes a pitched operand as a matrix with a leading dimension
-# -- for B = 1 the whole tensor is one (C, L) matrix with ld = pitch; for B > 1 the B sequences are B such matrices, one product each (the
-# packed (C, B L) matrix exists only when the pitch is L itself).  The helpers below hide that; every product and its summation order are the
-# ones of rounds 2 - 4 when the pitch equals L.
+# Channel-major tensors have PITCHED channel rows since round 5 (hyena_dna_amd._lib.empty_cm: the reference trainer's L = max_length - 1 is odd,
+# and a packed (C, B, L) tensor then has no aligned row but the first): row (c, b) at c cs + b L with cs = B L rounded up to 64 elements.  A
+# library GEMM takes such an operand as ONE (C, B L) matrix with leading dimension cs (_lib.cm_matrix) -- the products and their summation
+# order are the ones of rounds 2 - 4.  A tensor whose sequences are pitched individually (bs > L) has no such view: one product per sequence.
 def _pieces(t, L):
-    """t (C, B, L) packed or pitched rows -> [(C, n) matrix view, first flattened position, n]: one piece if packed, else one per sequence"""
+    """t (C, B, L) channel-major -> [(C, n) matrix view, first flattened position, n]: one piece if the sequences of a channel are adjacent"""
+    from . import _lib
     C, B, _ = t.shape
-    if t.is_contiguous():
-        return [(t.view(C, B * L), 0, B * L)]
+    m = _lib.cm_matrix(t)
+    if m is not None:
+        return [(m, 0, B * L)]
     return [(t[:, b, :], b * L, L) for b in range(B)]
 
 
 def cm_from_pm(w, x2, B, L):
-    """(C, B, L) pitched rows = w (C, K) x2^T for position-major x2 (B L, K)"""
+    """(C, B, L) channel-major (_lib.empty_cm layout) = w (C, K) x2^T for position-major x2 (B L, K)"""
     from . import _lib
-    out = _lib.empty_rows((w.shape[0], B), L, x2.dtype, x2.device)
+    out = _lib.empty_cm(w.shape[0], B, L, x2.dtype, x2.device)
     for m, p0, n in _pieces(out, L):
         torch.mm(w, x2[p0:p0 + n].t(), out=m)
     return out
@@ -185,7 +186,7 @@ class InProjCMFunc(torch.autograd.Function):
     def backward(ctx, dxT):
         from . import _lib
         u2, weight = ctx.saved_tensors
-        dxT = _lib.as_rows(dxT)
+        dxT = _lib.as_cm(dxT)
         du = dw = None
         if ctx.needs_input_grad[0]:
             du = pm_from_cm(dxT, weight).view(ctx.ushape)
@@ -247,7 +248,7 @@ class OutProjCMFunc(torch.autograd.Function):
     def forward(ctx, zT, weight, bias):
         from . import _lib
         K, B, L = zT.shape
-        zT = _lib.as_rows(zT)
+        zT = _lib.as_cm(zT)
         ctx.save_for_backward(zT, weight)
         ctx.has_bias = bias is not None
         return pm_from_cm(zT, weight.t(), bias).view(B, L, weight.shape[0])

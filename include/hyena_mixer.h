@@ -60,18 +60,23 @@ int hyena_cm_post_bwd(const void* dzT, const void* y, const void* xT, const floa
 int hyena_cm_pre_bwd(const void* dvg, const void* xT, const float* bin, const float* w, const float* b,
                      void* dxT, float* part, int B, int L, int Lx, int D, int dtype, void* stream);
 
-/* The same four kernels on PITCHED rows (round 5; see hyena_fftconv_fwd_ld in hyena_fftconv.h for why: the reference trainer's
- * L = max_length - 1 is odd):  ldx = elements between the starts of consecutive rows of xT / dxT (row (c, b) at (c B + b) ldx, ldx >= Lx),
- * lda = the same for every L-long tensor -- vg / y / dy / dvg: row (b, d) at (b D + d) lda;  zT / dzT: row (d, b) at (d B + b) lda
- * (lda >= L).  Elements beyond a row's length are never read or written.  The entry points above are these with ldx = Lx, lda = L. */
+/* The same four kernels on STRIDED / PITCHED rows (round 5; see hyena_fftconv_fwd_ld in hyena_fftconv.h for why: the reference trainer's
+ * L = max_length - 1 is odd, and rows of a packed tensor are then unaligned):
+ *   csx, bsx : layout of xT / dxT -- row (c, b) starts at element c csx + b bsx  (bsx >= Lx, csx >= (B - 1) bsx + Lx)
+ *   csz, bsz : layout of zT / dzT -- row (d, b) at d csz + b bsz                  (bsz >= L,  csz >= (B - 1) bsz + L)
+ *   lda      : row pitch of the (B, D, L) tensors vg / y / dy / dvg -- row (b, d) at (b D + d) lda  (lda >= L)
+ * Two layouts are in use (hyena_dna_amd/_lib.py): per-sequence pitch ld (cs = B ld, bs = ld: every row aligned; B = 1), and channel rows pitched
+ * over the FLATTENED positions (cs = B L rounded up, bs = L: one library GEMM still sees one (C, B L) matrix; B > 1).  Elements outside a row's
+ * length are never read or written.  The entry points above are these with the packed strides (cs = B len, bs = len, lda = L). */
 int hyena_cm_pre_fwd_ld(const void* xT, const float* bin, const float* w, const float* b, void* vg,
-                        int B, int L, int Lx, int D, int ldx, int lda, int dtype, void* stream);
+                        int B, int L, int Lx, int D, long csx, int bsx, int lda, int dtype, void* stream);
 int hyena_cm_post_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, void* zT,
-                         int B, int L, int Lx, int D, int ldx, int lda, int dtype, void* stream);
+                         int B, int L, int Lx, int D, long csx, int bsx, long csz, int bsz, int lda, int dtype, void* stream);
 int hyena_cm_post_bwd_ld(const void* dzT, const void* y, const void* xT, const float* bin, const float* w, const float* b,
-                         void* dy, void* dxT, float* part, int B, int L, int Lx, int D, int ldx, int lda, int dtype, void* stream);
+                         void* dy, void* dxT, float* part, int B, int L, int Lx, int D, long csx, int bsx, long csz, int bsz, int lda,
+                         int dtype, void* stream);
 int hyena_cm_pre_bwd_ld(const void* dvg, const void* xT, const float* bin, const float* w, const float* b,
-                        void* dxT, float* part, int B, int L, int Lx, int D, int ldx, int lda, int dtype, void* stream);
+                        void* dxT, float* part, int B, int L, int Lx, int D, long csx, int bsx, int lda, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

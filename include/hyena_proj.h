@@ -29,11 +29,12 @@ extern "C" {
 int hyena_proj_supported(int B, int Lx, int D, int dtype);
 int hyena_inproj_pre_fwd(const void* u, const void* W, const float* bin, const float* w, const float* b, void* xT, void* vg,
                          int B, int Lx, int Lc, int D, int dtype, void* stream);
-/* ... on PITCHED outputs (round 5; hyena_fftconv.h, hyena_fftconv_fwd_ld, says why): ldx = elements between the starts of consecutive xT rows
- * (row (c, b) at (c B + b) ldx, ldx >= Lx, B ldx < 2^31), ldv = the same for vg (row (b, d) at (b D + d) ldv, ldv >= Lc).  With both a
- * multiple of 8 and -- for B > 1 -- Lx too, every 16-byte store of the kernel is aligned.  The entry point above = ldx Lx, ldv Lc. */
+/* ... on STRIDED / PITCHED outputs (round 5; hyena_fftconv.h, hyena_fftconv_fwd_ld, says why; hyena_mixer.h, hyena_cm_*_ld, defines the layouts):
+ * xT row (c, b) at element c csx + b bsx (bsx >= Lx, (B - 1) bsx + Lx <= csx < 2^31); vg row (b, d) at (b D + d) ldv (ldv >= Lc).  The kernel
+ * walks the flattened positions in 64-position tiles: with csx a multiple of 8 and bsx = Lx every xT store is 16-byte aligned.  The entry
+ * point above = the packed strides (csx = B Lx, bsx = Lx, ldv = Lc). */
 int hyena_inproj_pre_fwd_ld(const void* u, const void* W, const float* bin, const float* w, const float* b, void* xT, void* vg,
-                            int B, int Lx, int Lc, int D, int ldx, int ldv, int dtype, void* stream);
+                            int B, int Lx, int Lc, int D, long csx, int bsx, int ldv, int dtype, void* stream);
 
 
 /* ---- out_proj with the second gate on its operand load (round 4) -----------------------------------------------------------------
@@ -51,11 +52,11 @@ int hyena_inproj_pre_fwd_ld(const void* u, const void* W, const float* bin, cons
 int hyena_outproj_supported(int B, int L, int D, int dtype);
 int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
                            const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int dtype, void* stream);
-/* ... on PITCHED operands: ldx = row pitch of xT (>= Lx), lda = row pitch of y AND of zT (row (b, d) of y at (b D + d) lda, row (d, b) of zT at
- * (d B + b) lda; >= L).  The entry point above = ldx Lx, lda L. */
+/* ... on STRIDED / PITCHED operands: xT row (c, b) at c csx + b bsx, zT row (d, b) at d csz + b bsz, y row (b, d) at (b D + d) lda (layouts:
+ * hyena_mixer.h, hyena_cm_*_ld).  The entry point above = the packed strides. */
 int hyena_outproj_gate_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
-                              const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int ldx, int lda, int dtype,
-                              void* stream);
+                              const float* bias, void* out, void* zT, int B, int L, int Lx, int D, long csx, int bsx, long csz, int bsz,
+                              int lda, int dtype, void* stream);
 /* ... with the block's residual add + LayerNorm in its epilogue (round 5).  In a prenorm block (flash_attn Block =
  * src/models/sequence/simple_lm.py:262-284, long_conv_lm.py:381-396) the mixer's output goes straight into
  *     residual' = dropout(mixer_out) + residual;   hidden = LayerNorm(residual')          (dropout p = 0 in every HyenaDNA configuration)
@@ -68,7 +69,7 @@ int hyena_outproj_gate_fwd_ld(const void* y, const void* xT, const float* bin, c
 int hyena_outproj_gate_addnorm_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
                                       const float* bias, const float* residual_in, const float* ln_weight, const float* ln_bias, float eps,
                                       void* out, float* residual_out, float* mean, float* rstd, void* zT, int B, int L, int Lx, int D,
-                                      int ldx, int lda, int dtype, void* stream);
+                                      long csx, int bsx, long csz, int bsz, int lda, int dtype, void* stream);
 
 
 /* ---- out_proj's input gradient with the second gate's backward in its epilogue (round 5) ---------------------------------------------
@@ -76,7 +77,7 @@ int hyena_outproj_gate_addnorm_fwd_ld(const void* y, const void* xT, const float
  * library GEMM writing dz^T = W_out^T dy^T, then hyena_cm_post_bwd reading it back):
  *     dz^T = round16(W_out^T dy^T)                     (never written)
  *     dyc[b, d, l] = dz * x0c                          gradient of the long convolution's output          (B, D, L), row pitch lda
- *     dxT[d, b, m] = w2 g[m] + w1 g[m + 1] + w0 g[m + 2],  g = dz * y      rows [0, D) of (3D, B, Lx), positions < L, row pitch ldx
+ *     dxT[d, b, m] = w2 g[m] + w1 g[m + 1] + w0 g[m + 2],  g = dz * y      rows [0, D) of (3D, B, Lx), positions < L, xT's layout (csx, bsx)
  *     part[d][run][8] = per-run partial sums of (dw0, dw1, dw2, db_sc, db_in) of the x0 channels' short filter / in_proj bias;
  *                       hyena_outproj_dgrad_partial_floats(B, L, D) floats = D x runs x 8; summing axis 1 gives the gradients (fixed order).
  * dy (B L, D) 16-bit; Wt (D, D) = out_proj.weight TRANSPOSED, contiguous; y, xT, bin, w, b as for hyena_outproj_gate_fwd_ld.
@@ -85,8 +86,8 @@ int hyena_outproj_gate_addnorm_fwd_ld(const void* y, const void* xT, const float
 int hyena_outproj_dgrad_supported(int B, int L, int D, int dtype);
 size_t hyena_outproj_dgrad_partial_floats(int B, int L, int D);
 int hyena_outproj_dgrad_gate_bwd_ld(const void* dy, const void* Wt, const void* y, const void* xT, const float* bin, const float* w,
-                                    const float* b, void* dyc, void* dxT, float* part, int B, int L, int Lx, int D, int ldx, int lda,
-                                    int dtype, void* stream);
+                                    const float* b, void* dyc, void* dxT, float* part, int B, int L, int Lx, int D, long csx, int bsx,
+                                    int lda, int dtype, void* stream);
 
 
 /* ---- the block's MLP (flash_attn.modules.mlp.Mlp = simple_lm.py:191-211; long_conv_lm.py:117-123: fc1 -> tanh-GELU -> fc2) ---------

@@ -32,9 +32,9 @@ for cfg in sys.argv[1:]:
     rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
     dy2, Wo = rn(B * L, D).to(dt), (rn(D, D) / D ** 0.5).to(dt)
     y = _lib.empty_rows((B, D), L, dt, dev).copy_(rn(B, D, L).to(dt))
-    xT = _lib.empty_rows((3 * D, B), L, dt, dev).copy_(rn(3 * D, B, L).to(dt))
+    xT = _lib.empty_cm(3 * D, B, L, dt, dev).copy_(rn(3 * D, B, L).to(dt))
     bin_, w, b = rn(3 * D) * 0.1, rn(3 * D, 3) * 0.5, rn(3 * D) * 0.1
-    dxT = _lib.empty_like_rows(xT)
+    dxT = _lib.empty_like_cm(xT)
     part = _lib.cm_partials(xT, L)
     WoT = Wo.t().contiguous()
 

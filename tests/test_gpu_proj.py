@@ -217,9 +217,9 @@ def test_out_proj_dgrad_with_the_gate_backward_on_gpu(gpu_lib, B, L, D, dtype):
         else:
             dy2, Wo = rn(B * L, D).to(dtype), (rn(D, D) / D ** 0.5).to(dtype)
         y = gpu_lib.empty_rows((B, D), L, dtype, dev).copy_(rn(B, D, L).to(dtype))
-        xT = gpu_lib.empty_rows((3 * D, B), L, dtype, dev).copy_(rn(3 * D, B, L).to(dtype))
+        xT = gpu_lib.empty_cm(3 * D, B, L, dtype, dev).copy_(rn(3 * D, B, L).to(dtype))
         bin_, w, b = rn(3 * D) * 0.1, rn(3 * D, 3) * 0.5, rn(3 * D) * 0.1
-        dx_f, dx_u = gpu_lib.empty_like_rows(xT).fill_(7.0), gpu_lib.empty_like_rows(xT).fill_(7.0)
+        dx_f, dx_u = gpu_lib.empty_like_cm(xT).fill_(7.0), gpu_lib.empty_like_cm(xT).fill_(7.0)
         dyc, part0 = gpu_lib.outproj_dgrad_gate_bwd(dy2, Wo.t().contiguous(), y, xT, bin_, w, b, dx_f)
         dzT = cm_from_pm(Wo.t(), dy2, B, L)
         part = gpu_lib.cm_partials(xT, L)
@@ -236,7 +236,7 @@ def test_out_proj_dgrad_with_the_gate_backward_on_gpu(gpu_lib, B, L, D, dtype):
             else:
                 assert torch.equal(dyc, dy_u) and torch.equal(dx_f[:D], dx_u[:D])
             assert (red_f - red_u).abs().max() <= 1e-4 * red_u.abs().max() + 1e-3
-            dx_2 = gpu_lib.empty_like_rows(xT).fill_(7.0)
+            dx_2 = gpu_lib.empty_like_cm(xT).fill_(7.0)
             dyc2, part2 = gpu_lib.outproj_dgrad_gate_bwd(dy2, Wo.t().contiguous(), y, xT, bin_, w, b, dx_2)
             assert torch.equal(dyc, dyc2) and torch.equal(dx_f[:D], dx_2[:D]) and torch.equal(part0[..., :5], part2[..., :5])      # (floats 5 - 7 of a record are padding, never written)
         else:
@@ -255,7 +255,7 @@ def test_out_proj_with_add_norm_epilogue_on_gpu(gpu_lib, B, L, D, dtype):
     g = torch.Generator(device=dev).manual_seed(L + D)
     rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
     y = gpu_lib.empty_rows((B, D), L, dtype, dev).copy_(rn(B, D, L).to(dtype))
-    xT = gpu_lib.empty_rows((3 * D, B), L, dtype, dev).copy_(rn(3 * D, B, L).to(dtype))
+    xT = gpu_lib.empty_cm(3 * D, B, L, dtype, dev).copy_(rn(3 * D, B, L).to(dtype))
     bin_, w, b = rn(3 * D) * 0.1, rn(3 * D, 3) * 0.5, rn(3 * D) * 0.1
     W = (rn(D, D) / D ** 0.5).to(dtype)
     bias = (rn(D) * 0.1).to(dtype).float()

@@ -266,7 +266,7 @@ def test_ragged_length_policy_of_the_fused_out_proj(emu_backend, monkeypatch):
         y.float().sum().backward()
         res.append([y.detach()] + [p.grad.clone() for p in op.parameters() if p.grad is not None])
     assert calls == [True]                                # training, ragged: the kernel, zT kept for the weight gradient
-    assert zts[0].shape == (D, B, L) and zts[0].stride() == (B * 128, 128, 1)      # rows 128 elements apart: aligned whatever L is
+    assert zts[0].shape == (D, B, L) and zts[0].stride() == (256, L, 1)            # channel rows pitched over the flattened positions (B L = 254 -> 256)
     for a_, b_ in zip(*res):
         assert torch.equal(a_, b_)
     monkeypatch.setattr(MX, "OUTPROJ_MFMA", True)
@@ -345,11 +345,11 @@ def test_out_proj_dgrad_with_the_gate_backward_in_its_epilogue(emu_backend, B, L
     from hyena_dna_amd.projection import cm_from_pm
     for exact in (True, False):
         dy2, Wo, y, xT, bin_, w, b = _dgrad_operands(B, L, Lx, D, dtype, seed=L + D + exact, exact=exact)
-        yp, xp = _lib.empty_rows((B, D), L, dtype, y.device), _lib.empty_rows((3 * D, B), Lx, dtype, y.device)
+        yp, xp = _lib.empty_rows((B, D), L, dtype, y.device), _lib.empty_cm(3 * D, B, Lx, dtype, y.device)
         yp.copy_(y)
         xp.copy_(xT)
         assert _lib.outproj_dgrad_supported(B, L, D, dtype)
-        dx_f, dx_u = _lib.empty_like_rows(xp).fill_(7.0), _lib.empty_like_rows(xp).fill_(7.0)
+        dx_f, dx_u = _lib.empty_like_cm(xp).fill_(7.0), _lib.empty_like_cm(xp).fill_(7.0)
         dyc, part0 = _lib.outproj_dgrad_gate_bwd(dy2, Wo.t().contiguous(), yp, xp, bin_, w, b, dx_f)
         dzT = cm_from_pm(Wo.t(), dy2, B, L)
         part = _lib.cm_partials(xp, L)
@@ -378,8 +378,8 @@ def test_operator_gradients_with_and_without_the_fused_dgrad(emu_backend, monkey
     u0 = torch.randn(B, L, D).to(torch.bfloat16)
     dy = torch.randn(B, L, D).to(torch.bfloat16)
     res = []
-    assert MX._dgrad_fused(2, 191, 128, emu_backend.empty_rows((2, 128), 191, torch.bfloat16, "cpu"), torch.bfloat16)          # "auto": pitched, B >= 2
-    assert not MX._dgrad_fused(1, 191, 128, emu_backend.empty_rows((1, 128), 191, torch.bfloat16, "cpu"), torch.bfloat16)      # B = 1: the library pair
+    assert MX._dgrad_fused(8, 191, 128, torch.bfloat16) and not MX._dgrad_fused(2, 191, 128, torch.bfloat16)      # "auto": many short sequences
+    assert not MX._dgrad_fused(8, 191, 128, torch.float32)
     for on in (True, False):
         monkeypatch.setattr(MX, "DGRAD_MFMA", on)
         op.zero_grad(set_to_none=True)
