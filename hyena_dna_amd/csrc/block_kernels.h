@@ -116,11 +116,11 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_fwd_kernel(AddNormArgs a
         const long long id = EMB ? a.ids[row] : 0;
         const bool bad_id = EMB && (unsigned long long)id >= (unsigned long long)a.V;   // never index the table with it
         blk_load<XDT, E>(a.x, EMB ? (size_t)(bad_id ? 0 : id) * a.D + c0 : off, r);          // EMB: the row of the embedding table
-        if (bad_id) {
+        if (a.seed != nullptr) blk_dropout<E>(r, off, seed, a.drop_below, a.keep_scale);
+        if (bad_id) {                                        // (after the dropout: the whole row, not only its kept elements)
             HY_UNROLL
             for (int e = 0; e < E; ++e) r[e] = __builtin_nanf("");
         }
-        if (a.seed != nullptr) blk_dropout<E>(r, off, seed, a.drop_below, a.keep_scale);
         if (a.res_in != nullptr) {
             float q[E];
             blk_load<DT_F32, E>(a.res_in, off, q);
