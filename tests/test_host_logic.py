@@ -166,7 +166,18 @@ def test_split_k_linear_gradients_match_linear():
     assert split_count(1 << 20) == 64 and split_count(32768) == 8 and split_count(160000) == 32 and split_count(8191) == 1
     # the lengths the reference dataset really yields are max_length - 1 (hg38_dataset.py:220): odd row counts split too
     assert split_count(999999) == 64 and split_count(449999) == 64 and split_count(159999) == 32 and split_count(2 * 32767) == 8
-    for dt, tol, rows in ((torch.float32, 1e-6, 8192), (torch.bfloat16, 1e-2, 8192), (torch.float32, 1e-6, 16383), (torch.bfloat16, 1e-2, 9999)):
+    # round 5: a row count that its slice count does not divide is cut into 256-row-aligned slices on two levels + a tail of < 256 rows
+    from hyena_dna_amd.projection import split_plan
+    assert split_plan(1 << 20) == ([(0, 64, 16384)], 1 << 20)                                   # divisible: one level, as before
+    for rows in (1048575, 999999, 449999, 2 * 159999, 8 * 32767, 32767, 70001):
+        levels, done = split_plan(rows)
+        pos = 0
+        for p0, s_, q in levels:
+            assert p0 == pos and q % 256 == 0 and s_ >= 1
+            pos += s_ * q
+        assert pos == done and 0 <= rows - done < 256
+    for dt, tol, rows in ((torch.float32, 1e-6, 8192), (torch.bfloat16, 1e-2, 8192), (torch.float32, 1e-6, 16383), (torch.bfloat16, 1e-2, 9999),
+                          (torch.float32, 1e-6, 35001)):
         g = torch.Generator().manual_seed(0)
         x = torch.randn(2, rows, 16, generator=g).to(dt).requires_grad_()
         w = (torch.randn(24, 16, generator=g) * 0.1).to(dt).requires_grad_()
