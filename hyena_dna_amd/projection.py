@@ -23,50 +23,70 @@ MAX_SPLITS = 64
 MIN_SLICE = 4096
 
 
-def split_count(rows):
+def split_count(rows, out_elems=None):
     """Number of equal position slices of the batched weight-gradient GEMM: the largest power of two <= MAX_SPLITS with
-    slices of >= MIN_SLICE rows.  ``rows`` need not be divisible by it: the ``rows % S`` leftover rows go through one small
-    tail GEMM (the reference dataset yields L = max_length - 1 -- 999,999 / 449,999 / 159,999 / 32,767,
-    hg38_dataset.py:220 -- so B*L is odd in real training)."""
+    slices of >= MIN_SLICE rows.  ``rows`` need not be divisible by it (split_plan; the reference dataset yields L = max_length - 1 --
+    999,999 / 449,999 / 159,999 / 32,767, hg38_dataset.py:220 -- so B*L is odd in real training).
+    ``out_elems``: size of the gradient.  A 256 x 256 gradient (out_proj at d_model 256) is ONE output tile per slice, so 64 slices are 64
+    workgroups on 256 CUs: such products take up to 256 slices (measured at 2^20 - 1 positions, scripts/wgrad_slice_probe.py: 64 x 16383 rows
+    527 us, 128 x 8191 342 us, 255 x 4096 337 us; the 768 x 256 and 1024 x 256 gradients are best at 64: 552 us vs 636 at 127)."""
+    cap = MAX_SPLITS * 4 if (out_elems is not None and out_elems <= 256 * 256) else MAX_SPLITS
     s = 1
-    while s < MAX_SPLITS and rows // (2 * s) >= MIN_SLICE:
+    while s < cap and rows // (2 * s) >= MIN_SLICE:
         s *= 2
     return s
 
 
-SLICE_ALIGN = 256
+SLICE_ALIGN = 64           # first-level slices: a multiple of 64 rows (64 x 16320 rows ran like 64 x 16128: 552 vs 551 us, and leave 4095 instead of 16383 rows)
+TAIL_SLICE = 256           # second level: the remainder in 256-row slices
 
 
-def split_plan(rows):
+def split_plan(rows, out_elems=None):
     """How a contraction over ``rows`` positions is cut into batched slices: ([(first row, slices, rows per slice), ...], rows covered).
     ``rows`` divisible by split_count(rows): one level, as in rounds 1 - 4.  Otherwise -- the reference trainer's B L = B (max_length - 1) --
-    the slices of the first level are shortened to a multiple of 256 rows (the library's kernels for an ODD contraction length ran 12 % slower,
-    and the rows % S leftover went through an fp32 product behind two conversion passes: + 0.1 ms per weight gradient at 2^20 - 1,
-    profiles/r5b_*), a second level takes the remainder in 256-row slices, and what is left (< 256 rows) goes through one small fp32 product."""
-    s = split_count(rows)
+    the slices of the first level are shortened to a multiple of 64 rows (the library's kernels for an ODD contraction length ran 12 - 17 %
+    slower -- 64 x 16383 rows 645 us, 64 x 16320 rows 552 us for in_proj's gradient -- and the rows % S leftover went through an fp32 product
+    behind two conversion passes), a second level takes the remainder in 256-row slices, and what is left (< 256 rows) goes through one small
+    fp32 product."""
+    s = split_count(rows, out_elems)
     q = rows // s
-    if rows % s == 0 or q < 2 * SLICE_ALIGN:
+    if rows % s == 0 or q < 2 * TAIL_SLICE:
         return [(0, s, q)], s * q
     q -= q % SLICE_ALIGN
     levels, pos = [(0, s, q)], s * q
-    s2 = (rows - pos) // SLICE_ALIGN
+    s2 = (rows - pos) // TAIL_SLICE
     if s2 > 0:
-        levels.append((pos, s2, SLICE_ALIGN))
-        pos += s2 * SLICE_ALIGN
+        levels.append((pos, s2, TAIL_SLICE))
+        pos += s2 * TAIL_SLICE
     return levels, pos
+
+
+def _tail_product(a_cn, b_nk, done):
+    """sum over the positions p >= done of a_cn[:, p] b_nk[p, :] in fp32 -- the < 256 rows split_plan leaves -- for views a_cn (C, n), b_nk (n, K) of
+    any strides.  On the GPU: the LAST 256 positions as one more 16-bit slice whose already-counted columns are zeroed in a small copy (an fp32
+    product of 255 rows behind two conversion passes took 80 + 12 us: the library schedules it on a handful of workgroups)."""
+    n = a_cn.shape[1]
+    r = n - done
+    if r <= 0:
+        return None
+    if not a_cn.is_cuda or n < TAIL_SLICE or a_cn.dtype == torch.float32:
+        return torch.mm(a_cn[:, done:].float(), b_nk[done:].float())
+    a = a_cn[:, n - TAIL_SLICE:].clone()
+    a[:, :TAIL_SLICE - r] = 0
+    return torch.bmm(a.unsqueeze(0), b_nk[n - TAIL_SLICE:].unsqueeze(0), out_dtype=torch.float32)[0]
 
 
 def split_k_weight_grad(dy2, x2):
     """dy2^T x2 (fp32) as batched position slices (split_plan) + a tail, partial sums added in a fixed order (deterministic)."""
     rows, n = dy2.shape
     k = x2.shape[1]
-    levels, done = split_plan(rows)
+    levels, done = split_plan(rows, n * k)
     dw = None
     for p0, s, q in levels:
         g = _bmm_f32(dy2[p0:p0 + s * q].view(s, q, n).transpose(1, 2), x2[p0:p0 + s * q].view(s, q, k)).sum(0)
         dw = g if dw is None else dw + g
     if done < rows:                                                 # the leftover rows
-        dw = dw + torch.mm(dy2[done:].t().float(), x2[done:].float())
+        dw = dw + _tail_product(dy2.t(), x2, done)
     return dw
 
 
@@ -165,12 +185,12 @@ def wgrad_cm_pm(d, x2):
     total = None
     for m, p0, n in _pieces(d, L):
         xs = x2[p0:p0 + n]
-        levels, done = split_plan(n)
+        levels, done = split_plan(n, C * k)
         for r0, s, q in levels:
             g = _bmm_f32(m[:, r0:r0 + s * q].reshape(C, s, q).permute(1, 0, 2), xs[r0:r0 + s * q].view(s, q, k)).sum(0)
             total = g if total is None else total + g
         if done < n:
-            total = total + torch.mm(m[:, done:].float(), xs[done:].float())
+            total = total + _tail_product(m, xs, done)
     return total
 
 
@@ -181,12 +201,12 @@ def wgrad_pm_cm(dy2, z):
     total = None
     for m, p0, n in _pieces(z, L):
         ds = dy2[p0:p0 + n]
-        levels, done = split_plan(n)
+        levels, done = split_plan(n, N * K)
         for r0, s, q in levels:
             g = _bmm_f32(ds[r0:r0 + s * q].view(s, q, N).transpose(1, 2), m[:, r0:r0 + s * q].reshape(K, s, q).permute(1, 2, 0)).sum(0)
             total = g if total is None else total + g
         if done < n:
-            total = total + torch.mm(ds[done:].t().float(), m[:, done:].t().float())
+            total = total + _tail_product(ds.t(), m.t(), done)
     return total
 
 

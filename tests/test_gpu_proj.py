@@ -265,3 +265,28 @@ def test_out_proj_with_add_norm_epilogue_on_gpu(gpu_lib, B, L, D, dtype):
     one = gpu_lib.outproj_gate_addnorm_fwd(y, xT, bin_, w, b, W, bias, True, res, lw, lb, 1e-5)
     for p, q in zip(two, one):
         assert torch.equal(p.reshape(-1), q.reshape(-1))
+
+
+@pytest.mark.parametrize("B,L", [(1, 1048575), (8, 32767), (2, 159999), (1, 70001), (3, 4099)])
+def test_weight_gradient_slicing_at_odd_position_counts(gpu_lib, B, L):
+    """projection.split_plan / _tail_product (round 5): the three weight-gradient products at the reference trainer's odd position counts --
+    first-level slices of a multiple of 64 rows, the remainder in 256-row slices, the last < 256 rows as a masked 16-bit slice -- against
+    the fp64 products, and twice for determinism."""
+    from hyena_dna_amd.projection import split_k_weight_grad, split_plan, wgrad_cm_pm, wgrad_pm_cm
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(B * L)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
+    P, D = B * L, 256
+    levels, done = split_plan(P, 3 * D * D)
+    assert 0 < P - done < 256 or P % 256 == 0
+    dy2, x2 = rn(P, D).bfloat16(), rn(P, D).bfloat16()
+    dT = gpu_lib.empty_cm(3 * D, B, L, torch.bfloat16, dev).copy_(rn(3 * D, B, L).bfloat16())
+    zT = gpu_lib.empty_cm(D, B, L, torch.bfloat16, dev).copy_(rn(D, B, L).bfloat16())
+    got = [split_k_weight_grad(dy2, x2), wgrad_cm_pm(dT, x2), wgrad_pm_cm(dy2, zT)]
+    again = [split_k_weight_grad(dy2, x2), wgrad_cm_pm(dT, x2), wgrad_pm_cm(dy2, zT)]
+    d2 = dT.permute(0, 1, 2).reshape(3 * D, P).double()
+    z2 = zT.reshape(D, P).double()
+    ref = [dy2.double().t() @ x2.double(), d2 @ x2.double(), dy2.double().t() @ z2.t()]
+    for a, b, r in zip(got, again, ref):
+        assert a.dtype == torch.float32 and a.shape == r.shape and torch.equal(a, b)
+        assert ((a.double() - r).norm() / r.norm()).item() < 2e-6

@@ -169,11 +169,12 @@ def test_split_k_linear_gradients_match_linear():
     # round 5: a row count that its slice count does not divide is cut into 256-row-aligned slices on two levels + a tail of < 256 rows
     from hyena_dna_amd.projection import split_plan
     assert split_plan(1 << 20) == ([(0, 64, 16384)], 1 << 20)                                   # divisible: one level, as before
+    assert split_plan(1 << 20, 256 * 256) == ([(0, 256, 4096)], 1 << 20) and split_count(32768, 256 * 256) == 8     # a one-tile gradient: more slices
     for rows in (1048575, 999999, 449999, 2 * 159999, 8 * 32767, 32767, 70001):
         levels, done = split_plan(rows)
         pos = 0
         for p0, s_, q in levels:
-            assert p0 == pos and q % 256 == 0 and s_ >= 1
+            assert p0 == pos and q % 64 == 0 and s_ >= 1
             pos += s_ * q
         assert pos == done and 0 <= rows - done < 256
     for dt, tol, rows in ((torch.float32, 1e-6, 8192), (torch.bfloat16, 1e-2, 8192), (torch.float32, 1e-6, 16383), (torch.bfloat16, 1e-2, 9999),
