@@ -977,10 +977,10 @@ def add_norm_bwd(dout, d_res_out, res_out, weight, mean, rstd, dx_dtype, need_dr
     dev = dout.device
     dx = torch.empty((rows, D), dtype=dx_dtype, device=dev)
     dres = torch.empty((rows, D), dtype=torch.float32, device=dev) if need_dres else None
-    dw = torch.zeros(D, dtype=torch.float32, device=dev)
-    db = torch.zeros(D, dtype=torch.float32, device=dev)
     if rows == 0:
-        return dx, dres, dw, db
+        return dx, dres, torch.zeros(D, dtype=torch.float32, device=dev), torch.zeros(D, dtype=torch.float32, device=dev)
+    dw = torch.empty(D, dtype=torch.float32, device=dev)          # (written in full by the fixed-order reduction: no zero fill -- 32 launches per model step)
+    db = torch.empty(D, dtype=torch.float32, device=dev)
     part = torch.empty(lib().hyena_add_norm_partial_floats(rows, D), dtype=torch.float32, device=dev)
     with _backend.guard(dev):
         check(lib().hyena_dropout_add_norm_bwd(dout.data_ptr(), dtype_code(dout.dtype), None if d_res_out is None else d_res_out.data_ptr(),
