@@ -32,7 +32,7 @@ def split_count(rows, out_elems=None):
     527 us, 128 x 8191 342 us, 255 x 4096 337 us; the 768 x 256 and 1024 x 256 gradients are best at 64: 552 us vs 636 at 127)."""
     cap = MAX_SPLITS * 4 if (out_elems is not None and out_elems <= 256 * 256) else MAX_SPLITS
     s = 1
-    while s < cap and rows // (2 * s) >= MIN_SLICE:
+    while s < cap and rows // (2 * s) >= MIN_SLICE - 64:           # (- 64: 8 x 32767 rows are cut like 8 x 32768 ones, not in half as many slices)
         s *= 2
     return s
 

@@ -163,9 +163,9 @@ def test_optim_tags_and_buffers_match_reference_contract():
 def test_split_k_linear_gradients_match_linear():
     """hyena_dna_amd/projection.py: the slice-batched weight gradient equals autograd's dy^T x (hyena.py:391,440)"""
     from hyena_dna_amd.projection import SplitKLinearFunc, split_count
-    assert split_count(1 << 20) == 64 and split_count(32768) == 8 and split_count(160000) == 32 and split_count(8191) == 1
+    assert split_count(1 << 20) == 64 and split_count(32768) == 8 and split_count(160000) == 32 and split_count(8191) == 2 and split_count(8000) == 1
     # the lengths the reference dataset really yields are max_length - 1 (hg38_dataset.py:220): odd row counts split too
-    assert split_count(999999) == 64 and split_count(449999) == 64 and split_count(159999) == 32 and split_count(2 * 32767) == 8
+    assert split_count(999999) == 64 and split_count(449999) == 64 and split_count(159999) == 32 and split_count(2 * 32767) == 16 and split_count(8 * 32767) == 64
     # round 5: a row count that its slice count does not divide is cut into 256-row-aligned slices on two levels + a tail of < 256 rows
     from hyena_dna_amd.projection import split_plan
     assert split_plan(1 << 20) == ([(0, 64, 16384)], 1 << 20)                                   # divisible: one level, as before
