@@ -810,16 +810,21 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, ColCfg<M1>::MIN_WAVES) co
                          (long)(row % a.inner) * a.inner_stride;
     c32* Wrow = (second ? a.W2 : a.W) + ((size_t)(row / a.inner) * a.w_bstride + (row % a.inner)) * M1 * 1024;
     const int nfull = a.L >> 1;                         // pairs n < nfull are complete; n == nfull is the odd tail
+    // odd L on PITCHED rows (inner_stride > L, round 5): the tail sample comes in with the regular pair loads -- pair nfull = (x[L - 1], the
+    // element behind the row's end: inside the row's pitch, loaded and discarded by a select, never part of any arithmetic) -- instead of
+    // by a separate predicated scalar load behind them (col_fwd<160, bf16>: 215 vs 204 us at 159999 x 2 / 160000 x 2, profiles/r5v_*)
+    const bool tail_pair = (a.L & 1) != 0 && a.inner_stride > (long)a.L;
+    const int nload = nfull + (tail_pair ? 1 : 0);
 
     // all global loads of the thread back to back: E input pairs (+ the table slice)
     // Rows n1 >= M1/2 (s >= E/2) lie beyond L/2 <= M/2 for every supported L: the zero padding is never loaded.
     constexpr int EL = T > 1 ? E / 2 : Cfg::EH;
     raw_t raw[EL];
-    if (nfull > 0) {
+    if (nload > 0) {
         HY_UNROLL
         for (int s = 0; s < EL; ++s) {
             const int n = (r + T * s) * 1024 + n2;
-            raw[s] = load_raw_pair<DT>(xrow, n < nfull ? n : 0);
+            raw[s] = load_raw_pair<DT>(xrow, n < nload ? n : 0);
         }
     }
     stage_col_tables<M1, Cfg::THREADS>(tlo, a.tab.tw_lo, tid);
@@ -827,9 +832,10 @@ __global__ void __launch_bounds__(ColCfg<M1>::THREADS, ColCfg<M1>::MIN_WAVES) co
     HY_UNROLL
     for (int s = 0; s < E; ++s) {
         const int n = (r + T * s) * 1024 + n2;
-        v[s] = (s < EL && n < nfull) ? Pair<DT>::cvt(raw[s < EL ? s : 0]) : mk(0.f, 0.f);
+        v[s] = (s < EL && n < nload) ? Pair<DT>::cvt(raw[s < EL ? s : 0]) : mk(0.f, 0.f);
+        if (tail_pair && n == nfull) v[s] = mk(v[s].x, 0.f);       // (a select: whatever lies behind the row's end -- NaN in the tests -- is dropped)
     }
-    if (a.L & 1) {                                      // odd L: the last sample is the real part of pair nfull
+    if ((a.L & 1) && !tail_pair) {                      // odd L on packed rows: the last sample is the real part of pair nfull
         HY_UNROLL
         for (int s = 0; s < E; ++s)
             if ((r + T * s) * 1024 + n2 == nfull) v[s] = mk(Elem<DT>::ld(xrow + a.L - 1), 0.f);

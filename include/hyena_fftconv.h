@@ -148,7 +148,8 @@ int hyena_fftconv_bwd_saved(const void* dout, const void* u, const float* bias, 
  * states where rows start instead:
  *     ldx : elements between the starts of consecutive rows of u / out / dout / du -- row (b, d) starts at element (b D + d) ldx
  *     ldk : the same for k / dk (fp32 elements) -- row d starts at element d ldk
- * ldx, ldk >= L; elements [L, ld) of a row are never read or written.  ldx = ldk = L is the packed layout of the entry points above (which
+ * ldx, ldk >= L; elements [L, ld) of a row are never written and never enter any arithmetic (for odd L on the two-level plan the ONE element behind
+ * a row's end is loaded together with the row's last sample and discarded -- it may hold anything, NaN included).  ldx = ldk = L is the packed layout of the entry points above (which
  * are these with that default).  hyena_dna_amd/_lib.py allocates the operator's channel-major tensors with ld = L rounded up to 64 elements
  * and hands PyTorch the [..., :L] views.
  * `saved` / `saved_bytes`: the optional spectrum buffer of hyena_fftconv_fwd_save / _bwd_saved, or NULL / 0.  With `saved` the backward does
