@@ -115,7 +115,7 @@ class HyenaMixerCMFunc(torch.autograd.Function):
         dzT = _lib.as_cm(dzT.to(xc.dtype))
         dxT = _lib.empty_like_cm(xc)
         if Lx > L:
-            dxT.zero_()
+            dxT[:, :, L:].zero_()                     # (the kernels write every position < L of every row)
         part = _lib.cm_partials(xc, L)
         dy = _lib.cm_post_bwd(dzT, y, xc, bi, w, b, dxT, part)
         need_vg = ctx.spectra is None or _lib.lib().hyena_fftconv_plan(int(L)) == _lib.PLAN_ONCHIP
@@ -256,7 +256,7 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
         # ---- the core's backward (HyenaMixerCMFunc.backward) ----
         dxT = _lib.empty_like_cm(xc)
         if Lx > L:
-            dxT.zero_()
+            dxT[:, :, L:].zero_()                     # (the kernels write every position < L of every row)
         part = _lib.cm_partials(xc, L)
         part0 = None
         if _dgrad_fused(B, L, D, xc.dtype):

@@ -241,9 +241,20 @@ class InProjPreCMFunc(torch.autograd.Function):
     are the library GEMMs of InProjCMFunc."""
 
     @staticmethod
-    def forward(ctx, u, weight, b_in, sf_weight, sf_bias, L):
+    def forward(ctx, u, weight, b_in, sf_weight, sf_bias, L, pad_to=0):
         from . import _lib
         B, Lx, K = u.shape
+        ctx.narrow = None
+        if pad_to > Lx:
+            # several sequences of a length that is not a multiple of 64 (the reference trainer's L = max_length - 1): the kernels run on sequences
+            # padded with zero positions to the next multiple -- every row of every channel-major tensor then starts aligned, as at the neighbouring
+            # aligned length, for one extra pass over u (32767 x 8: the layer 2.50 -> 2.4x ms against 2.33 at 32768 x 8; profiles/r5_stress.txt).
+            # Zero positions give zero rows of xT (it carries no bias), lie beyond the convolved length L and receive zero gradients.
+            up = torch.empty((B, pad_to, K), dtype=u.dtype, device=u.device)
+            up[:, :Lx].copy_(u)
+            up[:, Lx:].zero_()
+            ctx.narrow = Lx
+            u, Lx = up, pad_to
         ctx.save_for_backward(u.reshape(B * Lx, K), weight)
         ctx.ushape = u.shape
         bi = None if b_in is None else b_in.detach().to(torch.float32).contiguous()
@@ -258,12 +269,17 @@ class InProjPreCMFunc(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dxT, _dvg):
         if dxT is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         du, dw = InProjCMFunc.backward(ctx, dxT)
-        return du, dw, None, None, None, None
+        if du is not None and ctx.narrow is not None:
+            du = du[:, :ctx.narrow]
+        return du, dw, None, None, None, None, None
 
 
 INPROJ_MFMA = os.environ.get("HYENA_INPROJ_MFMA", "1") != "0"      # A/B knob: 0 = library GEMM + cm_pre_fwd
+
+
+PAD_SEQUENCES = os.environ.get("HYENA_PAD_SEQUENCES", "1") != "0"      # A/B knob: 0 = several odd-length sequences keep their length inside the kernels
 
 
 def in_proj_pre_cm(u, weight, b_in, sf_weight, sf_bias, L):
@@ -275,8 +291,9 @@ def in_proj_pre_cm(u, weight, b_in, sf_weight, sf_bias, L):
     B, Lx, K = u.shape
     if (INPROJ_MFMA and dt is not None and weight.shape == (3 * K, K) and sf_weight.shape[-1] == 3 and sf_weight.shape[0] == 3 * K
             and (u.is_cuda or _lib._backend.name != "hip") and L >= 1 and _lib.proj_supported(B, Lx, K, dt)):
+        pad_to = _lib.row_pitch(Lx) if (PAD_SEQUENCES and B > 1 and Lx == L and Lx % _lib.ROW_ALIGN != 0 and Lx >= 4 * _lib.ROW_ALIGN) else 0
         with torch.autocast("cuda" if u.is_cuda else "cpu", enabled=False):
-            return InProjPreCMFunc.apply(u.to(dt).contiguous(), weight.to(dt).contiguous(), b_in, sf_weight, sf_bias, L)
+            return InProjPreCMFunc.apply(u.to(dt).contiguous(), weight.to(dt).contiguous(), b_in, sf_weight, sf_bias, L, pad_to)
     return in_proj_cm(u, weight), None
 
 

@@ -390,3 +390,32 @@ def test_operator_gradients_with_and_without_the_fused_dgrad(emu_backend, monkey
     for n in res[0]:
         a_, b_ = res[0][n], res[1][n]
         assert ((a_ - b_).norm() / b_.norm().clamp_min(1e-20)).item() < 2e-2, n
+
+
+def test_several_odd_length_sequences_are_padded_inside_in_proj(emu_backend, monkeypatch):
+    """B > 1 sequences of a length that is not a multiple of 64 (the reference trainer's max_length - 1): projection.InProjPreCMFunc runs the
+    kernels on zero-padded sequences, so every channel-major row starts aligned.  Same values: the output and the input gradient bit for bit,
+    the parameter gradients to the summation order of the position sums (the padded positions add exact zeros)."""
+    import hyena_dna_amd.projection as P
+    from hyena_dna_amd.hyena import HyenaOperator
+    torch.manual_seed(21)
+    B, L, D = 3, 321, 128
+    op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10).to(torch.bfloat16)
+    u0 = torch.randn(B, L, D).to(torch.bfloat16)
+    dy = torch.randn(B, L, D).to(torch.bfloat16)
+    seen, real = [], emu_backend.inproj_pre_fwd
+    monkeypatch.setattr(emu_backend, "inproj_pre_fwd", lambda u, *a: (seen.append(tuple(u.shape)), real(u, *a))[1])
+    res = []
+    for pad in (True, False):
+        monkeypatch.setattr(P, "PAD_SEQUENCES", pad)
+        op.zero_grad(set_to_none=True)
+        u = u0.clone().requires_grad_(True)
+        y = op(u)
+        y.backward(dy)
+        res.append((y.detach(), u.grad, {n: p.grad.float() for n, p in op.named_parameters() if p.grad is not None}))
+    assert seen == [(B, 384, D), (B, L, D)]
+    assert res[0][0].shape == (B, L, D) and torch.equal(res[0][0], res[1][0]) and res[0][1].shape == (B, L, D) and torch.equal(res[0][1], res[1][1])
+    assert res[0][2].keys() == res[1][2].keys() and len(res[0][2]) > 10
+    for n in res[0][2]:
+        a_, b_ = res[0][2][n], res[1][2][n]
+        assert ((a_ - b_).norm() / b_.norm().clamp_min(1e-20)).item() < 1e-2, n           # (16-bit parameter gradients: one rounding of slightly different fp32 sums)
