@@ -247,8 +247,8 @@ class InProjPreCMFunc(torch.autograd.Function):
         ctx.narrow = None
         if pad_to > Lx:
             # several sequences of a length that is not a multiple of 64 (the reference trainer's L = max_length - 1): the kernels run on sequences
-            # padded with zero positions to the next multiple -- every row of every channel-major tensor then starts aligned, as at the neighbouring
-            # aligned length, for one extra pass over u (32767 x 8: the layer 2.50 -> 2.4x ms against 2.33 at 32768 x 8; profiles/r5_stress.txt).
+            # padded with zero positions to the next multiple -- xT / dxT rows then start aligned, as at the neighbouring aligned length, for one
+            # extra pass over u (off by default: measured slower, see PAD_SEQUENCES below).
             # Zero positions give zero rows of xT (it carries no bias), lie beyond the convolved length L and receive zero gradients.
             up = torch.empty((B, pad_to, K), dtype=u.dtype, device=u.device)
             up[:, :Lx].copy_(u)
@@ -279,7 +279,11 @@ class InProjPreCMFunc(torch.autograd.Function):
 INPROJ_MFMA = os.environ.get("HYENA_INPROJ_MFMA", "1") != "0"      # A/B knob: 0 = library GEMM + cm_pre_fwd
 
 
-PAD_SEQUENCES = os.environ.get("HYENA_PAD_SEQUENCES", "1") != "0"      # A/B knob: 0 = several odd-length sequences keep their length inside the kernels
+# Several sequences of a length that is not a multiple of 64 on zero-padded positions inside in_proj (InProjPreCMFunc, pad_to): built in round 5,
+# values identical, MEASURED SLOWER and therefore off -- 32767 x 8: the layer 2.528 vs 2.496 ms, 159999 x 2: 3.894 vs 3.814 ms (aligned neighbours
+# 2.318 / 3.740; profiles/r5_stress.txt): it aligns xT / dxT only -- zT, dzT and the position-major side keep B (max_length - 1) positions -- and costs a
+# pass over u.  HYENA_PAD_SEQUENCES=1 turns it on.
+PAD_SEQUENCES = os.environ.get("HYENA_PAD_SEQUENCES", "0") == "1"
 
 
 def in_proj_pre_cm(u, weight, b_in, sf_weight, sf_bias, L):
