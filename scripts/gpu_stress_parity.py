@@ -48,12 +48,21 @@ while time.time() - t0 < budget:
     if ri(0, 3) == 0:
         bias = torch.zeros(D)
     ud, kd, bd, gd = u.to(dev), k.to(dev), bias.to(dev), dout.to(dev)
+    pitched = bool(ri(0, 1))
+    if pitched:        # round 5: the layout the operator hands the convolution -- rows a multiple of 64 elements apart, NaN between them
+        def rows(t):
+            ld = _lib.row_pitch(t.shape[-1]) + 64 * ri(0, 1)
+            buf = torch.full(t.shape[:-1] + (ld,), float("nan"), dtype=t.dtype, device=dev)
+            buf[..., :t.shape[-1]] = t
+            return buf[..., :t.shape[-1]]
+        ud, kd, gd = rows(ud), rows(kd), rows(gd)
     a = run(ud, kd, bd, gd, chunk, saved)
     b = run(ud, kd, bd, gd, chunk, saved)
-    tag = dict(case=n, B=B, D=D, L=L, dtype=str(dtype), chunk=chunk, saved=saved)
+    tag = dict(case=n, B=B, D=D, L=L, dtype=str(dtype), chunk=chunk, saved=saved, pitched=pitched)
     for x, y, nm in zip(a, b, ("out", "du", "dk", "db")):
         assert torch.equal(x, y), ("NON-DETERMINISTIC " + nm, tag)
     out, du, dk, db = (t.cpu() for t in a)
+    assert all(bool(torch.isfinite(t).all()) for t in (out, du, dk, db)), ("read between the rows", tag)
     r_out, r_du, r_dk, r_db = _oracle(u.float(), k, bias, dout.float())
     if dtype == torch.float32:
         e_out, e_du = _rel(out, r_out), _rel(du, r_du)
