@@ -314,7 +314,7 @@ def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=8, warmup=
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         wall = tm.item()
     ms = wall * 1e3 / steps
-    loss = float(loss)                               # (also drops the last autograd graph before the capture below)
+    loss = float(loss.detach())                              # (also drops the last autograd graph before the capture below)
     graphed = None
     if L <= 65536 and world == 1 and graphed_ok and not emu:
         try:
