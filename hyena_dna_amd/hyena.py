@@ -11,17 +11,15 @@ Register with the reference's name-based instantiate (src/utils/registry.py:40-4
 ``registry.layer["hyena"] = "hyena_dna_amd.hyena.HyenaOperator"``.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .fftconv import fftconv_func, fftconv_ref
 from .filter import fused_filter_ok, hyena_filter_dl
-import os
-
 from .mixer import hyena_mixer_core, hyena_mixer_core_cm, hyena_mixer_out_cm, mixer_out_supported
-from .projection import hyena_linear, in_proj_cm, in_proj_pre_cm, out_proj_cm
+from .projection import hyena_linear, in_proj_pre_cm, out_proj_cm
 
 # Layout of the tensors between the operator's two projections: channel-major (x^T written by the in_proj GEMM, z^T read by
 # the out_proj GEMM, no transposes anywhere: csrc/cm_kernels.h) or the reference's position-major (B, L, 3D) with the
