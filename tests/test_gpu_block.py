@@ -125,7 +125,7 @@ def test_graphed_train_step_matches_eager(gpu_lib):
             loss = m_e.loss(ids, torch.roll(ids, -1, 1))
         loss.backward()
         o_e.step()
-        eager.append(float(loss))
+        eager.append(float(loss.detach()))
 
     m_g, o_g = make()
     before = [p.detach().clone() for p in m_g.parameters()]
