@@ -364,9 +364,14 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
                 Frag db[S1];
                 if (MOD) {
                     float dv[8 * S1];
+#ifdef F16_DBG_NO_P1LOAD        // (profiling builds only: what the first read of dk costs)
+                    HY_UNROLL
+                    for (int j = 0; j < 8 * S1; ++j) { dv[j] = 1e-3f * (float)(s0 + j + lane); HY_OPAQUE(dv[j]); }
+#else
                     HY_UNROLL
                     for (int j = 0; j < 8 * S1; ++j)
                         dv[j] = fb_ld(Db, vpos + (unsigned)(8 * half) * O4, (unsigned)(16 * (s0 + (j >> 3)) + (j & 7)) * O4);
+#endif
                     HY_UNROLL
                     for (int j = 0; j < 8 * S1; ++j) {
                         const int o = 16 * (s0 + (j >> 3)) + 8 * half + (j & 7);
@@ -423,6 +428,15 @@ __global__ void __launch_bounds__(FLT_THREADS, F16_BWD_MINW) flt16_layer_bwd_ker
                 // the raw operand words of S2 steps first (8 per step: fp32 values or pair words), then the arithmetic
                 uint32_t raw[S2][8];
                 const bool whole = (a.ldo & 3) == 0 && p0 + 16 * (kk0 + S2) <= L;
+#ifdef F16_DBG_NO_P2LOAD        // (profiling builds only, scripts/build_variant.sh: wrong results by construction -- what the second read of dk costs)
+                if (MOD) {
+                    HY_UNROLL
+                    for (int u = 0; u < S2; ++u) {
+                        HY_UNROLL
+                        for (int j = 0; j < 8; ++j) { raw[u][j] = 0x3c000000u + (unsigned)(kk0 + u + j + lane); HY_OPAQUE(raw[u][j]); }
+                    }
+                } else
+#endif
                 if (whole) {
                     HY_UNROLL
                     for (int u = 0; u < S2; ++u) {
