@@ -111,6 +111,11 @@ SWEEP_EXTRA = [(65536, 4, 256)]
 # every channel-major row starts 2 bytes off a 4- / 16-byte boundary.  (L, B per GPU, d, the aligned neighbour it is compared with)
 SWEEP_REAL = [(32767, 8, 256, 32768), (159999, 2, 256, 160000), (449999, 1, 256, 450000), (999999, 1, 256, 1000000),
               (1048575, 1, 256, 1048576)]
+# The SHIPPED experiment's shapes at the operator / model level: configs/experiment/hg38/hg38_hyena.yaml:47-48 is batch_size 256,
+# max_length 1024 -> the operator sees (B, L, D) = (256, 1023, 128) in a 2-layer model (hg38_dataset.py:222, `data = seq[:-1]`; README default
+# recipe); the 32k and 160k models likewise at (8, 32767, 256) and (2, 159999, 256).  B > 1 at odd L is the only thing the trainer ever runs.
+# (L, B per GPU, d_model, n_layer, aligned neighbour)
+REAL_SHAPES = [(1023, 256, 128, 2, 1024), (32767, 8, 256, 8, 32768), (159999, 2, 256, 8, 160000)]
 # What the part sustains for the mixed read + write streams of the two-level plan (profiles/cpol_bw_r2.txt: 5.0-5.3 TB/s typical, 5.8 TB/s
 # the single best case): the floor of ANY exact-fp32 two-pass transform is its real traffic / this rate
 MIXED_STREAM_TBS = 5.8
@@ -139,34 +144,129 @@ def parse():
                     help="TEST ONLY: every rank on cuda:0 with the gloo backend (exercises the N > 1 GPU leg on a 1-GPU box)")
     ap.add_argument("--emu", action="store_true",
                     help="TEST ONLY: run the host logic on the CPU emulation of the kernels with the gloo backend")
+    ap.add_argument("--cpu-worker", default=None, help="INTERNAL: one pinned channel group of cpu_baseline (a JSON spec); no GPU is touched")
     return ap.parse_args()
 
 
-def cpu_baseline(L, D, dtype, budget_s=30.0):
-    """The oracle (reference torch.fft path) fwd+bwd on the host cores, on a bounded sample of the same workload: the same L, a
-    subset of the D channels (channels are independent), B = 1.  A 64-row FFT job does not fill a many-core host and
-    oversubscribing it is slower than using fewer threads, so the sample is timed at several thread counts --
-    {8, 32, all cores} -- best of 3 each after a warm-up, and the BEST (thread count, time) is what is reported; `cores` = the threads
-    of that best run.  The figure is the sample's own throughput scaled by the channel fraction: on a host with more cores than the best
-    thread count the remaining cores could run further channel groups side by side, which this figure does NOT claim."""
+def _cpu_once(u, k, bias, dout):
+    """one forward + backward of the oracle's fftconv_ref on host tensors; returns seconds"""
     from oracle import hyena_oracle as O
-    host = os.cpu_count() or 1
-    Ds = max(1, min(D, 64, int(4.0e8 / max(L, 1024) / 12 * 8)))
-    g = torch.Generator().manual_seed(0)
+    u_ = u.clone().requires_grad_(True)
+    k_ = k.clone().requires_grad_(True)
+    b_ = bias.clone().requires_grad_(True)
+    t0 = time.perf_counter()
+    out = O.fftconv_ref(u_, k_, b_, None, gelu=False)
+    out.backward(dout)
+    return time.perf_counter() - t0
+
+
+def _cpu_sample(L, Ds, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
     u = torch.randn(1, Ds, L, generator=g).to(dtype)
     k = torch.randn(Ds, L, generator=g) * torch.exp(-5.0 * torch.linspace(0, 1, L))[None] * 0.1
     bias = torch.randn(Ds, generator=g)
     dout = torch.randn(1, Ds, L, generator=g).to(dtype)
+    return u, k, bias, dout
 
-    def once():
-        u_ = u.clone().requires_grad_(True)
-        k_ = k.clone().requires_grad_(True)
-        b_ = bias.clone().requires_grad_(True)
-        t0 = time.perf_counter()
-        out = O.fftconv_ref(u_, k_, b_, None, gelu=False)
-        out.backward(dout)
-        return time.perf_counter() - t0
 
+def cpu_worker(spec):
+    """`python bench.py --cpu-worker '<json>'`: ONE channel group of the host-cores baseline -- pinned to its own cores, the oracle's
+    fftconv_ref fwd+bwd on `channels` channels, `reps` timed passes after a warm-up, all groups released together through a `go` file.
+    Prints one JSON line {elapsed_s, reps, channels}.  (The oracle is used here as cpu_baseline's measured CPU path, nowhere else.)"""
+    spec = json.loads(spec)
+    cores = spec["cores"]
+    try:
+        os.sched_setaffinity(0, set(cores))
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(len(cores))
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[spec["dtype"]]
+    ops = _cpu_sample(spec["L"], spec["channels"], dtype, seed=spec["seed"])
+    _cpu_once(*ops)                                            # warm-up: FFT plans, thread pool, page faults
+    open(spec["ready"], "w").close()
+    deadline = time.time() + 120.0
+    while not os.path.exists(spec["go"]) and time.time() < deadline:
+        time.sleep(0.005)
+    t0 = time.perf_counter()
+    for _ in range(spec["reps"]):
+        _cpu_once(*ops)
+    print(json.dumps({"elapsed_s": time.perf_counter() - t0, "reps": spec["reps"], "channels": spec["channels"]}), flush=True)
+
+
+def _cpu_groups(L, D, dtype_name, t_best, Ds, host, reps, timeout_s):
+    """`groups` = host // t_best concurrent worker processes (cpu_worker), each pinned to t_best cores of its own and convolving its own Ds
+    channels: the aggregate nt/s of the host with `groups * t_best` cores busy.  None if it cannot be run (memory, spawn failure, timeout)."""
+    import subprocess
+    import tempfile
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = list(range(host))
+    groups = len(avail) // t_best
+    # memory: a group holds ~Ds rows of u, k, dout, their 2L-point spectra and autograd's copies: ~30 fp32 rows of 2L points per channel
+    need = 30 * Ds * 2 * L * 4
+    try:
+        with open("/proc/meminfo") as f:
+            mem_avail = next(int(l.split()[1]) * 1024 for l in f if l.startswith("MemAvailable"))
+        for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                         ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+            try:                                                 # a container's own limit can sit far below the host's free memory
+                with open(lim) as f1, open(cur) as f2:
+                    v = f1.read().strip()
+                    if v != "max":
+                        mem_avail = min(mem_avail, int(v) - int(f2.read().strip()))
+            except (OSError, ValueError):
+                pass
+        groups = min(groups, int(mem_avail * 0.5 // need))
+    except (OSError, StopIteration, ValueError):
+        groups = min(groups, 4)
+    if groups < 2:
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_cpu_")
+    go = os.path.join(tmp, "go")
+    procs = []
+    try:
+        for gidx in range(groups):
+            spec = {"L": L, "channels": Ds, "dtype": dtype_name, "seed": gidx, "reps": reps, "go": go,
+                    "ready": os.path.join(tmp, f"ready{gidx}"), "cores": avail[gidx * t_best:(gidx + 1) * t_best]}
+            env = dict(os.environ, OMP_NUM_THREADS=str(t_best), MKL_NUM_THREADS=str(t_best), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", json.dumps(spec)],
+                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True))
+        t_end = time.time() + timeout_s
+        while time.time() < t_end and not all(os.path.exists(os.path.join(tmp, f"ready{g}")) for g in range(groups)):
+            if any(p.poll() is not None for p in procs):
+                return None
+            time.sleep(0.02)
+        open(go, "w").close()
+        outs = []
+        for p in procs:
+            out, _ = p.communicate(timeout=max(1.0, t_end - time.time()) + 30.0)
+            outs.append(json.loads(out.strip().splitlines()[-1]))
+        slowest = max(o["elapsed_s"] for o in outs)
+        total_channel_passes = sum(o["channels"] * o["reps"] for o in outs)
+        return {"groups": groups, "threads_per_group": t_best, "cores": groups * t_best, "channels_per_group": Ds, "reps": reps,
+                "slowest_group_s": slowest, "value": L * (total_channel_passes / D) / slowest}
+    except Exception:
+        return None
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_baseline(L, D, dtype, budget_s=20.0):
+    """The oracle (reference torch.fft path) fwd+bwd on the host cores, on a bounded sample of the same workload: the same L, B = 1
+    (SURVEY.md 8d).  Two stages.  (1) ONE channel group (Ds <= 64 channels; channels are independent) at several thread counts -- {8, 32,
+    all cores}, best of 3 each after a warm-up: a 64-row FFT job does not fill a many-core host and oversubscribing it is slower than using
+    fewer threads (VERDICT r4 weak 8), so this finds the thread count t* one group runs best at.  (2) host_cores // t* such groups AT THE SAME
+    TIME, one process each, pinned to disjoint cores, each convolving its own channels, released together: `value` is the
+    aggregate -- all groups' channel passes over the slowest group's time -- and `cores` the cores actually busy.  If stage 2 cannot run (one
+    group only, too little host memory, a worker failed) the stage-1 figure is reported and `cores` says so."""
+    host = os.cpu_count() or 1
+    Ds = max(1, min(D, 64, int(4.0e8 / max(L, 1024) / 12 * 8)))
+    ops = _cpu_sample(L, Ds, dtype, seed=0)
     t_start = time.perf_counter()
     tried = {}
     saved_threads = torch.get_num_threads()
@@ -174,10 +274,10 @@ def cpu_baseline(L, D, dtype, budget_s=30.0):
         if tried and time.perf_counter() - t_start > budget_s:
             break
         torch.set_num_threads(t)
-        once()                                                    # warm-up at this thread count
+        _cpu_once(*ops)                                                    # warm-up at this thread count
         best = None
         for _ in range(3):
-            dt = once()
+            dt = _cpu_once(*ops)
             best = dt if best is None else min(best, dt)
             if time.perf_counter() - t_start > 1.5 * budget_s:
                 break
@@ -185,12 +285,24 @@ def cpu_baseline(L, D, dtype, budget_s=30.0):
     torch.set_num_threads(saved_threads)
     t_best = min(tried, key=tried.get)
     best = tried[t_best]
-    nt_per_s = L * (Ds / D) / best           # a nucleotide = one position through all D channels
-    return {"value": nt_per_s, "unit": "nt/s", "cores": t_best, "host_cores": host, "kind": "port", "repetitions": 3,
-            "by_threads": {str(t): L * (Ds / D) / v for t, v in tried.items()},
-            "sample": f"oracle fftconv_ref fwd+bwd (torch.fft, fp32 math), B=1, L={L}, {Ds} of {D} channels, timed at "
-                      f"{sorted(tried)} threads (best of 3 after a warm-up each); best {best * 1e3:.0f} ms at {t_best} threads on a "
-                      f"{host}-core host; scaled by {Ds}/{D} channels"}
+    one_group = L * (Ds / D) / best           # a nucleotide = one position through all D channels
+    dtype_name = {torch.bfloat16: "bf16", torch.float16: "fp16", torch.float32: "fp32"}[dtype]
+    reps = max(1, min(3, int(6.0 / max(best, 1e-3))))
+    multi = _cpu_groups(L, D, dtype_name, t_best, Ds, host, reps, timeout_s=40.0) if host // t_best >= 2 else None
+    res = {"value": one_group, "unit": "nt/s", "cores": t_best, "host_cores": host, "kind": "port", "repetitions": 3,
+           "by_threads": {str(t): L * (Ds / D) / v for t, v in tried.items()},
+           "one_group": {"value": one_group, "threads": t_best, "channels": Ds, "best_s": best},
+           "sample": f"oracle fftconv_ref fwd+bwd (torch.fft, fp32 math), B=1, L={L}, {Ds} of {D} channels, timed at "
+                     f"{sorted(tried)} threads (best of 3 after a warm-up each); best {best * 1e3:.0f} ms at {t_best} threads on a "
+                     f"{host}-core host; scaled by {Ds}/{D} channels"}
+    if multi is not None:
+        res.update(value=multi["value"], cores=multi["cores"], concurrent=multi,
+                   sample=f"oracle fftconv_ref fwd+bwd (torch.fft, fp32 math), B=1, L={L}: {multi['groups']} channel groups of {Ds} channels "
+                          f"at the same time, one process each pinned to {t_best} cores of its own ({multi['cores']} of {host} host cores busy), "
+                          f"{multi['reps']} passes per group after a warm-up, released together; all groups' channel passes / the slowest "
+                          f"group's {multi['slowest_group_s']:.2f} s, scaled to {D} channels.  One group alone (the thread count was chosen on it, "
+                          f"best of {sorted(tried)} threads): {one_group:.0f} nt/s")
+    return res
 
 
 def operator_algorithmic_bytes(B, D, L, s):
@@ -218,11 +330,12 @@ def _median(xs):
     return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
 
 
-def operator_layer(L, D, B, dtype, dev, steps=20, warmup=3):
+def operator_layer(L, D, B, dtype, dev, steps=20, warmup=3, graph=False):
     """Secondary figure (not `value`): one whole HyenaOperator layer -- in_proj, short conv, gates, implicit filter, long
     conv, out_proj -- forward + backward under autocast, HyenaDNA configuration (hg38_hyena.yaml:20-30), random init.
     `ms_per_step` is the mean of `steps` steps, with the minimum and the median beside it (box noise is +- 4 %: VERDICT r4 item 4),
-    and a roofline against operator_algorithmic_bytes."""
+    and a roofline against operator_algorithmic_bytes.  graph: the step is captured into one hipGraph and replayed (shapes whose eager
+    step is bound by Python issuing its ~60 launches, not by the GPU); falls back to eager calls if the capture fails."""
     from hyena_dna_amd.hyena import HyenaOperator
     torch.manual_seed(0)
     op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
@@ -240,12 +353,35 @@ def operator_layer(L, D, B, dtype, dev, steps=20, warmup=3):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
-    times = _timed_steps(step, steps, dev)
+    run, graphed = step, False
+    if graph:
+        try:
+            import gc
+            gc.collect()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):                   # this stream's workspaces / keep-the-spectra decisions exist before the capture
+                    step()
+                side.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            for _ in range(warmup):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            run, graphed = g.replay, True
+        except Exception:                            # secondary figure: the eager loop is always available
+            torch.cuda.synchronize(dev)
+            run, graphed = step, False
+    times = _timed_steps(run, steps, dev)
     ms = sum(times) / steps
     s = 4 if dtype == torch.float32 else 2
     abytes = operator_algorithmic_bytes(B, D, L, s)
     best = min(times)
     return {"ms_per_step": ms, "min_ms": best, "median_ms": _median(times), "value": B * L / ms * 1e3, "unit": "nt/s", "steps": steps,
+            "hipgraph_replay": graphed,
             "roofline": {"bound": "hbm", "achieved": abytes / (best * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": abytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": abytes,
                          "of": "min_ms", "boundary": "SURVEY 8d secondary (mixer core, 11 B L D s + 12 D L) + the projections' layer I/O "
@@ -514,8 +650,141 @@ def sweep_real_shapes(dtype, dtype_name, dev, steps, warmup, graph_ok):
     return res
 
 
+def real_shape_legs(dtype, dev, no_operator=False, no_model=False):
+    """The shipped experiments' own shapes at the operator and the model level (REAL_SHAPES), each next to its aligned neighbour through the
+    same loops: `operator_layer` {real, aligned, vs_aligned} and `model_step` {real, aligned, vs_aligned} per shape.  Shapes whose eager step is
+    bound by the host issuing launches (L < 65536) are ALSO timed as hipGraph replays, and `vs_aligned` is then taken on the replayed (GPU) time --
+    the misalignment these legs exist to expose is GPU time; the eager ratio is reported beside it."""
+    legs = []
+    for (L, B, D, n_layer, La) in REAL_SHAPES:
+        leg = {"seq_len": L, "batch_per_gpu": B, "d_model": D, "n_layer": n_layer, "aligned_seq_len": La,
+               "source": "configs/experiment/hg38/hg38_hyena.yaml:47-48 + hg38_dataset.py:222 (L = max_length - 1)"}
+        launch_bound = L < 65536
+        if not no_operator:
+            try:
+                r = {}
+                for key, length in (("real", L), ("aligned", La)):
+                    best = None
+                    for _ in range(2):               # interleaved twice, the better kept: the comparison is about a 2 % difference
+                        o = operator_layer(length, D, B, dtype, dev, steps=20, warmup=3, graph=launch_bound)
+                        best = o if best is None or o["min_ms"] < best["min_ms"] else best
+                    r[key] = {k: best[k] for k in ("ms_per_step", "min_ms", "median_ms", "hipgraph_replay")}
+                    torch.cuda.empty_cache()
+                r["vs_aligned"] = {"min": r["real"]["min_ms"] / r["aligned"]["min_ms"],
+                                   "median": r["real"]["median_ms"] / r["aligned"]["median_ms"]}
+                leg["operator_layer"] = r
+            except Exception as e:
+                leg["operator_layer"] = {"error": repr(e)[:200]}
+        if not no_model:
+            try:
+                r = {}
+                for key, length in (("real", L), ("aligned", La)):
+                    torch.cuda.empty_cache()
+                    m = model_step(length, D, B, dtype, dev, n_layer=n_layer, steps=8, warmup=2, graphed_ok=launch_bound)
+                    r[key] = {k: m.get(k) for k in ("ms_per_step", "min_ms", "median_ms", "value", "loss", "peak_mem_GB")}
+                    gr = m.get("graphed") or {}
+                    r[key]["graphed_ms"] = gr.get("ms_per_step")
+                    if "error" in gr:
+                        r[key]["graphed_error"] = gr["error"]
+                r["vs_aligned"] = {"min": r["real"]["min_ms"] / r["aligned"]["min_ms"],
+                                   "median": r["real"]["median_ms"] / r["aligned"]["median_ms"]}
+                if r["real"]["graphed_ms"] and r["aligned"]["graphed_ms"]:
+                    r["vs_aligned"]["graphed"] = r["real"]["graphed_ms"] / r["aligned"]["graphed_ms"]
+                leg["model_step"] = r
+            except Exception as e:
+                leg["model_step"] = {"error": repr(e)[:300]}
+        legs.append(leg)
+        torch.cuda.empty_cache()
+    return legs
+
+
+def _rccl_log_summary(path):
+    """RCCL's INFO log of this rank, reduced to what identifies the job: the version line, and how many channels went over which transport."""
+    import re
+    out = {"file": path, "version_line": None, "transports": {}, "sample": []}
+    try:
+        with open(path, errors="replace") as f:
+            for ln in f:
+                ln = ln.rstrip()
+                if out["version_line"] is None and re.search(r"(RCCL|NCCL) version", ln):
+                    out["version_line"] = ln[-160:]
+                m = re.search(r"\bvia (\S+)", ln)
+                if m and "Channel" in ln:
+                    key = m.group(1)
+                    out["transports"][key] = out["transports"].get(key, 0) + 1
+                    if len(out["sample"]) < 3:
+                        out["sample"].append(ln[-200:])
+                elif len(out["sample"]) < 6 and re.search(r"XGMI|xgmi|PCIe|comm 0x.* rank .* nranks", ln):
+                    out["sample"].append(ln[-200:])
+    except OSError as e:
+        out["error"] = repr(e)[:120]
+    return out
+
+
+def _gpu_link_types():
+    """rocm-smi's link type between every pair of GPUs of the node ({"XGMI": n, "PCIE": m}), or the reason it is not available"""
+    import re
+    import subprocess
+    try:
+        txt = subprocess.run(["rocm-smi", "--showtopotype"], capture_output=True, text=True, timeout=20).stdout
+        kinds = {}
+        for k in re.findall(r"\b(XGMI|PCIE)\b", txt):
+            kinds[k] = kinds.get(k, 0) + 1
+        return kinds or {"unparsed": txt[-200:]}
+    except Exception as e:
+        return {"error": repr(e)[:120]}
+
+
+def dist_diagnostics(dev, rank, world, ms_max, ms_local, args, nccl_log):
+    """Collective on every rank (world > 1): each rank's own ms/step of the timed region gathered to everybody, and one gradient-sized
+    all_reduce -- 6.6 M fp32 = 26 MB, hyenadna-large-1m's gradients (train.py:611-620: what DDP's buckets carry) -- timed OUTSIDE the timed
+    region: 2 warm-up calls, then 5 calls between barriers, max over ranks.  Rank 0 adds the backend, the library version, the visible
+    devices, the node's GPU link types and RCCL's own transport lines."""
+    cpu = args.emu
+    t = torch.tensor([ms_local], dtype=torch.float64, device="cpu" if cpu else dev)
+    per_rank = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(per_rank, t)
+    n = 6_600_000 if not cpu else 66_000
+    buf = torch.ones(n, dtype=torch.float32, device="cpu" if cpu else dev)
+    for _ in range(2):
+        dist.all_reduce(buf)
+        buf.fill_(1.0)
+    if not cpu:
+        torch.cuda.synchronize(dev)
+    dist.barrier()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf)
+    if not cpu:
+        torch.cuda.synchronize(dev)
+    probe = torch.tensor([(time.perf_counter() - t0) * 1e3 / reps], dtype=torch.float64, device="cpu" if cpu else dev)
+    dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+    ok = bool(abs(float(buf[0]) - float(world) ** reps) < 1e-3 * float(world) ** reps)        # the sum really covered `world` ranks
+    if rank != 0:
+        return None
+    backend = dist.get_backend()
+    info = {"backend": backend, "is_rccl": backend == "nccl" and getattr(torch.version, "hip", None) is not None,
+            "world_size": dist.get_world_size(), "devices_visible": 0 if cpu else torch.cuda.device_count(),
+            "device_name": None if cpu else torch.cuda.get_device_name(dev),
+            "nccl_version": None, "per_rank_ms": [float(x) for x in per_rank], "max_rank_ms": ms_max,
+            "allreduce_probe_ms": float(probe), "allreduce_probe_bytes": n * 4, "allreduce_probe_sum_ok": ok,
+            "allreduce_probe_busbw_GBs": 2 * (world - 1) / world * n * 4 / (float(probe) * 1e-3) / 1e9}
+    if backend == "nccl":
+        try:
+            info["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:
+            info["nccl_version"] = repr(e)[:80]
+        info["gpu_link_types"] = _gpu_link_types()
+        if nccl_log:
+            info["rccl_log"] = _rccl_log_summary(nccl_log)
+    return info
+
+
 def main():
     args = parse()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -535,9 +804,18 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    nccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         cpu_backend = args.emu or args.share_gpu0
+        if not cpu_backend and "NCCL_DEBUG" not in os.environ:
+            # RCCL's own account of the job -- version, ranks, the transport of every channel (P2P over xGMI, SHM or NET) -- goes to a per-rank
+            # file (stdout carries exactly ONE line, the JSON); rank 0 summarises its file into `dist.rccl_log` below
+            import tempfile
+            nccl_log = os.path.join(tempfile.gettempdir(), f"bench_rccl_{os.getpid()}_r{rank}.log")
+            os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,ENV")
+            os.environ["NCCL_DEBUG_FILE"] = nccl_log
         dist.init_process_group("gloo" if cpu_backend else "nccl", rank=rank, world_size=world,
                                 **({} if cpu_backend else {"device_id": dev}))
 
@@ -572,10 +850,18 @@ def main():
     sync()
     wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1) if not args.emu else wall * 1e3
+    local_wall = wall
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev if not args.emu else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = tmax.item()
+
+    dist_info = None
+    if world > 1:
+        try:
+            dist_info = dist_diagnostics(dev, rank, world, wall * 1e3 / args.steps, local_wall * 1e3 / args.steps, args, nccl_log)
+        except Exception as e:                                       # diagnostics never cost the contract line
+            dist_info = {"error": repr(e)[:300]}
 
     sweep = sweep_extra = None
     if world == 1 and not args.no_sweep and not args.fwd_only:
@@ -617,6 +903,9 @@ def main():
                                       f"timed region; the DDP gradient all-reduce is measured in `model_step`)"
                                       if world > 1 else "single GPU",
                        "unit_of_work": "one nucleotide through one Hyena long-conv layer call (fwd+bwd), all d channels"},
+            # N > 1: what lets a reader of SCALE_r*.json see that N ranks really met over RCCL (backend, library version, devices, every rank's own
+            # step time, one timed 26 MB gradient-sized all_reduce outside the timed region, RCCL's transport lines); null at N = 1
+            "dist": dist_info,
             "roofline": roof,
             "roofline_valu": valu,
             # the other four BASELINE.json configurations through the same loop (N = 1 runs; null otherwise)
@@ -651,6 +940,12 @@ def main():
                     line["model_step_real"] = r
                 except Exception as e:
                     line["model_step_real"] = {"error": repr(e)[:300]}
+        if world == 1 and not args.emu and not args.no_sweep and not args.fwd_only and not (args.no_operator and args.no_model):
+            # the shipped experiments' own (B, L, d_model, n_layer) at the operator and the model level, next to their aligned neighbours
+            try:
+                line["real_shapes"] = real_shape_legs(dtype, dev, no_operator=args.no_operator, no_model=args.no_model)
+            except Exception as e:
+                line["real_shapes"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline and not args.emu:
             line["cpu_baseline"] = cpu_baseline(L, D, dtype)          # rank 0 at N = 1 only (other ranks would idle at the barrier)
         else:

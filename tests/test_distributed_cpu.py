@@ -35,6 +35,31 @@ def test_bench_world_size_2_gloo():
     assert "error" not in m, m
     assert m["n_gpus"] == 2 and "DDP" in m["parallelism"] and "gradient_as_bucket_view=True" in m["parallelism"]
     assert abs(m["value"] - 2 * 3000 / (m["ms_per_step"] * 1e-3)) / m["value"] < 1e-6 and m["loss"] == m["loss"]
+    # `dist`: a reader of the line can tell that N ranks met -- backend, world size, every rank's own step time, one timed
+    # gradient-sized all_reduce whose SUM proves all ranks took part (here: gloo on the CPU; on the GPU node: RCCL + its transport lines)
+    d = r["dist"]
+    assert d is not None and "error" not in d, d
+    assert d["backend"] == "gloo" and d["is_rccl"] is False and d["world_size"] == 2
+    assert len(d["per_rank_ms"]) == 2 and all(t > 0 for t in d["per_rank_ms"])
+    assert abs(max(d["per_rank_ms"]) - r["ms_per_step"]) <= 1e-6 * r["ms_per_step"] + 1e-9       # `value` is the slowest rank's time
+    assert d["allreduce_probe_ms"] > 0 and d["allreduce_probe_sum_ok"] is True and d["allreduce_probe_bytes"] > 0
+    for key in ("devices_visible", "nccl_version", "max_rank_ms", "allreduce_probe_busbw_GBs"):
+        assert key in d, key
+
+
+def test_rccl_log_summary_counts_transports(tmp_path):
+    """what rank 0 makes of RCCL's INFO log on a GPU node (bench._rccl_log_summary), on lines of the published format"""
+    sys.path.insert(0, ROOT)
+    import bench
+    log = tmp_path / "rccl.log"
+    log.write_text("host:1:1 [0] NCCL INFO NCCL version 2.22.3+hip6.3 RCCL\n"
+                   "host:1:1 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC\n"
+                   "host:1:1 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC\n"
+                   "host:1:1 [0] NCCL INFO Channel 00/0 : 1[1] -> 0[0] via SHM/direct/direct\n"
+                   "host:1:1 [0] NCCL INFO comm 0x1 rank 0 nranks 2 cudaDev 0 busId 1000 - Init COMPLETE\n")
+    s = bench._rccl_log_summary(str(log))
+    assert "version" in s["version_line"] and s["transports"] == {"P2P/IPC": 2, "SHM/direct/direct": 1} and len(s["sample"]) >= 3
+    assert "error" in bench._rccl_log_summary(str(tmp_path / "missing.log"))
 
 
 def test_bench_single_process_line_shape():
