@@ -193,6 +193,14 @@ def lib():
                                            c_int, c_int, c_int, c_int, c_int, c_void_p]
         L.hyena_outproj_supported.restype = c_int
         L.hyena_outproj_supported.argtypes = [c_int, c_int, c_int, c_int]
+        L.hyena_proj_kernel_generation.restype = c_int
+        L.hyena_proj_kernel_generation.argtypes = [c_int, c_int]
+        gen = os.environ.get("HYENA_OUTPROJ_KERNEL")              # A/B knob: 1 = round 4's out_proj kernel, 2 (default) = round 6's
+        if gen in ("1", "2"):
+            L.hyena_proj_kernel_generation(0, int(gen))
+        gen = os.environ.get("HYENA_INPROJ_KERNEL")               # A/B knob: 1 (default) = rounds 3 / 4's in_proj kernel, 2 = round 6's (not faster: see the header)
+        if gen in ("1", "2"):
+            L.hyena_proj_kernel_generation(1, int(gen))
         L.hyena_outproj_gate_fwd.restype = c_int
         L.hyena_outproj_gate_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_int, c_int, c_int, c_int, c_int, c_void_p]
@@ -709,6 +717,12 @@ def inproj_pre_fwd(u, W, bin_, w, b, L):
                                             xT.data_ptr(), vg.data_ptr(), B, Lx, int(L), D, csx, bsx, ld_of(vg), dtype_code(u.dtype),
                                             _backend.stream(u.device)))
     return xT, vg
+
+
+def proj_kernel_generation(family, generation=0):
+    """include/hyena_proj.h, hyena_proj_kernel_generation: family 0 = out_proj forward, 1 = in_proj forward; generation 0 queries, 1 / 2 selects
+    (process-wide)."""
+    return int(lib().hyena_proj_kernel_generation(int(family), int(generation)))
 
 
 def outproj_supported(B, L, Lx, D, dtype):

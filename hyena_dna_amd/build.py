@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libhyena_fftconv.so")
 SOURCES = [os.path.join(CSRC, "fftconv.hip"), os.path.join(CSRC, "onchip.hip"), os.path.join(CSRC, "onchip_dk.hip"), os.path.join(CSRC, "cm.hip"), os.path.join(CSRC, "proj.hip"), os.path.join(CSRC, "filter16.hip")]
-HEADERS = [os.path.join(CSRC, "fftconv_kernels.h"), os.path.join(CSRC, "onchip_kernels.h"), os.path.join(CSRC, "onchip_host.h"), os.path.join(CSRC, "launch.h"), os.path.join(CSRC, "cm_kernels.h"), os.path.join(CSRC, "mixer_kernels.h"), os.path.join(CSRC, "filter_kernels.h"), os.path.join(CSRC, "filter16_kernels.h"), os.path.join(CSRC, "block_kernels.h"), os.path.join(CSRC, "proj_kernels.h"),
+HEADERS = [os.path.join(CSRC, "fftconv_kernels.h"), os.path.join(CSRC, "onchip_kernels.h"), os.path.join(CSRC, "onchip_host.h"), os.path.join(CSRC, "launch.h"), os.path.join(CSRC, "cm_kernels.h"), os.path.join(CSRC, "mixer_kernels.h"), os.path.join(CSRC, "filter_kernels.h"), os.path.join(CSRC, "filter16_kernels.h"), os.path.join(CSRC, "block_kernels.h"), os.path.join(CSRC, "proj_kernels.h"), os.path.join(CSRC, "proj2_kernels.h"),
            os.path.join(HERE, "..", "include", "hyena_fftconv.h"), os.path.join(HERE, "..", "include", "hyena_mixer.h"),
            os.path.join(HERE, "..", "include", "hyena_filter.h"), os.path.join(HERE, "..", "include", "hyena_block.h"), os.path.join(HERE, "..", "include", "hyena_proj.h")]
 # -fno-slp-vectorize: hipcc otherwise packs the butterflies into v_pk_*_f32 (no faster on CDNA4) at the

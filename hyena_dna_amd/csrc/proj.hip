@@ -1,5 +1,6 @@
 // proj.hip -- host side of the matrix-core input projection (proj_kernels.h; C ABI in include/hyena_proj.h).
 #include "proj_kernels.h"
+#include "proj2_kernels.h"
 #include "launch.h"
 #include "../../include/hyena_fftconv.h"
 #include "../../include/hyena_proj.h"
@@ -48,6 +49,33 @@ int launch_outproj(const pj::OutProjArgs& a, int grid, void* stream) {
     HY_LAUNCH((pj::outproj_gate_fwd_kernel<K, DT>), dim3(grid), dim3(pj::PJ_THREADS), C::LDS, stream, a);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
+// generation 2 (proj2_kernels.h): K / 16 wavefronts per workgroup, operand rows prefetched a tile ahead, whole-row epilogue
+template <int K, int DT>
+int launch_outproj2(const pj::OutProjArgs& a, int grid, void* stream) {
+    typedef pj::Op2Cfg<K> C;
+    if (a.ln_w != nullptr) {
+        static thread_local int done_ln = -1;
+        hy_allow_lds(pj::outproj_gate_fwd2_kernel<K, DT, true>, C::LDS, &done_ln);
+        HY_LAUNCH((pj::outproj_gate_fwd2_kernel<K, DT, true>), dim3(grid), dim3(C::THREADS), C::LDS, stream, a);
+        return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+    }
+    static thread_local int done = -1;
+    hy_allow_lds(pj::outproj_gate_fwd2_kernel<K, DT, false>, C::LDS, &done);
+    HY_LAUNCH((pj::outproj_gate_fwd2_kernel<K, DT, false>), dim3(grid), dim3(C::THREADS), C::LDS, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+template <int K, int DT>
+int launch_inproj2(const pj::InProjArgs& a, int grid, void* stream) {
+    typedef pj::Ip2Cfg<K> C;
+    static thread_local int done = -1;
+    hy_allow_lds(pj::inproj_pre_fwd2_kernel<K, DT>, C::LDS, &done);
+    HY_LAUNCH((pj::inproj_pre_fwd2_kernel<K, DT>), dim3(grid), dim3(pj::IP2_THREADS), C::LDS, stream, a);
+    return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
+}
+// which generation of a kernel family the entry points launch (hyena_proj_kernel_generation): A/B measurements and the tests of both
+int g_outproj_generation = 2;
+int g_inproj_generation = 1;        // generation 2 is built, parity-green and NOT faster at the long lengths (profiles/r6_inproj_gen2_not_kept.txt): selectable, not the default
+
 template <int K, int DT>
 int launch_dgrad(const pj::DgArgs& a, int grid, void* stream) {
     typedef pj::DgCfg<K> C;
@@ -148,6 +176,16 @@ int hyena_mlp_dh_dgelu_bwd(const void* dy, const void* W2T, const void* a_in, vo
     return dispatch_mlp<1>(a, K, dtype, grid, stream);
 }
 
+int hyena_proj_kernel_generation(int family, int generation) {
+    // family 0: out_proj forward, family 1: in_proj forward (1 = rounds 3 / 4's kernels, 2 = round 6's).  generation <= 0 queries.  Returns the
+    // generation in use afterwards, or -1 for an unknown family / generation.  Process-wide; not meant to be flipped while launches are in flight.
+    if (family != 0 && family != 1) return -1;
+    int& g = family == 0 ? g_outproj_generation : g_inproj_generation;
+    if (generation == 1 || generation == 2) g = generation;
+    else if (generation > 0) return -1;
+    return g;
+}
+
 int hyena_outproj_supported(int B, int L, int D, int dtype) {
     if (!(D == 128 || D == 256) || !(dtype == HYENA_BF16 || dtype == HYENA_F16)) return 0;
     if (B < 1 || L < 64) return 0;                          // at least one whole 64-position tile per sequence
@@ -184,7 +222,18 @@ int hyena_outproj_gate_addnorm_fwd_ld(const void* y, const void* xT, const float
     a.B = B; a.L = L; a.Lx = Lx; a.D = D; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda;
     a.tiles_per_seq = (L + pj::PJ_NT - 1) / pj::PJ_NT;
     a.tiles = B * a.tiles_per_seq;
-    // two workgroups per CU are resident; a few runs per slot balance the tail, runs of >= 8 tiles amortise the weight load
+    if (g_outproj_generation == 2) {
+        // one (d_model 256) or two (128) workgroups per CU are resident; a few runs per slot balance the tail, runs of >= 8 tiles amortise the
+        // weight load and the first tile's unhidden fetch
+        int runs2 = 256 * (D == 256 ? 4 : 8);
+        if (runs2 > a.tiles) runs2 = a.tiles;
+        a.tiles_per_wg = (a.tiles + runs2 - 1) / runs2;
+        if (a.tiles_per_wg < 8 && a.tiles >= 8) a.tiles_per_wg = 8;
+        runs2 = (a.tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+        if (D == 256) return dtype == HYENA_BF16 ? launch_outproj2<256, DT_BF16>(a, runs2, stream) : launch_outproj2<256, DT_F16>(a, runs2, stream);
+        return dtype == HYENA_BF16 ? launch_outproj2<128, DT_BF16>(a, runs2, stream) : launch_outproj2<128, DT_F16>(a, runs2, stream);
+    }
+    // generation 1: two workgroups per CU are resident; a few runs per slot balance the tail, runs of >= 8 tiles amortise the weight load
     int runs = 256 * 8;
     if (runs > a.tiles) runs = a.tiles;
     a.tiles_per_wg = (a.tiles + runs - 1) / runs;
@@ -243,6 +292,19 @@ int hyena_inproj_pre_fwd_ld(const void* u, const void* W, const float* bin, cons
     a.u = u; a.W = W; a.bin = bin; a.w = w; a.b = b; a.xT = xT; a.vg = vg; a.B = B; a.Lx = Lx; a.Lc = Lc; a.D = D; a.csx = csx; a.bsx = bsx; a.ldv = ldv;
     const size_t P = (size_t)B * Lx;
     a.tiles = (int)((P + pj::PJ_NT - 1) / pj::PJ_NT);
+    if (g_inproj_generation == 2) {
+        // generation 2: one workgroup (12 wavefronts, 128 channels x 3 groups) per CU is resident; four per CU in total balance the tail, runs of
+        // >= 16 tiles amortise the weight load and the warm-up tile
+        const int ncg2 = D / pj::IP2_CH;
+        int runs2 = 256 * 4 / ncg2;
+        if (runs2 > a.tiles) runs2 = a.tiles;
+        a.tiles_per_wg = (a.tiles + runs2 - 1) / runs2;
+        if (a.tiles_per_wg < 16 && a.tiles >= 16) a.tiles_per_wg = 16;
+        runs2 = (a.tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+        const int grid2 = ((runs2 + 7) / 8) * 8 * ncg2;
+        if (D == 256) return dtype == HYENA_BF16 ? launch_inproj2<256, DT_BF16>(a, grid2, stream) : launch_inproj2<256, DT_F16>(a, grid2, stream);
+        return dtype == HYENA_BF16 ? launch_inproj2<128, DT_BF16>(a, grid2, stream) : launch_inproj2<128, DT_F16>(a, grid2, stream);
+    }
     // One workgroup per CU is resident (its wavefronts hold the weights in ~350 registers): a few runs per CU balance the tail,
     // long runs amortise the weight load and the warm-up tile.
     // Two workgroups per CU are resident (each wavefront holds its 48 weight rows in 96 registers): a few runs per slot balance

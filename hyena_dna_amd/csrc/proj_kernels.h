@@ -160,6 +160,9 @@ __device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS c
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void glds16(const char* base, uint32_t voff, HY_LDS char* wave_base, int lane) {
     (void)lane;
+#ifdef PJ_DBG_NO_LD
+    return;                                  // (profiling builds only: the operand tile is never fetched -- results are wrong by construction)
+#endif
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :: "v"(voff), "s"(base), "s"((uint32_t)(size_t)wave_base) : "memory", "m0");
 }

@@ -79,6 +79,9 @@ class Mlp(nn.Module):
 
 
 FUSED_MLP = os.environ.get("HYENA_FUSED_MLP", "1") != "0"          # A/B knob: 0 = two library GEMMs + PyTorch's GELU
+# HyenaDNALM pads batches of several odd-length sequences to a multiple of 64 positions (HyenaDNALM._aligned_length); 0 = run them as they come
+PAD_SEQUENCES = os.environ.get("HYENA_LM_PAD_SEQUENCES", "1") != "0"
+_SEQ_ALIGN = 64
 
 
 def _mlp_dtype(x, weight):
@@ -471,10 +474,41 @@ class HyenaDNALM(nn.Module, GenerationMixin):
         residual = (dropped + residual) if residual is not None else dropped
         return bb.ln_f(residual.to(dtype=bb.ln_f.weight.dtype))
 
+    def _aligned_length(self, input_ids):
+        """Round 6: several sequences of a length that is not a multiple of 64 -- the reference trainer's own batches: L = max_length - 1
+        (hg38_dataset.py:222), B = 256 / 8 / 2 (hg38_hyena.yaml:47-48) -- run on sequences padded at the END to the next multiple of 64.  Every
+        operation of the model is causal or per-position (embedding, LayerNorm, MLP, short conv, long conv, gates), so positions < L see exactly the
+        values of the unpadded run (the long convolution may pick a different transform size: fp32 rounding level); the pad positions' logits
+        are dropped before anybody sees them, so they receive zero gradients and contribute nothing to any weight gradient.  What it buys: inside a
+        channel row of the flattened (C, B L) layout the rows of odd-length sequences start 2 bytes off every 4 / 16-byte boundary -- one layer at
+        32767 x 8 ran 11 % slower than at 32768 x 8, the step at 1023 x 256 x 128 6 % slower (profiles/r6a_bench_default.json).  Only when every
+        layer's l_max admits the padded length (hg38 configurations: l_max = max_length + 2), B > 1, and the fused kernels are in use."""
+        B, L = input_ids.shape
+        if not PAD_SEQUENCES or B <= 1 or L % _SEQ_ALIGN == 0 or L < _SEQ_ALIGN:
+            return L
+        from . import _lib
+        if not (input_ids.is_cuda or _lib._backend.name != "hip"):
+            return L
+        Lp = L + (-L) % _SEQ_ALIGN
+        emb = self.backbone.embeddings
+        if emb.max_position_embeddings > 0 and Lp > emb.max_position_embeddings:
+            return L
+        for blk in self.backbone.layers:
+            mixer = getattr(blk.mixer, "layer", blk.mixer)
+            if getattr(mixer, "l_max", Lp) < Lp:
+                return L
+        return Lp
+
     def forward(self, input_ids, position_ids=None, inference_params=None, state=None):
         # (the head through projection.hyena_linear: its weight gradient contracts 16 x 256 outputs over 10^6 tokens, which the GEMM library
         # runs on 16 workgroups -- 1.19 ms per step at 2^20 tokens, profiles/r4y_model_stats.csv -- and the split-K form does not)
+        L = input_ids.shape[1]
+        Lp = self._aligned_length(input_ids) if position_ids is None else L
+        if Lp != L:
+            input_ids = F.pad(input_ids, (0, Lp - L), value=0)     # any valid token id: the pad positions' outputs are dropped
         lm_logits = hyena_linear(self.hidden(input_ids, position_ids), self.lm_head.weight, self.lm_head.bias)
+        if Lp != L:
+            lm_logits = lm_logits[:, :L]                 # (a view: the pad positions' logits reach nobody -> zero gradients)
         return namedtuple("CausalLMOutput", ["logits"])(logits=lm_logits), None
 
     def loss(self, input_ids, targets, ignore_index=-100):

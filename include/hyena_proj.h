@@ -50,6 +50,16 @@ int hyena_inproj_pre_fwd_ld(const void* u, const void* W, const float* bin, cons
  * 63 positions identically; shorter sequences keep hyena_cm_post_fwd + the library GEMM).  Arithmetic: z = round(y * shortconv(xT + bin)) exactly as hyena_cm_post_fwd, then 16-bit operands with
  * fp32 accumulation on v_mfma_f32_32x32x16, out = one rounding of (sum + bias).  Asynchronous on `stream`; no workspace; no state. */
 int hyena_outproj_supported(int B, int L, int D, int dtype);
+/* Which generation of a kernel family the entry points launch.  family 1 = hyena_inproj_pre_fwd above: 1 = rounds 3 / 4's kernel (a wavefront holds 16
+ * channels of each of x0 / x1 / v, D[channel][position] on v_mfma_f32_16x16x32, 48 two-byte LDS writes per tile; the default), 2 = round 6's (32 channels of
+ * one group per wavefront on v_mfma_f32_32x32x16 with the operand tile as A -- a lane holds 16 consecutive positions of a channel: four 16-byte LDS
+ * writes per tile --, 12 wavefronts per workgroup, three per SIMD, the previous tile's row phase issued between the matrix instructions; same values bit
+ * for bit; measured 9 % faster at 32768 x 8 and 3 - 9 % SLOWER from 160000 x 2 up: selectable, not the default -- profiles/r6_inproj_gen2_not_kept.txt).  family 0 = the out_proj forward below: 1 = round 4's kernel (64 output channels per
+ * wavefront held in 128 registers, two wavefronts per SIMD, the operand rows of a tile fetched in four exposed batches), 2 = round 6's (default: 16
+ * output channels per wavefront, d_model / 16 wavefronts per workgroup, operand rows prefetched one tile ahead, whole-row epilogue; same values --
+ * zT bit for bit, out to the summation order of the matrix cores; with the add + LayerNorm epilogue bit for bit what the two separate launches give).
+ * generation <= 0 queries; returns the generation in use, -1 for an unknown family / generation.  Process-wide (A/B measurements, tests of both). */
+int hyena_proj_kernel_generation(int family, int generation);
 int hyena_outproj_gate_fwd(const void* y, const void* xT, const float* bin, const float* w, const float* b, const void* W,
                            const float* bias, void* out, void* zT, int B, int L, int Lx, int D, int dtype, void* stream);
 /* ... on STRIDED / PITCHED operands: xT row (c, b) at c csx + b bsx, zT row (d, b) at d csz + b bsz, y row (b, d) at (b D + d) lda (layouts:

@@ -10,6 +10,9 @@ Reference code exercised: ``HyenaFilter.filter`` (src/models/sequence/hyena.py:2
 MLP (199-215, Sin 96-106) -> ExponentialModulation (134-155), under ``torch.autocast('cpu', dtype)``, and autograd's backward of it.
 """
 import os
+# the vectors are pinned bit for bit: oneDNN's bf16 GEMMs sum in another order on AMX hosts than on AVX-512 ones -- mint (and check: tests/conftest.py)
+# on the AVX-512 kernels, which both kinds of host have
+os.environ.setdefault("ONEDNN_MAX_CPU_ISA", "AVX512_CORE_BF16")
 
 import torch
 

@@ -15,7 +15,7 @@ DEPS = SRC + [os.path.join(ROOT, "hyena_dna_amd", "csrc", "fftconv_kernels.h"), 
               os.path.join(ROOT, "hyena_dna_amd", "csrc", "filter_kernels.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "filter16_kernels.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "block_kernels.h"),
               os.path.join(ROOT, "include", "hyena_block.h"), os.path.join(ROOT, "include", "hyena_filter.h"), os.path.join(HERE, "hipemu.h"),
               os.path.join(ROOT, "include", "hyena_fftconv.h"), os.path.join(ROOT, "include", "hyena_mixer.h"),
-              os.path.join(ROOT, "hyena_dna_amd", "csrc", "proj_kernels.h"), os.path.join(ROOT, "include", "hyena_proj.h")]
+              os.path.join(ROOT, "hyena_dna_amd", "csrc", "proj_kernels.h"), os.path.join(ROOT, "hyena_dna_amd", "csrc", "proj2_kernels.h"), os.path.join(ROOT, "include", "hyena_proj.h")]
 
 
 def _fresh():

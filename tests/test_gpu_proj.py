@@ -8,11 +8,31 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 2])
+def outproj_gen(request, gpu_lib):
+    """both generations of the out_proj forward kernel (include/hyena_proj.h, hyena_proj_kernel_generation): round 4's and round 6's (default)"""
+    prev = gpu_lib.proj_kernel_generation(0)
+    assert gpu_lib.proj_kernel_generation(0, request.param) == request.param
+    yield request.param
+    torch.cuda.synchronize()
+    gpu_lib.proj_kernel_generation(0, prev)
+
+
+@pytest.fixture(params=[1, 2])
+def inproj_gen(request, gpu_lib):
+    """both generations of the in_proj forward kernel: rounds 3 / 4's and round 6's (default)"""
+    prev = gpu_lib.proj_kernel_generation(1)
+    assert gpu_lib.proj_kernel_generation(1, request.param) == request.param
+    yield request.param
+    torch.cuda.synchronize()
+    gpu_lib.proj_kernel_generation(1, prev)
+
+
 @pytest.mark.parametrize("B,Lx,Lc,D,dtype", [(8, 1024, 1024, 128, torch.bfloat16), (8, 32768, 32768, 256, torch.bfloat16),
                                              (2, 160000, 160000, 256, torch.bfloat16), (1, 1048576, 1048576, 256, torch.bfloat16),
                                              (1, 999999, 999999, 256, torch.bfloat16), (3, 4099, 4000, 128, torch.float16),
                                              (2, 70001, 70001, 256, torch.float16), (5, 9, 9, 128, torch.bfloat16)])
-def test_inproj_pre_fwd_on_gpu(gpu_lib, B, Lx, Lc, D, dtype):
+def test_inproj_pre_fwd_on_gpu(gpu_lib, inproj_gen, B, Lx, Lc, D, dtype):
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(Lx + D)
     rn = lambda *s: torch.randn(*s, generator=g, device=dev)      # noqa: E731
@@ -143,7 +163,7 @@ def test_colsum_on_gpu(gpu_lib, P, N, dtype):
                                             (2, 160000, 160000, 256, torch.bfloat16), (1, 1048576, 1048576, 256, torch.bfloat16),
                                             (3, 4096, 4104, 128, torch.float16), (2, 70016, 70016, 256, torch.float16),
                                             (1, 999999, 999999, 256, torch.bfloat16), (3, 4099, 4101, 128, torch.float16), (2, 32767, 32767, 256, torch.bfloat16)])
-def test_outproj_gate_fwd_on_gpu(gpu_lib, B, L, Lx, D, dtype):
+def test_outproj_gate_fwd_on_gpu(gpu_lib, outproj_gen, B, L, Lx, D, dtype):
     """The fused out_proj kernel (round 4) on the MI355X through the C ABI: zT BIT-IDENTICAL to cm_post_fwd, out against the library
     GEMM on that zT (one rounding of an fp32 sum either way: at most an ulp apart, almost everywhere identical), a slice against the
     fp64 product, determinism, the contract shapes."""
@@ -248,7 +268,7 @@ def test_out_proj_dgrad_with_the_gate_backward_on_gpu(gpu_lib, B, L, D, dtype):
 
 
 @pytest.mark.parametrize("B,L,D,dtype", [(8, 32767, 256, torch.bfloat16), (1, 1048575, 256, torch.bfloat16), (2, 4099, 128, torch.float16)])
-def test_out_proj_with_add_norm_epilogue_on_gpu(gpu_lib, B, L, D, dtype):
+def test_out_proj_with_add_norm_epilogue_on_gpu(gpu_lib, outproj_gen, B, L, D, dtype):
     """hyena_outproj_gate_addnorm_fwd_ld (round 5; off by default -- measured slower, profiles/r5c_outproj_addnorm_not_kept.txt): all five outputs
     are the bits of hyena_outproj_gate_fwd_ld followed by hyena_add_norm_fwd"""
     dev = torch.device("cuda", 0)
