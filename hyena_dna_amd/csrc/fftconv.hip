@@ -465,6 +465,8 @@ static int bwd_impl(const void* dout, const void* u, const float* k, const float
                 if ((st = oc::launch_spec(p.R, k, bias, workspace, d_tables, D, L, ld, stream))) return st;
                 H = workspace;
             }
+            if (dk != nullptr && oc::dkdu_ok(p.R, B))        // du rides on dk's transform of dout (M = 16384 by default: onchip_dk.hip)
+                return oc::launch_dkdu(p.R, dout, u, du, H, dk, dbias, partials, d_tables, B, D, L, ld, dtype, stream);
             if ((st = oc::launch_conv(p.R, dout, du, H, d_tables, B, D, L, ld, dtype, 1, stream))) return st;
         }
         if (dk != nullptr && oc::dk1_ok(p.R, B)) {          // B = 1: the spectrum of u behind the partial rows, then conv with the conjugate

@@ -31,6 +31,13 @@ int dk_slices(int R, int B, int D, int* nb_out);
 int launch_dk(int R, const void* dout, const void* u, float* dk, float* dbias, void* partials, const void* tab, int B, int D, int L,
               Pitch ld, int dtype, void* stream);
 
+// du AND dk from one launch (round 6, M <= 16384, B >= 2): dk_kernel also multiplies its transform of dout by conj(H) and inverts it -- dout is
+// transformed once instead of twice.  dkdu_ok: the calls it takes (default: M = 16384, where it wins 12 %; HYENA_FFTCONV_DUDK=1 / 0: every M <= 16384 /
+// never; profiles/r6_dudk_ab.txt)
+bool dkdu_ok(int R, int B);
+int launch_dkdu(int R, const void* dout, const void* u, void* du, const void* H, float* dk, float* dbias, void* partials, const void* tab, int B,
+                int D, int L, Pitch ld, int dtype, void* stream);
+
 // dk at B = 1, M = 32768: spectrum of the u rows into `Uspec` (spectrum_bytes(D, R) bytes of scratch), then the convolution kernel with
 // the conjugate and fp32 output rows -- nothing to accumulate over, so dk_kernel's shape (two spectra + an accumulator in registers) buys nothing
 bool dk1_ok(int R, int B);

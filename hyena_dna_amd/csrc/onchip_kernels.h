@@ -578,6 +578,9 @@ struct DkArgs {            // dk[d] = sum_b corr(dout[b, d], u[b, d]);  dbias[d]
     int B, D, L, dtype;
     int S, nb;             // batch slices per channel (grid.y) and batch items per slice: slice s owns b in [s nb, min(B, (s + 1) nb))
     int ldx, ldk;          // row pitch (elements, >= L) of dout / u and of dk (`part` rows are packed: pitch L)
+    // dk_kernel<..., DU = true> (round 6): du from the SAME transform of dout -- du[b, d] = corr(dout[b, d], H[d]) as conv_kernel computes it
+    void* du;              // (B, D, L), the type of dout, row pitch ldx
+    const c32* H;          // [D][M] filter spectrum (spec_kernel's)
 };
 
 // Wavefronts per SIMD the conv / spectrum kernels are compiled for (-> at most 128 VGPRs): a wavefront issues one VALU
@@ -780,8 +783,9 @@ __device__ __forceinline__ void dk_load(c32 (&v)[32], GBuf xb, bool bf, int tid,
     }
 }
 
-template <int R, int NP, bool HALF, int E0>
+template <int R, int NP, bool HALF, int E0, bool DU = false>
 __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
+    static_assert(!DU || NP == 1, "du rides on dk only where the row is one transform (M <= 16384)");
     typedef Cfg<R> C;
     typedef DkCfg<R, NP> K;
     constexpr int T = C::T, BP = K::BP;
@@ -841,6 +845,33 @@ __global__ void __launch_bounds__((DkCfg<R, NP>::WGT)) dk_kernel(DkArgs a) {
                     const c32 o = lds_ld(park + (q - NREG) * K::WGT);
                     lds_st(park + (q - NREG) * K::WGT, mk(o.x + lv * p.x, o.y + lv * p.y));
                 }
+            }
+            if constexpr (DU) {
+                // du of this batch item from the transform of dout that is in registers anyway: G conj(H) -> inverse -> the row (conv_kernel's
+                // arithmetic; the separate launch transforms dout a second time: 6.1 -> 5 transforms per row of a forward + backward step)
+                HY_SCHED_FENCE();
+                const GBuf hb = make_gbuf(a.H, (unsigned)a.D * (unsigned)C::M * 8u);
+                const unsigned ho = ((unsigned)d * (unsigned)C::M + (unsigned)tid) * 8u;
+                HY_UNROLL
+                for (int q0 = 0; q0 < 32; q0 += 8) {
+                    c32 h[8];
+                    HY_UNROLL
+                    for (int q = 0; q < 8; ++q) h[q] = gb_ld(hb, ho, (unsigned)((q0 + q) * T) * 8u);
+                    HY_UNROLL
+                    for (int q = 0; q < 8; ++q) v[q0 + q] = cmul(v[q0 + q], mk(h[q].x, -h[q].y));
+                    HY_SCHED_FENCE();
+                }
+                fft_inv<R>(v, c);
+                float y[32];
+                HY_UNROLL
+                for (int s = 0; s < 32; ++s) {
+                    const c32 w = twist_const<2>(s);
+                    y[s] = v[s].x * w.x + v[s].y * w.y;         // Re(v conj(twist))
+                }
+                // (no branch around the stores: a dead row group -- the batch ran out -- stores nothing because its descriptor is empty / its length 0)
+                const GBuf ob = WHOLE ? make_gbuf(a.du, whole) : make_gbuf(reinterpret_cast<char*>(a.du) + row, live ? rowbytes : 0u);
+                store_row<T, HALF, WHOLE>(ob, bf, tid, row_off, live ? a.L : 0, y);
+                HY_SCHED_FENCE();
             }
         }
         HY_UNROLL

@@ -25,12 +25,20 @@ from .projection import hyena_linear, in_proj_pre_cm, out_proj_cm
 # the out_proj GEMM, no transposes anywhere: csrc/cm_kernels.h) or the reference's position-major (B, L, 3D) with the
 # transposes fused into the shell kernels (csrc/mixer_kernels.h).  HYENA_MIXER_LAYOUT=position selects the latter (A/B).
 CHANNEL_MAJOR = os.environ.get("HYENA_MIXER_LAYOUT", "channel").lower() != "position"
-# Round 5: out_proj's kernel can carry the block's residual add + LayerNorm in its epilogue (HyenaOperator.forward_add_norm; bit-identical
-# results).  MEASURED SLOWER and therefore OFF by default (profiles/r5c_outproj_addnorm_not_kept.txt: 1 576 us against 594 + 658 us for the two
-# launches at L = 2^20, model step 161.3 against 157.4 ms): the matrix-core kernel runs two wavefronts per SIMD with 128 weight registers each, so
-# the row phase -- eight rows per wavefront, two six-step wavefront reductions per row behind a residual load -- has nothing to hide its latency
-# behind, while the stand-alone pass streams the same bytes at 5 TB/s with sixteen wavefronts per SIMD.  HYENA_ADD_NORM_FUSED=1 turns it on.
-ADD_NORM_FUSED = os.environ.get("HYENA_ADD_NORM_FUSED", "0") == "1"
+# out_proj's kernel can carry the block's residual add + LayerNorm in its epilogue (HyenaOperator.forward_add_norm; bit-identical results).  Round 5's
+# kernel measured slower everywhere (profiles/r5c_outproj_addnorm_not_kept.txt); round 6's generation 2 (csrc/proj2_kernels.h: whole rows per wavefront,
+# residual rows prefetched) wins at d_model 128 with many short sequences -- the shipped experiment's shape: 1024 x 256 x 128: 120 vs 141 us for the two
+# launches, 1023 x 256: 156 vs 180 -- and still loses at d_model 256 (2^20: 1304 - 1346 vs 1095 - 1166 us; 32768 x 8: 301 vs 257;
+# profiles/r6c_bench_outproj_gen1_gen2.txt): "auto" (default) = fused at d_model 128 only; HYENA_ADD_NORM_FUSED=1 / 0 forces it.
+ADD_NORM_FUSED = {"1": True, "0": False}.get(os.environ.get("HYENA_ADD_NORM_FUSED", "auto"), "auto")
+
+
+def _add_norm_fused(d_model):
+    if ADD_NORM_FUSED == "auto":
+        from . import _lib
+        return d_model == 128 and _lib.proj_kernel_generation(0) == 2
+    return bool(ADD_NORM_FUSED)
+
 
 __all__ = ["HyenaOperator", "HyenaFilter", "PositionalEmbedding", "ExponentialModulation", "Sin"]
 
@@ -279,12 +287,14 @@ class HyenaOperator(nn.Module):
         when the call is not served this way (the caller then runs ``forward`` and its own add + LayerNorm -- same values, bit for bit)."""
         l = u.size(-2)
         l_filter = min(l, self.l_max)
-        if not (CHANNEL_MAJOR and ADD_NORM_FUSED and self._fused_ok() and 0 < l_filter <= _lib_max_l() and l_filter == l and u.shape[0] > 0
+        if not (CHANNEL_MAJOR and ADD_NORM_FUSED is not False and self._fused_ok() and 0 < l_filter <= _lib_max_l() and l_filter == l and u.shape[0] > 0
                 and not self.return_state and norm_weight is not None and norm_bias is not None
                 and (residual is None or residual.shape == u.shape)):
             return None
         dt = torch.get_autocast_dtype("cuda" if u.is_cuda else "cpu") if torch.is_autocast_enabled() else u.dtype
         if dt not in (torch.bfloat16, torch.float16):
+            return None
+        if not (u.is_cuda or not _fused_filter_requires_gpu()) or not _add_norm_fused(self.d_model):
             return None
         k = self.filter_fn.filter_dl(l_filter)
         fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias

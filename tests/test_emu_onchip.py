@@ -258,3 +258,34 @@ def test_pitched_rows_give_the_packed_bits(emu_backend, B, D, L, dtype):
     # a pitch below L is refused
     assert _lib.lib().hyena_fftconv_fwd_ld(up.data_ptr(), kp.data_ptr(), None, outp.data_ptr(), B, D, L, L - 1, ld, _lib.dtype_code(dtype),
                                            tables.data_ptr(), ws.data_ptr(), ws.numel(), 0, None, 0, stream) == 1
+
+
+@pytest.mark.parametrize("B,D,L,dtype", [(17, 3, 700, torch.bfloat16), (16, 8, 1024, torch.float32), (9, 2, 1025, torch.float16), (8, 8, 2048, torch.bfloat16),
+                                         (5, 2, 4096, torch.float32), (3, 2, 8192, torch.bfloat16), (2, 2, 16384, torch.bfloat16), (3, 1, 16383, torch.float32),
+                                         (40, 3, 700, torch.bfloat16), (9, 4, 5000, torch.float16)])
+def test_du_from_dks_transform_of_dout(emu_backend, monkeypatch, B, D, L, dtype):
+    """Round 6: HYENA_FFTCONV_DUDK=1 -- dk_kernel<.., DU = true> also multiplies its transform of dout by conj(H) and inverts it, so
+    the separate du launch (which transforms dout a second time) is gone at M <= 16384, B >= 2.  dk and dbias: the same kernel code, the same bits; du:
+    conv_kernel's arithmetic (bitwise under the emulator), incl. batch slices, ragged last row groups and pitched rows; the oracle's values."""
+    monkeypatch.setenv("HYENA_FFTCONV_SMALL", "0")          # (the one-launch short-row pair would serve the small cases otherwise)
+    u, k, bias, dout = _inputs(B, D, L, dtype, seed=B + L)
+
+    def pitched(t):
+        r = emu_backend.empty_rows(t.shape[:-1], t.shape[-1], t.dtype, t.device)
+        r.copy_(t)
+        return r
+
+    res = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("HYENA_FFTCONV_DUDK", knob)
+        for lay in ("packed", "pitched"):
+            ud, gd, kd = (pitched(u), pitched(dout), pitched(k)) if lay == "pitched" else (u, dout, k)
+            out, saved = emu_backend.fftconv_fwd(ud, kd, bias, save=True)
+            res[knob, lay, "saved"] = emu_backend.fftconv_bwd(gd, ud, kd, bias, saved=saved)
+            res[knob, lay, "recomputed"] = emu_backend.fftconv_bwd(gd, ud, kd, bias)
+    ref = res["0", "packed", "saved"]
+    for key, (du, dk, dbias) in res.items():
+        assert torch.equal(du, ref[0]) and torch.equal(dk, ref[1]) and torch.equal(dbias, ref[2]), key
+    r_out, r_du, r_dk, r_db = _oracle(u.float(), k, bias, dout.float())
+    tol = 3e-6 if dtype == torch.float32 else (6e-3 if dtype == torch.bfloat16 else 8e-4)
+    assert _rel(ref[0].float(), r_du) < tol and _rel(ref[1], r_dk) < 3e-6
