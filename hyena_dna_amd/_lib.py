@@ -349,8 +349,20 @@ def ld_of(t):
 
 
 def as_rows(t):
-    """t itself if its layout is pitched rows (ld_of), else a packed copy"""
-    return t if ld_of(t) is not None else t.contiguous()
+    """t itself if its layout is pitched rows (ld_of), else a packed copy.  A pitched view of ODD length must also own one element behind its last row:
+    on pitched rows the two-level plan takes a row's last sample with its regular pair load (csrc/fftconv_kernels.h, tail_pair) and drops the element
+    behind it by a select -- that element has to be readable (a caller's view such as buf[..., 1:] of a (B, D, L + 1) tensor ends exactly
+    at its storage's end; empty_rows' buffers never do)."""
+    ld = ld_of(t)
+    if ld is None:
+        return t.contiguous()
+    L = t.shape[-1] if t.dim() else 0
+    if t.dim() >= 2 and ld > L and (L & 1) and t.numel() > 0:
+        rows = t.numel() // L
+        last = t.storage_offset() + (rows - 1) * ld + L              # first element behind the last row
+        if last >= t.untyped_storage().nbytes() // t.element_size():
+            return t.contiguous()
+    return t
 
 
 def empty_like_rows(t, dtype=None):

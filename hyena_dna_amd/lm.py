@@ -103,10 +103,18 @@ class FusedMlpFunc(torch.autograd.Function):
     reduction -- 12 of the ~28 GB a layer's MLP moves at L = 2^20."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
-        from . import _lib
+    def forward(ctx, x, w1, b1, w2, b2, dt=None):
+        # dt: autocast's compute type -- w1 ... b2 are then the fp32 PARAMETERS, used through their per-step shadows (_castcache: one batched cast
+        # per optimizer step), and their gradients go back in fp32; None: operands already in the compute type
+        from . import _castcache, _lib
+        ctx.ptypes = (w1.dtype, b1.dtype, w2.dtype, b2.dtype, dt)
+        if dt is not None:
+            b1f = _castcache.rounded_f32(b1, dt)                             # b1 rounded to the compute type (autocast semantics), in fp32
+            w1, w2, b2 = _castcache.shadow(w1, dt), _castcache.shadow(w2, dt), _castcache.shadow(b2, dt)
+        else:
+            b1f = b1.float().contiguous()
         x2 = x.reshape(-1, x.shape[-1])
-        a, h = _lib.mlp_fc1_gelu_fwd(x2, w1, b1.float().contiguous())       # b1 arrives rounded to the compute type (autocast semantics)
+        a, h = _lib.mlp_fc1_gelu_fwd(x2, w1, b1f)
         y = torch.addmm(b2, h, w2.t())
         ctx.save_for_backward(x2, w1, w2, a, h)
         ctx.xshape = x.shape
@@ -114,26 +122,30 @@ class FusedMlpFunc(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from . import _lib
+        from . import _castcache, _lib
         from .projection import split_k_weight_grad
         x2, w1, w2, a, h = ctx.saved_tensors
+        t_w1, t_b1, t_w2, t_b2, dt = ctx.ptypes
+        cdt = dt if dt is not None else dy.dtype
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         da, db1 = _lib.mlp_dh_dgelu_bwd(dy2, w2.t().contiguous(), a)
         dx = dw1 = dw2 = db2 = None
         if ctx.needs_input_grad[0]:
             dx = torch.mm(da, w1).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw1 = split_k_weight_grad(da, x2).to(w1.dtype)
+            dw1 = _castcache.wgrad_out(split_k_weight_grad(da, x2), t_w1, cdt)
         if ctx.needs_input_grad[3]:
-            dw2 = split_k_weight_grad(dy2, h).to(w2.dtype)
+            dw2 = _castcache.wgrad_out(split_k_weight_grad(dy2, h), t_w2, cdt)
         if ctx.needs_input_grad[4]:
-            db2 = _lib.colsum(dy2).to(dy.dtype)
-        return dx, dw1, db1.to(dy.dtype) if ctx.needs_input_grad[2] else None, dw2, db2
+            db2 = _castcache.wgrad_out(_lib.colsum(dy2), t_b2, cdt)
+        return dx, dw1, _castcache.wgrad_out(db1, t_b1, cdt) if ctx.needs_input_grad[2] else None, dw2, db2, None
 
 
 def fused_mlp(x, w1, b1, w2, b2):
     dt = _mlp_dtype(x, w1)
     with torch.autocast("cuda" if x.is_cuda else "cpu", enabled=False):
+        if all(t.dtype == torch.float32 for t in (w1, b1, w2, b2)):        # autocast over fp32 parameters: through their per-step shadows
+            return FusedMlpFunc.apply(x.to(dt).contiguous(), w1, b1, w2, b2, dt)
         return FusedMlpFunc.apply(x.to(dt).contiguous(), w1.to(dt).contiguous(), b1.to(dt), w2.to(dt).contiguous(), b2.to(dt))
 
 
@@ -616,6 +628,8 @@ class GraphedTrainStep:
             del snap_p, had_state
             gc.collect()
             side.synchronize()
+            from . import _castcache
+            _castcache.invalidate()                    # the batched weight cast becomes part of the captured step
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=side):
                 self.loss = self._fwd_bwd().detach()

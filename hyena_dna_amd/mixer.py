@@ -13,7 +13,7 @@ backward kernels (3 taps) instead of being stored.
 """
 import torch
 
-from . import _gradmode, _lib
+from . import _castcache, _gradmode, _lib
 
 __all__ = ["hyena_mixer_core", "HyenaMixerFunc", "hyena_mixer_core_cm", "HyenaMixerCMFunc", "hyena_mixer_out_cm", "HyenaMixerOutCMFunc",
            "mixer_out_supported"]
@@ -201,8 +201,8 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
             y, spectra = _lib.fftconv_fwd(vg, kf, bf, save=True)
         else:
             y = _lib.fftconv_fwd(vg, kf, bf, grad=want_grad)
-        wo = w_out.detach().to(xc.dtype).contiguous()
-        bo = None if b_out is None else b_out.detach().to(xc.dtype).to(torch.float32).contiguous()      # rounded as autocast rounds it
+        wo = _castcache.shadow(w_out, xc.dtype)                                # (an fp32 parameter: its per-step shadow; else a plain cast)
+        bo = _castcache.rounded_f32(b_out, xc.dtype)                           # rounded as autocast rounds it, in fp32
         none = torch.empty(0, device=xc.device)
         ctx.norm = ln_w is not None
         if ctx.norm:
@@ -248,9 +248,9 @@ class HyenaMixerOutCMFunc(torch.autograd.Function):
         # ---- out_proj's backward (projection.OutProjCMFunc.backward) ----
         dW = dbo = None
         if ctx.needs_input_grad[8]:
-            dW = wgrad_pm_cm(dy2, zT if ctx.has_z else _lib.cm_post_fwd(y, xc, bi, w, b)).to(wo_dtype)
+            dW = _castcache.wgrad_out(wgrad_pm_cm(dy2, zT if ctx.has_z else _lib.cm_post_fwd(y, xc, bi, w, b)), wo_dtype, xc.dtype)
         if bo_dtype is not None and ctx.needs_input_grad[9]:
-            dbo = _lib.colsum(dy2).to(bo_dtype)
+            dbo = _castcache.wgrad_out(_lib.colsum(dy2), bo_dtype, xc.dtype)
         if not any(ctx.needs_input_grad[:6]):
             return (None, None, None, None, None, None, None, None, dW, dbo) + norm_grads
         # ---- the core's backward (HyenaMixerCMFunc.backward) ----

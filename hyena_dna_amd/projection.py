@@ -16,6 +16,8 @@ import os
 import torch
 import torch.nn.functional as F
 
+from . import _castcache
+
 __all__ = ["hyena_linear", "SplitKLinearFunc", "split_count", "split_k_weight_grad", "in_proj_cm", "out_proj_cm", "in_proj_pre_cm"]
 
 MIN_ROWS = 32768          # below this the library's own schedule is fine
@@ -30,7 +32,7 @@ def split_count(rows, out_elems=None):
     ``out_elems``: size of the gradient.  A 256 x 256 gradient (out_proj at d_model 256) is ONE output tile per slice, so 64 slices are 64
     workgroups on 256 CUs: such products take up to 256 slices (measured at 2^20 - 1 positions, scripts/wgrad_slice_probe.py: 64 x 16383 rows
     527 us, 128 x 8191 342 us, 255 x 4096 337 us; the 768 x 256 and 1024 x 256 gradients are best at 64: 552 us vs 636 at 127)."""
-    cap = MAX_SPLITS * 4 if (out_elems is not None and out_elems <= 256 * 256) else MAX_SPLITS
+    cap = MAX_SPLITS * 4 if (out_elems is not None and out_elems == 256 * 256) else MAX_SPLITS       # (the measured shape only: ADVICE r5)
     s = 1
     while s < cap and rows // (2 * s) >= MIN_SLICE - 64:           # (- 64: 8 x 32767 rows are cut like 8 x 32768 ones, not in half as many slices)
         s *= 2
@@ -91,15 +93,22 @@ def split_k_weight_grad(dy2, x2):
 
 
 class SplitKLinearFunc(torch.autograd.Function):
+    """``dt``: the 16-bit compute type under autocast -- ``weight`` / ``bias`` are then the fp32 PARAMETERS, used through their per-step shadows
+    (_castcache), and their gradients go back in the parameters' own type; None: the operands as they come"""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, dt=None):
+        w = weight if dt is None else _castcache.shadow(weight, dt)
+        b = bias if dt is None or bias is None else _castcache.shadow(bias, dt)
+        ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        ctx.ptypes = (weight.dtype, None if bias is None else bias.dtype, dt)
+        return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        wdt, bdt, dt = ctx.ptypes
         n, k = weight.shape
         dy2 = dy.reshape(-1, n)
         x2 = x.reshape(-1, k)
@@ -107,11 +116,12 @@ class SplitKLinearFunc(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dy2, weight).view(x.shape)
         if ctx.needs_input_grad[1]:
-            dw = split_k_weight_grad(dy2, x2).to(weight.dtype)
+            dw = _castcache.wgrad_out(split_k_weight_grad(dy2, x2), wdt, dt)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             from . import _lib
-            db = _lib.colsum(dy2.contiguous()).to(dy.dtype) if dy2.is_cuda else dy2.sum(0, dtype=torch.float32).to(dy.dtype)
-        return dx, dw, db
+            db = _lib.colsum(dy2.contiguous()) if dy2.is_cuda else dy2.sum(0, dtype=torch.float32)
+            db = _castcache.wgrad_out(db, bdt, dt if dt is not None else dy.dtype)
+        return dx, dw, db, None
 
 
 def hyena_linear(x, weight, bias):
@@ -121,7 +131,7 @@ def hyena_linear(x, weight, bias):
             dt = torch.get_autocast_dtype("cuda")
             if dt in (torch.bfloat16, torch.float16):
                 with torch.autocast("cuda", enabled=False):
-                    return SplitKLinearFunc.apply(x.to(dt).contiguous(), weight.to(dt), None if bias is None else bias.to(dt))
+                    return SplitKLinearFunc.apply(x.to(dt).contiguous(), weight, bias, dt)
         elif x.dtype == weight.dtype and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
             return SplitKLinearFunc.apply(x.contiguous(), weight, bias)          # plain fp32 / 16-bit training: same pathology
     return F.linear(x, weight, bias)
@@ -214,12 +224,14 @@ class InProjCMFunc(torch.autograd.Function):
     """xT (N, B, L) = W (N, K) u^T, WITHOUT the bias (the shell kernels add it on load and return its gradient)."""
 
     @staticmethod
-    def forward(ctx, u, weight):
+    def forward(ctx, u, weight, dt=None):
         B, L, K = u.shape
         u2 = u.reshape(B * L, K)
-        ctx.save_for_backward(u2, weight)
+        w = weight if dt is None else _castcache.shadow(weight, dt)           # (dt: autocast's compute type; weight is then the fp32 parameter)
+        ctx.save_for_backward(u2, w)
         ctx.ushape = u.shape
-        return cm_from_pm(weight, u2, B, L)
+        ctx.ptypes = (weight.dtype, dt)
+        return cm_from_pm(w, u2, B, L)
 
     @staticmethod
     def backward(ctx, dxT):
@@ -230,8 +242,8 @@ class InProjCMFunc(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             du = pm_from_cm(dxT, weight).view(ctx.ushape)
         if ctx.needs_input_grad[1]:
-            dw = wgrad_cm_pm(dxT, u2).to(weight.dtype)
-        return du, dw
+            dw = _castcache.wgrad_out(wgrad_cm_pm(dxT, u2), *ctx.ptypes)
+        return du, dw, None
 
 
 class InProjPreCMFunc(torch.autograd.Function):
@@ -241,9 +253,12 @@ class InProjPreCMFunc(torch.autograd.Function):
     are the library GEMMs of InProjCMFunc."""
 
     @staticmethod
-    def forward(ctx, u, weight, b_in, sf_weight, sf_bias, L, pad_to=0):
+    def forward(ctx, u, weight, b_in, sf_weight, sf_bias, L, pad_to=0, dt=None):
         from . import _lib
         B, Lx, K = u.shape
+        ctx.ptypes = (weight.dtype, dt)
+        if dt is not None:
+            weight = _castcache.shadow(weight, dt)                           # (dt: autocast's compute type; weight is then the fp32 parameter)
         ctx.narrow = None
         if pad_to > Lx:
             # several sequences of a length that is not a multiple of 64 (the reference trainer's L = max_length - 1): the kernels run on sequences
@@ -269,11 +284,11 @@ class InProjPreCMFunc(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dxT, _dvg):
         if dxT is None:
-            return None, None, None, None, None, None, None
-        du, dw = InProjCMFunc.backward(ctx, dxT)
+            return None, None, None, None, None, None, None, None
+        du, dw, _ = InProjCMFunc.backward(ctx, dxT)
         if du is not None and ctx.narrow is not None:
             du = du[:, :ctx.narrow]
-        return du, dw, None, None, None, None, None
+        return du, dw, None, None, None, None, None, None
 
 
 INPROJ_MFMA = os.environ.get("HYENA_INPROJ_MFMA", "1") != "0"      # A/B knob: 0 = library GEMM + cm_pre_fwd
@@ -297,6 +312,8 @@ def in_proj_pre_cm(u, weight, b_in, sf_weight, sf_bias, L):
             and (u.is_cuda or _lib._backend.name != "hip") and L >= 1 and _lib.proj_supported(B, Lx, K, dt)):
         pad_to = _lib.row_pitch(Lx) if (PAD_SEQUENCES and B > 1 and Lx == L and Lx % _lib.ROW_ALIGN != 0 and Lx >= 4 * _lib.ROW_ALIGN) else 0
         with torch.autocast("cuda" if u.is_cuda else "cpu", enabled=False):
+            if weight.dtype == torch.float32:          # (autocast over fp32 parameters: the weight through its per-step shadow)
+                return InProjPreCMFunc.apply(u.to(dt).contiguous(), weight, b_in, sf_weight, sf_bias, L, pad_to, dt)
             return InProjPreCMFunc.apply(u.to(dt).contiguous(), weight.to(dt).contiguous(), b_in, sf_weight, sf_bias, L, pad_to)
     return in_proj_cm(u, weight), None
 
@@ -305,10 +322,13 @@ class OutProjCMFunc(torch.autograd.Function):
     """y (B, L, N) = zT^T W^T + b for zT (K, B, L)."""
 
     @staticmethod
-    def forward(ctx, zT, weight, bias):
+    def forward(ctx, zT, weight, bias, dt=None):
         from . import _lib
         K, B, L = zT.shape
         zT = _lib.as_cm(zT)
+        ctx.ptypes = (weight.dtype, None if bias is None else bias.dtype, dt)
+        if dt is not None:                                                   # (autocast's compute type; weight / bias are then the fp32 parameters)
+            weight, bias = _castcache.shadow(weight, dt), _castcache.shadow(bias, dt)
         ctx.save_for_backward(zT, weight)
         ctx.has_bias = bias is not None
         return pm_from_cm(zT, weight.t(), bias).view(B, L, weight.shape[0])
@@ -323,12 +343,13 @@ class OutProjCMFunc(torch.autograd.Function):
         dz = dw = db = None
         if ctx.needs_input_grad[0]:
             dz = cm_from_pm(weight.t(), dy2, B, L)                            # (K, B, L): channel-major, straight from the GEMM
+        wdt, bdt, dt = ctx.ptypes
         if ctx.needs_input_grad[1]:
-            dw = wgrad_pm_cm(dy2, zT).to(weight.dtype)
+            dw = _castcache.wgrad_out(wgrad_pm_cm(dy2, zT), wdt, dt)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             from . import _lib
-            db = _lib.colsum(dy2.contiguous()).to(dy.dtype)
-        return dz, dw, db
+            db = _castcache.wgrad_out(_lib.colsum(dy2.contiguous()), bdt, dt if dt is not None else dy.dtype)
+        return dz, dw, db, None
 
 
 def _autocast_dtype(x):
@@ -344,6 +365,8 @@ def in_proj_cm(u, weight):
     dt = _autocast_dtype(u)
     if dt is not None:
         with torch.autocast("cuda" if u.is_cuda else "cpu", enabled=False):
+            if weight.dtype == torch.float32:
+                return InProjCMFunc.apply(u.to(dt).contiguous(), weight, dt)
             return InProjCMFunc.apply(u.to(dt).contiguous(), weight.to(dt))
     return InProjCMFunc.apply(u.contiguous(), weight.to(u.dtype))
 
@@ -353,5 +376,7 @@ def out_proj_cm(zT, weight, bias):
     dt = _autocast_dtype(zT)
     if dt is not None:
         with torch.autocast("cuda" if zT.is_cuda else "cpu", enabled=False):
+            if weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32):
+                return OutProjCMFunc.apply(zT.to(dt), weight, bias, dt)
             return OutProjCMFunc.apply(zT.to(dt), weight.to(dt), None if bias is None else bias.to(dt))
     return OutProjCMFunc.apply(zT, weight.to(zT.dtype), None if bias is None else bias.to(zT.dtype))
