@@ -470,6 +470,12 @@ __global__ void __launch_bounds__(IP2_THREADS, 3) inproj_pre_fwd2_kernel(InProjA
         }
     };
 
+#if defined(PJ_PROFILE) && !defined(HIPEMU)
+    unsigned long long pj_d[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pj_t, pj_start, pj_rt0, pj_rt1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pj_rt0)::"memory");
+    PJ_NOW(pj_t);
+    pj_start = pj_t;
+#endif
     // t = t_end is the drain iteration: no product, only the last tile's row phase
     for (int t = t_first; t <= t_end; ++t, sl0 += PJ_NT) {
         const bool have = t < t_end;
@@ -479,12 +485,15 @@ __global__ void __launch_bounds__(IP2_THREADS, 3) inproj_pre_fwd2_kernel(InProjA
         // tile t has landed: behind its loads only the row-phase stores of the previous iteration were issued (an interior tile: 4 + nunits of them)
         if (counted) { if (wave < 4) PJ_VMWAIT(6); else PJ_VMWAIT(5); }
         else PJ_VMWAIT(0);
+        PJ_MARK(0);
         PJ_BARRIER();                                                        // everybody's share of tile t has landed; the tile of t - 1 is parked; everybody has read the last fragment of t - 1
+        PJ_MARK(1);
         if (t + 1 < t_end) {                                                 // tile t + 1 into the other buffer: a whole tile to land
             if (t + 1 < t_whole) issue_operand_tile2<K, true>(ubase, p0 + PJ_NT, P, ubuf + ((t + 1) & 1) * C::UBUF, wave, lane PJ_VMQ_ARG);
             else issue_operand_tile2<K, false>(ubase, p0 + PJ_NT, P, ubuf + ((t + 1) & 1) * C::UBUF, wave, lane PJ_VMQ_ARG);
         }
         counted = false;
+        PJ_MARK(2);
         acc_t acc[2];
         HY_UNROLL
         for (int pt = 0; pt < 2; ++pt) {
@@ -582,7 +591,9 @@ __global__ void __launch_bounds__(IP2_THREADS, 3) inproj_pre_fwd2_kernel(InProjA
             if (pend) row_phase_generic();
             product(0, C::KS);
         }
+        PJ_MARK(3);
         PJ_BARRIER();                                                        // everybody is done with the parked tile of t - 1
+        PJ_MARK(4);
         if (have) {
             // the previous tile's last two positions become this tile's halo (slots 6, 7: one dword per row), each wavefront in its own rows
             if (lane < IP2_CB) {
@@ -608,7 +619,21 @@ __global__ void __launch_bounds__(IP2_THREADS, 3) inproj_pre_fwd2_kernel(InProjA
         pend = have && t >= t_begin;
         pend_fast = p0 + PJ_NT <= P && sl0 >= 2 && sl0 + PJ_NT <= a.Lc;
         prev_p0 = p0; prev_sb = sb; prev_sl0 = sl0;
+        PJ_MARK(5);
     }
+#if defined(PJ_PROFILE) && !defined(HIPEMU)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PJ_MARK(9);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pj_rt1)::"memory");
+    if (pj_prof_buf != nullptr && lane == 0) {
+        unsigned long long* o = pj_prof_buf + ((size_t)blockIdx.x * IP2_WAVES + wave) * 16;
+        HY_UNROLL
+        for (int i = 0; i < 10; ++i) o[i] = pj_d[i];
+        o[10] = (unsigned long long)(t_end - t_first + 1);
+        o[11] = pj_t - pj_start;
+        o[12] = pj_rt1 - pj_rt0;
+    }
+#endif
 }
 
 }  // namespace pj
