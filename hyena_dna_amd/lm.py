@@ -583,7 +583,8 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep: hipGraph replays of a whole step are only reliable on this ROCm runtime with "
                                "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP runtime initialises "
                                "(call hyena_dna_amd.prepare_graph_runtime() before the first torch.cuda call, or export the "
-                               "variable); see hyena_dna_amd/__init__.py")
+                               "variable; a process that exported it at start-up but touched torch.cuda before importing this package says so "
+                               "with HYENA_GRAPH_SAFE_OVERRIDE=1); see hyena_dna_amd/__init__.py and INTEGRATION.md section 6")
         self.model, self.optimizer = model, optimizer
         self.ids, self.targets = input_ids.clone(), targets.clone()
         self.autocast_dtype, self.ignore_index = autocast_dtype, ignore_index
