@@ -55,8 +55,8 @@ int launch_outproj2(const pj::OutProjArgs& a, int grid, void* stream) {
     typedef pj::Op2Cfg<K> C;
     if (a.ln_w != nullptr) {
         static thread_local int done_ln = -1;
-        hy_allow_lds(pj::outproj_gate_fwd2_kernel<K, DT, true>, C::LDS, &done_ln);
-        HY_LAUNCH((pj::outproj_gate_fwd2_kernel<K, DT, true>), dim3(grid), dim3(C::THREADS), C::LDS, stream, a);
+        hy_allow_lds(pj::outproj_gate_fwd2_kernel<K, DT, true>, C::LDS_LN, &done_ln);
+        HY_LAUNCH((pj::outproj_gate_fwd2_kernel<K, DT, true>), dim3(grid), dim3(C::THREADS), C::LDS_LN, stream, a);
         return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
     }
     static thread_local int done = -1;

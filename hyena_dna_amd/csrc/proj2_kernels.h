@@ -36,6 +36,11 @@ template <int K> struct Op2Cfg {
     static constexpr int OBUF = PJ_NT * OROW;
     static constexpr int ROWS = PJ_NT / WAVES;                 // whole output rows a wavefront owns in the row phase (4 / 8)
     static constexpr size_t LDS = (size_t)ZBUF + TAPB + OBUF;  // 73 KB at K = 256 (one workgroup per CU), 37 KB at K = 128 (two)
+    // LN: + the tile's fp32 residual rows, brought in by LDS-direct loads a whole tile phase ahead (a wavefront fetches the rows it will normalise
+    // into its own slice): 64 KB at K = 256 (137 KB in all), 32 KB at K = 128 (69 KB: still two workgroups per CU)
+    static constexpr int RROW = K * 4;
+    static constexpr int RBUF = PJ_NT * RROW;
+    static constexpr size_t LDS_LN = LDS + RBUF;
 };
 
 template <int K, int DT, bool LN>
@@ -44,6 +49,7 @@ __global__ void __launch_bounds__(Op2Cfg<K>::THREADS, 4) outproj_gate_fwd2_kerne
     typedef typename Elem<DT>::type elem_t;
     static_assert(sizeof(elem_t) == 2, "16-bit element types only");
     HY_SMEM(smem);
+    PJ_VMQ_DECL;
     const int tid = (int)threadIdx.x, wave = HY_SGPR(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
     const int r = lane >> 3, c = lane & 7;                    // staging role: row of the round, 16-byte piece (8 positions)
     const int run = blockIdx.x;
@@ -56,6 +62,7 @@ __global__ void __launch_bounds__(Op2Cfg<K>::THREADS, 4) outproj_gate_fwd2_kerne
     HY_LDS char* const zt = HY_LDS_CAST(char, smem);
     HY_LDS float* const taps = reinterpret_cast<HY_LDS float*>(HY_LDS_CAST(char, smem) + C::ZBUF);
     HY_LDS char* const ot = HY_LDS_CAST(char, smem) + C::ZBUF + C::TAPB;
+    HY_LDS char* const rt = HY_LDS_CAST(char, smem) + C::LDS + wave * (C::ROWS * C::RROW);       // LN: this wavefront's residual rows
 
     for (int k = tid; k < K; k += C::THREADS) {
         taps[k * 8 + 0] = a.w[k * 3]; taps[k * 8 + 1] = a.w[k * 3 + 1]; taps[k * 8 + 2] = a.w[k * 3 + 2];
@@ -112,6 +119,16 @@ __global__ void __launch_bounds__(Op2Cfg<K>::THREADS, 4) outproj_gate_fwd2_kerne
         int b, l0;
         tile_origin(t, b, l0);
         const int lp = l0 + 8 * c;
+        if constexpr (LN) {
+            // this wavefront's ROWS residual rows of the tile (ROWS K 4 bytes, contiguous in memory) -> its LDS slice, 1 KB per instruction; they land
+            // under phase A, the product and two barriers (in registers they spilled, and half of them had to be requested behind the park: exposed)
+            if (a.res_in != nullptr) {
+                const char* rb = reinterpret_cast<const char*>(a.res_in) + ((size_t)b * a.L + l0 + wave * C::ROWS) * (size_t)C::RROW;
+                HY_UNROLL
+                for (int i = 0; i < C::ROWS * C::RROW / 1024; ++i)
+                    glds16(HY_UNIFORM_PTR(const char, rb), (uint32_t)(i * 1024 + lane * 16), rt + i * 1024, lane PJ_VMQ_ARG);
+            }
+        }
         // ---- phase A: z = round(y * shortconv(x0)) -> zT (global), pairs of channels -> the swizzled z tile ----
         HY_UNROLL
         for (int ii = 0; ii < C::RND; ++ii) {
@@ -152,22 +169,7 @@ __global__ void __launch_bounds__(Op2Cfg<K>::THREADS, 4) outproj_gate_fwd2_kerne
         }
         // the next tile's rows: in flight under this tile's product and row phase
         if (t + 1 < t_end) fetch(t + 1);
-        // LN: this wavefront's residual rows -- the first half in flight under the product, the second half requested behind the park (all of them
-        // at once next to the prefetched operand rows: 8 - 36 spilled registers under the 128 of four wavefronts per SIMD)
-        constexpr int E = K / 64, RH = C::ROWS / 2;
-        float res[LN ? C::ROWS : 1][E];
-        auto fetch_res = [&](int i0) {
-            HY_UNROLL
-            for (int i = i0; i < i0 + RH; ++i) {
-                const size_t off = ((size_t)b * a.L + l0 + wave * C::ROWS + i) * N + lane * E;
-                if (a.res_in != nullptr) blk_load<DT_F32, E>(a.res_in, off, res[i]);
-                else {
-                    HY_UNROLL
-                    for (int e = 0; e < E; ++e) res[i][e] = 0.f;
-                }
-            }
-        };
-        if constexpr (LN) fetch_res(0);
+        constexpr int E = K / 64;
         PJ_BARRIER();                                         // the z tile is complete
         // ---- phase B: out^T tile = W z^T on the matrix cores: D[channel 4 kq + i][position 16 pt + j] ----
         acc4_t acc[PJ_NT / 16];
@@ -196,7 +198,6 @@ __global__ void __launch_bounds__(Op2Cfg<K>::THREADS, 4) outproj_gate_fwd2_kerne
             dst[0] = p2[0];
             dst[1] = p2[1];
         }
-        if constexpr (LN) fetch_res(RH);
         PJ_BARRIER();                                         // the output tile is complete; everybody is done with the z tile
         // ---- row phase: this wavefront's ROWS whole rows of the tile ----
         if constexpr (LN) {
@@ -204,6 +205,7 @@ __global__ void __launch_bounds__(Op2Cfg<K>::THREADS, 4) outproj_gate_fwd2_kerne
             // and arithmetic; residual', out, mean and rstd are its bits
             const int c0 = lane * E;
             const float inv_d = 1.f / (float)K;
+            PJ_VMWAIT(0);                                     // my residual rows have landed (requested a whole tile phase ago; with them the next tile's operand rows)
             HY_UNROLL
             for (int i = 0; i < C::ROWS; ++i) {
                 const int pos = wave * C::ROWS + i;
@@ -214,8 +216,10 @@ __global__ void __launch_bounds__(Op2Cfg<K>::THREADS, 4) outproj_gate_fwd2_kerne
                 HY_UNROLL
                 for (int e = 0; e < E; ++e) v[e] = Elem<DT>::dec(xe[e]);
                 if (a.res_in != nullptr) {
+                    float q[E];
+                    __builtin_memcpy(q, rt + i * C::RROW + c0 * 4, sizeof(q));
                     HY_UNROLL
-                    for (int e = 0; e < E; ++e) v[e] += res[i][e];
+                    for (int e = 0; e < E; ++e) v[e] += q[e];
                 }
                 float sm = 0.f;
                 HY_UNROLL

@@ -27,9 +27,9 @@ from .projection import hyena_linear, in_proj_pre_cm, out_proj_cm
 CHANNEL_MAJOR = os.environ.get("HYENA_MIXER_LAYOUT", "channel").lower() != "position"
 # out_proj's kernel can carry the block's residual add + LayerNorm in its epilogue (HyenaOperator.forward_add_norm; bit-identical results).  Round 5's
 # kernel measured slower everywhere (profiles/r5c_outproj_addnorm_not_kept.txt); round 6's generation 2 (csrc/proj2_kernels.h: whole rows per wavefront,
-# residual rows prefetched) wins at d_model 128 with many short sequences -- the shipped experiment's shape: 1024 x 256 x 128: 120 vs 141 us for the two
-# launches, 1023 x 256: 156 vs 180 -- and still loses at d_model 256 (2^20: 1304 - 1346 vs 1095 - 1166 us; 32768 x 8: 301 vs 257;
-# profiles/r6c_bench_outproj_gen1_gen2.txt): "auto" (default) = fused at d_model 128 only; HYENA_ADD_NORM_FUSED=1 / 0 forces it.
+# residual rows prefetched by LDS-direct loads) wins at d_model 128 with many short sequences -- the shipped experiment's shape: 1024 x 256 x 128: 110 vs 131 us
+# for the two launches, 1023 x 256: 121 vs 169 -- and still loses at d_model 256 (2^20: 1266 - 1270 vs 1120 - 1144 us; 32768 x 8: 298 vs 255;
+# profiles/r6l_bench_outproj_ln_lds_residual.txt): "auto" (default) = fused at d_model 128 only; HYENA_ADD_NORM_FUSED=1 / 0 forces it.
 ADD_NORM_FUSED = {"1": True, "0": False}.get(os.environ.get("HYENA_ADD_NORM_FUSED", "auto"), "auto")
 
 
