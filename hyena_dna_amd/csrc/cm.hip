@@ -14,7 +14,13 @@ bool cm_ok(const void* xT, const float* w, const float* b, int B, int L, int Lx,
            (dtype == HYENA_F32 || dtype == HYENA_BF16 || dtype == HYENA_F16);
 }
 int cm_tiles(int L) { return (L + CM_TILE - 1) / CM_TILE; }
-dim3 cm_grid(int B, int L, int D) { return dim3(cm_tiles(L), D, B); }
+// (channel, batch) rows per workgroup: sequences that leave at least half of a 2048-position tile empty share it, 2 / 4 / 8 batch items of one channel
+int cm_rpw(int B, int L) {
+    int r = 1;
+    while (r < 8 && L * 2 * r <= CM_TILE && r * 2 <= B) r *= 2;
+    return r;
+}
+dim3 cm_grid(int B, int L, int D) { const int r = cm_rpw(B, L); return dim3(cm_tiles(L), D, (B + r - 1) / r); }
 const size_t CM_SMEM = 2 * 5 * 4 * sizeof(float);
 
 #define HY_CM_DISPATCH(kernel, smem)                                                                                      \
@@ -31,7 +37,8 @@ extern "C" {
 
 size_t hyena_cm_partial_floats(int B, int L, int D) {
     if (B < 1 || L < 1 || D < 1) return 0;
-    return (size_t)3 * D * B * cm_tiles(L) * CM_NP;
+    const int r = cm_rpw(B, L);
+    return (size_t)3 * D * ((B + r - 1) / r) * cm_tiles(L) * CM_NP;
 }
 
 int hyena_cm_pre_fwd_ld(const void* xT, const float* bin, const float* w, const float* b, void* vg, int B, int L, int Lx, int D, long csx,
@@ -40,7 +47,7 @@ int hyena_cm_pre_fwd_ld(const void* xT, const float* bin, const float* w, const 
     if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || vg == nullptr) return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = nullptr; a.a1 = nullptr; a.o0 = vg; a.dxT = nullptr; a.part = nullptr;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda; a.rpw = cm_rpw(B, L);
     HY_CM_DISPATCH(cm_pre_fwd_kernel, 0);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
@@ -50,7 +57,7 @@ int hyena_cm_post_fwd_ld(const void* y, const void* xT, const float* bin, const 
     if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || y == nullptr || zT == nullptr || !cm_layout_ok(csz, bsz, B, L)) return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = y; a.a1 = nullptr; a.o0 = zT; a.dxT = nullptr; a.part = nullptr;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda; a.rpw = cm_rpw(B, L);
     HY_CM_DISPATCH(cm_post_fwd_kernel, 0);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
@@ -62,7 +69,7 @@ int hyena_cm_post_bwd_ld(const void* dzT, const void* y, const void* xT, const f
         return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = y; a.a1 = dzT; a.o0 = dy; a.dxT = dxT; a.part = part;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda; a.rpw = cm_rpw(B, L);
     HY_CM_DISPATCH(cm_post_bwd_kernel, CM_SMEM);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }
@@ -73,7 +80,7 @@ int hyena_cm_pre_bwd_ld(const void* dvg, const void* xT, const float* bin, const
     if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || dvg == nullptr || dxT == nullptr || part == nullptr) return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = dvg; a.a1 = nullptr; a.o0 = nullptr; a.dxT = dxT; a.part = part;
-    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda;
+    a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda; a.rpw = cm_rpw(B, L);
     HY_CM_DISPATCH(cm_pre_bwd_kernel, CM_SMEM);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }

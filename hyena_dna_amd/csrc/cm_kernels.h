@@ -44,7 +44,25 @@ struct CmArgs {
                         // channel rows pitched over the FLATTENED positions -- what a library GEMM takes as one matrix -- csx >= B Lx, bsx = Lx)
     long csz; int bsz;  // zT / dzT (d, b) likewise
     int lda;            // row pitch (elements, >= L) of the (B, D, L) tensors vg / y / dy / dvg: row (b, d) at (b D + d) lda
+    int rpw;            // (channel, batch) rows per workgroup: 1, or 2 / 4 / 8 for sequences of at most CM_TILE / rpw positions (round 6: a 2048-position
+                        // tile is half empty at L = 1024 -- the shipped experiment's 256 x 1023 x 128 -- and every workgroup pays its reduction and
+                        // record; the rows of one workgroup share the channel and differ in b: grid.z = ceil(B / rpw), one record per workgroup)
 };
+// thread -> (batch item, first position); dead threads (beyond B) get l0 = L: they load zeros, store nothing and add zeros to the sums
+struct CmPos { int b, l0; };
+__device__ __forceinline__ CmPos cm_pos(const CmArgs& a) {
+    CmPos p;
+    if (a.rpw <= 1) {
+        p.b = blockIdx.z;
+        p.l0 = (int)(blockIdx.x * CM_THREADS + threadIdx.x) * CM_V;
+        return p;
+    }
+    const int tpr = CM_THREADS / a.rpw, r = (int)threadIdx.x / tpr, tx = (int)threadIdx.x % tpr;
+    const int b = (int)blockIdx.z * a.rpw + r;
+    p.b = b < a.B ? b : a.B - 1;
+    p.l0 = b < a.B ? tx * CM_V : a.L + CM_V;             // (grid.x = 1: rpw > 1 only when a row fits CM_TILE / rpw positions)
+    return p;
+}
 
 // v[i] = row[l0 + i] for i in [LO, HI), zero outside [0, L).  Interior vectors move as 16-byte (8 x 16-bit) or 2 x 16-byte
 // accesses (rows of odd length start under-aligned: gfx950 global memory handles that).
@@ -134,8 +152,9 @@ template <int DT> struct CmEs { static constexpr size_t V = (DT == DT_F32) ? 4 :
 template <int DT>
 __global__ void __launch_bounds__(CM_THREADS) cm_pre_fwd_kernel(CmArgs a) {
     constexpr size_t ES = CmEs<DT>::V;
-    const int d = blockIdx.y, b = blockIdx.z;
-    const int l0 = (blockIdx.x * CM_THREADS + threadIdx.x) * CM_V;
+    const int d = blockIdx.y;
+    const CmPos ps = cm_pos(a);
+    const int b = ps.b, l0 = ps.l0;
     if (l0 >= a.L) return;
     const CmTap t1 = cm_tap(a, a.D + d), tv = cm_tap(a, 2 * a.D + d);
     float x1[CM_V + 2], xv[CM_V + 2], c1[CM_V], cv[CM_V], o[CM_V];
@@ -152,8 +171,9 @@ __global__ void __launch_bounds__(CM_THREADS) cm_pre_fwd_kernel(CmArgs a) {
 template <int DT>
 __global__ void __launch_bounds__(CM_THREADS) cm_post_fwd_kernel(CmArgs a) {
     constexpr size_t ES = CmEs<DT>::V;
-    const int d = blockIdx.y, b = blockIdx.z;
-    const int l0 = (blockIdx.x * CM_THREADS + threadIdx.x) * CM_V;
+    const int d = blockIdx.y;
+    const CmPos ps = cm_pos(a);
+    const int b = ps.b, l0 = ps.l0;
     if (l0 >= a.L) return;
     const CmTap t0 = cm_tap(a, d);
     float x0[CM_V + 2], c0[CM_V], y[CM_V], o[CM_V];
@@ -226,8 +246,9 @@ __global__ void __launch_bounds__(CM_THREADS) cm_post_bwd_kernel(CmArgs a) {
     constexpr size_t ES = CmEs<DT>::V;
     HY_SMEM(smem);
     HY_LDS float* red = HY_LDS_CAST(float, smem);
-    const int d = blockIdx.y, b = blockIdx.z;
-    const int l0 = (blockIdx.x * CM_THREADS + threadIdx.x) * CM_V;      // (threads beyond L still take part in the sums)
+    const int d = blockIdx.y;
+    const CmPos pos = cm_pos(a);
+    const int b = pos.b, l0 = pos.l0;                                  // (threads beyond L still take part in the sums)
     const CmTap t0 = cm_tap(a, d);
     float x0[CM_V + 2], dz[CM_V + 2], y[CM_V + 2], c0[CM_V], dy[CM_V], da[CM_V + 2];
     cm_ld<DT, CM_V + 2>(cm_cb(a.xT, d, b, a.csx, a.bsx, ES), l0 - 2, a.Lx, x0);
@@ -244,7 +265,7 @@ __global__ void __launch_bounds__(CM_THREADS) cm_post_bwd_kernel(CmArgs a) {
         p = cm_sc_bwd<DT>(da, x0, l0, a.L, t0, const_cast<char*>(cm_cb(a.dxT, d, b, a.csx, a.bsx, ES)), a.Lx);
     const int cs[1] = {d};
     const CmPart ps[1] = {p};
-    cm_store_parts<1>(a, cs, b * gridDim.x + blockIdx.x, a.B * gridDim.x, ps, red);
+    cm_store_parts<1>(a, cs, blockIdx.z * gridDim.x + blockIdx.x, gridDim.z * gridDim.x, ps, red);
 }
 
 // dvg -> dxT rows D + d (through x1c: gradient dvg * vc) and 2D + d (through vc: gradient dvg * x1c), and their partials
@@ -253,8 +274,9 @@ __global__ void __launch_bounds__(CM_THREADS) cm_pre_bwd_kernel(CmArgs a) {
     constexpr size_t ES = CmEs<DT>::V;
     HY_SMEM(smem);
     HY_LDS float* red = HY_LDS_CAST(float, smem);
-    const int d = blockIdx.y, b = blockIdx.z;
-    const int l0 = (blockIdx.x * CM_THREADS + threadIdx.x) * CM_V;
+    const int d = blockIdx.y;
+    const CmPos pos = cm_pos(a);
+    const int b = pos.b, l0 = pos.l0;
     const CmTap t1 = cm_tap(a, a.D + d), tv = cm_tap(a, 2 * a.D + d);
     // conv outputs are needed at l0 .. l0 + V + 1, hence raw inputs at l0 - 2 .. l0 + V + 1
     float x1[CM_V + 4], xv[CM_V + 4], g[CM_V + 2], c1[CM_V + 2], cv[CM_V + 2], da1[CM_V + 2], dav[CM_V + 2];
@@ -275,7 +297,7 @@ __global__ void __launch_bounds__(CM_THREADS) cm_pre_bwd_kernel(CmArgs a) {
     }
     const int cs[2] = {a.D + d, 2 * a.D + d};
     const CmPart ps[2] = {p1, pv};
-    cm_store_parts<2>(a, cs, b * gridDim.x + blockIdx.x, a.B * gridDim.x, ps, red);
+    cm_store_parts<2>(a, cs, blockIdx.z * gridDim.x + blockIdx.x, gridDim.z * gridDim.x, ps, red);
 }
 
 }  // namespace hyena

@@ -151,7 +151,7 @@ OUTPROJ_MFMA = _os.environ.get("HYENA_OUTPROJ_MFMA", "1") != "0"      # A/B knob
 # out_proj's input gradient with the gate backward in its epilogue (csrc/proj_kernels.h::outproj_dgrad_gate_bwd_kernel, round 5) against the pair
 # it can replace, library GEMM (dz^T) + cm_post_bwd, measured on the MI355X (profiles/r5e_outproj_dgrad.txt): the kernel wins at many short
 # sequences (32768 x 8: 190 vs 205 us), ties at 160000 x 2 (224 vs 226) and loses at B = 1 (L = 2^20: 756 - 800 vs 719 us; the pair streams its
-# bytes at 4.9 TB/s, the matrix-core kernel at 3.4 - 3.6).  "auto" (default) takes it where it wins; HYENA_OUTPROJ_DGRAD_MFMA=1 / 0 forces it.
+# bytes at 4.9 TB/s, the matrix-core kernel at 3.4 - 3.6).  "auto" (default) takes it where it wins (_dgrad_fused); HYENA_OUTPROJ_DGRAD_MFMA=1 / 0 forces it.
 DGRAD_MFMA = {"1": True, "0": False}.get(_os.environ.get("HYENA_OUTPROJ_DGRAD_MFMA", "auto"), "auto")
 
 
@@ -160,7 +160,12 @@ def _dgrad_fused(B, L, D, dtype):
         return False
     if DGRAD_MFMA is True:
         return True
-    return B >= 8
+    # round 6 (profiles/r6o_bench_dgrad.txt, after cm_post_bwd learned to put several short rows into one workgroup): the kernel wins wherever a batch
+    # has at least two sequences -- 32768 x 8: 180 vs 193 us, 32767 x 8: 189 vs 227, 160000 x 2: 222 vs 237, 4096 x 64: 180 vs 194 -- except for the
+    # many very short rows of the d_model 128 models (1024 x 256 x 128: 105 vs 96 us), and loses at B = 1 (2^20: 938 vs 684)
+    if D == 128 and L <= 2048:
+        return False
+    return B >= 2
 
 
 def mixer_out_supported(xT, L, out_weight):

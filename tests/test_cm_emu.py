@@ -22,7 +22,9 @@ def _ref_core_cm(xT, b_in, w, b, k, bias, L):
 
 @pytest.mark.parametrize("B,Lx,L,D,dtype", [(2, 70, 70, 8, torch.float32), (1, 2100, 2048, 6, torch.float32), (2, 130, 64, 5, torch.float32),
                                             (3, 4099, 4099, 3, torch.float32), (2, 3000, 3000, 4, torch.bfloat16),
-                                            (1, 9, 9, 2, torch.float32), (2, 2049, 2049, 2, torch.float16)])
+                                            (1, 9, 9, 2, torch.float32), (2, 2049, 2049, 2, torch.float16),
+                                            # several short rows per workgroup (round 6: 2 / 4 / 8 batch items of a channel share a 2048-position tile), ragged batches
+                                            (5, 1023, 1023, 4, torch.bfloat16), (9, 300, 257, 3, torch.float32), (19, 130, 128, 2, torch.float16)])
 def test_cm_core_vs_oracle(emu_backend, B, Lx, L, D, dtype):
     from hyena_dna_amd.mixer import hyena_mixer_core_cm
     g = torch.Generator().manual_seed(Lx + D)
