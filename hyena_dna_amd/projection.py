@@ -41,6 +41,7 @@ def split_count(rows, out_elems=None):
 
 SLICE_ALIGN = 64           # first-level slices: a multiple of 64 rows (64 x 16320 rows ran like 64 x 16128: 552 vs 551 us, and leave 4095 instead of 16383 rows)
 TAIL_SLICE = 256           # second level: the remainder in 256-row slices
+_MASKED_TAIL_ON_HOST = False   # tests only: take _tail_product's masked-slice branch (the GPU's) for host tensors too, so its indexing is covered without a GPU
 
 
 def split_plan(rows, out_elems=None):
@@ -71,11 +72,11 @@ def _tail_product(a_cn, b_nk, done):
     r = n - done
     if r <= 0:
         return None
-    if not a_cn.is_cuda or n < TAIL_SLICE or a_cn.dtype == torch.float32:
+    if not (a_cn.is_cuda or _MASKED_TAIL_ON_HOST) or n < TAIL_SLICE or a_cn.dtype == torch.float32:
         return torch.mm(a_cn[:, done:].float(), b_nk[done:].float())
     a = a_cn[:, n - TAIL_SLICE:].clone()
     a[:, :TAIL_SLICE - r] = 0
-    return torch.bmm(a.unsqueeze(0), b_nk[n - TAIL_SLICE:].unsqueeze(0), out_dtype=torch.float32)[0]
+    return _bmm_f32(a.unsqueeze(0), b_nk[n - TAIL_SLICE:].unsqueeze(0))[0]
 
 
 def split_k_weight_grad(dy2, x2):

@@ -399,15 +399,22 @@ def build_dataset(cfg, split="train"):
 
 def precision_dtype(precision):
     """trainer.precision -> the autocast type (None: no autocast).  Lightning 1.8.6 spellings: 16 / "16" / "16-mixed" -> float16 (with a loss
-    scaler, see train), "bf16" / "bf16-mixed" -> bfloat16, 32 / "32" / "32-true" -> None."""
-    p = str(precision)
+    scaler, see train), "bf16" / "bf16-mixed" -> bfloat16, 32 / "32" / "32-true" -> None.  Lightning's other spellings are refused BY NAME: "64" /
+    "64-true" (this package's kernels compute in fp32 or 16 bits) and the "16-true" / "bf16-true" of Lightning 2 (16-bit PARAMETERS: the reference's
+    pinned Lightning 1.8.6 has no such mode and the fused optimizer path keeps fp32 master weights)."""
+    p = str(precision).strip().lower()
     if p in ("16", "16-mixed"):
         return torch.float16
     if p in ("bf16", "bf16-mixed"):
         return torch.bfloat16
     if p in ("32", "32-true"):
         return None
-    raise ValueError(f"trainer.precision={precision!r}: expected 16, bf16 or 32")
+    if p in ("64", "64-true"):
+        raise ValueError(f"trainer.precision={precision!r}: double precision is not served (kernels compute in fp32 or 16 bits); use 32")
+    if p in ("16-true", "bf16-true"):
+        raise ValueError(f"trainer.precision={precision!r}: 16-bit parameters (Lightning 2's '-true' modes) are not served; the mixed modes "
+                         f"16 / 16-mixed / bf16 / bf16-mixed keep fp32 master weights as the reference's Lightning 1.8.6 does")
+    raise ValueError(f"trainer.precision={precision!r}: expected one of 16, 16-mixed, bf16, bf16-mixed, 32, 32-true")
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -28,7 +28,8 @@ def main():
     ap.add_argument("--experiment", default="hg38/hg38_hyena")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--synthetic-genome", default=None)
-    ap.add_argument("--graphed", action="store_true", help="capture the whole step into one hipGraph (lm.GraphedTrainStep)")
+    ap.add_argument("--graphed", action="store_true", help="capture the whole step into one hipGraph (lm.GraphedTrainStep); needs trainer.precision=bf16 or 32 -- the shipped config's "
+                         "precision 16 is fp16 + a host-side loss scaler, which a captured step cannot skip updates for")
     ap.add_argument("--emu", action="store_true", help="TEST ONLY: kernels under tests/hipemu on the CPU")
     ap.add_argument("overrides", nargs="*")
     args = ap.parse_args()

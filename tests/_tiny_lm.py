@@ -45,8 +45,9 @@ class TinyLM(nn.Module):
         return F.linear(h, self.emb.weight)                 # tied head (long_conv_lm.py:462-465)
 
 
-def train(device, steps, d=64, L=256, B=4, n_layer=2, autocast_dtype=None, seed=0):
-    """next-nucleotide prediction on periodic synthetic DNA (period 7) through the vectorised tokenizer; returns the losses"""
+def train(device, steps, d=64, L=256, B=4, n_layer=2, autocast_dtype=None, seed=0, lr=3e-3, warmup=0):
+    """next-nucleotide prediction on periodic synthetic DNA (period 7) through the vectorised tokenizer; returns the losses.
+    `warmup`: the learning rate ramps linearly to `lr` over that many updates (0: constant)"""
     from hyena_dna_amd.tokenizer import DNACharTokenizerLUT
     torch.manual_seed(seed)
     tok = DNACharTokenizerLUT()
@@ -55,9 +56,12 @@ def train(device, steps, d=64, L=256, B=4, n_layer=2, autocast_dtype=None, seed=
     data, target = zip(*(tok.sample(s, L + 1, add_eos=True) for s in seqs))
     data, target = torch.stack(data).to(device), torch.stack(target).to(device)
     model = TinyLM(16, d, L, n_layer).to(device)
-    opt = torch.optim.AdamW(model.parameters(), lr=3e-3)
+    opt = torch.optim.AdamW(model.parameters(), lr=lr)
     losses = []
-    for _ in range(steps):
+    for it in range(steps):
+        if warmup:
+            for g in opt.param_groups:
+                g["lr"] = lr * min(1.0, (it + 1) / warmup)
         opt.zero_grad(set_to_none=True)
         with torch.autocast(device_type="cuda" if device != "cpu" else "cpu", dtype=autocast_dtype or torch.bfloat16,
                             enabled=autocast_dtype is not None):

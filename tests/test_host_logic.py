@@ -160,6 +160,36 @@ def test_optim_tags_and_buffers_match_reference_contract():
         HyenaOperator(d_model=8, l_max=34, fused_bias_fc=True)
 
 
+def test_tail_product_masked_slice_branch_on_host(monkeypatch):
+    """projection._tail_product's GPU branch -- the last 256 positions as one 16-bit slice whose already-counted columns are zeroed -- taken for host
+    tensors (projection._MASKED_TAIL_ON_HOST, tests only): equals the plain product of the leftover rows, through all three weight-gradient callers'
+    operand layouts (that indexing was reachable on a GPU only)"""
+    import hyena_dna_amd.projection as P
+    g = torch.Generator().manual_seed(5)
+    for n, done in ((70001, 69888), (999, 768), (256, 1), (300, 299), (513, 513)):
+        a = torch.randn(24, n, generator=g).to(torch.bfloat16)                    # (C, n) as dy2.t() / a channel-major matrix
+        b = torch.randn(n, 16, generator=g).to(torch.bfloat16)
+        want = torch.mm(a[:, done:].float(), b[done:].float()) if done < n else None
+        monkeypatch.setattr(P, "_MASKED_TAIL_ON_HOST", False)
+        plain = P._tail_product(a, b, done)
+        monkeypatch.setattr(P, "_MASKED_TAIL_ON_HOST", True)
+        for av, bv in ((a, b), (a.t().contiguous().t(), b), (a, b.t().contiguous().t())):       # row- and column-major views of both operands
+            got = P._tail_product(av, bv, done)
+            if want is None:
+                assert got is None and plain is None
+                continue
+            assert torch.allclose(got, want, rtol=1e-5, atol=1e-4) and torch.allclose(plain, want, rtol=1e-5, atol=1e-4), (n, done)
+        assert a[:, n - min(n, 256):].abs().sum() > 0                                          # (the masking works on a copy)
+    # and through the whole split: an odd row count whose plan leaves a tail
+    monkeypatch.setattr(P, "_MASKED_TAIL_ON_HOST", True)
+    dy2 = torch.randn(70001, 24, generator=g).to(torch.bfloat16)
+    x2 = torch.randn(70001, 16, generator=g).to(torch.bfloat16)
+    assert P.split_plan(70001, 24 * 16)[1] < 70001
+    ref = torch.mm(dy2.t().double(), x2.double())
+    got = P.split_k_weight_grad(dy2, x2).double()
+    assert ((got - ref).norm() / ref.norm()).item() < 1e-6
+
+
 def test_split_k_linear_gradients_match_linear():
     """hyena_dna_amd/projection.py: the slice-batched weight gradient equals autograd's dy^T x (hyena.py:391,440)"""
     from hyena_dna_amd.projection import SplitKLinearFunc, split_count

@@ -163,3 +163,15 @@ def test_runner_trains_on_a_synthetic_genome(tmp_path):
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2500:])
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert r["steps"] == 12 and r["fell"] and all(l == l for l in r["losses"]), r
+
+
+def test_precision_spellings():
+    """trainer.precision: Lightning 1.8.6's mixed modes are served, the others refused by name"""
+    import torch
+    from hyena_dna_amd import runner
+    assert runner.precision_dtype(16) == torch.float16 and runner.precision_dtype("16-mixed") == torch.float16
+    assert runner.precision_dtype("bf16") == torch.bfloat16 and runner.precision_dtype("BF16-mixed") == torch.bfloat16
+    assert runner.precision_dtype(32) is None and runner.precision_dtype("32-true") is None
+    for bad, word in ((64, "double"), ("16-true", "16-bit parameters"), ("bf16-true", "16-bit parameters"), ("fp8", "expected one of")):
+        with pytest.raises(ValueError, match=word):
+            runner.precision_dtype(bad)
