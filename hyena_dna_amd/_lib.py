@@ -662,13 +662,24 @@ def cm_pre_fwd(xT, bin_, w, b, L):
     return vg
 
 
-def cm_post_fwd(y, xT, bin_, w, b):
-    """y (B, D, L), xT (3D, B, Lx) -> zT (D, B, L)."""
+def rows_as_cm_strides(t):
+    """(cs, bs) that address a (B, D, L) tensor of pitched rows as rows (d, b): cs = its row pitch, bs = D times that (include/hyena_mixer.h)"""
+    ld = ld_of(t)
+    return ld, t.shape[1] * ld
+
+
+def cm_post_fwd(y, xT, bin_, w, b, rows_out=False):
+    """y (B, D, L), xT (3D, B, Lx) -> zT (D, B, L); rows_out: the same values as a (B, D, L) tensor of pitched rows (the next convolution's input
+    when the operator's order is >= 3)."""
     B, D, L = y.shape
     xT, y = as_cm(xT), as_rows(y)
     csx, bsx = cm_strides(xT)
-    zT = empty_cm(D, B, L, xT.dtype, xT.device)
-    csz, bsz = cm_strides(zT)
+    if rows_out:
+        zT = empty_like_rows(y, dtype=xT.dtype)
+        csz, bsz = rows_as_cm_strides(zT)
+    else:
+        zT = empty_cm(D, B, L, xT.dtype, xT.device)
+        csz, bsz = cm_strides(zT)
     with _backend.guard(xT.device):
         check(lib().hyena_cm_post_fwd_ld(y.data_ptr(), xT.data_ptr(), None if bin_ is None else bin_.data_ptr(), w.data_ptr(), b.data_ptr(),
                                          zT.data_ptr(), B, L, xT.shape[2], D, csx, bsx, csz, bsz, ld_of(y), dtype_code(xT.dtype),
@@ -682,12 +693,19 @@ def cm_partials(xT, L):
     return torch.empty(n, dtype=torch.float32, device=xT.device).view(D3, -1, 8)
 
 
-def cm_post_bwd(dzT, y, xT, bin_, w, b, dxT, part):
-    """-> dy (B, D, L) with y's row pitch; fills dxT[0:D] (positions < L) and part[0:D].  dxT must have xT's layout."""
+def cm_post_bwd(dzT, y, xT, bin_, w, b, dxT, part, dz_rows=False):
+    """-> dy (B, D, L) with y's row pitch; fills dxT[0:D] (positions < L) and part[0:D].  dxT must have xT's layout.
+    dz_rows: dzT is a (B, D, L) tensor of pitched rows (the gradient a convolution hands back for its input) instead of channel-major (D, B, L)."""
     B, D, L = y.shape
-    xT, y, dzT = as_cm(xT), as_rows(y), as_cm(dzT)
+    xT, y = as_cm(xT), as_rows(y)
     csx, bsx = cm_strides(xT)
-    csz, bsz = cm_strides(dzT)
+    if dz_rows:
+        dzT = as_rows(dzT)
+        assert tuple(dzT.shape) == (B, D, L)
+        csz, bsz = rows_as_cm_strides(dzT)
+    else:
+        dzT = as_cm(dzT)
+        csz, bsz = cm_strides(dzT)
     assert cm_strides(dxT) == (csx, bsx)
     dy = empty_like_rows(y)
     with _backend.guard(xT.device):

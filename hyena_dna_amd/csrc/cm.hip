@@ -9,6 +9,12 @@ using namespace hyena;
 namespace {
 // a (C, B, len) layout: row (c, b) at c cs + b bs; rows must not overlap
 bool cm_layout_ok(long cs, int bs, int B, int len) { return bs >= len && cs >= (long)(B - 1) * bs + len; }
+// zT / dzT of the post kernels may also be BATCH-major rows -- row (d, b) at d cs + b bs with bs >= (D - 1) cs + len: the (B, D, len) layout the
+// convolution takes, cs = its row pitch, bs = D cs -- so that the gate between two long convolutions (HyenaOperator at order >= 3, hyena.py:414-423)
+// writes the next convolution's input, and reads its gradient, in place (round 6)
+bool cm_zlayout_ok(long cs, int bs, int B, int D, int len) {
+    return cm_layout_ok(cs, bs, B, len) || (cs >= len && (long)bs >= (long)(D - 1) * cs + len);
+}
 bool cm_ok(const void* xT, const float* w, const float* b, int B, int L, int Lx, int D, long csx, int bsx, int lda, int dtype) {
     return xT != nullptr && w != nullptr && b != nullptr && B >= 1 && L >= 1 && Lx >= L && D >= 1 && cm_layout_ok(csx, bsx, B, Lx) && lda >= L &&
            (dtype == HYENA_F32 || dtype == HYENA_BF16 || dtype == HYENA_F16);
@@ -54,7 +60,7 @@ int hyena_cm_pre_fwd_ld(const void* xT, const float* bin, const float* w, const 
 
 int hyena_cm_post_fwd_ld(const void* y, const void* xT, const float* bin, const float* w, const float* b, void* zT, int B, int L, int Lx,
                          int D, long csx, int bsx, long csz, int bsz, int lda, int dtype, void* stream) {
-    if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || y == nullptr || zT == nullptr || !cm_layout_ok(csz, bsz, B, L)) return HYENA_ERR_BAD_ARG;
+    if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || y == nullptr || zT == nullptr || !cm_zlayout_ok(csz, bsz, B, D, L)) return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = y; a.a1 = nullptr; a.o0 = zT; a.dxT = nullptr; a.part = nullptr;
     a.B = B; a.L = L; a.D = D; a.Lx = Lx; a.csx = csx; a.bsx = bsx; a.csz = csz; a.bsz = bsz; a.lda = lda; a.rpw = cm_rpw(B, L);
@@ -65,7 +71,7 @@ int hyena_cm_post_fwd_ld(const void* y, const void* xT, const float* bin, const 
 int hyena_cm_post_bwd_ld(const void* dzT, const void* y, const void* xT, const float* bin, const float* w, const float* b, void* dy,
                          void* dxT, float* part, int B, int L, int Lx, int D, long csx, int bsx, long csz, int bsz, int lda, int dtype,
                          void* stream) {
-    if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || !cm_layout_ok(csz, bsz, B, L) || dzT == nullptr || y == nullptr || dy == nullptr || dxT == nullptr || part == nullptr)
+    if (!cm_ok(xT, w, b, B, L, Lx, D, csx, bsx, lda, dtype) || !cm_zlayout_ok(csz, bsz, B, D, L) || dzT == nullptr || y == nullptr || dy == nullptr || dxT == nullptr || part == nullptr)
         return HYENA_ERR_BAD_ARG;
     CmArgs a;
     a.xT = xT; a.bin = bin; a.w = w; a.b = b; a.a0 = y; a.a1 = dzT; a.o0 = dy; a.dxT = dxT; a.part = part;

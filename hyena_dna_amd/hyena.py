@@ -18,8 +18,8 @@ import torch.nn as nn
 
 from .fftconv import fftconv_func, fftconv_ref
 from .filter import fused_filter_ok, hyena_filter_dl
-from .mixer import hyena_mixer_core, hyena_mixer_core_cm, hyena_mixer_out_cm, mixer_out_supported
-from .projection import hyena_linear, in_proj_pre_cm, out_proj_cm
+from .mixer import hyena_mixer_core, hyena_mixer_core_cm, hyena_mixer_core_cm_order_n, hyena_mixer_out_cm, mixer_out_supported
+from .projection import hyena_linear, in_proj_cm, in_proj_pre_cm, out_proj_cm
 
 # Layout of the tensors between the operator's two projections: channel-major (x^T written by the in_proj GEMM, z^T read by
 # the out_proj GEMM, no transposes anywhere: csrc/cm_kernels.h) or the reference's position-major (B, L, 3D) with the
@@ -31,6 +31,10 @@ CHANNEL_MAJOR = os.environ.get("HYENA_MIXER_LAYOUT", "channel").lower() != "posi
 # for the two launches, 1023 x 256: 121 vs 169 -- and still loses at d_model 256 (2^20: 1266 - 1270 vs 1120 - 1144 us; 32768 x 8: 298 vs 255;
 # profiles/r6l_bench_outproj_ln_lds_residual.txt): "auto" (default) = fused at d_model 128 only; HYENA_ADD_NORM_FUSED=1 / 0 forces it.
 ADD_NORM_FUSED = {"1": True, "0": False}.get(os.environ.get("HYENA_ADD_NORM_FUSED", "auto"), "auto")
+# order >= 3 (configs/model/layer/hyena_dna.yaml:3): the channel-major route of mixer.HyenaMixerCMOrderNFunc -- both projections as channel-major GEMMs,
+# every gate one of the order-2 shell kernels on a row view of x^T, nothing transposed -- instead of the reference's op-by-op graph around the HIP
+# convolution (profiles/r6t_order3.txt).  HYENA_ORDER_N_FUSED=0: the generic route (A/B).
+ORDER_N_FUSED = os.environ.get("HYENA_ORDER_N_FUSED", "1") != "0"
 
 
 def _add_norm_fused(d_model):
@@ -186,7 +190,30 @@ class HyenaFilter(_OptimModule):
             k = k / torch.norm(k, dim=0, p=1, keepdim=True)
         return k
 
-    def _fused_filter_ok(self, L, layers, z):
+    def filter_dl_split(self, L, n):
+        """``filter_dl(L)`` for a filter of D n channels in the reference's '(v o)' order (hyena.py:408: channel v n + o belongs to convolution o
+        of an operator of order n + 1) as n tensors (D, L), one per convolution.  With the fused filter kernels: one launch chain per convolution
+        over the rows o, o + n, ... of the last linear layer and of the decay rates -- each result is written in the layout its convolution reads,
+        nothing is gathered or split afterwards, and the kernels' 64 / 128 / 256 output channels are d_model instead of d_model (order - 1); the
+        inner layers are evaluated n times (64 x 64 products: < 10 % of a call).  Otherwise: row views of filter_dl(L)."""
+        if n == 1:
+            return [self.filter_dl(L)]
+        z, t = self.pos_emb(L)
+        layers = [self.implicit_filter[i] for i in range(len(self.implicit_filter))]
+        lin = layers[0::2]
+        # short filters are launch-bound (two launch chains cost 0.4 ms more than one at 1023 x 128, profiles/r6t_order3.txt): there, one call over
+        # all D n channels where the kernels take that width, and row views of it
+        one_call = L <= 8192 and self._fused_filter_ok(L, layers, z)
+        if not one_call and self._fused_filter_ok(L, layers, z, out_channels=lin[-1].out_features // n):
+            mod = self.modulation
+            deltas = mod.deltas.reshape(-1)
+            return [hyena_filter_dl(z[0], t.reshape(-1), lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias,
+                                    lin[3].weight[o::n], layers[1].freq.reshape(-1), deltas[o::n], mod.shift, self.modulate) for o in range(n)]
+        k = self.filter_dl(L)
+        k = k.reshape(k.shape[0] // n, n, k.shape[-1])
+        return [k[:, o] for o in range(n)]
+
+    def _fused_filter_ok(self, L, layers, z, out_channels=None):
         """The fused HIP filter kernels (include/hyena_filter.h) cover exactly the HyenaDNA filter configuration."""
         if len(layers) != 7:
             return False
@@ -199,7 +226,7 @@ class HyenaFilter(_OptimModule):
             return False
         if isinstance(self.modulation.deltas, nn.Parameter) and self.modulation.deltas.requires_grad and torch.is_grad_enabled():
             return False
-        return fused_filter_ok(L, z.shape[-1], lin[0].out_features, lin[3].out_features, 2, self.normalized, False)
+        return fused_filter_ok(L, z.shape[-1], lin[0].out_features, out_channels or lin[3].out_features, 2, self.normalized, False)
 
     def forward(self, x, L, k=None, bias=None, *args, **kwargs):
         if k is None:
@@ -274,11 +301,26 @@ class HyenaOperator(nn.Module):
         self.filter_fn = HyenaFilter(self.head_dim * inner_factor * (order - 1), order=filter_order, seq_len=l_max,
                                      channels=1, dropout=filter_dropout, **filter_args)
 
-    def _fused_ok(self):
-        """The fused HIP mixer core covers exactly the HyenaDNA operator configuration."""
-        return (self.order == 2 and self.num_heads == 1 and self.num_blocks == 1 and self.inner_factor == 1
+    def _shell_ok(self):
+        """what the fused shell kernels cover besides the order: one head, one block, inner factor 1, no outer mixing / post-order FFN, 3 short taps"""
+        return (self.num_heads == 1 and self.num_blocks == 1 and self.inner_factor == 1
                 and not self.outer_mixing and not self.post_order_ffn and self.short_filter_order == 3
                 and (self.dropout.p == 0.0 or not self.training) and not getattr(self.filter_fn, "bidirectional", False))
+
+    def _fused_ok(self):
+        """The fused HIP mixer core covers exactly the HyenaDNA operator configuration."""
+        return self.order == 2 and self._shell_ok()
+
+    def _route(self, l):
+        """which implementation ``forward`` takes for a length-l input: "fused" (order 2: the HyenaDNA configuration), "order_n" (order >= 3 on
+        the same kernels, channel-major) or "generic" (the reference's graph around the HIP convolution)"""
+        l_filter = min(l, self.l_max)
+        if self._fused_ok() and l_filter <= _lib_max_l():
+            return "fused"
+        if (self.order >= 3 and ORDER_N_FUSED and CHANNEL_MAJOR and self._shell_ok() and l_filter <= _lib_max_l()
+                and isinstance(self.activation, nn.Identity)):
+            return "order_n"
+        return "generic"
 
     def forward_add_norm(self, u, residual, norm_weight, norm_bias, eps):
         """``forward(u)`` followed by the prenorm block's ``residual' = out + residual; hidden = LayerNorm(residual')`` (flash_attn Block with
@@ -332,6 +374,13 @@ class HyenaOperator(nn.Module):
                 x = hyena_linear(u, self.in_proj.weight, self.in_proj.bias)     # (B, L, 3D), hipBLASLt GEMM
                 z = hyena_mixer_core(x, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter)
                 y = hyena_linear(self.activation(z), self.out_proj.weight, self.out_proj.bias)
+            return (y, None) if self.return_state else y
+        if self._route(l) == "order_n":
+            ks = self.filter_fn.filter_dl_split(l_filter, self.order - 1)       # one (D, l) filter per convolution ('(v o)' channels, hyena.py:408)
+            fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
+            xT = in_proj_cm(u, self.in_proj.weight)                             # ((order + 1) D, B, L), bias added on load by the shell kernels
+            zT = hyena_mixer_core_cm_order_n(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, ks, fb, l_filter, self.order)
+            y = out_proj_cm(zT, self.out_proj.weight, self.out_proj.bias)
             return (y, None) if self.return_state else y
         u = self.in_proj(u).transpose(1, 2)                                     # b l d -> b d l
         uc = self.short_filter(u)[..., :l_filter]

@@ -16,7 +16,7 @@ import torch
 from . import _castcache, _gradmode, _lib
 
 __all__ = ["hyena_mixer_core", "HyenaMixerFunc", "hyena_mixer_core_cm", "HyenaMixerCMFunc", "hyena_mixer_out_cm", "HyenaMixerOutCMFunc",
-           "mixer_out_supported"]
+           "mixer_out_supported", "hyena_mixer_core_cm_order_n", "HyenaMixerCMOrderNFunc"]
 
 
 class HyenaMixerFunc(torch.autograd.Function):
@@ -139,6 +139,115 @@ def hyena_mixer_core_cm(xT, b_in, sf_weight, sf_bias, k, bias, L, vg=None):
         zero = 0 * (b_in.sum() + sf_weight.sum() + sf_bias.sum() + k.sum() + bias.sum())
         return xT[:D, :, :L] * 0 + zero.to(xT.dtype)
     return _gradmode.apply(HyenaMixerCMFunc, xT, b_in, sf_weight, sf_bias, k, bias, L, vg)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Order >= 3 (round 6; configs/model/layer/hyena_dna.yaml:3 ships ``order: 3``).  hyena.py:404-439 with n = order - 1 long convolutions:
+#     (x_0 ... x_n, v) = short_conv(x^T + b_in).split(D);   v <- conv(v * x_n, k_0);   v <- conv(v * x_{n-o}, k_o)  (o = 1 ... n - 1);   z = v * x_0
+# No new kernel: every gate is one of the order-2 shell kernels on a THREE-GROUP ROW VIEW of x^T (channel rows lead, so x^T[s D : (s + 3) D] is a
+# channel-major tensor of its own) --
+#     v * x_n            = cm_pre_fwd  on the view that starts at group n - 1   (its groups 1, 2 are x_n, v)
+#     y_{o-1} * x_{n-o}  = cm_post_fwd on the view that starts at group n - o   (its group 0), written as the next convolution's (B, D, L) rows
+#     y_{n-1} * x_0      = cm_post_fwd on the view that starts at group 0, channel-major for out_proj
+# and the backward runs the same views in reverse: every group of dx^T is written exactly once (group 0 and groups 1 ... n - 1 by cm_post_bwd,
+# groups n, n + 1 by cm_pre_bwd), the short-filter / in_proj-bias records of each launch cover the groups it wrote.
+# ---------------------------------------------------------------------------------------------------------------------
+class HyenaMixerCMOrderNFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xT, b_in, sf_weight, sf_bias, bias, L, order, *ks):
+        """xT ((order + 1) D, B, Lx) = W_in u^T without the bias; ks: order - 1 filters (D, L), one per convolution (HyenaFilter.filter_dl_split);
+        bias (D (order - 1),) in '(v o)' order (hyena.py:410-412) -> zT (D, B, L)"""
+        G = order + 1
+        n = order - 1
+        GD, B, Lx = xT.shape
+        D = GD // G
+        xc = _lib.as_cm(xT)
+        bi = b_in.detach().to(torch.float32).contiguous()
+        w = sf_weight.detach().to(torch.float32).reshape(GD, 3).contiguous()
+        b = sf_bias.detach().to(torch.float32).contiguous()
+        kfs = []
+        for k in ks:
+            kf = k.detach().to(torch.float32)
+            ld = _lib.ld_of(kf)
+            if ld is None or ld > _lib.row_pitch(L):               # a row view of a '(v o)' block: gather it (dk comes back with k's pitch)
+                rows = _lib.empty_rows((D,), L, torch.float32, kf.device)
+                rows.copy_(kf)
+                kf = rows
+            kfs.append(_lib.as_rows(kf))
+        bf = bias.detach().to(torch.float32).reshape(D, n).t().contiguous()          # (n, D)
+        want_grad = any(_gradmode.needs(ctx))
+
+        def view(s):
+            return xc[s * D:(s + 3) * D], bi[s * D:(s + 3) * D], w[s * D:(s + 3) * D], b[s * D:(s + 3) * D]
+
+        v = _lib.cm_pre_fwd(*view(n - 1), L)
+        ys = []
+        for o in range(n):
+            y = _lib.fftconv_fwd(v, kfs[o], bf[o], grad=want_grad)
+            ys.append(y)
+            if o + 1 < n:
+                v = _lib.cm_post_fwd(y, *view(n - o - 1), rows_out=True)
+        zT = _lib.cm_post_fwd(ys[-1], *view(0))
+        ctx.save_for_backward(xc, bi, w, b, bf, *kfs, *ys)
+        ctx.meta = (b_in.dtype, sf_weight.shape, sf_weight.dtype, sf_bias.dtype, [k.dtype for k in ks], bias.shape, bias.dtype, L, order)
+        return zT
+
+    @staticmethod
+    def backward(ctx, dzT):
+        xc, bi, w, b, bf, *rest = ctx.saved_tensors
+        bin_dtype, w_shape, w_dtype, b_dtype, k_dtypes, bias_shape, bias_dtype, L, order = ctx.meta
+        G, n = order + 1, order - 1
+        kfs, ys = rest[:n], rest[n:]
+        GD, B, Lx = xc.shape
+        D = GD // G
+        dzT = _lib.as_cm(dzT.to(xc.dtype))
+        dxT = _lib.empty_like_cm(xc)
+        if Lx > L:
+            dxT[:, :, L:].zero_()
+
+        def view(s):
+            return xc[s * D:(s + 3) * D], bi[s * D:(s + 3) * D], w[s * D:(s + 3) * D], b[s * D:(s + 3) * D]
+
+        need_dk = ctx.needs_input_grad[4] or any(ctx.needs_input_grad[7:])
+        red = torch.empty(GD, 5, dtype=torch.float32, device=xc.device)
+        # z = y_{n-1} * x_0
+        part = _lib.cm_partials(view(0)[0], L)
+        dy = _lib.cm_post_bwd(dzT, ys[n - 1], *view(0), dxT[0:3 * D], part)
+        red[0:D] = part[:D, :, :5].sum(dim=1)
+        dks, dbs = [None] * n, [None] * n
+        for o in range(n - 1, -1, -1):
+            # the input of convolution o, recomputed (one elementwise pass) instead of kept
+            if o == 0:
+                v = _lib.cm_pre_fwd(*view(n - 1), L)
+            else:
+                v = _lib.cm_post_fwd(ys[o - 1], *view(n - o), rows_out=True)
+            dv, dks[o], dbs[o] = _lib.fftconv_bwd(dy, v, kfs[o], bf[o], need_du=True, need_dk=need_dk, saved=None)
+            s = n - o if o > 0 else n - 1
+            part = _lib.cm_partials(view(s)[0], L)
+            if o > 0:                                                 # v = y_{o-1} * x_{n-o}: group 0 of the view at n - o
+                dy = _lib.cm_post_bwd(dv, ys[o - 1], *view(s), dxT[s * D:(s + 3) * D], part, dz_rows=True)
+                red[s * D:(s + 1) * D] = part[:D, :, :5].sum(dim=1)
+            else:                                                     # v = x_n * v: groups 1, 2 of the view at n - 1
+                _lib.cm_pre_bwd(dv, *view(s), dxT[s * D:(s + 3) * D], part)
+                red[(s + 1) * D:(s + 3) * D] = part[D:, :, :5].sum(dim=1)
+        dw = red[:, :3].reshape(w_shape).to(w_dtype)
+        db = red[:, 3].to(b_dtype)
+        dbin = red[:, 4].to(bin_dtype)
+        dbias = None
+        if need_dk:
+            dbias = torch.stack(dbs, dim=1).reshape(bias_shape).to(bias_dtype)            # back to '(v o)' order
+            dks = [dk.to(t) for dk, t in zip(dks, k_dtypes)]
+        return (dxT, dbin, dw, db, dbias, None, None, *dks)
+
+
+def hyena_mixer_core_cm_order_n(xT, b_in, sf_weight, sf_bias, ks, bias, L, order):
+    """zT (D, B, L) of an operator of order >= 2 from xT ((order + 1) D, B, Lx), channel-major; ks: its order - 1 filters (HyenaMixerCMOrderNFunc)"""
+    assert len(ks) == order - 1
+    if xT.shape[1] == 0 or L == 0:
+        D = xT.shape[0] // (order + 1)
+        zero = 0 * (b_in.sum() + sf_weight.sum() + sf_bias.sum() + sum(k.sum() for k in ks) + bias.sum())
+        return xT[:D, :, :L] * 0 + zero.to(xT.dtype)
+    return _gradmode.apply(HyenaMixerCMOrderNFunc, xT, b_in, sf_weight, sf_bias, bias, L, order, *ks)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

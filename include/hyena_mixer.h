@@ -64,6 +64,9 @@ int hyena_cm_pre_bwd(const void* dvg, const void* xT, const float* bin, const fl
  * L = max_length - 1 is odd, and rows of a packed tensor are then unaligned):
  *   csx, bsx : layout of xT / dxT -- row (c, b) starts at element c csx + b bsx  (bsx >= Lx, csx >= (B - 1) bsx + Lx)
  *   csz, bsz : layout of zT / dzT -- row (d, b) at d csz + b bsz                  (bsz >= L,  csz >= (B - 1) bsz + L)
+ *              or BATCH-major rows: bsz >= (D - 1) csz + L, csz >= L -- the (B, D, L) layout of the convolution's tensors (csz = its row pitch,
+ *              bsz = D csz): the gate between two long convolutions of an operator of order >= 3 (hyena.py:414-423) then writes the next
+ *              convolution's input, and reads its gradient, in place (round 6)
  *   lda      : row pitch of the (B, D, L) tensors vg / y / dy / dvg -- row (b, d) at (b D + d) lda  (lda >= L)
  * Two layouts are in use (hyena_dna_amd/_lib.py): per-sequence pitch ld (cs = B ld, bs = ld: every row aligned; B = 1), and channel rows pitched
  * over the FLATTENED positions (cs = B L rounded up, bs = L: one library GEMM still sees one (C, B L) matrix; B > 1).  Elements outside a row's

@@ -104,13 +104,13 @@ def test_mixer_core_cm_at_contract_shapes_vs_oracle(gpu_lib, B, L, D):
     assert _per_channel_rel(leaves[4].grad.float(), ref_leaves[4].grad, 0) < 2e-2
 
 
-def _operator_and_oracle(B, L, D, seed, device=None, dtype=torch.float64, short_conv=O.short_conv_taps, filter_fn=None):
+def _operator_and_oracle(B, L, D, seed, device=None, dtype=torch.float64, short_conv=O.short_conv_taps, filter_fn=None, order=2):
     """(operator, u, dy, oracle results): the oracle's HyenaOperator.forward (O.hyena_operator) + autograd, evaluated on `device`
     (default cuda:0) in `dtype`"""
     from hyena_dna_amd.hyena import HyenaOperator
     device = device or torch.device("cuda", 0)
     torch.manual_seed(seed)
-    op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
+    op = HyenaOperator(d_model=D, l_max=L + 2, order=order, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
                        lr=6e-4, wd=0.0, lr_pos_emb=0.0)
     with torch.no_grad():                       # biases are zero-initialised by the LM; give them values here
         for n, p in op.named_parameters():
@@ -127,7 +127,7 @@ def _operator_and_oracle(B, L, D, seed, device=None, dtype=torch.float64, short_
     for i in (3, 5):                            # hyena.py:199: ONE freq parameter shared by the three activations
         leaves[f"filter_fn.implicit_filter.{i}.freq"] = leaves["filter_fn.implicit_filter.1.freq"]
     u_ref = u.to(device=device, dtype=dtype).requires_grad_(True)
-    y_ref = O.hyena_operator(leaves, u_ref, l_max=L + 2, short_conv_fn=short_conv, filter_fn=filter_fn)
+    y_ref = O.hyena_operator(leaves, u_ref, l_max=L + 2, order=order, short_conv_fn=short_conv, filter_fn=filter_fn)
     y_ref.backward(dy.to(device=device, dtype=dtype))
     ref = dict(y=y_ref.detach().cpu(), du=u_ref.grad.cpu(), grads={n: None if leaves[n].grad is None else leaves[n].grad.cpu() for n in params})
     del leaves, u_ref, y_ref
@@ -171,6 +171,50 @@ def test_operator_at_contract_shapes_vs_oracle(gpu_lib, B, L, D, monkeypatch):
             monkeypatch.delenv("HYENA_FILTER_AUTOCAST")
             ty, tg = 1.5e-2, 3e-2
         assert y.shape == ref["y"].shape
+        e = _rel(y.float(), ref["y"])
+        assert e < ty, (mode, "y", e)
+        assert _per_channel_rel(y.float(), ref["y"], 2) < 3 * ty, (mode, "y per channel")
+        e = _rel(ud.grad.float(), ref["du"])
+        assert e < tg, (mode, "du", e)
+        for n, p in op.named_parameters():
+            r = ref["grads"][n]
+            if r is None:
+                assert p.grad is None or torch.count_nonzero(p.grad) == 0, n
+                continue
+            e = _rel(p.grad.float(), r)
+            assert e < tg, (mode, n, e)
+        del y, ud
+        torch.cuda.empty_cache()
+
+
+ORDER_SHAPES = [(4, 1023, 128, 3), (2, 8191, 128, 3), (1, 131071, 256, 3), (2, 32767, 256, 4)]
+
+
+@pytest.mark.parametrize("B,L,D,order", ORDER_SHAPES)
+def test_operator_of_higher_order_vs_oracle(gpu_lib, B, L, D, order, monkeypatch):
+    """order 3 / 4 (configs/model/layer/hyena_dna.yaml:3; hyena.py:404-439) on the channel-major route of round 6 (mixer.HyenaMixerCMOrderNFunc)
+    at the trainer's odd lengths, against O.hyena_operator in float64: fp32, and bf16 autocast with the fp32 filter kernels; then the generic
+    route (the reference's graph around the HIP convolution) against the same oracle values in fp32"""
+    import hyena_dna_amd.hyena as H
+    dev = torch.device("cuda", 0)
+    op, u, dy, ref = _operator_and_oracle(B, L, D, seed=L // 5 + order, order=order)
+    op = op.to(dev)
+    for mode in ("fp32", "bf16", "generic-fp32"):
+        monkeypatch.setattr(H, "ORDER_N_FUSED", mode != "generic-fp32")
+        assert op._route(L) == ("generic" if mode == "generic-fp32" else "order_n")
+        op.zero_grad(set_to_none=True)
+        ud = u.to(dev).requires_grad_(True)
+        if mode == "bf16":
+            monkeypatch.setenv("HYENA_FILTER_AUTOCAST", "fp32")
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = op(ud.to(torch.bfloat16))
+            y.float().backward(dy.to(dev))
+            monkeypatch.delenv("HYENA_FILTER_AUTOCAST")
+            ty, tg = 2e-2, 4e-2                   # (one more 16-bit gate and convolution per extra order than the order-2 bounds above)
+        else:
+            y = op(ud)
+            y.backward(dy.to(dev))
+            ty, tg = 3e-5, 3e-4
         e = _rel(y.float(), ref["y"])
         assert e < ty, (mode, "y", e)
         assert _per_channel_rel(y.float(), ref["y"], 2) < 3 * ty, (mode, "y per channel")
