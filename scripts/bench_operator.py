@@ -8,7 +8,7 @@ from hyena_dna_amd.hyena import HyenaOperator
 dev = torch.device("cuda", 0)
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-D = 256
+D = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4].isdigit() else 256
 torch.manual_seed(0)
 op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
                    lr=6e-4, wd=0.0, lr_pos_emb=0.0).to(dev)

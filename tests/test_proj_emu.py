@@ -218,6 +218,44 @@ def test_outproj_gate_fwd_vs_cm_post_and_gemm(emu_backend, outproj_gen, B, L, Lx
     assert ((out2.float() - want2).abs() <= eps * want2.abs() + 1e-3 * eps).all()
 
 
+@pytest.mark.parametrize("B,L,Lx,D,dtype", [(9, 65, 65, 128, torch.bfloat16), (5, 127, 131, 128, torch.float16), (8, 191, 191, 256, torch.bfloat16),
+                                            (3, 1023, 1023, 128, torch.bfloat16)])
+def test_outproj_rows_at_odd_offsets_in_aligned_pieces(emu_backend, outproj_gen, B, L, Lx, D, dtype):
+    """several odd-length sequences per channel row in the flattened layout of _lib.empty_cm (what the operator hands the kernel): rows start at every
+    offset (b L + l0) mod 8 elements from a 16-byte boundary -- first / last tile of a sequence, the pulled-back last tile: zT bit-identical to cm_post_fwd,
+    out to the product of that zT; and nothing outside the rows is written (the pitch elements behind a channel row keep their NaN fill).
+    (Round 6 tried reading / writing such rows in ALIGNED 16-byte pieces shifted in registers: slower, profiles/r6v_outproj_aligned_pieces_not_kept.txt.)"""
+    g = torch.Generator().manual_seed(B * 1000 + L + D)
+    y = torch.randn(B, D, L, generator=g).to(dtype)
+    xT = emu_backend.empty_cm(3 * D, B, Lx, dtype, torch.device("cpu"))
+    xT.copy_((torch.randn(3 * D, B, Lx, generator=g) * 0.5).to(dtype))
+    assert emu_backend.cm_strides(xT)[0] % 8 == 0 and Lx % 2 == 1
+    bin_ = torch.randn(3 * D, generator=g) * 0.1
+    w = torch.randn(3 * D, 3, generator=g) * 0.5
+    b = torch.randn(3 * D, generator=g) * 0.1
+    W = (torch.randn(D, D, generator=g) / D ** 0.5).to(dtype)
+    bias = (torch.randn(D, generator=g) * 0.1).to(dtype).float()
+    out, zT = emu_backend.outproj_gate_fwd(y, xT, bin_, w, b, W, bias, want_z=True)
+    z_ref = emu_backend.cm_post_fwd(y, xT, bin_, w, b)
+    assert torch.equal(zT, z_ref)
+    want = (z_ref.permute(1, 2, 0).float() @ W.float().t() + bias)
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert ((out.float() - want).abs() <= eps * want.abs() + 1e-3 * eps).all()
+    # a zT whose pitch elements are poisoned first: the partial pieces at a tile's two ends must not touch them
+    zbuf = emu_backend.empty_cm(D, B, L, dtype, torch.device("cpu"))
+    cs = emu_backend.cm_strides(zbuf)[0]
+    flat = torch.as_strided(zbuf, (D, cs), (cs, 1))
+    flat.fill_(float("nan"))
+    import ctypes  # noqa: F401  (the wrapper allocates its own zT; call the C entry point on ours)
+    lib = emu_backend.lib()
+    out2 = torch.empty(B, L, D, dtype=dtype)
+    csx, bsx = emu_backend.cm_strides(xT)
+    emu_backend.check(lib.hyena_outproj_gate_fwd_ld(y.data_ptr(), xT.data_ptr(), bin_.data_ptr(), w.data_ptr(), b.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                                    out2.data_ptr(), zbuf.data_ptr(), B, L, Lx, D, csx, bsx, cs, L, L, emu_backend.dtype_code(dtype), None))
+    assert torch.equal(zbuf, z_ref) and torch.equal(out2, out)
+    assert torch.isnan(flat[:, B * L:]).all()
+
+
 @pytest.mark.parametrize("L", [128, 136])
 def test_operator_with_and_without_the_fused_out_proj(emu_backend, outproj_gen, monkeypatch, L):
     """HyenaOperator (bf16 tensors) through HyenaMixerOutCMFunc vs the round-3 path (cm_post_fwd + library GEMM): output and every
