@@ -330,7 +330,7 @@ def _median(xs):
     return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
 
 
-def operator_layer(L, D, B, dtype, dev, steps=20, warmup=3, graph=False):
+def operator_layer(L, D, B, dtype, dev, steps=20, warmup=3, graph=False, order=2):
     """Secondary figure (not `value`): one whole HyenaOperator layer -- in_proj, short conv, gates, implicit filter, long
     conv, out_proj -- forward + backward under autocast, HyenaDNA configuration (hg38_hyena.yaml:20-30), random init.
     `ms_per_step` is the mean of `steps` steps, with the minimum and the median beside it (box noise is +- 4 %: VERDICT r4 item 4),
@@ -338,7 +338,7 @@ def operator_layer(L, D, B, dtype, dev, steps=20, warmup=3, graph=False):
     step is bound by Python issuing its ~60 launches, not by the GPU); falls back to eager calls if the capture fails."""
     from hyena_dna_amd.hyena import HyenaOperator
     torch.manual_seed(0)
-    op = HyenaOperator(d_model=D, l_max=L + 2, order=2, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
+    op = HyenaOperator(d_model=D, l_max=L + 2, order=order, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10,
                        lr=6e-4, wd=0.0, lr_pos_emb=0.0).to(dev)
     u = torch.randn(B, L, D, device=dev, dtype=dtype, requires_grad=True)
     dy = torch.randn(B, L, D, device=dev, dtype=dtype)
@@ -378,8 +378,12 @@ def operator_layer(L, D, B, dtype, dev, steps=20, warmup=3, graph=False):
     times = _timed_steps(run, steps, dev)
     ms = sum(times) / steps
     s = 4 if dtype == torch.float32 else 2
-    abytes = operator_algorithmic_bytes(B, D, L, s)
     best = min(times)
+    if order != 2:             # (no roofline model for the deeper recurrence: the leg reports times and the route taken)
+        return {"ms_per_step": ms, "min_ms": best, "median_ms": _median(times), "value": B * L / ms * 1e3, "unit": "nt/s", "steps": steps, "order": order,
+                "route": op._route(L), "workload": f"one HyenaOperator layer of order {order} (configs/model/layer/hyena_dna.yaml) fwd+bwd, L={L}, d={D}, B={B}, "
+                                                   f"{str(dtype).split('.')[-1]} autocast; secondary figure"}
+    abytes = operator_algorithmic_bytes(B, D, L, s)
     return {"ms_per_step": ms, "min_ms": best, "median_ms": _median(times), "value": B * L / ms * 1e3, "unit": "nt/s", "steps": steps,
             "hipgraph_replay": graphed,
             "roofline": {"bound": "hbm", "achieved": abytes / (best * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -919,6 +923,22 @@ def main():
                 line["operator_layer"] = operator_layer(L, D, B, dtype, dev)
             except Exception as e:                                   # secondary: never lose the contract line over it
                 line["operator_layer"] = {"error": repr(e)[:200]}
+            # order 3 (configs/model/layer/hyena_dna.yaml:3) on the same kernels (mixer.HyenaMixerCMOrderNFunc), next to the op-by-op route it replaces
+            try:
+                import hyena_dna_amd.hyena as _H
+                r3 = operator_layer(L, D, B, dtype, dev, steps=6, warmup=2, order=3)
+                saved = _H.ORDER_N_FUSED
+                _H.ORDER_N_FUSED = False
+                try:
+                    g3 = operator_layer(L, D, B, dtype, dev, steps=3, warmup=1, order=3)
+                finally:
+                    _H.ORDER_N_FUSED = saved
+                r3["generic_route"] = {k: g3[k] for k in ("ms_per_step", "min_ms", "median_ms", "route")}
+                r3["vs_generic_route"] = g3["min_ms"] / r3["min_ms"]
+                line["operator_layer_order3"] = r3
+                torch.cuda.empty_cache()
+            except Exception as e:
+                line["operator_layer_order3"] = {"error": repr(e)[:200]}
         line["model_step"] = model_res
         if world == 1 and not args.emu and not args.no_sweep and not args.fwd_only and L % 2 == 0:
             # the layer and the model at the length the reference's trainer feeds them for this max_length: L - 1
