@@ -182,13 +182,19 @@ class HyenaMixerCMOrderNFunc(torch.autograd.Function):
 
         v = _lib.cm_pre_fwd(*view(n - 1), L)
         ys = []
+        spectra = [None] * n
+        keep = want_grad and _lib.save_spectra_default(B, D, L, device=v.device)      # the forward's spectra for the backward, as HyenaMixerCMFunc keeps them
         for o in range(n):
-            y = _lib.fftconv_fwd(v, kfs[o], bf[o], grad=want_grad)
+            if keep:
+                y, spectra[o] = _lib.fftconv_fwd(v, kfs[o], bf[o], save=True)
+            else:
+                y = _lib.fftconv_fwd(v, kfs[o], bf[o], grad=want_grad)
             ys.append(y)
             if o + 1 < n:
                 v = _lib.cm_post_fwd(y, *view(n - o - 1), rows_out=True)
         zT = _lib.cm_post_fwd(ys[-1], *view(0))
         ctx.save_for_backward(xc, bi, w, b, bf, *kfs, *ys)
+        ctx.spectra = spectra
         ctx.meta = (b_in.dtype, sf_weight.shape, sf_weight.dtype, sf_bias.dtype, [k.dtype for k in ks], bias.shape, bias.dtype, L, order)
         return zT
 
@@ -209,6 +215,7 @@ class HyenaMixerCMOrderNFunc(torch.autograd.Function):
             return xc[s * D:(s + 3) * D], bi[s * D:(s + 3) * D], w[s * D:(s + 3) * D], b[s * D:(s + 3) * D]
 
         need_dk = ctx.needs_input_grad[4] or any(ctx.needs_input_grad[7:])
+        onchip = _lib.lib().hyena_fftconv_plan(int(L)) == _lib.PLAN_ONCHIP
         red = torch.empty(GD, 5, dtype=torch.float32, device=xc.device)
         # z = y_{n-1} * x_0
         part = _lib.cm_partials(view(0)[0], L)
@@ -216,12 +223,17 @@ class HyenaMixerCMOrderNFunc(torch.autograd.Function):
         red[0:D] = part[:D, :, :5].sum(dim=1)
         dks, dbs = [None] * n, [None] * n
         for o in range(n - 1, -1, -1):
-            # the input of convolution o, recomputed (one elementwise pass) instead of kept
-            if o == 0:
+            # the input of convolution o, recomputed (one elementwise pass) instead of kept -- unless the saved spectra hold its transform (two-level plan)
+            sp = ctx.spectra[o]
+            ctx.spectra[o] = None
+            if sp is not None and not onchip:
+                v = None
+            elif o == 0:
                 v = _lib.cm_pre_fwd(*view(n - 1), L)
             else:
                 v = _lib.cm_post_fwd(ys[o - 1], *view(n - o), rows_out=True)
-            dv, dks[o], dbs[o] = _lib.fftconv_bwd(dy, v, kfs[o], bf[o], need_du=True, need_dk=need_dk, saved=None)
+            dv, dks[o], dbs[o] = _lib.fftconv_bwd(dy, v, kfs[o], bf[o], need_du=True, need_dk=need_dk, saved=sp)
+            del sp
             s = n - o if o > 0 else n - 1
             part = _lib.cm_partials(view(s)[0], L)
             if o > 0:                                                 # v = y_{o-1} * x_{n-o}: group 0 of the view at n - o
