@@ -156,3 +156,30 @@ def test_filter_split_runs_one_launch_chain_per_convolution(emu_backend):
     for name, p in ff.named_parameters():
         if p.grad is not None:
             assert _rel(got[name], p.grad) < 2e-4, (name, _rel(got[name], p.grad))
+
+
+def test_lm_with_order_3_mixers_both_routes_agree(emu_backend, monkeypatch):
+    """HyenaDNALM built from the shipped layer config's ``order: 3`` (configs/model/layer/hyena_dna.yaml): the model's loss and every gradient are the
+    same whether its mixers take the channel-major route or the op-by-op route -- and batches of several odd-length sequences are still padded to 64"""
+    import hyena_dna_amd.hyena as H
+    import hyena_dna_amd.lm as LM
+    L, D = 71, 64
+    layer = dict(l_max=130, order=3, filter_order=64, emb_dim=5, short_filter_order=3, modulate=True, w=10)
+    torch.manual_seed(0)
+    m = LM.HyenaDNALM(d_model=D, n_layer=2, d_inner=4 * D, vocab_size=12, layer=layer, resid_dropout=0.0, embed_dropout=0.0,
+                      pad_vocab_size_multiple=8, fused_dropout_add_ln=True, residual_in_fp32=True)
+    ids = torch.randint(7, 11, (3, L))
+    tgt = torch.roll(ids, -1, 1)
+    assert m._aligned_length(ids) == 128
+    params = [p for p in m.parameters() if p.requires_grad]
+    res = {}
+    for route in ("order_n", "generic"):
+        monkeypatch.setattr(H, "ORDER_N_FUSED", route == "order_n")
+        assert all(blk.mixer._route(128) == route for blk in m.backbone.layers)
+        loss = m.loss(ids, tgt)
+        res[route] = (loss.item(), torch.autograd.grad(loss, params, allow_unused=True))
+    assert abs(res["order_n"][0] - res["generic"][0]) < 2e-6
+    for a, b in zip(res["order_n"][1], res["generic"][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert _rel(a, b) < 2e-4
