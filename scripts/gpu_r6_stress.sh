@@ -9,3 +9,4 @@ timeout 260 python scripts/gpu_stress_operator.py 170 21 2>&1 | tail -3 | tee $O
 HYENA_INPROJ_KERNEL=2 HYENA_OUTPROJ_DGRAD_MFMA=1 timeout 200 python scripts/gpu_stress_operator.py 110 22 2>&1 | tail -3 | tee $OUT/stress_operator_gen2.txt
 HYENA_OUTPROJ_KERNEL=1 timeout 160 python scripts/gpu_stress_operator.py 80 23 2>&1 | tail -3 | tee $OUT/stress_operator_outproj_gen1.txt
 timeout 200 python scripts/gpu_stress_filter16.py 110 2>&1 | tail -3 | tee $OUT/stress_filter16.txt
+STRESS_ORDERS=3,4,3,5 timeout 260 python scripts/gpu_stress_operator.py 170 24 2>&1 | tail -3 | tee $OUT/stress_operator_orders.txt

@@ -1,7 +1,8 @@
 """Randomised stress of the fused operator path on the GPU: HyenaOperator forward + backward (fused shell, fused filter, HIP long
 convolution; channel-major or position-major per HYENA_MIXER_LAYOUT) against the SAME module forced onto its generic PyTorch-op path,
 fp32 (tight tolerance), each fused result computed twice and required to be bitwise identical.
-python scripts/gpu_stress_operator.py [seconds] [seed]"""
+python scripts/gpu_stress_operator.py [seconds] [seed]      STRESS_ORDERS=2,3,4: the operator's order is drawn from that list (default 2;
+orders above 2 take mixer.HyenaMixerCMOrderNFunc)"""
 import os
 import sys
 import time
@@ -17,6 +18,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda", 0)
 rng = torch.Generator().manual_seed(seed)
 fused_ok = HyenaOperator._fused_ok
+orders = [int(x) for x in os.environ.get("STRESS_ORDERS", "2").split(",")]
 
 
 def ri(lo, hi):
@@ -25,6 +27,8 @@ def ri(lo, hi):
 
 def run(op, u, dy, fused, autocast):
     HyenaOperator._fused_ok = fused_ok if fused else (lambda self: False)
+    hyena.ORDER_N_FUSED = fused
+    assert op._route(u.shape[1]) == (("fused" if op.order == 2 else "order_n") if fused else "generic")
     op.zero_grad(set_to_none=True)
     x = u.clone().requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
@@ -32,6 +36,7 @@ def run(op, u, dy, fused, autocast):
     y.backward(dy.to(y.dtype))
     torch.cuda.synchronize()
     HyenaOperator._fused_ok = fused_ok
+    hyena.ORDER_N_FUSED = True
     return [y.detach(), x.grad] + [p.grad for p in op.parameters()]
 
 
@@ -50,14 +55,15 @@ while time.time() - t0 < budget:
     if autocast and n % 2 == 0:
         L = max(64, L // 64 * 64)      # multiples of 64 as well as ragged lengths through the fused out_proj kernel (csrc/proj_kernels.h; any L >= 64)
     torch.manual_seed(1000 * seed + n)
-    op = HyenaOperator(d_model=D, l_max=L + ri(0, 3), order=2, filter_order=64, emb_dim=[3, 5][ri(0, 1)], short_filter_order=3,
+    order = orders[ri(0, len(orders) - 1)]
+    op = HyenaOperator(d_model=D, l_max=L + ri(0, 3), order=order, filter_order=64, emb_dim=[3, 5][ri(0, 1)], short_filter_order=3,
                        modulate=True, w=10).to(dev)
     names = [nm for nm, _ in op.named_parameters()]
     u = torch.randn(B, L, D, device=dev)
     dy = torch.randn(B, L, D, device=dev)
     a = run(op, u, dy, True, autocast)
     b = run(op, u, dy, True, autocast)
-    tag = dict(case=n, B=B, L=L, D=D, autocast=autocast, layout="channel" if hyena.CHANNEL_MAJOR else "position")
+    tag = dict(case=n, B=B, L=L, D=D, order=order, autocast=autocast, layout="channel" if hyena.CHANNEL_MAJOR else "position")
     for i, (x, y) in enumerate(zip(a, b)):
         assert (x is None and y is None) or torch.equal(x, y), ("NON-DETERMINISTIC", (["y", "du"] + names)[i], tag)
     if not autocast:
@@ -79,7 +85,7 @@ while time.time() - t0 < budget:
             if x is None:
                 continue
             e = rel(x.float(), y.float())
-            assert e < 8e-2, ((["y", "du"] + names)[i], e, tag)
+            assert e < (8e-2 if order == 2 else 2.5e-1), ((["y", "du"] + names)[i], e, tag)
             worst16 = max(worst16, e)
     n += 1
 print(f"{n} operator cases in {time.time() - t0:.0f} s ({'channel' if hyena.CHANNEL_MAJOR else 'position'}-major shell): bitwise deterministic; "
