@@ -82,6 +82,8 @@ FUSED_MLP = os.environ.get("HYENA_FUSED_MLP", "1") != "0"          # A/B knob: 0
 # HyenaDNALM pads batches of several odd-length sequences to a multiple of 64 positions (HyenaDNALM._aligned_length); 0 = run them as they come
 PAD_SEQUENCES = os.environ.get("HYENA_LM_PAD_SEQUENCES", "1") != "0"
 _SEQ_ALIGN = 64
+_PAD_SINGLE_MIN = int(os.environ.get("HYENA_LM_PAD_SINGLE_MIN", "8192"))      # a single sequence is padded from this length on (_aligned_length) ...
+_PAD_SINGLE_ROWS = 4096                                                        # ... if the padded length is a multiple of this (64 weight-gradient slices of 64-aligned rows)
 
 
 def _mlp_dtype(x, weight):
@@ -494,9 +496,15 @@ class HyenaDNALM(nn.Module, GenerationMixin):
         are dropped before anybody sees them, so they receive zero gradients and contribute nothing to any weight gradient.  What it buys: inside a
         channel row of the flattened (C, B L) layout the rows of odd-length sequences start 2 bytes off every 4 / 16-byte boundary -- one layer at
         32767 x 8 ran 11 % slower than at 32768 x 8, the step at 1023 x 256 x 128 6 % slower (profiles/r6a_bench_default.json).  Only when every
-        layer's l_max admits the padded length (hg38 configurations: l_max = max_length + 2), B > 1, and the fused kernels are in use."""
+        layer's l_max admits the padded length (hg38 configurations: l_max = max_length + 2) and the fused kernels are in use."""
         B, L = input_ids.shape
-        if not PAD_SEQUENCES or B <= 1 or L % _SEQ_ALIGN == 0 or L < _SEQ_ALIGN:
+        # ONE odd-length sequence: its rows are aligned (pitched), what is left are the library weight-gradient products over an odd number of
+        # positions (2^20 - 1: dW1 712 vs 612 us, dW_in 611 vs 571, dW_out 303 vs 260 per layer: profiles/r6_wgrad_plan.txt).  Padded where that
+        # turns them into the aligned one-level plan -- the padded length a multiple of 4096 (2^20 - 1, 32767: model step 157.5 -> 156.3 ms at
+        # 2^20 - 1); at 999 999 / 449 999 the padded count still needs the two-level plan and padding bought nothing (profiles/r6aa_*)
+        if not PAD_SEQUENCES or L % _SEQ_ALIGN == 0 or L < _SEQ_ALIGN:
+            return L
+        if B <= 1 and (L < _PAD_SINGLE_MIN or (L + (-L) % _SEQ_ALIGN) % _PAD_SINGLE_ROWS != 0):
             return L
         from . import _lib
         if not (input_ids.is_cuda or _lib._backend.name != "hip"):

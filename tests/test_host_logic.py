@@ -200,7 +200,9 @@ def test_split_k_linear_gradients_match_linear():
     from hyena_dna_amd.projection import split_plan
     assert split_plan(1 << 20) == ([(0, 64, 16384)], 1 << 20)                                   # divisible: one level, as before
     assert split_plan(1 << 20, 256 * 256) == ([(0, 256, 4096)], 1 << 20) and split_count(32768, 256 * 256) == 8     # a one-tile gradient: more slices
-    for rows in (1048575, 999999, 449999, 2 * 159999, 8 * 32767, 32767, 70001):
+    # round 6: equal slices of an ODD number of rows (10^6 = 64 x 15625) are the slow case themselves: cut like a count the slice count does not divide
+    assert split_plan(1000000) == ([(0, 64, 15616), (999424, 2, 256)], 999936) and split_plan(64 * 4092) == ([(0, 64, 4092)], 64 * 4092)
+    for rows in (1048575, 999999, 449999, 2 * 159999, 8 * 32767, 32767, 70001, 1000000):
         levels, done = split_plan(rows)
         pos = 0
         for p0, s_, q in levels:

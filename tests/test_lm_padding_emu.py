@@ -14,13 +14,15 @@ def _model(L, d=64, n_layer=2, seed=0):
                          pad_vocab_size_multiple=8, fused_dropout_add_ln=True, residual_in_fp32=True)
 
 
-@pytest.mark.parametrize("B,L", [(3, 127), (2, 191)])
+@pytest.mark.parametrize("B,L", [(3, 127), (2, 191), (1, 189)])
 def test_padded_batch_equals_unpadded_batch(emu_backend, monkeypatch, B, L):
     model = _model(L)
     g = torch.Generator().manual_seed(L)
     ids = torch.randint(7, 11, (B, L), generator=g)
     tgt = torch.roll(ids, -1, 1)
     res = {}
+    monkeypatch.setattr(LM, "_PAD_SINGLE_MIN", 100)             # (B = 1: a single sequence counts as long from here on)
+    monkeypatch.setattr(LM, "_PAD_SINGLE_ROWS", 64)
     for pad in (True, False):
         monkeypatch.setattr(LM, "PAD_SEQUENCES", pad)
         assert model._aligned_length(ids) == (L + (-L) % 64 if pad else L)
@@ -42,7 +44,15 @@ def test_padding_only_where_it_applies(emu_backend, monkeypatch):
     monkeypatch.setattr(LM, "PAD_SEQUENCES", True)
     model = _model(127)                                                   # l_max = 130 admits 128
     assert model._aligned_length(torch.zeros(2, 127, dtype=torch.long)) == 128
-    assert model._aligned_length(torch.zeros(1, 127, dtype=torch.long)) == 127        # one sequence: the flattened layout is aligned anyway
+    assert model._aligned_length(torch.zeros(1, 127, dtype=torch.long)) == 127        # one short sequence: its rows are aligned anyway
+    monkeypatch.setattr(LM, "_PAD_SINGLE_MIN", 100)                                   # (one LONG sequence is padded: the odd weight-gradient products ...
+    monkeypatch.setattr(LM, "_PAD_SINGLE_ROWS", 128)                                  #  ... where the padded length is a multiple of the slice grid)
+    assert model._aligned_length(torch.zeros(1, 127, dtype=torch.long)) == 128
+    monkeypatch.setattr(LM, "_PAD_SINGLE_ROWS", 4096)
+    assert model._aligned_length(torch.zeros(1, 127, dtype=torch.long)) == 127
+    monkeypatch.setattr(LM, "_PAD_SINGLE_MIN", 8192)
+    big = _model(32767, d=64, n_layer=1)
+    assert big._aligned_length(torch.zeros(1, 32767, dtype=torch.long)) == 32768 and big._aligned_length(torch.zeros(1, 32700, dtype=torch.long)) == 32700
     assert model._aligned_length(torch.zeros(4, 128, dtype=torch.long)) == 128
     assert model._aligned_length(torch.zeros(4, 33, dtype=torch.long)) == 33          # shorter than one 64-position tile
     tight = _model(124)                                                   # l_max = 127 < 128: the operator would truncate -> not padded
