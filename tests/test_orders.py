@@ -183,3 +183,15 @@ def test_lm_with_order_3_mixers_both_routes_agree(emu_backend, monkeypatch):
         assert (a is None) == (b is None)
         if a is not None:
             assert _rel(a, b) < 2e-4
+
+
+def test_order_n_route_empty_batch(emu_backend):
+    """B = 0 through the channel-major route: an empty result that is still connected to every parameter (zero gradients, not None) -- as the reference's ops give"""
+    import hyena_dna_amd.hyena as H
+    op = H.HyenaOperator(d_model=8, l_max=66, order=3, filter_order=16, emb_dim=3, short_filter_order=3, modulate=True, w=10)
+    u = torch.zeros(0, 64, 8, requires_grad=True)
+    assert op._route(64) == "order_n"
+    y = op(u)
+    assert y.shape == (0, 64, 8)
+    y.sum().backward()
+    assert all(p.grad is None or torch.count_nonzero(p.grad) == 0 for p in op.parameters())
