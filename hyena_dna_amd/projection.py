@@ -81,17 +81,51 @@ def _tail_product(a_cn, b_nk, done):
     return _bmm_f32(a.unsqueeze(0), b_nk[n - TAIL_SLICE:].unsqueeze(0))[0]
 
 
+# What split_plan leaves behind its first level -- the 256-row second level and the tail, up to ~4160 rows -- as ONE batched product over zero-padded
+# copies (round 6: the two small products, their partial sums and additions cost a big weight gradient 65 - 100 us at 2^20 - 1 rows against ~45 this way,
+# profiles/r6_wgrad_plan.txt).  HYENA_WGRAD_LEFTOVER=split: the separate second level + masked tail of round 5 (A/B).
+MERGE_LEFTOVER = os.environ.get("HYENA_WGRAD_LEFTOVER", "merged") != "split"
+
+
+def _leftover_product(a_cn, b_nk, start):
+    """sum over the positions p >= start of a_cn[:, p] b_nk[p, :] in fp32, for views a_cn (C, n), b_nk (n, K) of any strides: the positions copied into
+    zero-padded 16-bit scratch operands of a whole number of 256-row slices, one batched product, the slices' sums added in order"""
+    n = a_cn.shape[1]
+    r = n - start
+    if r <= 0:
+        return None
+    if not (a_cn.is_cuda or _MASKED_TAIL_ON_HOST) or a_cn.dtype == torch.float32:
+        return torch.mm(a_cn[:, start:].float(), b_nk[start:].float())
+    s2 = (r + TAIL_SLICE - 1) // TAIL_SLICE
+    w = s2 * TAIL_SLICE
+    A = torch.empty((a_cn.shape[0], w), dtype=a_cn.dtype, device=a_cn.device)
+    Bm = torch.empty((w, b_nk.shape[1]), dtype=b_nk.dtype, device=b_nk.device)
+    A[:, :r] = a_cn[:, start:]
+    Bm[:r] = b_nk[start:]
+    if r < w:
+        A[:, r:].zero_()
+        Bm[r:].zero_()
+    return _bmm_f32(A.view(a_cn.shape[0], s2, TAIL_SLICE).permute(1, 0, 2), Bm.view(s2, TAIL_SLICE, b_nk.shape[1])).sum(0)
+
+
+def _use_merged(t):
+    return MERGE_LEFTOVER and (t.is_cuda or _MASKED_TAIL_ON_HOST)
+
+
 def split_k_weight_grad(dy2, x2):
-    """dy2^T x2 (fp32) as batched position slices (split_plan) + a tail, partial sums added in a fixed order (deterministic)."""
+    """dy2^T x2 (fp32) as batched position slices (split_plan) + the leftover rows, partial sums added in a fixed order (deterministic)."""
     rows, n = dy2.shape
     k = x2.shape[1]
     levels, done = split_plan(rows, n * k)
+    if _use_merged(dy2):
+        levels = levels[:1]
+        done = levels[0][0] + levels[0][1] * levels[0][2]
     dw = None
     for p0, s, q in levels:
         g = _bmm_f32(dy2[p0:p0 + s * q].view(s, q, n).transpose(1, 2), x2[p0:p0 + s * q].view(s, q, k)).sum(0)
         dw = g if dw is None else dw + g
     if done < rows:                                                 # the leftover rows
-        dw = dw + _tail_product(dy2.t(), x2, done)
+        dw = dw + (_leftover_product(dy2.t(), x2, done) if _use_merged(dy2) else _tail_product(dy2.t(), x2, done))
     return dw
 
 
@@ -199,11 +233,14 @@ def wgrad_cm_pm(d, x2):
     for m, p0, n in _pieces(d, L):
         xs = x2[p0:p0 + n]
         levels, done = split_plan(n, C * k)
+        if _use_merged(d):
+            levels = levels[:1]
+            done = levels[0][0] + levels[0][1] * levels[0][2]
         for r0, s, q in levels:
             g = _bmm_f32(m[:, r0:r0 + s * q].reshape(C, s, q).permute(1, 0, 2), xs[r0:r0 + s * q].view(s, q, k)).sum(0)
             total = g if total is None else total + g
         if done < n:
-            total = total + _tail_product(m, xs, done)
+            total = total + (_leftover_product(m, xs, done) if _use_merged(d) else _tail_product(m, xs, done))
     return total
 
 
@@ -215,11 +252,14 @@ def wgrad_pm_cm(dy2, z):
     for m, p0, n in _pieces(z, L):
         ds = dy2[p0:p0 + n]
         levels, done = split_plan(n, N * K)
+        if _use_merged(z):
+            levels = levels[:1]
+            done = levels[0][0] + levels[0][1] * levels[0][2]
         for r0, s, q in levels:
             g = _bmm_f32(ds[r0:r0 + s * q].view(s, q, N).transpose(1, 2), m[:, r0:r0 + s * q].reshape(K, s, q).permute(1, 2, 0)).sum(0)
             total = g if total is None else total + g
         if done < n:
-            total = total + _tail_product(ds.t(), m.t(), done)
+            total = total + (_leftover_product(ds.t(), m.t(), done) if _use_merged(z) else _tail_product(ds.t(), m.t(), done))
     return total
 
 

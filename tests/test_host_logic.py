@@ -190,6 +190,41 @@ def test_tail_product_masked_slice_branch_on_host(monkeypatch):
     assert ((got - ref).norm() / ref.norm()).item() < 1e-6
 
 
+def test_leftover_rows_as_one_padded_batched_product(monkeypatch):
+    """projection._leftover_product (round 6): what split_plan leaves behind its first level -- second level + tail -- copied into zero-padded scratch
+    operands and multiplied as ONE batch of 256-row slices; through the three weight-gradient callers and their operand layouts, against the float64
+    products, and equal to the split form of round 5 to fp32 rounding"""
+    import hyena_dna_amd.projection as P
+    from hyena_dna_amd import _lib
+    monkeypatch.setattr(P, "_MASKED_TAIL_ON_HOST", True)
+    g = torch.Generator().manual_seed(11)
+    for B, L in ((1, 70001), (8, 4097), (3, 12001)):
+        rows = B * L
+        C, K, N = 24, 16, 8
+        d = _lib.empty_cm(C, B, L, torch.bfloat16, torch.device("cpu"))
+        d.copy_(torch.randn(C, B, L, generator=g).to(torch.bfloat16))
+        z = _lib.empty_cm(K, B, L, torch.bfloat16, torch.device("cpu"))
+        z.copy_(torch.randn(K, B, L, generator=g).to(torch.bfloat16))
+        x2 = torch.randn(rows, K, generator=g).to(torch.bfloat16)
+        dy2 = torch.randn(rows, N, generator=g).to(torch.bfloat16)
+        assert P.split_plan(rows, C * K)[0][0][1] * P.split_plan(rows, C * K)[0][0][2] < rows          # (there IS a leftover)
+        want = {"cm_pm": d.reshape(C, rows).double() @ x2.double(), "pm_cm": dy2.t().double() @ z.reshape(K, rows).t().double(),
+                "pm_pm": dy2.t().double() @ x2.double()}
+        res = {}
+        for merged in (True, False):
+            monkeypatch.setattr(P, "MERGE_LEFTOVER", merged)
+            res[merged] = {"cm_pm": P.wgrad_cm_pm(d, x2), "pm_cm": P.wgrad_pm_cm(dy2, z), "pm_pm": P.split_k_weight_grad(dy2, x2)}
+        for name, ref in want.items():
+            for merged in (True, False):
+                got = res[merged][name]
+                assert got.dtype == torch.float32 and ((got.double() - ref).norm() / ref.norm()).item() < 1e-6, (name, merged, B, L)
+            assert torch.allclose(res[True][name], res[False][name], rtol=1e-5, atol=1e-3)
+    # fp32 operands: a plain product of the leftover rows
+    a = torch.randn(24, 5000, generator=g)
+    b = torch.randn(5000, 16, generator=g)
+    assert torch.allclose(P._leftover_product(a, b, 4608), a[:, 4608:] @ b[4608:], rtol=1e-5, atol=1e-5) and P._leftover_product(a, b, 5000) is None
+
+
 def test_split_k_linear_gradients_match_linear():
     """hyena_dna_amd/projection.py: the slice-batched weight gradient equals autograd's dy^T x (hyena.py:391,440)"""
     from hyena_dna_amd.projection import SplitKLinearFunc, split_count
