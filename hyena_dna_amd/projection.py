@@ -88,28 +88,32 @@ MERGE_LEFTOVER = os.environ.get("HYENA_WGRAD_LEFTOVER", "merged") != "split"
 
 
 def _leftover_product(a_cn, b_nk, start):
-    """sum over the positions p >= start of a_cn[:, p] b_nk[p, :] in fp32, for views a_cn (C, n), b_nk (n, K) of any strides: the positions copied into
-    zero-padded 16-bit scratch operands of a whole number of 256-row slices, one batched product, the slices' sums added in order"""
+    """sum over the positions p >= start of a_cn[:, p] b_nk[p, :] in fp32, for views a_cn (C, n), b_nk (n, K) of any strides: the LAST w positions, w the
+    leftover rounded up to whole 256-row slices, as one batched product -- a_cn's slice copied with its already-counted leading columns zeroed (what
+    _tail_product does for one slice), b_nk's taken as it lies (its leading rows meet zeros); the slices' sums added in order"""
     n = a_cn.shape[1]
     r = n - start
     if r <= 0:
         return None
-    if not (a_cn.is_cuda or _MASKED_TAIL_ON_HOST) or a_cn.dtype == torch.float32:
-        return torch.mm(a_cn[:, start:].float(), b_nk[start:].float())
     s2 = (r + TAIL_SLICE - 1) // TAIL_SLICE
     w = s2 * TAIL_SLICE
-    A = torch.empty((a_cn.shape[0], w), dtype=a_cn.dtype, device=a_cn.device)
-    Bm = torch.empty((w, b_nk.shape[1]), dtype=b_nk.dtype, device=b_nk.device)
-    A[:, :r] = a_cn[:, start:]
-    Bm[:r] = b_nk[start:]
-    if r < w:
-        A[:, r:].zero_()
-        Bm[r:].zero_()
-    return _bmm_f32(A.view(a_cn.shape[0], s2, TAIL_SLICE).permute(1, 0, 2), Bm.view(s2, TAIL_SLICE, b_nk.shape[1])).sum(0)
+    if not (a_cn.is_cuda or _MASKED_TAIL_ON_HOST) or a_cn.dtype == torch.float32 or n < w:
+        return torch.mm(a_cn[:, start:].float(), b_nk[start:].float())
+    A = a_cn[:, n - w:].clone(memory_format=torch.contiguous_format)
+    if w > r:
+        A[:, :w - r].zero_()
+    Bv = b_nk[n - w:]
+    return _bmm_f32(A.view(a_cn.shape[0], s2, TAIL_SLICE).permute(1, 0, 2), Bv.reshape(s2, TAIL_SLICE, b_nk.shape[1])).sum(0)
 
 
-def _use_merged(t):
-    return MERGE_LEFTOVER and (t.is_cuda or _MASKED_TAIL_ON_HOST)
+MERGE_MAX_ROWS = 4352          # a 256 x 256 gradient is cut into 256 first-level slices and leaves up to 16383 rows: copying those costs more than the
+                               # second product saves (dW_out at 2^20 - 1: 303 -> 333 us merged) -- such leftovers keep round 5's view-based second level
+
+
+def _use_merged(t, levels=None, rows=0):
+    if not (MERGE_LEFTOVER and (t.is_cuda or _MASKED_TAIL_ON_HOST)):
+        return False
+    return levels is None or rows - (levels[0][0] + levels[0][1] * levels[0][2]) <= MERGE_MAX_ROWS
 
 
 def split_k_weight_grad(dy2, x2):
@@ -117,7 +121,8 @@ def split_k_weight_grad(dy2, x2):
     rows, n = dy2.shape
     k = x2.shape[1]
     levels, done = split_plan(rows, n * k)
-    if _use_merged(dy2):
+    merged = _use_merged(dy2, levels, rows)
+    if merged:
         levels = levels[:1]
         done = levels[0][0] + levels[0][1] * levels[0][2]
     dw = None
@@ -125,7 +130,7 @@ def split_k_weight_grad(dy2, x2):
         g = _bmm_f32(dy2[p0:p0 + s * q].view(s, q, n).transpose(1, 2), x2[p0:p0 + s * q].view(s, q, k)).sum(0)
         dw = g if dw is None else dw + g
     if done < rows:                                                 # the leftover rows
-        dw = dw + (_leftover_product(dy2.t(), x2, done) if _use_merged(dy2) else _tail_product(dy2.t(), x2, done))
+        dw = dw + (_leftover_product(dy2.t(), x2, done) if merged else _tail_product(dy2.t(), x2, done))
     return dw
 
 
@@ -233,14 +238,15 @@ def wgrad_cm_pm(d, x2):
     for m, p0, n in _pieces(d, L):
         xs = x2[p0:p0 + n]
         levels, done = split_plan(n, C * k)
-        if _use_merged(d):
+        merged = _use_merged(d, levels, n)
+        if merged:
             levels = levels[:1]
             done = levels[0][0] + levels[0][1] * levels[0][2]
         for r0, s, q in levels:
             g = _bmm_f32(m[:, r0:r0 + s * q].reshape(C, s, q).permute(1, 0, 2), xs[r0:r0 + s * q].view(s, q, k)).sum(0)
             total = g if total is None else total + g
         if done < n:
-            total = total + (_leftover_product(m, xs, done) if _use_merged(d) else _tail_product(m, xs, done))
+            total = total + (_leftover_product(m, xs, done) if merged else _tail_product(m, xs, done))
     return total
 
 
@@ -252,14 +258,15 @@ def wgrad_pm_cm(dy2, z):
     for m, p0, n in _pieces(z, L):
         ds = dy2[p0:p0 + n]
         levels, done = split_plan(n, N * K)
-        if _use_merged(z):
+        merged = _use_merged(z, levels, n)
+        if merged:
             levels = levels[:1]
             done = levels[0][0] + levels[0][1] * levels[0][2]
         for r0, s, q in levels:
             g = _bmm_f32(ds[r0:r0 + s * q].view(s, q, N).transpose(1, 2), m[:, r0:r0 + s * q].reshape(K, s, q).permute(1, 2, 0)).sum(0)
             total = g if total is None else total + g
         if done < n:
-            total = total + (_leftover_product(ds.t(), m.t(), done) if _use_merged(z) else _tail_product(ds.t(), m.t(), done))
+            total = total + (_leftover_product(ds.t(), m.t(), done) if merged else _tail_product(ds.t(), m.t(), done))
     return total
 
 
