@@ -262,6 +262,9 @@ def lib():
         L.hyena_dropout_add_norm_bwd.restype = c_int
         L.hyena_dropout_add_norm_bwd.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]
+        L.hyena_dropout_add_norm_bwd_colsum.restype = c_int
+        L.hyena_dropout_add_norm_bwd_colsum.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]
         L.hyena_embed_add_norm_supported.restype = c_int
         L.hyena_embed_add_norm_supported.argtypes = [c_int, c_int, c_int]
         L.hyena_embed_add_norm_fwd.restype = c_int
@@ -831,6 +834,10 @@ def colsum(x2):
     """x2 (P, N) 16-bit contiguous -> (N,) fp32 = x2.sum(0) (the bias gradient of a linear layer) in one pass at the memory rate;
     falls back to torch's reduction for shapes the kernel does not serve (and for host tensors outside the test double)."""
     P, N = x2.shape
+    from . import _gradsum
+    got = _gradsum.take(x2)              # the tensor's producer (add_norm_bwd) may have summed its columns already
+    if got is not None:
+        return got
     code = _DTYPES.get(x2.dtype)
     if code is None or not (x2.is_cuda or _backend.name != "hip") or not x2.is_contiguous() or not lib().hyena_colsum_supported(P, N, code):
         return x2.sum(0, dtype=torch.float32)
@@ -1014,8 +1021,10 @@ def embed_add_norm_bwd(dout, d_res_out, res_out, ids, V, weight, mean, rstd, dro
     return dt, dw, db
 
 
-def add_norm_bwd(dout, d_res_out, res_out, weight, mean, rstd, dx_dtype, need_dres, dropout_p=0.0, seed=None):
-    """-> dx0 (rows, D) dx_dtype, d_residual_in fp32 or None, dweight (D,), dbias (D,).  (``dropout_p``, ``seed``): the forward's."""
+def add_norm_bwd(dout, d_res_out, res_out, weight, mean, rstd, dx_dtype, need_dres, dropout_p=0.0, seed=None, offer_colsum=True):
+    """-> dx0 (rows, D) dx_dtype, d_residual_in fp32 or None, dweight (D,), dbias (D,).  (``dropout_p``, ``seed``): the forward's.
+    offer_colsum (16-bit dx0): the kernel also sums dx0's columns -- the bias gradient of the linear layer in front of this norm -- and leaves them
+    in the side table of ``_gradsum`` for that layer's backward (``colsum`` below asks there first)."""
     _require_gpu(dout, "dout")
     rows, D = dout.shape
     dev = dout.device
@@ -1026,10 +1035,15 @@ def add_norm_bwd(dout, d_res_out, res_out, weight, mean, rstd, dx_dtype, need_dr
     dw = torch.empty(D, dtype=torch.float32, device=dev)          # (written in full by the fixed-order reduction: no zero fill -- 32 launches per model step)
     db = torch.empty(D, dtype=torch.float32, device=dev)
     part = torch.empty(lib().hyena_add_norm_partial_floats(rows, D), dtype=torch.float32, device=dev)
+    from . import _gradsum
+    want = offer_colsum and _gradsum.ENABLED and dx_dtype in (torch.bfloat16, torch.float16)
+    cs = torch.empty(D, dtype=torch.float32, device=dev) if want else None
     with _backend.guard(dev):
-        check(lib().hyena_dropout_add_norm_bwd(dout.data_ptr(), dtype_code(dout.dtype), None if d_res_out is None else d_res_out.data_ptr(),
-                                               res_out.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), float(dropout_p),
-                                               seed.data_ptr() if dropout_p > 0.0 else None, dx.data_ptr(), dtype_code(dx_dtype),
-                                               None if dres is None else dres.data_ptr(), dw.data_ptr(), db.data_ptr(), part.data_ptr(),
-                                               rows, D, _backend.stream(dev)))
+        check(lib().hyena_dropout_add_norm_bwd_colsum(dout.data_ptr(), dtype_code(dout.dtype), None if d_res_out is None else d_res_out.data_ptr(),
+                                                      res_out.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), float(dropout_p),
+                                                      seed.data_ptr() if dropout_p > 0.0 else None, dx.data_ptr(), dtype_code(dx_dtype),
+                                                      None if dres is None else dres.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                      None if cs is None else cs.data_ptr(), part.data_ptr(), rows, D, _backend.stream(dev)))
+    if want:
+        _gradsum.offer(dx, cs)
     return dx, dres, dw, db

@@ -32,7 +32,9 @@ struct AddNormArgs {
     const float* saved;     // bwd: residual' as written by the forward
     float* mean;            // (rows,)  fwd: out, bwd: in
     float* rstd;            // (rows,)
-    float* part;            // bwd: [gridDim.x][2][D] partial (dweight | dbias)
+    float* part;            // bwd: [gridDim.x][np][D] partial (dweight | dbias [| column sums of the dx0 values as stored])
+    int np = 2;             // bwd: 2, or 3: also the column sums of dx0 -- the bias gradient of the linear layer that produced x0 (out_proj, fc2:
+                            // round 6; their own streaming pass over dx0 cost 94 us each at 2^20 x 256)
     long rows;
     int D;
     float eps;
@@ -147,12 +149,13 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_fwd_kernel(AddNormArgs a
 template <int GDT, int ODT, int E, bool EMB = false>
 __global__ void __launch_bounds__(BLK_THREADS) add_norm_bwd_kernel(AddNormArgs a) {
     HY_SMEM(smem);
-    HY_LDS float* red = HY_LDS_CAST(float, smem);            // [BLK_WAVES][2][64 * E]  (EMB: also [BLK_VMAX][64 * E], whichever is larger)
+    HY_LDS float* red = HY_LDS_CAST(float, smem);            // [BLK_WAVES][np][64 * E]  (EMB: also [BLK_VMAX][64 * E], whichever is larger)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = lane * E;
-    float w[E], dw[E], db[E];
+    float w[E], dw[E], db[E], dxs[E];
     HY_UNROLL
-    for (int e = 0; e < E; ++e) { w[e] = a.weight[c0 + e]; dw[e] = 0.f; db[e] = 0.f; }
+    for (int e = 0; e < E; ++e) { w[e] = a.weight[c0 + e]; dw[e] = 0.f; db[e] = 0.f; dxs[e] = 0.f; }
+    const int np = EMB ? 2 : a.np;
     float eacc[EMB ? BLK_VMAX : 1][E];                       // EMB: this wavefront's sums of d x0 per token class (its rows, in order)
     HY_UNROLL
     for (int q = 0; q < (EMB ? BLK_VMAX : 1); ++q) {
@@ -202,6 +205,10 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_bwd_kernel(AddNormArgs a
             }
         } else {
             blk_store<ODT, E>(a.out, off, dr);
+            if (np == 3) {                                   // (the values as stored: what a column sum over the dx0 tensor would read)
+                HY_UNROLL
+                for (int e = 0; e < E; ++e) dxs[e] += Elem<ODT>::dec(Elem<ODT>::cvt(dr[e]));
+            }
         }
     }
     const int D = 64 * E;
@@ -227,15 +234,16 @@ __global__ void __launch_bounds__(BLK_THREADS) add_norm_bwd_kernel(AddNormArgs a
     // weight / bias gradient partials of this workgroup: the 4 wavefronts are added in order
     HY_UNROLL
     for (int e = 0; e < E; ++e) {
-        red[(wave * 2 + 0) * D + c0 + e] = dw[e];
-        red[(wave * 2 + 1) * D + c0 + e] = db[e];
+        red[(wave * np + 0) * D + c0 + e] = dw[e];
+        red[(wave * np + 1) * D + c0 + e] = db[e];
+        if (np == 3) red[(wave * np + 2) * D + c0 + e] = dxs[e];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * D; i += BLK_THREADS) {
+    for (int i = threadIdx.x; i < np * D; i += BLK_THREADS) {
         float s = 0.f;
         HY_UNROLL
-        for (int q = 0; q < BLK_WAVES; ++q) s += red[q * 2 * D + i];
-        a.part[(size_t)blockIdx.x * 2 * D + i] = s;
+        for (int q = 0; q < BLK_WAVES; ++q) s += red[q * np * D + i];
+        a.part[(size_t)blockIdx.x * np * D + i] = s;
     }
 }
 

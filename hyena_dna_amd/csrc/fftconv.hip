@@ -835,7 +835,7 @@ int blk_launch_e(bool fwd, const AddNormArgs& a, void* stream) {
     case e:                                                                                                               \
         if (fwd) HY_LAUNCH((add_norm_fwd_kernel<XDT, ODT, e>), dim3(grid), dim3(BLK_THREADS), 0, stream, a);              \
         else HY_LAUNCH((add_norm_bwd_kernel<XDT, ODT, e>), dim3(grid), dim3(BLK_THREADS),                                 \
-                       (size_t)BLK_WAVES * 2 * 64 * e * sizeof(float), stream, a);                                        \
+                       (size_t)BLK_WAVES * 3 * 64 * e * sizeof(float), stream, a);                                        \
         break;
     switch (a.D / 64) {
         HY_BLK_CASE(1)
@@ -990,7 +990,7 @@ int hyena_embed_add_norm_bwd(const void* dout, int dout_dtype, const float* d_re
 
 size_t hyena_add_norm_partial_floats(long rows, int D) {
     if (rows < 1 || D < 1) return 0;
-    return (size_t)blk_grid(rows) * 2 * D;
+    return (size_t)blk_grid(rows) * 3 * D;          // (dweight | dbias | column sums of dx0: the third plane is used by the _colsum entry point only)
 }
 
 int hyena_add_norm_bwd(const void* dout, int dout_dtype, const float* d_residual_out, const float* residual_out,
@@ -1004,21 +1004,31 @@ int hyena_dropout_add_norm_bwd(const void* dout, int dout_dtype, const float* d_
                                const float* weight, const float* mean, const float* rstd, float dropout_p,
                                const unsigned long long* seed, void* dx0, int dx_dtype, float* d_residual_in, float* dweight,
                                float* dbias, float* partial, long rows, int D, void* stream) {
+    return hyena_dropout_add_norm_bwd_colsum(dout, dout_dtype, d_residual_out, residual_out, weight, mean, rstd, dropout_p, seed, dx0, dx_dtype,
+                                             d_residual_in, dweight, dbias, nullptr, partial, rows, D, stream);
+}
+
+int hyena_dropout_add_norm_bwd_colsum(const void* dout, int dout_dtype, const float* d_residual_out, const float* residual_out,
+                                      const float* weight, const float* mean, const float* rstd, float dropout_p,
+                                      const unsigned long long* seed, void* dx0, int dx_dtype, float* d_residual_in, float* dweight,
+                                      float* dbias, float* dx0_colsum, float* partial, long rows, int D, void* stream) {
     if (dout == nullptr || residual_out == nullptr || weight == nullptr || mean == nullptr || rstd == nullptr || dx0 == nullptr ||
         dweight == nullptr || dbias == nullptr || partial == nullptr || rows < 1 || !hyena_add_norm_supported(D, dout_dtype, dx_dtype))
         return HYENA_ERR_BAD_ARG;
     AddNormArgs a;
     a.x = dout; a.res_in = d_residual_out; a.weight = weight; a.bias = nullptr; a.out = dx0; a.res_out = d_residual_in;
     a.saved = residual_out; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.part = partial;
+    a.np = dx0_colsum != nullptr ? 3 : 2;
     a.rows = rows; a.D = D; a.eps = 0.f; a.ids = nullptr; a.part_e = nullptr; a.V = 0;
     if (!blk_set_dropout(a, dropout_p, seed)) return HYENA_ERR_BAD_ARG;
     const int st = blk_launch(false, dout_dtype, dx_dtype, a, stream);
     if (st) return st;
     const int grid = blk_grid(rows);
-    // partial rows are [dweight (D) | dbias (D)]: two reductions with a row stride of 2 D
+    // partial rows are [dweight (D) | dbias (D) (| column sums of dx0 (D))]: reductions with a row stride of np D
     RedBatch red;
-    red.add(partial, dweight, grid, D, 2 * D, 0);
-    red.add(partial + D, dbias, grid, D, 2 * D, 0);
+    red.add(partial, dweight, grid, D, a.np * D, 0);
+    red.add(partial + D, dbias, grid, D, a.np * D, 0);
+    if (dx0_colsum != nullptr) red.add(partial + 2 * D, dx0_colsum, grid, D, a.np * D, 0);
     HY_LAUNCH(filter_reduce_multi_kernel, dim3(red.blocks()), dim3(256), FLT_RED_SMEM, stream, red.jobs);
     return hy_launch_error() ? HYENA_ERR_LAUNCH : HYENA_OK;
 }

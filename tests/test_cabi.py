@@ -124,7 +124,7 @@ def test_block_host_only_entry_points(product_lib):
     assert L.hyena_embed_add_norm_supported(17, 256, BF16) == 0 and L.hyena_embed_add_norm_supported(16, 512, BF16) == 0
     assert L.hyena_embed_add_norm_supported(0, 256, BF16) == 0
     rows, D = 1 << 20, 256
-    grid = L.hyena_add_norm_partial_floats(rows, D) // (2 * D)
+    grid = L.hyena_add_norm_partial_floats(rows, D) // (3 * D)           # (dweight | dbias | round 6: the column sums of dx0) per workgroup
     assert grid == 2048 and L.hyena_embed_add_norm_partial_floats(rows, D) == grid * (2 + 16) * D
     # dropout: p outside [0, 1) or a missing seed is refused before anything is launched
     assert L.hyena_dropout_add_norm_fwd(None, BF16, None, None, None, ctypes.c_float(1e-5), ctypes.c_float(0.1), None, None, BF16, None, None,

@@ -288,3 +288,33 @@ def test_embedding_inside_the_first_add_norm_pass_on_gpu(gpu_lib, shape, D, V, o
     rows[5] = rows[11] = False
     assert torch.isnan(res_b.reshape(-1, D)[~rows]).all() and torch.isnan(out_b.reshape(-1, D)[~rows].float()).all()
     assert torch.equal(res_b.reshape(-1, D)[rows], res.detach().reshape(-1, D)[rows])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,D,dt,p", [(1 << 20, 256, torch.bfloat16, 0.0), (261888, 128, torch.bfloat16, 0.0), (70001, 256, torch.float16, 0.1), (999, 512, torch.bfloat16, 0.0)])
+def test_add_norm_bwd_column_sums_of_dx0_on_gpu(gpu_lib, rows, D, dt, p):
+    """hyena_dropout_add_norm_bwd_colsum (round 6): the column sums of the dx0 the kernel writes -- the bias gradient of out_proj / fc2 -- equal a
+    float64 column sum of that tensor to fp32 summation accuracy, reach `_lib.colsum` through the side table, and leave every other output bit-identical"""
+    from hyena_dna_amd import _gradsum
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(rows % 1000 + D)
+    dout = torch.randn(rows, D, generator=g, device=dev).to(dt)
+    dres = torch.randn(rows, D, generator=g, device=dev)
+    res_out = torch.randn(rows, D, generator=g, device=dev)
+    w = 1.0 + 0.2 * torch.randn(D, generator=g, device=dev)
+    mean = res_out.mean(1).contiguous()
+    rstd = (1.0 / torch.sqrt(res_out.var(1, unbiased=False) + 1e-5)).contiguous()
+    seed = torch.tensor([987654321], dtype=torch.int64, device=dev)
+    ref = gpu_lib.add_norm_bwd(dout, dres, res_out, w, mean, rstd, dt, need_dres=True, dropout_p=p, seed=seed, offer_colsum=False)
+    _gradsum.reset()
+    out = gpu_lib.add_norm_bwd(dout, dres, res_out, w, mean, rstd, dt, need_dres=True, dropout_p=p, seed=seed)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    h0 = _gradsum.stats()["hits"]
+    cs = gpu_lib.colsum(out[0])
+    assert _gradsum.stats()["hits"] == h0 + 1
+    want = out[0].double().sum(0)
+    scale = out[0].double().abs().sum(0)
+    assert ((cs.double() - want).abs() <= 2e-6 * scale + 1e-6).all()
+    own = gpu_lib.colsum(out[0])                                       # the slot is empty now: the streaming kernel's own pass
+    assert _gradsum.stats()["hits"] == h0 + 1 and ((own.double() - want).abs() <= 2e-6 * scale + 1e-6).all()
