@@ -394,7 +394,7 @@ def operator_layer(L, D, B, dtype, dev, steps=20, warmup=3, graph=False, order=2
                         f"L={L}, d={D}, B={B}, {str(dtype).split('.')[-1]} autocast; secondary figure, not `value`"}
 
 
-def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=8, warmup=2, emu=False, graphed_ok=True):
+def model_step(L, D, B, dtype, dev, rank=0, world=1, n_layer=8, steps=8, warmup=3, emu=False, graphed_ok=True):
     """Secondary figure (not `value`): the full hyenadna pre-training step of north_star configuration 5 on synthetic tokens --
     embedding -> n_layer x [add+LayerNorm -> HyenaOperator -> add+LayerNorm -> MLP (d -> 4d -> d, tanh-GELU)] -> LayerNorm ->
     tied LM head -> cross entropy, backward, AdamW step -- random init, autocast (hg38_hyena.yaml: d_model 256, n_layer 8,

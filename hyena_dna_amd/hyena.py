@@ -37,6 +37,55 @@ ADD_NORM_FUSED = {"1": True, "0": False}.get(os.environ.get("HYENA_ADD_NORM_FUSE
 ORDER_N_FUSED = os.environ.get("HYENA_ORDER_N_FUSED", "1") != "0"
 
 
+# The implicit filter depends on parameters only.  Its kernels are latency-bound (2 wavefronts per SIMD, eight dependent round trips per tile: 2.5 - 2.9 TB/s),
+# the projections next to it are bandwidth-bound: on a SECOND STREAM the filter's forward overlaps in_proj, and -- autograd runs a node's backward on the
+# stream of its forward -- its backward overlaps the projections' input / weight gradient GEMMs (round 6: model step 153.5 -> 151.0 ms at 2^20 x 256,
+# 34.1 -> 33.5 at 32768 x 8, 48.5 -> 47.2 at 159999 x 2; profiles/r6af_filter_side_stream.txt).  Results are bit-identical.  "auto" (default): on for
+# device tensors of at least _FILTER_SIDE_MIN_L positions outside a stream capture and outside multi-process jobs (DistributedDataParallel launches
+# its bucket all-reduces from whichever stream marks a bucket ready: gradients written on a second stream are not this package's to order there);
+# HYENA_FILTER_SIDE_STREAM=1 / 0 forces it on (still never inside a capture) / off.
+FILTER_SIDE_STREAM = {"1": True, "0": False}.get(os.environ.get("HYENA_FILTER_SIDE_STREAM", "auto"), "auto")
+_FILTER_SIDE_MIN_L = 8192
+_side_streams = {}
+
+
+def _filter_side_stream(u, l):
+    if FILTER_SIDE_STREAM is False or not (u.is_cuda and CHANNEL_MAJOR) or torch.cuda.is_current_stream_capturing():
+        return None
+    if FILTER_SIDE_STREAM == "auto":
+        if l < _FILTER_SIDE_MIN_L:
+            return None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return None
+    s = _side_streams.get(u.device.index)
+    if s is None:
+        s = _side_streams[u.device.index] = torch.cuda.Stream(u.device)
+    return s
+
+
+class _FilterOnSideStream:
+    """with _FilterOnSideStream(u, l) as f:  k = f.run(lambda: filter_dl(...));  ... work on the caller's stream ...;  f.join(k)"""
+
+    def __init__(self, u, l):
+        self.side = _filter_side_stream(u, l)
+        self.cur = torch.cuda.current_stream(u.device) if self.side is not None else None
+
+    def run(self, fn):
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(self.cur)                   # (the parameters' last update happened on the caller's stream)
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self, ks):
+        if self.side is not None:
+            self.cur.wait_stream(self.side)
+            for k in (ks if isinstance(ks, (list, tuple)) else [ks]):
+                k.record_stream(self.cur)
+        return ks
+
+
 def _add_norm_fused(d_model):
     if ADD_NORM_FUSED == "auto":
         from . import _lib
@@ -338,9 +387,11 @@ class HyenaOperator(nn.Module):
             return None
         if not (u.is_cuda or not _fused_filter_requires_gpu()) or not _add_norm_fused(self.d_model):
             return None
-        k = self.filter_fn.filter_dl(l_filter)
+        fside = _FilterOnSideStream(u, l_filter)
+        k = fside.run(lambda: self.filter_fn.filter_dl(l_filter))
         fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
         xT, vg = in_proj_pre_cm(u, self.in_proj.weight, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, l_filter)
+        fside.join(k)
         if not mixer_out_supported(xT, l_filter, self.out_proj.weight):
             # (xT is already made: finish on the unfused route so that nothing is computed twice)
             zT = hyena_mixer_core_cm(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter, vg=vg)
@@ -354,7 +405,8 @@ class HyenaOperator(nn.Module):
         l = u.size(-2)
         l_filter = min(l, self.l_max)
         if self._fused_ok() and l_filter <= _lib_max_l():
-            k = self.filter_fn.filter_dl(l_filter)                              # (D, l), rows contiguous along l
+            fside = _FilterOnSideStream(u, l_filter)
+            k = fside.run(lambda: self.filter_fn.filter_dl(l_filter))           # (D, l), rows contiguous along l; on the second stream, next to in_proj
             fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
             if CHANNEL_MAJOR:
                 # x^T = W_in u^T straight out of the GEMM (3D, B, L): nothing between the projections is ever transposed
@@ -362,6 +414,7 @@ class HyenaOperator(nn.Module):
                 # from its epilogue -- csrc/proj_kernels.h; otherwise the library GEMM and vg = None)
                 xT, vg = in_proj_pre_cm(u, self.in_proj.weight, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias,
                                         l_filter)
+                fside.join(k)
                 if l_filter > 0 and xT.shape[1] > 0 and mixer_out_supported(xT, l_filter, self.out_proj.weight):
                     # out_proj as this package's matrix-core kernel, the `* x0` gate on its operand load (csrc/proj_kernels.h, round 4)
                     y = hyena_mixer_out_cm(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, k, fb, l_filter,
@@ -376,9 +429,11 @@ class HyenaOperator(nn.Module):
                 y = hyena_linear(self.activation(z), self.out_proj.weight, self.out_proj.bias)
             return (y, None) if self.return_state else y
         if self._route(l) == "order_n":
-            ks = self.filter_fn.filter_dl_split(l_filter, self.order - 1)       # one (D, l) filter per convolution ('(v o)' channels, hyena.py:408)
+            fside = _FilterOnSideStream(u, l_filter)
+            ks = fside.run(lambda: self.filter_fn.filter_dl_split(l_filter, self.order - 1))   # one (D, l) filter per convolution ('(v o)' channels, hyena.py:408)
             fb = self.filter_fn.bias if self.filter_fn.use_bias else 0 * self.filter_fn.bias
             xT = in_proj_cm(u, self.in_proj.weight)                             # ((order + 1) D, B, L), bias added on load by the shell kernels
+            fside.join(ks)
             zT = hyena_mixer_core_cm_order_n(xT, self.in_proj.bias, self.short_filter.weight, self.short_filter.bias, ks, fb, l_filter, self.order)
             y = out_proj_cm(zT, self.out_proj.weight, self.out_proj.bias)
             return (y, None) if self.return_state else y
