@@ -349,11 +349,16 @@ def _release_and_settle(dev, budget_s=12.0):
     import gc
     gc.collect()
     torch.cuda.synchronize(dev)
+    before = torch.cuda.memory_reserved(dev)
     torch.cuda.empty_cache()
     torch.cuda.synchronize(dev)
+    released = before - torch.cuda.memory_reserved(dev)
     probe = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    # the hold comes a few hundred ms AFTER a big release (seen at step 11 - 17 of the next leg, always ~5.7 s): after one, keep the probe running for 8 s
+    # so that it meets the probe and not a timed step
+    t_min = time.perf_counter() + (8.0 if released > (32 << 30) else 0.0)
     best, calm, t_end = None, 0, time.perf_counter() + budget_s
-    while time.perf_counter() < t_end and calm < 3:
+    while time.perf_counter() < t_end and (calm < 3 or time.perf_counter() < t_min):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         probe.fill_(1)
