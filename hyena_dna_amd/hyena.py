@@ -47,6 +47,7 @@ ORDER_N_FUSED = os.environ.get("HYENA_ORDER_N_FUSED", "1") != "0"
 FILTER_SIDE_STREAM = {"1": True, "0": False}.get(os.environ.get("HYENA_FILTER_SIDE_STREAM", "auto"), "auto")
 _FILTER_SIDE_MIN_L = 8192
 _side_streams = {}
+_device_bytes = {}
 
 
 def _filter_side_stream(u, l):
@@ -57,6 +58,12 @@ def _filter_side_stream(u, l):
             return None
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return None
+        # the second stream has an allocator pool of its own (2^20 x 256, 8 layers: 207 GiB reserved instead of 133): not when memory is already tight
+        total = _device_bytes.get(u.device.index)
+        if total is None:
+            total = _device_bytes[u.device.index] = torch.cuda.get_device_properties(u.device).total_memory
+        if torch.cuda.memory_reserved(u.device) > 0.8 * total:
             return None
     s = _side_streams.get(u.device.index)
     if s is None:

@@ -54,6 +54,11 @@ def test_auto_policy_of_the_second_stream(gpu_lib, monkeypatch):
     monkeypatch.setattr(dist, "is_initialized", lambda: True)
     monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 8)
     assert H._filter_side_stream(t, 1 << 20) is None                                    # multi-process jobs: one stream (DDP orders its buckets on it)
+    monkeypatch.undo()
+    monkeypatch.setattr(H, "FILTER_SIDE_STREAM", "auto")
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a, **k: int(0.9 * torch.cuda.get_device_properties(0).total_memory))
+    assert H._filter_side_stream(t, 1 << 20) is None                                    # memory already tight: no second allocator pool
+    monkeypatch.undo()
     monkeypatch.setattr(H, "FILTER_SIDE_STREAM", False)
     assert H._filter_side_stream(t, 1 << 20) is None
 
