@@ -72,7 +72,10 @@ def _filter_side_stream(u, l):
 
 
 class _FilterOnSideStream:
-    """with _FilterOnSideStream(u, l) as f:  k = f.run(lambda: filter_dl(...));  ... work on the caller's stream ...;  f.join(k)"""
+    """f = _FilterOnSideStream(u, l);  k = f.run(lambda: filter_dl(...));  ... in_proj on the caller's stream ...;  f.join(k)
+    run: the second stream first waits for the caller's (the parameters' last update happened there), then evaluates the filter -- PyTorch records the
+    autograd node's stream, so its backward runs there too, after the engine has made it wait for the gradient's producer.  join: the caller's stream
+    waits for the filter and the result's memory is marked as used on it (the allocator must not recycle it while the convolution reads it)."""
 
     def __init__(self, u, l):
         self.side = _filter_side_stream(u, l)
